@@ -1,0 +1,223 @@
+#!/usr/bin/env python3
+"""TEST INFRASTRUCTURE ONLY -- golden-vector generator (runs in the BUILD container only).
+
+Imports the reference's own /root/reference/networks/MPN.py UNMODIFIED (through oracle/pyg_standin for
+the five torch_geometric symbols it needs, networks/MPN.py:3-4), runs it on CPU with fixed seeds, and
+writes inputs + parameters + expected outputs/gradients as small .npz fixtures into tests/golden/.
+Only the vectors are committed; no reference source travels.  Refuses to run without /root/reference.
+
+  G1 is_directed / undirect_graph truth table            (networks/MPN.py:498-523)
+  G2 EdgeAggregation fwd + grads                          (networks/MPN.py:6-56)
+  G3 TAGConv fwd + grads, K in {1,3,6}                    (PyG, call sites :477-484,:545)
+  G4 MaskEmbdMultiMPN fwd, per-layer activations, all parameter grads under MSELoss (:456-559)
+  G6 three AdamW training steps driven by a restatement of utils/training.py:55-77
+  G7 collate fixture (analytic; PyG absent) + batch == concatenation of singles
+
+usage:  python oracle/make_goldens.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+OUT = os.path.join(ROOT, "tests", "golden")
+
+if not os.path.isdir(REF):
+    sys.exit("make_goldens.py needs the reference checkout at /root/reference (build container only)")
+
+sys.path.insert(0, os.path.join(HERE, "pyg_standin"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+from networks.MPN import EdgeAggregation, MaskEmbdMultiMPN  # noqa: E402  (the reference, unmodified)
+from torch_geometric.nn import TAGConv  # noqa: E402  (stand-in)
+
+from poweflownet_amd.data import Batch, Data  # noqa: E402
+from poweflownet_amd.synth import make_graph, make_topology  # noqa: E402
+
+torch.set_num_threads(1)  # deterministic summation order on CPU
+
+
+def npz(name, **arrays):
+    conv = {}
+    for k, v in arrays.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def seven_node_multigraph():
+    """7 nodes; node 6 isolated; branch (1,2) appears twice (parallel line); stored once per branch."""
+    return torch.tensor([[0, 1, 1, 2, 3, 0, 4],
+                         [1, 2, 2, 3, 4, 4, 5]], dtype=torch.long)
+
+
+def bidir(ei):
+    return torch.cat([ei, ei.flip(0)], dim=1)
+
+
+# ----------------------------------------------------------------------------------- G1
+def g1():
+    m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
+    cases = {
+        "stored_once": seven_node_multigraph(),
+        "symmetric": bidir(seven_node_multigraph()),
+        "empty": torch.zeros(2, 0, dtype=torch.long),
+        # only the first edge has its reverse -> heuristic says "undirected" (false negative)
+        "first_edge_only_reversed": torch.tensor([[0, 1, 1, 2], [1, 0, 2, 3]], dtype=torch.long),
+        # first edge lacks its reverse although all others have one -> "directed"
+        "first_edge_only_missing": torch.tensor([[0, 1, 2, 2, 3], [1, 2, 1, 3, 2]], dtype=torch.long),
+        "self_loop_first": torch.tensor([[2, 0], [2, 1]], dtype=torch.long),
+    }
+    arrays = {}
+    for name, ei in cases.items():
+        ea = torch.arange(ei.shape[1] * 2, dtype=torch.float32).reshape(-1, 2)
+        flag = bool(m.is_directed(ei))
+        ei2, ea2 = m.undirect_graph(ei, ea)
+        arrays[f"{name}.edge_index"] = ei
+        arrays[f"{name}.edge_attr"] = ea
+        arrays[f"{name}.directed"] = np.array(flag)
+        arrays[f"{name}.out_edge_index"] = ei2
+        arrays[f"{name}.out_edge_attr"] = ea2
+    arrays["names"] = np.array(list(cases.keys()))
+    npz("g1_is_directed", **arrays)
+
+
+# ----------------------------------------------------------------------------------- G2 / G3
+def g2():
+    ei = bidir(seven_node_multigraph())          # the layer sees the post-undirect list
+    ei_asym = torch.cat([ei, torch.tensor([[5, 2], [0, 0]])], dim=1)  # + two one-way edges (non-symmetric set)
+    for tag, (fi, h, fo), edges in (("4_8_8", (4, 8, 8), ei), ("8_8_4", (8, 8, 4), ei_asym),
+                                    ("129_129_129", (129, 129, 129), ei), ("129_129_4", (129, 129, 4), ei_asym)):
+        torch.manual_seed(100 + fi + fo)
+        layer = EdgeAggregation(fi, 2, h, fo)
+        x = torch.randn(7, fi, requires_grad=True)
+        ea = torch.randn(edges.shape[1], 2, requires_grad=True)
+        gout = torch.randn(7, fo)
+        out = layer(x, edges, ea)
+        out.backward(gout)
+        l1, l2 = layer.edge_aggr[0], layer.edge_aggr[2]
+        npz(f"g2_edge_aggregation_{tag}", x=x, edge_index=edges, edge_attr=ea, grad_out=gout,
+            w1=l1.weight, b1=l1.bias, w2=l2.weight, b2=l2.bias, out=out,
+            grad_x=x.grad, grad_edge_attr=ea.grad, grad_w1=l1.weight.grad, grad_b1=l1.bias.grad,
+            grad_w2=l2.weight.grad, grad_b2=l2.bias.grad)
+
+
+def g3():
+    ei = bidir(seven_node_multigraph())
+    ei_asym = torch.cat([ei, torch.tensor([[5, 2], [0, 0]])], dim=1)
+    for K, (cin, cout), edges in ((1, (8, 8), ei), (3, (129, 129), ei), (6, (129, 129), ei_asym), (3, (8, 5), ei_asym)):
+        torch.manual_seed(200 + K + cout)
+        layer = TAGConv(cin, cout, K=K)
+        with torch.no_grad():
+            layer.bias.normal_()                 # zero-init bias would hide a missing bias add
+        x = torch.randn(7, cin, requires_grad=True)
+        gout = torch.randn(7, cout)
+        out = layer(x, edges)
+        out.backward(gout)
+        arrays = dict(x=x, edge_index=edges, grad_out=gout, bias=layer.bias, out=out, grad_x=x.grad,
+                      grad_bias=layer.bias.grad, K=np.array(K))
+        for k, lin in enumerate(layer.lins):
+            arrays[f"w{k}"] = lin.weight
+            arrays[f"grad_w{k}"] = lin.weight.grad
+        npz(f"g3_tagconv_K{K}_{cin}_{cout}", **arrays)
+
+
+# ----------------------------------------------------------------------------------- G4 / G6
+def batch_of(n, e, B, seed):
+    topo = make_topology(n, e, 0)
+    return Batch.from_data_list([make_graph(n, e, seed=seed + b, edge_index=topo) for b in range(B)])
+
+
+def model_fixture(name, model, data, store_params=True):
+    model.eval()
+    acts = []
+    hooks = [l.register_forward_hook(lambda m, i, o: acts.append(o.detach().clone())) for l in model.layers]
+    out = model(data)
+    for h in hooks:
+        h.remove()
+    loss = torch.nn.MSELoss()(out, data.y)
+    model.zero_grad()
+    loss.backward()
+    arrays = dict(x=data.x, y=data.y, pred_mask=data.pred_mask, bus_type=data.bus_type, edge_index=data.edge_index,
+                  edge_attr=data.edge_attr, batch=data.batch, out=out, loss=loss,
+                  cfg=np.array([model.nfeature_dim, model.efeature_dim, model.output_dim, model.hidden_dim,
+                                model.n_gnn_layers, model.K]))
+    for i, a in enumerate(acts):
+        arrays[f"act.{i}"] = a
+    for k, p in model.named_parameters():
+        if store_params:
+            arrays[f"param.{k}"] = p
+        arrays[f"grad.{k}"] = p.grad
+    npz(name, **arrays)
+
+
+def g4_g6():
+    torch.manual_seed(1234)                      # train.py:70
+    tiny = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
+    model_fixture("g4_model_tiny", tiny, batch_of(14, 20, 2, seed=11))
+
+    torch.manual_seed(1234)
+    std = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0)
+    npz("g4_params_standard", **{f"param.{k}": p for k, p in std.named_parameters()})
+    d14 = batch_of(14, 20, 2, seed=21)
+    model_fixture("g4_model_case14", std, d14, store_params=False)
+    model_fixture("g4_model_case118", std, batch_of(118, 186, 2, seed=31), store_params=False)
+
+    torch.manual_seed(4321)
+    wide = MaskEmbdMultiMPN(4, 2, 4, 33, 3, 6, 0.0)   # odd H, K=6 (wide.json's K) at fixture-friendly size
+    model_fixture("g4_model_wideK6", wide, batch_of(14, 20, 3, seed=41))
+
+    # G6: restatement of the loop body utils/training.py:55-77 (else-branch loss, :72) around the reference model
+    std.train()                                   # dropout_rate == 0 -> deterministic
+    opt = torch.optim.AdamW(std.parameters(), lr=1e-3)           # train.py:123
+    loss_fn = torch.nn.MSELoss()                                 # train.py:103
+    arrays = {}
+    for step in range(1, 4):
+        opt.zero_grad()
+        out = std(d14)
+        loss = loss_fn(out, d14.y)
+        loss.backward()
+        opt.step()
+        arrays[f"loss.{step}"] = loss.detach()
+        if step in (1, 3):
+            for k, p in std.named_parameters():
+                arrays[f"param_after{step}.{k}"] = p
+    npz("g6_train_step", **arrays)
+
+
+# ----------------------------------------------------------------------------------- G7
+def g7():
+    ei = seven_node_multigraph()
+    graphs = [make_graph(7, ei.shape[1], seed=70 + b, edge_index=ei) for b in range(3)]
+    big = Data(x=torch.cat([g.x for g in graphs]), y=torch.cat([g.y for g in graphs]),
+               bus_type=torch.cat([g.bus_type for g in graphs]), pred_mask=torch.cat([g.pred_mask for g in graphs]),
+               edge_index=torch.cat([ei, ei + 7, ei + 14], dim=1), edge_attr=torch.cat([g.edge_attr for g in graphs]),
+               batch=torch.tensor([0] * 7 + [1] * 7 + [2] * 7))
+    torch.manual_seed(7)
+    m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0).eval()
+    singles = []
+    for g in graphs:
+        g.batch = torch.zeros(7, dtype=torch.long)
+        singles.append(m(g))
+    arrays = dict(batch_out=m(big), singles_out=torch.cat(singles), ptr=np.array([0, 7, 14, 21]))
+    for k in ("x", "y", "bus_type", "pred_mask", "edge_index", "edge_attr", "batch"):
+        arrays[f"big.{k}"] = getattr(big, k)
+    for b, g in enumerate(graphs):
+        for k in ("x", "y", "bus_type", "pred_mask", "edge_index", "edge_attr"):
+            arrays[f"g{b}.{k}"] = getattr(g, k)
+    for k, p in m.named_parameters():
+        arrays[f"param.{k}"] = p
+    npz("g7_collate", **arrays)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    g1(); g2(); g3(); g4_g6(); g7()

@@ -1,0 +1,154 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the MaskEmbdMultiMPN hot path.
+
+A build-authored, pure-torch (no torch_geometric) restatement of the *reference dataflow* of
+/root/reference/networks/MPN.py: materialised cat[x_i, x_j, e], per-edge Linear-ReLU-Linear,
+index_add aggregation, TAGConv as K gather-scale-scatter hops + (K+1) GEMMs.  It is
+
+  * the parity checker for the HIP path in tests/ (-m gpu) and __graft_entry__.smoke(),
+  * the timed `cpu_baseline` leg of bench.py (kind "port"),
+
+and NOTHING else: the product (poweflownet_amd/) never imports it and has no CPU fallback.
+
+How it is pinned: tests/test_oracle.py checks every function here against tests/golden/*.npz,
+which oracle/make_goldens.py produced IN THE BUILD CONTAINER by importing the reference's own
+networks/MPN.py unmodified (through oracle/pyg_standin for the five PyG symbols it needs).
+The PyG primitives underneath (propagate/TAGConv/degree) are third-party, unpinned by the
+reference and absent from the image -> parity at *that* boundary is UNPINNED against PyG itself;
+it is cross-checked analytically (dense sum_k A_hat^k X W_k^T + b, explicit per-edge loops).
+
+Reference lines each function follows are cited in its docstring.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+# --------------------------------------------------------------------------- graph helpers
+def is_directed(edge_index: torch.Tensor) -> bool:
+    """networks/MPN.py:498-504 -- one-edge heuristic: with (u0, v0) the first stored edge, the
+    list is 'directed' iff no edge (v0 -> u0) exists.  E == 0 -> False."""
+    if edge_index.shape[1] == 0:
+        return False
+    u0, v0 = edge_index[0, 0], edge_index[1, 0]
+    back = edge_index[1][edge_index[0] == v0]
+    return not bool((back == u0).any())
+
+
+def undirect_graph(edge_index: torch.Tensor, edge_attr: torch.Tensor):
+    """networks/MPN.py:506-523 -- originals first, reversed copies second; attrs duplicated."""
+    if not is_directed(edge_index):
+        return edge_index, edge_attr
+    rev = edge_index.flip(0)
+    return torch.cat([edge_index, rev], dim=1), torch.cat([edge_attr, edge_attr], dim=0)
+
+
+def in_degree(edge_index: torch.Tensor, num_nodes: int, dtype=torch.float32) -> torch.Tensor:
+    """PyG utils.degree / gcn_norm degree: occurrences of each node in edge_index[1] (multiplicity kept)."""
+    deg = torch.zeros(num_nodes, dtype=dtype, device=edge_index.device)
+    return deg.index_add_(0, edge_index[1], torch.ones(edge_index.shape[1], dtype=dtype, device=edge_index.device))
+
+
+# --------------------------------------------------------------------------- the two layers
+def edge_aggregation(x, edge_index, edge_attr, w1, b1, w2, b2):
+    """EdgeAggregation.forward / .message (networks/MPN.py:23-56) under PyG propagate(aggr='add'):
+    out[i] = sum_{e: dst(e)=i} ( W2 relu(W1 [x_i ; x_src(e) ; a_e] + b1) + b2 ).
+    Concat order target, source, attr (:28).  The degree `norm` computed at :43-47 is dead."""
+    src, dst = edge_index[0], edge_index[1]
+    z = torch.cat([x.index_select(0, dst), x.index_select(0, src), edge_attr], dim=-1)
+    msg = F.linear(F.relu(F.linear(z, w1, b1)), w2, b2)
+    out = torch.zeros(x.shape[0], msg.shape[1], dtype=msg.dtype, device=msg.device)
+    return out.index_add(0, dst, msg)
+
+
+def tag_conv(x, edge_index, lin_weights, bias):
+    """PyG TAGConv.forward (call sites networks/MPN.py:477-484, :545), normalize=True,
+    add_self_loops=False: out = sum_k (A_hat^k x) W_k^T + b."""
+    src, dst = edge_index[0], edge_index[1]
+    n = x.shape[0]
+    dis = in_degree(edge_index, n, x.dtype).pow(-0.5)
+    dis = torch.where(torch.isinf(dis), torch.zeros_like(dis), dis)
+    w = dis.index_select(0, src) * dis.index_select(0, dst)
+    out = F.linear(x, lin_weights[0])
+    for wk in lin_weights[1:]:
+        x = torch.zeros_like(x).index_add(0, dst, w.unsqueeze(1) * x.index_select(0, src))
+        out = out + F.linear(x, wk)
+    if bias is not None:
+        out = out + bias
+    return out
+
+
+# --------------------------------------------------------------------------- modules (same state_dict keys)
+class EdgeAggregation(nn.Module):
+    """Mirror of networks/MPN.py:6-56: ctor (nfeature_dim, efeature_dim, hidden_dim, output_dim),
+    parameters under edge_aggr.0 / edge_aggr.2."""
+
+    def __init__(self, nfeature_dim, efeature_dim, hidden_dim, output_dim):
+        super().__init__()
+        self.nfeature_dim, self.efeature_dim, self.output_dim = nfeature_dim, efeature_dim, output_dim
+        self.edge_aggr = nn.Sequential(nn.Linear(2 * nfeature_dim + efeature_dim, hidden_dim), nn.ReLU(),
+                                       nn.Linear(hidden_dim, output_dim))
+
+    def forward(self, x, edge_index, edge_attr):
+        l1, l2 = self.edge_aggr[0], self.edge_aggr[2]
+        return edge_aggregation(x, edge_index, edge_attr, l1.weight, l1.bias, l2.weight, l2.bias)
+
+
+class TAGConv(nn.Module):
+    """Mirror of PyG TAGConv(in_channels, out_channels, K): lins.{k}.weight, bias (zero init)."""
+
+    def __init__(self, in_channels, out_channels, K=3):
+        super().__init__()
+        self.in_channels, self.out_channels, self.K = in_channels, out_channels, K
+        self.lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=False) for _ in range(K + 1)])
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x, edge_index):
+        return tag_conv(x, edge_index, [l.weight for l in self.lins], self.bias)
+
+
+class MaskEmbdMultiMPN(nn.Module):
+    """Mirror of networks/MPN.py:456-559 (ctor :462-496, forward :525-559)."""
+
+    def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
+        super().__init__()
+        if n_gnn_layers < 2:
+            raise ValueError("n_gnn_layers == 1 is shape-broken in the reference (networks/MPN.py:475-477)")
+        self.nfeature_dim, self.efeature_dim, self.output_dim = nfeature_dim, efeature_dim, output_dim
+        self.hidden_dim, self.n_gnn_layers, self.K, self.dropout_rate = hidden_dim, n_gnn_layers, K, dropout_rate
+        layers = [EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, hidden_dim), TAGConv(hidden_dim, hidden_dim, K)]
+        for _ in range(n_gnn_layers - 2):
+            layers += [EdgeAggregation(hidden_dim, efeature_dim, hidden_dim, hidden_dim), TAGConv(hidden_dim, hidden_dim, K)]
+        layers.append(EdgeAggregation(hidden_dim, efeature_dim, hidden_dim, output_dim))
+        self.layers = nn.ModuleList(layers)
+        self.mask_embd = nn.Sequential(nn.Linear(nfeature_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, nfeature_dim))
+        self.dropout = nn.Dropout(dropout_rate)
+
+    is_directed = staticmethod(is_directed)
+    undirect_graph = staticmethod(undirect_graph)
+
+    def forward(self, data, return_intermediates: bool = False):
+        assert data.x.shape[-1] == 4                                       # :528
+        x = self.mask_embd(data.pred_mask.float()) + data.x               # :533,:537
+        edge_index, edge_attr = undirect_graph(data.edge_index, data.edge_attr)   # :539
+        inter = [x]
+        for layer in self.layers[:-1]:                                     # :541-547
+            x = layer(x, edge_index, edge_attr) if isinstance(layer, EdgeAggregation) else layer(x, edge_index)
+            inter.append(x)                                                # pre-activation layer output
+            x = F.relu(self.dropout(x))
+        x = self.layers[-1](x, edge_index, edge_attr)                      # :554-555
+        inter.append(x)
+        return (x, inter) if return_intermediates else x
+
+
+def train_step(model, data, optimizer, loss_fn=None):
+    """The per-batch body of train_epoch (utils/training.py:55-77) for the default-else loss branch
+    (:72): zero_grad -> forward -> loss(out, y) -> backward -> step.  Returns the loss tensor."""
+    loss_fn = loss_fn if loss_fn is not None else nn.MSELoss()
+    optimizer.zero_grad()
+    out = model(data)
+    loss = loss_fn(out, data.y)
+    loss.backward()
+    optimizer.step()
+    return loss.detach()
