@@ -189,7 +189,7 @@ def g4_g6():
         arrays[f"loss.{step}"] = loss.detach()
         if step in (1, 3):
             for k, p in std.named_parameters():
-                arrays[f"param_after{step}.{k}"] = p
+                arrays[f"param_after{step}.{k}"] = p.detach().clone()
     npz("g6_train_step", **arrays)
 
 
