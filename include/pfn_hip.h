@@ -1,0 +1,154 @@
+/*
+ * pfn_hip.h -- C ABI of libpfn_hip.so: the MI355X (gfx950) implementation of PowerFlowNet's
+ * message-passing hot path (MaskEmbdMultiMPN forward + backward).
+ *
+ * The reference has no FFI of its own: its boundary is the Python class surface of
+ * networks/MPN.py.  Each entry point below names the reference interface it
+ * replaces (file:line into /root/reference).  The host-side mirror of that class surface
+ * (poweflownet_amd/networks/MPN.py) binds these symbols with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (except `params`/`grads` tables, which are
+ *     HOST arrays of device pointers, and out-parameters documented as host);
+ *   - all floating point is fp32; node/edge ids arrive as int64 (the PyG layout) and are narrowed to
+ *     int32 inside pfn_graph_build;
+ *   - work is enqueued on `stream` (a hipStream_t passed as void*); no entry point synchronises,
+ *     allocates or frees device memory except where stated, so every call is hipGraph-capturable;
+ *   - activations handed between layers use a padded row stride ld = pfn_padded_ld(F) = roundup(F, 4)
+ *     floats whose pad columns are kept zero;
+ *   - return value: 0 on success, a negative PFN_E* code otherwise; pfn_last_error() gives the text.
+ */
+#ifndef PFN_HIP_H
+#define PFN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PFN_ABI_VERSION 1
+
+enum {
+    PFN_OK = 0,
+    PFN_EINVAL = -1,      /* bad argument (null pointer, misaligned ld, unsupported dimension) */
+    PFN_ENOSPACE = -2,    /* a caller-provided workspace is too small */
+    PFN_EHIP = -3,        /* a HIP runtime call failed */
+    PFN_EINDEX = -4       /* edge_index holds a node id outside [0, n_nodes) */
+};
+
+/* Model hyper-parameters: the constructor arguments of MaskEmbdMultiMPN (networks/MPN.py:462-470). */
+typedef struct pfn_mpn_config {
+    int32_t nfeature_dim;   /* node input width (4, asserted networks/MPN.py:528) */
+    int32_t efeature_dim;   /* edge feature width (2) */
+    int32_t output_dim;     /* node output width (4) */
+    int32_t hidden_dim;     /* H */
+    int32_t n_gnn_layers;   /* L >= 2 (L == 1 is shape-broken in the reference, networks/MPN.py:475-477) */
+    int32_t K;              /* TAGConv hops */
+    float dropout_rate;     /* p of nn.Dropout (networks/MPN.py:496) */
+    int32_t training;       /* 1: dropout active (model.train()), 0: model.eval() */
+} pfn_mpn_config;
+
+int pfn_abi_version(void);
+const char* pfn_last_error(void);            /* thread-local, valid until the next failing call */
+int64_t pfn_padded_ld(int64_t features);     /* roundup(features, 4) */
+
+/* ------------------------------------------------------------------------------------------ graph
+ * Replaces MaskEmbdMultiMPN.is_directed + undirect_graph (networks/MPN.py:498-523) and the per-call
+ * PyG bookkeeping underneath propagate()/gcn_norm (degree scatter, index_select lifting):
+ * one pass turns the stored edge list into destination-sorted and source-sorted CSR adjacency
+ * (rows ordered by edge id, so segment sums run in the reference's edge order), in-degree and
+ * D^-1/2.  `mode`: -1 = apply the reference's first-edge heuristic on device (no host sync),
+ * 0 = use the list as given, 1 = always append the reversed copies.                              */
+size_t pfn_graph_workspace_bytes(int64_t n_nodes, int64_t e_stored);
+int pfn_graph_build(const int64_t* edge_index /* [2, e_stored] */, int64_t e_stored, int64_t n_nodes,
+                    int mode, void* graph_ws, size_t graph_ws_bytes, void* stream);
+/* Synchronising debug/validation read-back (host out-params): directed flag, effective edge count,
+ * error flag (non-zero when an id was out of range -> PFN_EINDEX).                               */
+int pfn_graph_info(const void* graph_ws, int64_t n_nodes, int64_t e_stored, int32_t* directed,
+                   int64_t* e_effective, void* stream);
+/* Copies the effective (post-undirect) edge list back out as int64 [2, 2*e_stored] (tests). */
+int pfn_graph_export_edges(const void* graph_ws, int64_t n_nodes, int64_t e_stored,
+                           int64_t* edge_index_out, void* stream);
+
+/* -------------------------------------------------------------------------------------- whole model
+ * Parameter table order (host array of device pointers), mirroring the module tree of
+ * networks/MPN.py:462-496:
+ *   for each layer i of `layers`:  EdgeAggregation -> W1 (H, 2*Fi+Fe), b1 (H), W2 (Fo, H), b2 (Fo)
+ *                                  TAGConv         -> W_0 .. W_K (H, H) each, bias (H)
+ *   then mask_embd: Wa (H, F0), ba (H), Wb (F0, H), bb (F0).
+ * All in the nn.Linear (out, in) row-major layout of the state_dict.  pfn_mpn_num_params gives the
+ * table length; `grads` uses the same order.                                                      */
+int pfn_mpn_num_params(const pfn_mpn_config* cfg);
+size_t pfn_mpn_workspace_bytes(const pfn_mpn_config* cfg, int64_t n_nodes, int64_t e_stored);
+
+/* MaskEmbdMultiMPN.forward (networks/MPN.py:525-559), including EdgeAggregation.forward/message
+ * (:23-56) and TAGConv.forward.  x [N, F0] f32, pred_mask [N, F0] (mask_dtype 0: int64, the dataset
+ * layout of datasets/PowerFlowData.py:193; 1: float32), edge_attr [e_stored, Fe] f32, out [N, output_dim] f32.  `ws` receives the activations backward needs.  `rng_state`: device
+ * uint64[2] {seed, offset}; read when training && dropout_rate > 0 and advanced by one per call.   */
+int pfn_mpn_forward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
+                    const float* const* params, const float* x, const void* pred_mask,
+                    int mask_dtype, const float* edge_attr, float* out, void* ws, size_t ws_bytes,
+                    uint64_t* rng_state, void* stream);
+
+/* Autograd of the above (what loss.backward() runs, utils/training.py:74): grad_out [N, output_dim];
+ * writes every entry of `grads` (overwrites, does not accumulate); grad_x [N, F0] and
+ * grad_edge_attr [e_stored, Fe] are optional (NULL to skip).  `ws` is the buffer forward filled.   */
+int pfn_mpn_backward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
+                     const float* const* params, float* const* grads, const float* x,
+                     const void* pred_mask, int mask_dtype, const float* edge_attr, const float* grad_out,
+                     float* grad_x, float* grad_edge_attr, void* ws, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------- single layers
+ * EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, output_dim).forward (networks/MPN.py:30-56):
+ *   out[i] = sum_{e -> i} ( W2 relu(W1 [x_i ; x_src(e) ; a_e] + b1) + b2 ).
+ * x [N, ldx] (ldx = pfn_padded_ld(Fi), pad zero), out [N, ldo].  `ws` (pfn_edge_aggr_workspace_bytes)
+ * keeps P|Q and S for backward.  The graph must have been built from the list the layer is given
+ * (mode 0 when the caller already undirected it).                                                  */
+size_t pfn_edge_aggr_workspace_bytes(int64_t n_nodes, int64_t e_stored, int fi, int fe, int h, int fo);
+int pfn_edge_aggr_forward(const void* graph_ws, int64_t n_nodes, int64_t e_stored, int fi, int fe, int h,
+                          int fo, const float* x, int64_t ldx, const float* edge_attr, const float* w1,
+                          const float* b1, const float* w2, const float* b2, float* out, int64_t ldo,
+                          void* ws, size_t ws_bytes, void* stream);
+int pfn_edge_aggr_backward(const void* graph_ws, int64_t n_nodes, int64_t e_stored, int fi, int fe, int h,
+                           int fo, const float* x, int64_t ldx, const float* edge_attr, const float* w1,
+                           const float* b1, const float* w2, const float* b2, const float* grad_out,
+                           int64_t ldgo, float* grad_x, int64_t ldgx, float* grad_edge_attr, float* grad_w1,
+                           float* grad_b1, float* grad_w2, float* grad_b2, void* ws, size_t ws_bytes,
+                           void* stream);
+
+/* TAGConv(in, out, K).forward (PyG; call sites networks/MPN.py:477-484,:545):
+ *   out = sum_k (A_hat^k x) W_k^T + b,  A_hat = D^-1/2 A D^-1/2, no self loops.
+ * weights: host array of K+1 device pointers (lins.k.weight, (out, in) each).                     */
+size_t pfn_tag_conv_workspace_bytes(int64_t n_nodes, int64_t e_stored, int cin, int cout, int K);
+int pfn_tag_conv_forward(const void* graph_ws, int64_t n_nodes, int64_t e_stored, int cin, int cout, int K,
+                         const float* x, int64_t ldx, const float* const* weights, const float* bias,
+                         float* out, int64_t ldo, void* ws, size_t ws_bytes, void* stream);
+int pfn_tag_conv_backward(const void* graph_ws, int64_t n_nodes, int64_t e_stored, int cin, int cout, int K,
+                          const float* x, int64_t ldx, const float* const* weights, const float* grad_out,
+                          int64_t ldgo, float* grad_x, int64_t ldgx, float* const* grad_weights,
+                          float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+
+/* ----------------------------------------------------------------------------------------- utilities
+ * The segmented scatter-add in isolation (PyG SumAggregation / scatter_add_ under propagate):
+ * out[i] = sum_{e -> i} x[src(e)], F columns, ld = pfn_padded_ld(F).  Used for the roofline run.  */
+int pfn_scatter_add(const void* graph_ws, int64_t n_nodes, int64_t e_stored, const float* x, float* out,
+                    int64_t features, void* stream);
+/* Row (un)padding between the caller's dense [N, F] tensors and the internal [N, ld] layout.      */
+int pfn_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t n_rows,
+                 int64_t features, void* stream);
+/* MSELoss(out, y) forward+backward in one pass (train.py:103; utils/training.py:72-74):
+ * loss[0] = mean((out-y)^2), grad[i] = 2 (out[i]-y[i]) / count.                                    */
+int pfn_mse_loss(const float* out, const float* y, int64_t count, float* loss, float* grad, void* ws,
+                 size_t ws_bytes, void* stream);
+/* AdamW on one flat buffer (train.py:123; torch defaults betas (0.9,0.999), eps 1e-8, wd 0.01).
+ * `step` is a device int64 counter incremented by the call (capturable).                           */
+int pfn_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                   float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
+                   void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PFN_HIP_H */

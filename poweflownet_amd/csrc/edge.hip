@@ -1,0 +1,410 @@
+// Segmented gather / scatter-add kernels over the CSR adjacency (gfx950, HBM/L2-bound).
+//
+// These replace what PyG's propagate() does around the reference's message functions:
+//   * index_select lifting of x_i / x_j            (EdgeAggregation.forward, networks/MPN.py:53)
+//   * the materialised cat[x_i, x_j, e]            (EdgeAggregation.message, networks/MPN.py:28)
+//   * scatter_add of messages onto edge_index[1]   (aggr='add', networks/MPN.py:11)
+//   * TAGConv's K weighted gather-scatter hops     (PyG TAGConv.propagate; call site :545)
+// Work item = (node row, 16-byte column chunk): consecutive lanes read consecutive float4s of the same
+// neighbour row (528 B contiguous for H = 129), every row is reduced by one lane sequentially in edge-id
+// order -> no atomics, deterministic, same summation order as the reference's sequential scatter.
+#include "pfn_internal.hpp"
+
+namespace pfn {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 fma4(float a, float4 x, float4 acc) {
+    acc.x = fmaf(a, x.x, acc.x);
+    acc.y = fmaf(a, x.y, acc.y);
+    acc.z = fmaf(a, x.z, acc.z);
+    acc.w = fmaf(a, x.w, acc.w);
+    return acc;
+}
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ------------------------------------------------------------------------------------------- hop
+template <bool NORM>
+__global__ __launch_bounds__(256) void hop_kernel(int n, int nchunk, const int* __restrict__ rowptr,
+                                                  const int* __restrict__ nbr, const float* __restrict__ dinv,
+                                                  const float* __restrict__ x, const float* __restrict__ add,
+                                                  float* __restrict__ y, const float* __restrict__ gate,
+                                                  float gate_scale, int ld) {
+    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = (int)(item / nchunk);
+    if (row >= n) return;
+    const int col = (int)(item - (long)row * nchunk) * 4;
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    const float di = NORM ? dinv[row] : 1.0f;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int p = beg;
+    for (; p + 4 <= end; p += 4) {   // 4 independent gathers in flight per lane
+        const int s0 = nbr[p], s1 = nbr[p + 1], s2 = nbr[p + 2], s3 = nbr[p + 3];
+        const float4 v0 = ld4(x + (size_t)s0 * ld + col), v1 = ld4(x + (size_t)s1 * ld + col);
+        const float4 v2 = ld4(x + (size_t)s2 * ld + col), v3 = ld4(x + (size_t)s3 * ld + col);
+        if (NORM) {
+            acc = fma4(dinv[s0] * di, v0, acc);
+            acc = fma4(dinv[s1] * di, v1, acc);
+            acc = fma4(dinv[s2] * di, v2, acc);
+            acc = fma4(dinv[s3] * di, v3, acc);
+        } else {
+            acc = add4(add4(add4(add4(acc, v0), v1), v2), v3);
+        }
+    }
+    for (; p < end; ++p) {
+        const int s0 = nbr[p];
+        const float4 v0 = ld4(x + (size_t)s0 * ld + col);
+        if (NORM) acc = fma4(dinv[s0] * di, v0, acc);
+        else acc = add4(acc, v0);
+    }
+    const size_t o = (size_t)row * ld + col;
+    if (add) acc = add4(acc, ld4(add + o));
+    if (gate) {
+        const float4 g = ld4(gate + o);
+        acc.x = g.x > 0.f ? acc.x * gate_scale : 0.f;
+        acc.y = g.y > 0.f ? acc.y * gate_scale : 0.f;
+        acc.z = g.z > 0.f ? acc.z * gate_scale : 0.f;
+        acc.w = g.w > 0.f ? acc.w * gate_scale : 0.f;
+    }
+    st4(y + o, acc);
+}
+
+int launch_hop(const GraphView& g, const HopArgs& a, hipStream_t s) {
+    if (g.n == 0) return PFN_OK;
+    const int nchunk = a.ld / 4;
+    const long items = (long)g.n * nchunk;
+    const int blocks = (int)((items + 255) / 256);
+    const int* rp = a.transpose ? g.rowptr_out : g.rowptr_in;
+    const int* nb = a.transpose ? g.out_dst : g.in_src;
+    if (a.normalize)
+        hop_kernel<true><<<blocks, 256, 0, s>>>(g.n, nchunk, rp, nb, g.dinv, a.x, a.add, a.y, a.gate, a.gate_scale, a.ld);
+    else
+        hop_kernel<false><<<blocks, 256, 0, s>>>(g.n, nchunk, rp, nb, g.dinv, a.x, a.add, a.y, a.gate, a.gate_scale, a.ld);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+// ------------------------------------------------------------------------------ EdgeAggregation fwd
+// The per-edge Linear(2Fi+Fe -> H) splits into per-node terms P = x W1[:, :Fi]^T + b1, Q = x W1[:, Fi:2Fi]^T
+// (node GEMMs) and a per-edge residue sum_f a_e[f] W1[:, 2Fi+f]; the second Linear commutes with the
+// segment sum, so only S[i] = sum_e relu(P[i] + Q[src] + residue) is formed per edge.
+// LDS holds the Fe residue columns of W1 (strided in the nn.Linear layout) for the whole block.
+template <int FE>
+__global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_stored, const int* __restrict__ rowptr,
+                                                       const int* __restrict__ nbr, const int* __restrict__ eid,
+                                                       const float* __restrict__ P, const float* __restrict__ Q,
+                                                       const float* __restrict__ ea, const float* __restrict__ w1,
+                                                       float* __restrict__ S, int ld, int h, int fi, int fe_rt) {
+    extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld]
+    const int fe = FE > 0 ? FE : fe_rt;
+    const int ldw = 2 * fi + fe;
+    for (int i = threadIdx.x; i < fe * ld; i += blockDim.x) {
+        const int f = i / ld, k = i - f * ld;
+        we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
+    }
+    __syncthreads();
+    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = (int)(item / nchunk);
+    if (row >= n) return;
+    const int col = (int)(item - (long)row * nchunk) * 4;
+    const float4 p4 = ld4(P + (size_t)row * ld + col);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    for (int p = beg; p < end; ++p) {
+        const int s = nbr[p];
+        int id = eid[p];
+        id = id >= e_stored ? id - e_stored : id;
+        float4 v = add4(p4, ld4(Q + (size_t)s * ld + col));
+        if (FE == 2) {
+            const float2 a = *reinterpret_cast<const float2*>(ea + (size_t)id * 2);
+            v = fma4(a.x, ld4(we + col), v);
+            v = fma4(a.y, ld4(we + ld + col), v);
+        } else {
+            for (int f = 0; f < fe; ++f) v = fma4(ea[(size_t)id * fe + f], ld4(we + f * ld + col), v);
+        }
+        acc.x += fmaxf(v.x, 0.f);
+        acc.y += fmaxf(v.y, 0.f);
+        acc.z += fmaxf(v.z, 0.f);
+        acc.w += fmaxf(v.w, 0.f);
+    }
+    st4(S + (size_t)row * ld + col, acc);
+}
+
+int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
+    if (g.n == 0) return PFN_OK;
+    const int nchunk = a.ld / 4;
+    const long items = (long)g.n * nchunk;
+    const int blocks = (int)((items + 255) / 256);
+    const size_t lds = (size_t)a.fe * a.ld * sizeof(float);
+    if (a.fe == 2)
+        edge_fwd_kernel<2><<<blocks, 256, lds, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q,
+                                                    a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe);
+    else
+        edge_fwd_kernel<0><<<blocks, 256, lds, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q,
+                                                    a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+// ------------------------------------------------------------------------------ EdgeAggregation bwd
+// dh_e = dS[dst(e)] where the recomputed pre-activation P[dst] + Q[src] + residue is > 0.
+//   dst walk (by-destination CSR):  dP[i] = sum_{e -> i} dh_e ;  dWe[f] += a_e[f] * dh_e
+//   src walk (by-source CSR):       dQ[j] = sum_{e: src(e) = j} dh_e
+// dWe is reduced deterministically: per-block ordered partial -> launch_dwe_reduce.
+#define PFN_MAX_FE 8
+
+template <int FE>
+__global__ __launch_bounds__(256) void edge_bwd_dst_kernel(int n, int nchunk, int e_stored,
+                                                           const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                           const int* __restrict__ eid, const float* __restrict__ P,
+                                                           const float* __restrict__ Q, const float* __restrict__ dS,
+                                                           const float* __restrict__ ea, const float* __restrict__ w1,
+                                                           float* __restrict__ dP, float* __restrict__ dWe_partial,
+                                                           int ld, int h, int fi) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // we[FE][ld] | part[256][FE] float4
+    float* we = smem;
+    float4* part = reinterpret_cast<float4*>(smem + FE * ld);
+    const int ldw = 2 * fi + FE;
+    for (int i = threadIdx.x; i < FE * ld; i += blockDim.x) {
+        const int f = i / ld, k = i - f * ld;
+        we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
+    }
+    __syncthreads();
+    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = (int)(item / nchunk);
+    const int col = (int)(item - (long)row * nchunk) * 4;
+    float4 dwe[FE];
+#pragma unroll
+    for (int f = 0; f < FE; ++f) dwe[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < n) {
+        const float4 p4 = ld4(P + (size_t)row * ld + col);
+        const float4 g4 = ld4(dS + (size_t)row * ld + col);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int beg = rowptr[row], end = rowptr[row + 1];
+        for (int p = beg; p < end; ++p) {
+            const int s = nbr[p];
+            int id = eid[p];
+            id = id >= e_stored ? id - e_stored : id;
+            float4 v = add4(p4, ld4(Q + (size_t)s * ld + col));
+            float a[FE];
+#pragma unroll
+            for (int f = 0; f < FE; ++f) {
+                a[f] = ea[(size_t)id * FE + f];
+                v = fma4(a[f], ld4(we + f * ld + col), v);
+            }
+            float4 dh;
+            dh.x = v.x > 0.f ? g4.x : 0.f;
+            dh.y = v.y > 0.f ? g4.y : 0.f;
+            dh.z = v.z > 0.f ? g4.z : 0.f;
+            dh.w = v.w > 0.f ? g4.w : 0.f;
+            acc = add4(acc, dh);
+#pragma unroll
+            for (int f = 0; f < FE; ++f) dwe[f] = fma4(a[f], dh, dwe[f]);
+        }
+        st4(dP + (size_t)row * ld + col, acc);
+    }
+    // ordered in-block reduction over the rows this block touched, per column chunk
+#pragma unroll
+    for (int f = 0; f < FE; ++f) part[threadIdx.x * FE + f] = dwe[f];
+    __syncthreads();
+    const long item0 = (long)blockIdx.x * blockDim.x;
+    for (int c = threadIdx.x; c < nchunk; c += blockDim.x) {
+        int t = (int)(((long)c - item0 % nchunk + nchunk) % nchunk);   // first thread of this block on chunk c
+        float4 sum[FE];
+#pragma unroll
+        for (int f = 0; f < FE; ++f) sum[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (; t < (int)blockDim.x; t += nchunk) {
+#pragma unroll
+            for (int f = 0; f < FE; ++f) sum[f] = add4(sum[f], part[t * FE + f]);
+        }
+#pragma unroll
+        for (int f = 0; f < FE; ++f) st4(dWe_partial + ((size_t)blockIdx.x * FE + f) * ld + c * 4, sum[f]);
+    }
+}
+
+template <int FE>
+__global__ __launch_bounds__(256) void edge_bwd_src_kernel(int n, int nchunk, int e_stored,
+                                                           const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                           const int* __restrict__ eid, const float* __restrict__ P,
+                                                           const float* __restrict__ Q, const float* __restrict__ dS,
+                                                           const float* __restrict__ ea, const float* __restrict__ w1,
+                                                           float* __restrict__ dQ, int ld, int h, int fi) {
+    extern __shared__ __attribute__((aligned(16))) float we[];
+    const int ldw = 2 * fi + FE;
+    for (int i = threadIdx.x; i < FE * ld; i += blockDim.x) {
+        const int f = i / ld, k = i - f * ld;
+        we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
+    }
+    __syncthreads();
+    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = (int)(item / nchunk);
+    if (row >= n) return;
+    const int col = (int)(item - (long)row * nchunk) * 4;
+    const float4 q4 = ld4(Q + (size_t)row * ld + col);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    for (int p = beg; p < end; ++p) {
+        const int d = nbr[p];
+        int id = eid[p];
+        id = id >= e_stored ? id - e_stored : id;
+        float4 v = add4(ld4(P + (size_t)d * ld + col), q4);
+        const float4 g4 = ld4(dS + (size_t)d * ld + col);
+#pragma unroll
+        for (int f = 0; f < FE; ++f) v = fma4(ea[(size_t)id * FE + f], ld4(we + f * ld + col), v);
+        acc.x += v.x > 0.f ? g4.x : 0.f;
+        acc.y += v.y > 0.f ? g4.y : 0.f;
+        acc.z += v.z > 0.f ? g4.z : 0.f;
+        acc.w += v.w > 0.f ? g4.w : 0.f;
+    }
+    st4(dQ + (size_t)row * ld + col, acc);
+}
+
+int edge_bwd_dst_blocks(const GraphView& g, int ld) {
+    const long items = (long)g.n * (ld / 4);
+    return (int)((items + 255) / 256);
+}
+
+template <int FE>
+static int launch_edge_bwd_fe(const GraphView& g, const EdgeBwdArgs& a, hipStream_t s) {
+    const int nchunk = a.ld / 4;
+    const int blocks = edge_bwd_dst_blocks(g, a.ld);
+    const size_t lds_dst = (size_t)FE * a.ld * sizeof(float) + (size_t)256 * FE * sizeof(float4);
+    edge_bwd_dst_kernel<FE><<<blocks, 256, lds_dst, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P,
+                                                         a.Q, a.dS, a.edge_attr, a.w1, a.dP, a.dWe_partial, a.ld, a.h,
+                                                         a.fi);
+    PFN_CHECK_LAUNCH();
+    edge_bwd_src_kernel<FE><<<blocks, 256, (size_t)FE * a.ld * sizeof(float), s>>>(
+        g.n, nchunk, g.e_stored, g.rowptr_out, g.out_dst, g.out_eid, a.P, a.Q, a.dS, a.edge_attr, a.w1, a.dQ, a.ld, a.h,
+        a.fi);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t*, hipStream_t s) {
+    if (g.n == 0) return PFN_OK;
+    switch (a.fe) {
+        case 1: return launch_edge_bwd_fe<1>(g, a, s);
+        case 2: return launch_edge_bwd_fe<2>(g, a, s);
+        case 3: return launch_edge_bwd_fe<3>(g, a, s);
+        case 4: return launch_edge_bwd_fe<4>(g, a, s);
+        case 5: return launch_edge_bwd_fe<5>(g, a, s);
+        case 6: return launch_edge_bwd_fe<6>(g, a, s);
+        default: set_error("edge feature width %d unsupported in backward (1..6)", a.fe); return PFN_EINVAL;
+    }
+}
+
+// dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered sum over blocks)
+__global__ __launch_bounds__(256) void dwe_reduce_kernel(const float* __restrict__ partial, int nblocks, int fe, int ld,
+                                                         int h, float* __restrict__ gw1, int ldw, int col0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= fe * h) return;
+    const int f = i / h, k = i - f * h;
+    float acc = 0.f;
+    for (int b = 0; b < nblocks; ++b) acc += partial[((size_t)b * fe + f) * ld + k];
+    gw1[(size_t)k * ldw + col0 + f] = acc;
+}
+
+int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, float* gw1, int ldw, int col0,
+                      hipStream_t s) {
+    dwe_reduce_kernel<<<(fe * h + 255) / 256, 256, 0, s>>>(partial, nblocks, fe, ld, h, gw1, ldw, col0);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+// d edge_attr[e][f] = sum over the (one or two) effective copies of stored edge e of  We_f . dh_copy.
+// One wave per stored edge walks H; only launched when the caller asks for grad_edge_attr.
+__global__ __launch_bounds__(256) void edge_attr_grad_kernel(int e_stored, const int* __restrict__ rowptr_in,
+                                                             const int* __restrict__ in_src,
+                                                             const int* __restrict__ in_eid, int n,
+                                                             const float* __restrict__ P, const float* __restrict__ Q,
+                                                             const float* __restrict__ dS, const float* __restrict__ ea,
+                                                             const float* __restrict__ w1, float* __restrict__ gea,
+                                                             int ld, int h, int fi, int fe) {
+    // work item: one (destination row, slot) pair = one effective edge; a wave per effective edge
+    const int wave = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int lane = threadIdx.x & 63;
+    const int e_eff = rowptr_in[n];
+    if (wave >= e_eff) return;
+    // binary search the destination row owning slot `wave`
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rowptr_in[mid] <= wave) lo = mid; else hi = mid;
+    }
+    const int dst = lo, src = in_src[wave];
+    int id = in_eid[wave];
+    id = id >= e_stored ? id - e_stored : id;
+    const int ldw = 2 * fi + fe;
+    float part[PFN_MAX_FE];
+    for (int f = 0; f < fe; ++f) part[f] = 0.f;
+    for (int k = lane; k < h; k += 64) {
+        float v = P[(size_t)dst * ld + k] + Q[(size_t)src * ld + k];
+        for (int f = 0; f < fe; ++f) v = fmaf(ea[(size_t)id * fe + f], w1[(size_t)k * ldw + 2 * fi + f], v);
+        const float dh = v > 0.f ? dS[(size_t)dst * ld + k] : 0.f;
+        for (int f = 0; f < fe; ++f) part[f] = fmaf(w1[(size_t)k * ldw + 2 * fi + f], dh, part[f]);
+    }
+    for (int f = 0; f < fe; ++f) {
+        float v = part[f];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if (lane == 0) atomicAdd(&gea[(size_t)id * fe + f], v);   // at most two copies per stored edge
+    }
+}
+
+int launch_edge_attr_grad(const GraphView& g, const EdgeBwdArgs& a, hipStream_t s) {
+    if (g.e_stored == 0) return PFN_OK;
+    if (a.fe > PFN_MAX_FE) {
+        set_error("edge feature width %d > %d", a.fe, PFN_MAX_FE);
+        return PFN_EINVAL;
+    }
+    PFN_CHECK_HIP(hipMemsetAsync(a.grad_edge_attr, 0, (size_t)g.e_stored * a.fe * sizeof(float), s));
+    const long waves = 2l * g.e_stored;   // upper bound on effective edges
+    const int blocks = (int)((waves * 64 + 255) / 256);
+    edge_attr_grad_kernel<<<blocks, 256, 0, s>>>(g.e_stored, g.rowptr_in, g.in_src, g.in_eid, g.n, a.P, a.Q, a.dS,
+                                                 a.edge_attr, a.w1, a.grad_edge_attr, a.ld, a.h, a.fi, a.fe);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+// ------------------------------------------------------------------------------------ small kernels
+template <typename T>
+__global__ void mask_to_float_kernel(const T* __restrict__ m, float* __restrict__ o, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = (float)m[i];
+}
+int launch_mask_to_float(const void* mask, int mask_dtype, float* out, int64_t count, hipStream_t s) {
+    if (count == 0) return PFN_OK;
+    const int blocks = (int)((count + 255) / 256);
+    if (mask_dtype == 0) mask_to_float_kernel<int64_t><<<blocks, 256, 0, s>>>(static_cast<const int64_t*>(mask), out, count);
+    else if (mask_dtype == 1) mask_to_float_kernel<float><<<blocks, 256, 0, s>>>(static_cast<const float*>(mask), out, count);
+    else {
+        set_error("mask_dtype must be 0 (int64) or 1 (float32)");
+        return PFN_EINVAL;
+    }
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+__global__ void pad_rows_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd,
+                                int64_t rows, int64_t f) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * ldd) return;
+    const int64_t r = i / ldd, c = i - r * ldd;
+    dst[i] = c < f ? src[r * lds_ + c] : 0.f;
+}
+int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t f,
+                    hipStream_t s) {
+    const int64_t total = rows * ld_dst;
+    if (total == 0) return PFN_OK;
+    pad_rows_kernel<<<(int)((total + 255) / 256), 256, 0, s>>>(src, ld_src, dst, ld_dst, rows, f);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+__global__ void rng_advance_kernel(uint64_t* rng) { rng[1] += 1; }
+int launch_rng_advance(uint64_t* rng, hipStream_t s) {
+    rng_advance_kernel<<<1, 1, 0, s>>>(rng);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+}  // namespace pfn

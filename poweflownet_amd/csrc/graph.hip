@@ -1,0 +1,274 @@
+// Graph preparation for the message-passing hot path (gfx950).
+//
+// Replaces, per forward call: MaskEmbdMultiMPN.is_directed / undirect_graph (networks/MPN.py:498-523),
+// the index_select lifting and degree scatter PyG performs under propagate()/gcn_norm, and the dead
+// degree computation of EdgeAggregation.forward (networks/MPN.py:43-47, not reproduced: it does not
+// reach the output).  One histogram pass, one scan, one fill, one per-row ordering pass; no host sync:
+// the "directed" decision of the reference's first-edge heuristic is taken on device and consumed by
+// the later kernels through flags[].
+#include <stdarg.h>
+#include <stdio.h>
+
+#include <algorithm>
+
+#include "pfn_internal.hpp"
+
+namespace pfn {
+
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+const char* last_error() { return g_err; }
+
+GraphView graph_view(void* ws, int64_t n, int64_t e) {
+    Carver c(ws);
+    GraphView g;
+    g.n = (int)n;
+    g.e_stored = (int)e;
+    g.flags = c.take<int>(64);
+    g.rowptr_in = c.take<int>(n + 1);
+    g.rowptr_out = c.take<int>(n + 1);
+    g.in_src = c.take<int>(2 * e + 1);
+    g.in_eid = c.take<int>(2 * e + 1);
+    g.out_dst = c.take<int>(2 * e + 1);
+    g.out_eid = c.take<int>(2 * e + 1);
+    g.cur_in = c.take<int>(n + 1);
+    g.cur_out = c.take<int>(n + 1);
+    g.deg = c.take<float>(n + 1);
+    g.dinv = c.take<float>(n + 1);
+    g.bytes = c.off;
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------- kernels
+// Pass 1: histogram of destinations / sources, range check, and the first-edge heuristic:
+// "directed" iff no stored edge (v0 -> u0) exists for the first stored edge (u0 -> v0).
+__global__ __launch_bounds__(256) void graph_hist_kernel(const int64_t* __restrict__ ei, int e, int n, int* cnt_dst,
+                                                         int* cnt_src, int* flags) {
+    const int64_t u0 = ei[0], v0 = ei[e];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) {
+        const int64_t s = ei[i], d = ei[(size_t)e + i];
+        if (s < 0 || s >= n || d < 0 || d >= n) {
+            atomicOr(&flags[2], 1);
+            continue;
+        }
+        atomicAdd(&cnt_dst[d], 1);
+        atomicAdd(&cnt_src[s], 1);
+        if (s == v0 && d == u0) atomicOr(&flags[3], 1);
+    }
+}
+
+// Pass 2 (single block): decide `directed`, form in/out degrees, exclusive-scan them into the two
+// rowptr arrays, emit deg / deg^-1/2, and clear the histograms so pass 3 can reuse them as cursors.
+__global__ __launch_bounds__(1024) void graph_scan_kernel(int n, int e, int mode, int* cnt_dst, int* cnt_src,
+                                                          int* rowptr_in, int* rowptr_out, float* deg, float* dinv,
+                                                          int* flags) {
+    __shared__ int wsum_in[16], wsum_out[16];
+    __shared__ int carry_in, carry_out;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int directed = (mode == 1) ? 1 : (mode == 0 ? 0 : (e > 0 && flags[3] == 0));
+    if (tid == 0) {
+        carry_in = 0;
+        carry_out = 0;
+        flags[0] = directed;
+        flags[1] = directed ? 2 * e : e;
+    }
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        int di = 0, dout = 0;
+        if (i < n) {
+            const int cd = cnt_dst[i], cs = cnt_src[i];
+            di = directed ? cd + cs : cd;
+            dout = directed ? cd + cs : cs;
+            cnt_dst[i] = 0;
+            cnt_src[i] = 0;
+            deg[i] = (float)di;
+            dinv[i] = di > 0 ? 1.0f / sqrtf((float)di) : 0.0f;
+        }
+        int si = di, so = dout;   // inclusive wave scan
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int ti = __shfl_up(si, off), to = __shfl_up(so, off);
+            if (lane >= off) {
+                si += ti;
+                so += to;
+            }
+        }
+        if (lane == 63) {
+            wsum_in[wave] = si;
+            wsum_out[wave] = so;
+        }
+        __syncthreads();
+        int pre_in = carry_in, pre_out = carry_out;
+        for (int w = 0; w < wave; ++w) {
+            pre_in += wsum_in[w];
+            pre_out += wsum_out[w];
+        }
+        if (i < n) {
+            rowptr_in[i] = pre_in + si - di;
+            rowptr_out[i] = pre_out + so - dout;
+        }
+        __syncthreads();
+        if (tid == 1023) {
+            carry_in = pre_in + si;
+            carry_out = pre_out + so;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        rowptr_in[n] = carry_in;
+        rowptr_out[n] = carry_out;
+    }
+}
+
+// Pass 3: place every effective edge into both adjacencies (slot order inside a row is arbitrary here).
+__global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restrict__ ei, int e, int n,
+                                                         const int* __restrict__ rowptr_in,
+                                                         const int* __restrict__ rowptr_out, int* cur_in, int* cur_out,
+                                                         int* in_src, int* in_eid, int* out_dst, int* out_eid,
+                                                         const int* flags) {
+    const int directed = flags[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) {
+        const int64_t s64 = ei[i], d64 = ei[(size_t)e + i];
+        if (s64 < 0 || s64 >= n || d64 < 0 || d64 >= n) continue;
+        const int s = (int)s64, d = (int)d64;
+        int p = rowptr_in[d] + atomicAdd(&cur_in[d], 1);
+        in_src[p] = s;
+        in_eid[p] = i;
+        p = rowptr_out[s] + atomicAdd(&cur_out[s], 1);
+        out_dst[p] = d;
+        out_eid[p] = i;
+        if (directed) {   // reversed copy (d -> s), edge id e + i: "originals first, reverses second"
+            p = rowptr_in[s] + atomicAdd(&cur_in[s], 1);
+            in_src[p] = d;
+            in_eid[p] = e + i;
+            p = rowptr_out[d] + atomicAdd(&cur_out[d], 1);
+            out_dst[p] = s;
+            out_eid[p] = e + i;
+        }
+    }
+}
+
+// Pass 4: order each row by edge id -> segment sums run in the stored edge order (the order the
+// reference's sequential scatter_add visits them) and results are run-to-run deterministic.
+__global__ __launch_bounds__(256) void graph_sort_rows_kernel(int n, const int* __restrict__ rowptr_in,
+                                                              const int* __restrict__ rowptr_out, int* in_src,
+                                                              int* in_eid, int* out_dst, int* out_eid) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const bool out_side = t >= n;
+    const int row = out_side ? t - n : t;
+    const int* rp = out_side ? rowptr_out : rowptr_in;
+    int* nbr = out_side ? out_dst : in_src;
+    int* eid = out_side ? out_eid : in_eid;
+    const int beg = rp[row], end = rp[row + 1];
+    for (int i = beg + 1; i < end; ++i) {
+        const int ke = eid[i], kn = nbr[i];
+        int j = i - 1;
+        while (j >= beg && eid[j] > ke) {
+            eid[j + 1] = eid[j];
+            nbr[j + 1] = nbr[j];
+            --j;
+        }
+        eid[j + 1] = ke;
+        nbr[j + 1] = kn;
+    }
+}
+
+__global__ void graph_export_kernel(int n, const int* __restrict__ rowptr_in, const int* __restrict__ in_src,
+                                    const int* __restrict__ in_eid, const int* flags, int cap, int64_t* out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    for (int p = rowptr_in[row]; p < rowptr_in[row + 1]; ++p) {
+        out[in_eid[p]] = in_src[p];
+        out[(size_t)cap + in_eid[p]] = row;
+    }
+}
+
+}  // namespace pfn
+
+using namespace pfn;
+
+extern "C" {
+
+int pfn_abi_version(void) { return PFN_ABI_VERSION; }
+const char* pfn_last_error(void) { return pfn::last_error(); }
+int64_t pfn_padded_ld(int64_t f) { return round_up(f, 4); }
+
+size_t pfn_graph_workspace_bytes(int64_t n, int64_t e) {
+    if (n < 0 || e < 0) return 0;
+    return graph_view(nullptr, n, e).bytes;
+}
+
+int pfn_graph_build(const int64_t* edge_index, int64_t e, int64_t n, int mode, void* ws, size_t ws_bytes,
+                    void* stream) {
+    PFN_CHECK_ARG(n >= 0 && e >= 0, "pfn_graph_build: negative sizes");
+    PFN_CHECK_ARG(n < (1ll << 30) && e < (1ll << 29), "pfn_graph_build: graph too large for int32 adjacency");
+    PFN_CHECK_ARG(ws != nullptr, "pfn_graph_build: null workspace");
+    PFN_CHECK_ARG(mode >= -1 && mode <= 1, "pfn_graph_build: mode must be -1, 0 or 1");
+    PFN_CHECK_ARG(e == 0 || edge_index != nullptr, "pfn_graph_build: null edge_index");
+    GraphView g = graph_view(ws, n, e);
+    if (ws_bytes < g.bytes) {
+        set_error("pfn_graph_build: workspace %zu < %zu bytes", ws_bytes, g.bytes);
+        return PFN_ENOSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PFN_CHECK_HIP(hipMemsetAsync(g.flags, 0, 64 * sizeof(int), s));
+    PFN_CHECK_HIP(hipMemsetAsync(g.cur_in, 0, (size_t)(n + 1) * sizeof(int), s));
+    PFN_CHECK_HIP(hipMemsetAsync(g.cur_out, 0, (size_t)(n + 1) * sizeof(int), s));
+    const int ie = (int)e, in = (int)n;
+    if (ie > 0) {
+        const int blocks = (int)std::min<int64_t>((e + 255) / 256, 2048);
+        graph_hist_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.cur_in, g.cur_out, g.flags);
+        PFN_CHECK_LAUNCH();
+    }
+    graph_scan_kernel<<<1, 1024, 0, s>>>(in, ie, mode, g.cur_in, g.cur_out, g.rowptr_in, g.rowptr_out, g.deg, g.dinv,
+                                         g.flags);
+    PFN_CHECK_LAUNCH();
+    if (ie > 0) {
+        const int blocks = (int)std::min<int64_t>((e + 255) / 256, 2048);
+        graph_fill_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.rowptr_in, g.rowptr_out, g.cur_in, g.cur_out,
+                                                 g.in_src, g.in_eid, g.out_dst, g.out_eid, g.flags);
+        PFN_CHECK_LAUNCH();
+        graph_sort_rows_kernel<<<(2 * in + 255) / 256, 256, 0, s>>>(in, g.rowptr_in, g.rowptr_out, g.in_src, g.in_eid,
+                                                                   g.out_dst, g.out_eid);
+        PFN_CHECK_LAUNCH();
+    }
+    return PFN_OK;
+}
+
+int pfn_graph_info(const void* ws, int64_t n, int64_t e, int32_t* directed, int64_t* e_eff, void* stream) {
+    PFN_CHECK_ARG(ws != nullptr, "pfn_graph_info: null workspace");
+    GraphView g = graph_view(const_cast<void*>(ws), n, e);
+    int h[4] = {0, 0, 0, 0};
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PFN_CHECK_HIP(hipMemcpyAsync(h, g.flags, sizeof(h), hipMemcpyDeviceToHost, s));
+    PFN_CHECK_HIP(hipStreamSynchronize(s));
+    if (directed) *directed = h[0];
+    if (e_eff) *e_eff = h[1];
+    if (h[2]) {
+        set_error("edge_index holds a node id outside [0, %lld)", (long long)n);
+        return PFN_EINDEX;
+    }
+    return PFN_OK;
+}
+
+int pfn_graph_export_edges(const void* ws, int64_t n, int64_t e, int64_t* out, void* stream) {
+    PFN_CHECK_ARG(ws != nullptr && out != nullptr, "pfn_graph_export_edges: null pointer");
+    GraphView g = graph_view(const_cast<void*>(ws), n, e);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PFN_CHECK_HIP(hipMemsetAsync(out, 0xff, (size_t)4 * e * sizeof(int64_t), s));
+    if (n > 0) {
+        graph_export_kernel<<<((int)n + 255) / 256, 256, 0, s>>>((int)n, g.rowptr_in, g.in_src, g.in_eid, g.flags,
+                                                                 (int)(2 * e), out);
+        PFN_CHECK_LAUNCH();
+    }
+    return PFN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,659 @@
+// Layer and whole-model drivers + the C ABI of libpfn_hip.so (gfx950).
+//
+// Mirrors, call for call, the dataflow of the reference's MaskEmbdMultiMPN.forward
+// (networks/MPN.py:525-559), EdgeAggregation.forward/message (:23-56) and PyG TAGConv.forward
+// (call sites :477-484,:545), plus their autograd, as sequences of the HIP kernels in graph.hip /
+// edge.hip / gemm.hip.  Nothing here synchronises or allocates: every buffer is carved out of the
+// caller's workspace, so a whole training step can be captured into one hipGraph.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "pfn_internal.hpp"
+
+namespace pfn {
+
+static GemmArgs gemm_defaults(int M, int ncols, int ldc) {
+    GemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = M;
+    a.ncols = ncols;
+    a.ldc = ldc;
+    a.ngroup = 1;
+    a.gate_scale = 1.f;
+    a.bias_group = -1;
+    return a;
+}
+static GemmTerm term(const float* A, int lda, int K, const float* W, int ldw, int wk0, int wn0, int trans, int group) {
+    GemmTerm t;
+    t.A = A; t.W = W; t.lda = lda; t.K = K; t.ldw = ldw; t.wk0 = wk0; t.wn0 = wn0; t.trans = trans; t.group = group;
+    t.pad_ = 0;
+    return t;
+}
+
+struct Act {
+    int act = ACT_NONE;
+    float p = 0.f;
+    const uint64_t* rng = nullptr;
+    uint32_t stream = 0;
+};
+struct Gate {
+    const float* y = nullptr;   // post-activation output of the producing layer
+    int ld = 0;
+    float scale = 1.f;
+};
+
+// ---------------------------------------------------------------------------------- EdgeAggregation
+struct EaSaved { float *P, *Q, *S; };
+struct EaScratch { float *dS, *dP, *dQ, *dWe; ReduceWs red; };
+
+static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
+                      const float* w1, const float* b1, const float* w2, const float* b2, float* out, int ldo,
+                      const Act& act, const EaSaved& sv, hipStream_t s) {
+    const int ld = ld_of(h), ldw1 = 2 * fi + fe;
+    {   // P = x W1[:, :Fi]^T + b1 ; Q = x W1[:, Fi:2Fi]^T
+        GemmArgs a = gemm_defaults(g.n, h, ld);
+        a.ngroup = 2;
+        a.C[0] = sv.P;
+        a.C[1] = sv.Q;
+        a.nterm = 2;
+        a.term[0] = term(x, ldx, fi, w1, ldw1, 0, 0, 1, 0);
+        a.term[1] = term(x, ldx, fi, w1, ldw1, fi, 0, 1, 1);
+        a.bias = b1;
+        a.bias_group = 0;
+        PFN_TRY(launch_gemm_nt(a, s));
+    }
+    {
+        EdgeFwdArgs e{sv.P, sv.Q, ea, w1, sv.S, ld, h, fi, fe};
+        PFN_TRY(launch_edge_fwd(g, e, s));
+    }
+    {   // out = S W2^T + deg * b2   (the second Linear commutes with the segment sum)
+        GemmArgs a = gemm_defaults(g.n, fo, ldo);
+        a.C[0] = out;
+        a.nterm = 1;
+        a.term[0] = term(sv.S, ld, h, w2, h, 0, 0, 1, 0);
+        a.rowscale = g.deg;
+        a.rowbias = b2;
+        a.act = act.act;
+        a.p_drop = act.p;
+        a.rng = act.rng;
+        a.rng_stream = act.stream;
+        PFN_TRY(launch_gemm_nt(a, s));
+    }
+    return PFN_OK;
+}
+
+static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
+                       const float* w1, const float* w2, const float* gout, int ldgo, const Gate& gate, float* gx,
+                       int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
+                       const EaScratch& sc, hipStream_t s) {
+    const int ld = ld_of(h), ldw1 = 2 * fi + fe;
+    {   // dS = gout W2
+        GemmArgs a = gemm_defaults(g.n, h, ld);
+        a.C[0] = sc.dS;
+        a.nterm = 1;
+        a.term[0] = term(gout, ldgo, fo, w2, h, 0, 0, 0, 0);
+        PFN_TRY(launch_gemm_nt(a, s));
+    }
+    EdgeBwdArgs e{sv.P, sv.Q, sc.dS, ea, w1, sc.dP, sc.dQ, sc.dWe, gea, ld, h, fi, fe};
+    PFN_TRY(launch_edge_bwd(g, e, nullptr, s));
+    if (g.n > 0) PFN_TRY(launch_dwe_reduce(sc.dWe, edge_bwd_dst_blocks(g, ld), fe, ld, h, gw1, ldw1, 2 * fi, s));
+    else PFN_TRY(launch_dwe_reduce(sc.dWe, 0, fe, ld, h, gw1, ldw1, 2 * fi, s));
+    if (gea) PFN_TRY(launch_edge_attr_grad(g, e, s));
+    if (gx) {   // dx = dP W1[:, :Fi] + dQ W1[:, Fi:2Fi], gated by the producing layer's activation
+        GemmArgs a = gemm_defaults(g.n, fi, ldgx);
+        a.C[0] = gx;
+        a.nterm = 2;
+        a.term[0] = term(sc.dP, ld, h, w1, ldw1, 0, 0, 0, 0);
+        a.term[1] = term(sc.dQ, ld, h, w1, ldw1, 0, fi, 0, 0);
+        a.gate = gate.y;
+        a.ldg = gate.ld;
+        a.gate_scale = gate.scale;
+        PFN_TRY(launch_gemm_nt(a, s));
+    }
+    TnPair pairs[3] = {
+        {gout, sv.S, gw2, ldgo, ld, fo, h, h, 0, 0, 0},
+        {sc.dP, x, gw1, ld, ldx, h, fi, ldw1, 0, 0, 0},
+        {sc.dQ, x, gw1, ld, ldx, h, fi, ldw1, 0, fi, 0},
+    };
+    ColsumJob jobs[2] = {{gout, g.deg, gb2, ldgo, fo}, {sc.dP, nullptr, gb1, ld, h}};
+    PFN_TRY(launch_weight_grads(pairs, 3, jobs, 2, g.n, sc.red, s));
+    return PFN_OK;
+}
+
+// ------------------------------------------------------------------------------------------ TAGConv
+static int tag_forward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx,
+                       const float* const* w, const float* bias, float* out, int ldo, const Act& act, float* xk,
+                       hipStream_t s) {
+    // xk: K buffers of n * ldx floats holding A_hat^k x, k = 1..K
+    const size_t stride = (size_t)g.n * ldx;
+    const float* prev = x;
+    for (int k = 1; k <= K; ++k) {
+        HopArgs hp{prev, nullptr, xk + (size_t)(k - 1) * stride, nullptr, 1.f, ldx, 1, 0};
+        PFN_TRY(launch_hop(g, hp, s));
+        prev = hp.y;
+    }
+    GemmArgs a = gemm_defaults(g.n, cout, ldo);
+    a.C[0] = out;
+    if (K + 1 > 8) {
+        set_error("TAGConv: K = %d unsupported (max 7)", K);
+        return PFN_EINVAL;
+    }
+    a.nterm = K + 1;
+    for (int k = 0; k <= K; ++k)
+        a.term[k] = term(k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, w[k], cin, 0, 0, 1, 0);
+    a.bias = bias;
+    a.act = act.act;
+    a.p_drop = act.p;
+    a.rng = act.rng;
+    a.rng_stream = act.stream;
+    return launch_gemm_nt(a, s);
+}
+
+struct TagScratch { float* G; float *z0, *z1; ReduceWs red; };
+
+static int tag_backward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx,
+                        const float* const* w, const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx,
+                        float* const* gw, float* gbias, const float* xk, const TagScratch& sc, hipStream_t s) {
+    const size_t stride = (size_t)g.n * ldx;
+    if (gx) {
+        if (ldgx != ldx) {
+            set_error("TAGConv backward: grad_x stride %d != x stride %d", ldgx, ldx);
+            return PFN_EINVAL;
+        }
+        // G_k = gout W_k ; dx = G_0 + A^T (G_1 + A^T (G_2 + ...))   (Horner over the transposed adjacency)
+        GemmArgs a = gemm_defaults(g.n, cin, ldx);
+        a.ngroup = K + 1;
+        a.nterm = K + 1;
+        for (int k = 0; k <= K; ++k) {
+            a.C[k] = (K == 0) ? gx : sc.G + (size_t)k * stride;
+            a.term[k] = term(gout, ldgo, cout, w[k], cin, 0, 0, 0, k);
+        }
+        if (K == 0) {
+            a.gate = gate.y;
+            a.ldg = gate.ld;
+            a.gate_scale = gate.scale;
+        }
+        PFN_TRY(launch_gemm_nt(a, s));
+        const float* z = sc.G + (size_t)K * stride;
+        for (int k = K - 1; k >= 0; --k) {
+            float* dst = (k == 0) ? gx : ((k & 1) ? sc.z1 : sc.z0);
+            HopArgs hp{z, sc.G + (size_t)k * stride, dst, k == 0 ? gate.y : nullptr, k == 0 ? gate.scale : 1.f, ldx, 1, 1};
+            PFN_TRY(launch_hop(g, hp, s));
+            z = dst;
+        }
+    }
+    std::vector<TnPair> pairs;
+    for (int k = 0; k <= K; ++k)
+        pairs.push_back({gout, k == 0 ? x : xk + (size_t)(k - 1) * stride, gw[k], ldgo, ldx, cout, cin, cin, 0, 0, 0});
+    ColsumJob job{gout, nullptr, gbias, ldgo, cout};
+    return launch_weight_grads(pairs.data(), (int)pairs.size(), &job, gbias ? 1 : 0, g.n, sc.red, s);
+}
+
+// -------------------------------------------------------------------------------------- whole model
+struct Layout {
+    // dims
+    int n, e, f0, fe, fo, h, L, K, ld, ld0, ldo, nlayers;
+    // forward-saved
+    float *maskf, *me_h, *x0;
+    std::vector<float*> y;       // per layer output (post-activation); last = nullptr (caller's out)
+    std::vector<EaSaved> ea;     // per EA layer
+    std::vector<float*> xk;      // per TAG layer: K * n * ld
+    // backward scratch
+    float *gA, *gB, *dh;
+    EaScratch eas;
+    TagScratch tags;
+    size_t bytes;
+};
+static bool is_ea(int i) { return (i & 1) == 0; }
+
+static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, Layout& lo) {
+    PFN_CHECK_ARG(c.n_gnn_layers >= 2, "n_gnn_layers must be >= 2 (L == 1 is shape-broken in the reference)");
+    PFN_CHECK_ARG(c.K >= 0 && c.K <= 7, "K must be in [0, 7]");
+    PFN_CHECK_ARG(c.nfeature_dim > 0 && c.efeature_dim > 0 && c.efeature_dim <= 6 && c.output_dim > 0 && c.hidden_dim > 0,
+                  "bad feature dimensions");
+    PFN_CHECK_ARG(c.dropout_rate >= 0.f && c.dropout_rate < 1.f, "dropout_rate must be in [0, 1)");
+    lo.n = (int)n; lo.e = (int)e;
+    lo.f0 = c.nfeature_dim; lo.fe = c.efeature_dim; lo.fo = c.output_dim; lo.h = c.hidden_dim;
+    lo.L = c.n_gnn_layers; lo.K = c.K;
+    lo.ld = ld_of(lo.h); lo.ld0 = ld_of(lo.f0); lo.ldo = ld_of(lo.fo);
+    lo.nlayers = 2 * lo.L - 1;   // E T E T ... E
+    Carver cv(ws);
+    const size_t nld = (size_t)n * lo.ld;
+    lo.maskf = cv.take<float>((size_t)n * lo.ld0);
+    lo.me_h = cv.take<float>(nld);
+    lo.x0 = cv.take<float>((size_t)n * lo.ld0);
+    lo.y.assign(lo.nlayers, nullptr);
+    lo.ea.assign(lo.nlayers, EaSaved{nullptr, nullptr, nullptr});
+    lo.xk.assign(lo.nlayers, nullptr);
+    for (int i = 0; i < lo.nlayers; ++i) {
+        if (i + 1 < lo.nlayers) lo.y[i] = cv.take<float>(nld);
+        if (is_ea(i)) {
+            lo.ea[i].P = cv.take<float>(nld);
+            lo.ea[i].Q = cv.take<float>(nld);
+            lo.ea[i].S = cv.take<float>(nld);
+        } else {
+            lo.xk[i] = cv.take<float>(nld * std::max(1, lo.K));
+        }
+    }
+    lo.gA = cv.take<float>(nld);
+    lo.gB = cv.take<float>(nld);
+    lo.dh = cv.take<float>(nld);
+    lo.eas.dS = cv.take<float>(nld);
+    lo.eas.dP = cv.take<float>(nld);
+    lo.eas.dQ = cv.take<float>(nld);
+    const size_t dwe_blocks = (size_t)((n * (lo.ld / 4) + 255) / 256) + 1;
+    lo.eas.dWe = cv.take<float>(dwe_blocks * lo.fe * lo.ld);
+    lo.tags.G = cv.take<float>(nld * (lo.K + 1));
+    lo.tags.z0 = cv.take<float>(nld);
+    lo.tags.z1 = cv.take<float>(nld);
+    const int maxf = std::max(std::max(lo.h, lo.f0), lo.fo);
+    const size_t red = reduce_ws_floats(n, maxf, maxf, 8);
+    lo.eas.red.partial = cv.take<float>(red);
+    lo.eas.red.floats = red;
+    lo.tags.red = lo.eas.red;
+    lo.bytes = cv.off;
+    return PFN_OK;
+}
+
+// parameter table cursor (order documented in pfn_hip.h)
+struct ParamCursor {
+    const float* const* p;
+    float* const* g;
+    int i = 0;
+    const float* next() { return p[i++]; }
+};
+
+static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
+                         const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr, float* out,
+                         uint64_t* rng, hipStream_t s) {
+    const bool drop = c.training && c.dropout_rate > 0.f;
+    PFN_CHECK_ARG(!drop || rng != nullptr, "training with dropout needs rng_state");
+    const int nparams = pfn_mpn_num_params(&c);
+    const float* const* me = params + (nparams - 4);   // Wa, ba, Wb, bb
+    // mask_embd(mask) + x   (networks/MPN.py:533,:537)
+    PFN_TRY(launch_mask_to_float(pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0, s));
+    {
+        GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
+        a.C[0] = lo.me_h;
+        a.nterm = 1;
+        a.term[0] = term(lo.maskf, lo.ld0, lo.f0, me[0], lo.f0, 0, 0, 1, 0);
+        a.bias = me[1];
+        a.act = ACT_RELU;
+        PFN_TRY(launch_gemm_nt(a, s));
+    }
+    {
+        GemmArgs a = gemm_defaults(lo.n, lo.f0, lo.ld0);
+        a.C[0] = lo.x0;
+        a.nterm = 1;
+        a.term[0] = term(lo.me_h, lo.ld, lo.h, me[2], lo.h, 0, 0, 1, 0);
+        a.bias = me[3];
+        a.resid = x;
+        a.ldr = lo.ld0;
+        PFN_TRY(launch_gemm_nt(a, s));
+    }
+    const float* cur = lo.x0;
+    int ldc = lo.ld0, fcur = lo.f0, pi = 0;
+    for (int i = 0; i < lo.nlayers; ++i) {
+        const bool last = i + 1 == lo.nlayers;
+        Act act;
+        if (!last) {
+            act.act = drop ? ACT_DROPOUT_RELU : ACT_RELU;   // dropout then ReLU (:546-547)
+            act.p = c.dropout_rate;
+            act.rng = rng;
+            act.stream = (uint32_t)i;
+        }
+        float* y = last ? out : lo.y[i];
+        const int ldy = last ? lo.ldo : lo.ld;
+        if (is_ea(i)) {
+            const int fo = last ? lo.fo : lo.h;
+            PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
+                               params[pi + 3], y, ldy, act, lo.ea[i], s));
+            pi += 4;
+            fcur = fo;
+        } else {
+            PFN_TRY(tag_forward(g, lo.h, lo.h, lo.K, cur, ldc, params + pi, params[pi + lo.K + 1], y, ldy, act, lo.xk[i], s));
+            pi += lo.K + 2;
+        }
+        cur = y;
+        ldc = ldy;
+    }
+    if (drop) PFN_TRY(launch_rng_advance(rng, s));
+    return PFN_OK;
+}
+
+static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
+                          float* const* grads, const float* x, const float* edge_attr, const float* gout, float* gx,
+                          float* gea, hipStream_t s) {
+    const bool drop = c.training && c.dropout_rate > 0.f;
+    const float gscale = drop ? 1.f / (1.f - c.dropout_rate) : 1.f;
+    const int nparams = pfn_mpn_num_params(&c);
+    // parameter offsets per layer
+    std::vector<int> poff(lo.nlayers);
+    int pi = 0;
+    for (int i = 0; i < lo.nlayers; ++i) {
+        poff[i] = pi;
+        pi += is_ea(i) ? 4 : lo.K + 2;
+    }
+    if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)lo.e * lo.fe * sizeof(float), s));
+    const float* gcur = gout;
+    int ldg = lo.ldo;
+    for (int i = lo.nlayers - 1; i >= 0; --i) {
+        const bool last = i + 1 == lo.nlayers;
+        const float* inp = i == 0 ? lo.x0 : lo.y[i - 1];
+        const int ldi = i == 0 ? lo.ld0 : lo.ld;
+        Gate gate;
+        if (i > 0) {
+            gate.y = inp;
+            gate.ld = ldi;
+            gate.scale = gscale;
+        }
+        float* gnext = (gcur == lo.gA) ? lo.gB : lo.gA;
+        const int p0 = poff[i];
+        if (is_ea(i)) {
+            const int fi = i == 0 ? lo.f0 : lo.h, fo = last ? lo.fo : lo.h;
+            PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], params[p0 + 2], gcur, ldg, gate,
+                                gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2], grads[p0 + 3], gea, lo.ea[i],
+                                lo.eas, s));
+        } else {
+            PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, params + p0, gcur, ldg, gate, gnext, ldi, grads + p0,
+                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s));
+        }
+        gcur = gnext;
+        ldg = ldi;
+    }
+    // mask_embd backward: x0 = me_h Wb^T + bb + x ; me_h = relu(maskf Wa^T + ba)
+    const float* const* me = params + (nparams - 4);
+    float* const* gme = grads + (nparams - 4);
+    {
+        GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
+        a.C[0] = lo.dh;
+        a.nterm = 1;
+        a.term[0] = term(gcur, lo.ld0, lo.f0, me[2], lo.h, 0, 0, 0, 0);
+        a.gate = lo.me_h;
+        a.ldg = lo.ld;
+        PFN_TRY(launch_gemm_nt(a, s));
+    }
+    TnPair pairs[2] = {
+        {gcur, lo.me_h, gme[2], lo.ld0, lo.ld, lo.f0, lo.h, lo.h, 0, 0, 0},
+        {lo.dh, lo.maskf, gme[0], lo.ld, lo.ld0, lo.h, lo.f0, lo.f0, 0, 0, 0},
+    };
+    ColsumJob jobs[2] = {{gcur, nullptr, gme[3], lo.ld0, lo.f0}, {lo.dh, nullptr, gme[1], lo.ld, lo.h}};
+    PFN_TRY(launch_weight_grads(pairs, 2, jobs, 2, lo.n, lo.eas.red, s));
+    if (gx) PFN_CHECK_HIP(hipMemcpyAsync(gx, gcur, (size_t)lo.n * lo.ld0 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return PFN_OK;
+}
+
+// ---------------------------------------------------------------------------------------- utilities
+__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ o, const float* __restrict__ y,
+                                                          int64_t n, float inv_n, float* __restrict__ grad,
+                                                          float* __restrict__ partial) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = o[i] - y[i];
+        acc = fmaf(d, d, acc);
+        if (grad) grad[i] = 2.f * d * inv_n;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict__ partial, int nb, float inv_n,
+                                                        float* __restrict__ loss) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] * inv_n;
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
+                                                    float b1, float b2, float eps, float wd,
+                                                    const int64_t* __restrict__ step) {
+    const float t = (float)(step[0] + 1);
+    const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
+    const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i];
+        float pi = p[i] * (1.f - lr * wd);               // decoupled weight decay
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        p[i] = pi - step_size * (mi / denom);
+    }
+}
+__global__ void step_inc_kernel(int64_t* step) { step[0] += 1; }
+
+}  // namespace pfn
+
+using namespace pfn;
+
+// =============================================================================================== C ABI
+extern "C" {
+
+int pfn_mpn_num_params(const pfn_mpn_config* c) {
+    if (!c || c->n_gnn_layers < 2) return -1;
+    return c->n_gnn_layers * 4 + (c->n_gnn_layers - 1) * (c->K + 2) + 4;
+}
+
+size_t pfn_mpn_workspace_bytes(const pfn_mpn_config* c, int64_t n, int64_t e) {
+    if (!c) return 0;
+    Layout lo;
+    if (make_layout(*c, n, e, nullptr, lo) != PFN_OK) return 0;
+    return lo.bytes;
+}
+
+static int check_common(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const void* ws) {
+    PFN_CHECK_ARG(c != nullptr, "null config");
+    PFN_CHECK_ARG(gws != nullptr, "null graph workspace");
+    PFN_CHECK_ARG(ws != nullptr, "null model workspace");
+    PFN_CHECK_ARG(n >= 0 && e >= 0 && n < (1ll << 30) && e < (1ll << 29), "bad graph size");
+    return PFN_OK;
+}
+
+int pfn_mpn_forward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
+                    const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr, float* out, void* ws,
+                    size_t ws_bytes, uint64_t* rng, void* stream) {
+    PFN_TRY(check_common(c, gws, n, e, ws));
+    PFN_CHECK_ARG(params && (n == 0 || (x && pred_mask && out)) && (e == 0 || edge_attr), "pfn_mpn_forward: null tensor");
+    Layout lo;
+    PFN_TRY(make_layout(*c, n, e, ws, lo));
+    if (ws_bytes < lo.bytes) {
+        set_error("pfn_mpn_forward: workspace %zu < %zu bytes", ws_bytes, lo.bytes);
+        return PFN_ENOSPACE;
+    }
+    GraphView g = graph_view(const_cast<void*>(gws), n, e);
+    PFN_CHECK_ARG(c->nfeature_dim % 4 == 0, "nfeature_dim must be a multiple of 4 (the reference asserts 4, networks/MPN.py:528)");
+    return model_forward(*c, g, lo, params, x, pred_mask, mask_dtype, edge_attr, out, rng, static_cast<hipStream_t>(stream));
+}
+
+int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
+                     float* const* grads, const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr,
+                     const float* gout, float* gx, float* gea, void* ws, size_t ws_bytes, void* stream) {
+    (void)pred_mask; (void)mask_dtype;
+    PFN_TRY(check_common(c, gws, n, e, ws));
+    PFN_CHECK_ARG(params && grads && (n == 0 || (x && gout)), "pfn_mpn_backward: null tensor");
+    Layout lo;
+    PFN_TRY(make_layout(*c, n, e, ws, lo));
+    if (ws_bytes < lo.bytes) {
+        set_error("pfn_mpn_backward: workspace %zu < %zu bytes", ws_bytes, lo.bytes);
+        return PFN_ENOSPACE;
+    }
+    GraphView g = graph_view(const_cast<void*>(gws), n, e);
+    return model_backward(*c, g, lo, params, grads, x, edge_attr, gout, gx, gea, static_cast<hipStream_t>(stream));
+}
+
+// ------------------------------------------------------------------------------------- single layers
+struct EaLayerWs { EaSaved sv; EaScratch sc; size_t bytes; };
+static EaLayerWs ea_layer_ws(void* ws, int64_t n, int fi, int fe, int h, int fo) {
+    Carver cv(ws);
+    EaLayerWs w;
+    const int ld = ld_of(h);
+    const size_t nld = (size_t)n * ld;
+    w.sv.P = cv.take<float>(nld);
+    w.sv.Q = cv.take<float>(nld);
+    w.sv.S = cv.take<float>(nld);
+    w.sc.dS = cv.take<float>(nld);
+    w.sc.dP = cv.take<float>(nld);
+    w.sc.dQ = cv.take<float>(nld);
+    w.sc.dWe = cv.take<float>(((size_t)((n * (ld / 4) + 255) / 256) + 1) * fe * ld);
+    const int maxf = std::max(std::max(h, fi), fo);
+    w.sc.red.floats = reduce_ws_floats(n, maxf, maxf, 3);
+    w.sc.red.partial = cv.take<float>(w.sc.red.floats);
+    w.bytes = cv.off;
+    return w;
+}
+
+size_t pfn_edge_aggr_workspace_bytes(int64_t n, int64_t e, int fi, int fe, int h, int fo) {
+    (void)e;
+    return ea_layer_ws(nullptr, n, fi, fe, h, fo).bytes;
+}
+
+int pfn_edge_aggr_forward(const void* gws, int64_t n, int64_t e, int fi, int fe, int h, int fo, const float* x,
+                          int64_t ldx, const float* ea, const float* w1, const float* b1, const float* w2,
+                          const float* b2, float* out, int64_t ldo, void* ws, size_t ws_bytes, void* stream) {
+    PFN_CHECK_ARG(gws && ws && w1 && b1 && w2 && b2, "pfn_edge_aggr_forward: null pointer");
+    PFN_CHECK_ARG(ldx == ld_of(fi) && ldo == ld_of(fo), "pfn_edge_aggr_forward: row strides must be pfn_padded_ld(F)");
+    PFN_CHECK_ARG(fe >= 1 && fe <= 6, "efeature_dim must be in [1, 6]");
+    EaLayerWs w = ea_layer_ws(ws, n, fi, fe, h, fo);
+    if (ws_bytes < w.bytes) {
+        set_error("pfn_edge_aggr_forward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+        return PFN_ENOSPACE;
+    }
+    GraphView g = graph_view(const_cast<void*>(gws), n, e);
+    return ea_forward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, b1, w2, b2, out, (int)ldo, Act{}, w.sv,
+                      static_cast<hipStream_t>(stream));
+}
+
+int pfn_edge_aggr_backward(const void* gws, int64_t n, int64_t e, int fi, int fe, int h, int fo, const float* x,
+                           int64_t ldx, const float* ea, const float* w1, const float* b1, const float* w2,
+                           const float* b2, const float* gout, int64_t ldgo, float* gx, int64_t ldgx, float* gea,
+                           float* gw1, float* gb1, float* gw2, float* gb2, void* ws, size_t ws_bytes, void* stream) {
+    (void)b1; (void)b2;
+    PFN_CHECK_ARG(gws && ws && w1 && w2 && gout && gw1 && gb1 && gw2 && gb2, "pfn_edge_aggr_backward: null pointer");
+    PFN_CHECK_ARG(ldx == ld_of(fi) && ldgo == ld_of(fo) && (!gx || ldgx == ld_of(fi)),
+                  "pfn_edge_aggr_backward: row strides must be pfn_padded_ld(F)");
+    PFN_CHECK_ARG(fe >= 1 && fe <= 6, "efeature_dim must be in [1, 6]");
+    EaLayerWs w = ea_layer_ws(ws, n, fi, fe, h, fo);
+    if (ws_bytes < w.bytes) {
+        set_error("pfn_edge_aggr_backward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+        return PFN_ENOSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    GraphView g = graph_view(const_cast<void*>(gws), n, e);
+    if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)e * fe * sizeof(float), s));
+    return ea_backward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, w2, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gw1, gb1, gw2,
+                       gb2, gea, w.sv, w.sc, s);
+}
+
+struct TagLayerWs { float* xk; TagScratch sc; size_t bytes; };
+static TagLayerWs tag_layer_ws(void* ws, int64_t n, int cin, int cout, int K) {
+    Carver cv(ws);
+    TagLayerWs w;
+    const size_t nld = (size_t)n * ld_of(cin);
+    w.xk = cv.take<float>(nld * std::max(1, K));
+    w.sc.G = cv.take<float>(nld * (K + 1));
+    w.sc.z0 = cv.take<float>(nld);
+    w.sc.z1 = cv.take<float>(nld);
+    const int maxf = std::max(cin, cout);
+    w.sc.red.floats = reduce_ws_floats(n, maxf, maxf, K + 1);
+    w.sc.red.partial = cv.take<float>(w.sc.red.floats);
+    w.bytes = cv.off;
+    return w;
+}
+
+size_t pfn_tag_conv_workspace_bytes(int64_t n, int64_t e, int cin, int cout, int K) {
+    (void)e;
+    return tag_layer_ws(nullptr, n, cin, cout, K).bytes;
+}
+
+int pfn_tag_conv_forward(const void* gws, int64_t n, int64_t e, int cin, int cout, int K, const float* x, int64_t ldx,
+                         const float* const* weights, const float* bias, float* out, int64_t ldo, void* ws,
+                         size_t ws_bytes, void* stream) {
+    PFN_CHECK_ARG(gws && ws && weights, "pfn_tag_conv_forward: null pointer");
+    PFN_CHECK_ARG(ldx == ld_of(cin) && ldo == ld_of(cout), "pfn_tag_conv_forward: row strides must be pfn_padded_ld(F)");
+    PFN_CHECK_ARG(K >= 0 && K <= 7, "K must be in [0, 7]");
+    TagLayerWs w = tag_layer_ws(ws, n, cin, cout, K);
+    if (ws_bytes < w.bytes) {
+        set_error("pfn_tag_conv_forward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+        return PFN_ENOSPACE;
+    }
+    GraphView g = graph_view(const_cast<void*>(gws), n, e);
+    return tag_forward(g, cin, cout, K, x, (int)ldx, weights, bias, out, (int)ldo, Act{}, w.xk,
+                       static_cast<hipStream_t>(stream));
+}
+
+int pfn_tag_conv_backward(const void* gws, int64_t n, int64_t e, int cin, int cout, int K, const float* x, int64_t ldx,
+                          const float* const* weights, const float* gout, int64_t ldgo, float* gx, int64_t ldgx,
+                          float* const* gweights, float* gbias, void* ws, size_t ws_bytes, void* stream) {
+    PFN_CHECK_ARG(gws && ws && weights && gout && gweights, "pfn_tag_conv_backward: null pointer");
+    PFN_CHECK_ARG(ldx == ld_of(cin) && ldgo == ld_of(cout), "pfn_tag_conv_backward: row strides must be pfn_padded_ld(F)");
+    PFN_CHECK_ARG(K >= 0 && K <= 7, "K must be in [0, 7]");
+    TagLayerWs w = tag_layer_ws(ws, n, cin, cout, K);
+    if (ws_bytes < w.bytes) {
+        set_error("pfn_tag_conv_backward: workspace %zu < %zu bytes", ws_bytes, w.bytes);
+        return PFN_ENOSPACE;
+    }
+    GraphView g = graph_view(const_cast<void*>(gws), n, e);
+    return tag_backward(g, cin, cout, K, x, (int)ldx, weights, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gweights, gbias,
+                        w.xk, w.sc, static_cast<hipStream_t>(stream));
+}
+
+// ----------------------------------------------------------------------------------------- utilities
+int pfn_scatter_add(const void* gws, int64_t n, int64_t e, const float* x, float* out, int64_t f, void* stream) {
+    PFN_CHECK_ARG(gws && (n == 0 || (x && out)), "pfn_scatter_add: null pointer");
+    GraphView g = graph_view(const_cast<void*>(gws), n, e);
+    HopArgs hp{x, nullptr, out, nullptr, 1.f, ld_of((int)f), 0, 0};
+    return launch_hop(g, hp, static_cast<hipStream_t>(stream));
+}
+
+int pfn_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t f, void* stream) {
+    PFN_CHECK_ARG(rows == 0 || (src && dst), "pfn_pad_rows: null pointer");
+    PFN_CHECK_ARG(f <= ld_src && ld_dst >= 0, "pfn_pad_rows: bad strides");
+    return launch_pad_rows(src, ld_src, dst, ld_dst, rows, std::min(f, ld_dst), static_cast<hipStream_t>(stream));
+}
+
+int pfn_mse_loss(const float* out, const float* y, int64_t count, float* loss, float* grad, void* ws, size_t ws_bytes,
+                 void* stream) {
+    PFN_CHECK_ARG(out && y && loss && ws, "pfn_mse_loss: null pointer");
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 256));
+    if (ws_bytes < nb * sizeof(float)) {
+        set_error("pfn_mse_loss: workspace too small (need %zu bytes)", nb * sizeof(float));
+        return PFN_ENOSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const float inv_n = count > 0 ? 1.0f / (float)count : 0.f;
+    mse_partial_kernel<<<nb, 256, 0, s>>>(out, y, count, inv_n, grad, static_cast<float*>(ws));
+    PFN_CHECK_LAUNCH();
+    mse_final_kernel<<<1, 256, 0, s>>>(static_cast<float*>(ws), nb, inv_n, loss);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+int pfn_adamw_step(float* p, const float* g, float* m, float* v, int64_t count, float lr, float b1, float b2,
+                   float eps, float wd, int64_t* step, void* stream) {
+    PFN_CHECK_ARG(p && g && m && v && step, "pfn_adamw_step: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 2048));
+    adamw_kernel<<<nb, 256, 0, s>>>(p, g, m, v, count, lr, b1, b2, eps, wd, step);
+    PFN_CHECK_LAUNCH();
+    step_inc_kernel<<<1, 1, 0, s>>>(step);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+}  // extern "C"

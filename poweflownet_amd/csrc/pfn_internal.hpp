@@ -1,0 +1,184 @@
+// Internal declarations shared by the HIP translation units of libpfn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/pfn_hip.h"
+
+namespace pfn {
+
+// ------------------------------------------------------------------------------------------ errors
+void set_error(const char* fmt, ...);
+#define PFN_CHECK_ARG(cond, ...)                 \
+    do {                                         \
+        if (!(cond)) {                           \
+            ::pfn::set_error(__VA_ARGS__);       \
+            return PFN_EINVAL;                   \
+        }                                        \
+    } while (0)
+#define PFN_CHECK_HIP(expr)                                                              \
+    do {                                                                                 \
+        hipError_t e__ = (expr);                                                         \
+        if (e__ != hipSuccess) {                                                         \
+            ::pfn::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return PFN_EHIP;                                                             \
+        }                                                                                \
+    } while (0)
+#define PFN_CHECK_LAUNCH() PFN_CHECK_HIP(hipGetLastError())
+#define PFN_TRY(expr)              \
+    do {                           \
+        int rc__ = (expr);         \
+        if (rc__ != PFN_OK) return rc__; \
+    } while (0)
+
+static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+static inline int ld_of(int f) { return (int)round_up(f, 4); }
+
+// bump allocator over a caller-provided workspace (256-byte aligned sub-buffers)
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    template <typename T>
+    T* take(size_t count) {
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (size_t)round_up((int64_t)(count * sizeof(T)), 256);
+        return p;
+    }
+};
+
+// ------------------------------------------------------------------------------------------- graph
+// Device-side view of the adjacency built by pfn_graph_build.  "in" = CSR by destination (row i lists
+// the edges arriving at i: what the forward aggregation walks); "out" = CSR by source (what the
+// gradient w.r.t. the gathered operand walks).  eid >= e_stored marks the reversed copy of eid - e_stored.
+struct GraphView {
+    int n;          // nodes
+    int e_stored;   // stored edges
+    int* flags;     // [0] directed, [1] effective edge count, [2] index error, [3] reverse-found scratch
+    int* rowptr_in;   // [n+1]
+    int* rowptr_out;  // [n+1]
+    int* in_src;      // [2*e_stored]
+    int* in_eid;
+    int* out_dst;
+    int* out_eid;
+    int* cur_in;      // [n] scratch: histogram, then fill cursor
+    int* cur_out;     // [n]
+    float* deg;       // [n] in-degree (multiplicity kept)
+    float* dinv;      // [n] deg^-1/2, 0 where deg == 0
+    size_t bytes;
+};
+GraphView graph_view(void* ws, int64_t n, int64_t e_stored);
+
+// ------------------------------------------------------------------------------------------- GEMMs
+// C[g] (M x ldc) = sum over terms t with t.group == g of  A_t (M x K_t) * B_t (K_t x ncols)  + epilogue.
+// B_t[k][n] = trans ? W[(wn0 + n) * ldw + wk0 + k] : W[(wk0 + k) * ldw + wn0 + n]   (weights stay in
+// their nn.Linear layout; nothing is repacked).
+struct GemmTerm {
+    const float* A;
+    const float* W;
+    int lda, K, ldw, wk0, wn0, trans, group, pad_;
+};
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_DROPOUT_RELU = 2 };
+struct GemmArgs {
+    int M, ncols, ldc, nterm, ngroup, ncb;
+    float* C[8];            // per group
+    GemmTerm term[8];
+    const float* bias;      // [ncols] or null
+    int bias_group;         // group that receives the bias (-1: all)
+    const float* rowscale;  // [M] or null  : + rowscale[m] * rowbias[n]
+    const float* rowbias;   // [ncols]
+    const float* resid;     // [M x ldr] or null
+    int ldr;
+    int act;
+    float p_drop;
+    const uint64_t* rng;    // device {seed, offset}
+    uint32_t rng_stream;
+    const float* gate;      // [M x ldg] or null : out *= gate > 0 ? gate_scale : 0
+    int ldg;
+    float gate_scale;
+};
+int launch_gemm_nt(const GemmArgs& a, hipStream_t s);
+
+// dW[(gn0 + i) * ldg + gk0 + j] = sum_m A[m][a0 + i] * B[m][b0 + j],  i < na, j < nb  (A = grad of the
+// layer output, B = the layer input: the nn.Linear weight gradient), reduced deterministically in two stages.
+struct TnPair {
+    const float* A;
+    const float* B;
+    float* G;
+    int lda, ldb, na, nb, ldg, gn0, gk0, pad_;
+};
+struct ColsumJob {
+    const float* A;         // [M x lda]
+    const float* rowscale;  // [M] or null
+    float* out;             // [ncols]
+    int lda, ncols;
+};
+struct ReduceWs {
+    float* partial;   // scratch for split partials
+    size_t floats;
+};
+size_t reduce_ws_floats(int64_t M, int max_na, int max_nb, int max_pairs);
+int launch_weight_grads(const TnPair* pairs, int npairs, const ColsumJob* jobs, int njobs, int64_t M,
+                        ReduceWs ws, hipStream_t s);
+
+// ------------------------------------------------------------------------------------- edge kernels
+// y[i] = (add ? add[i] : 0) + dinv[i] * sum_{e in row i} dinv[nbr(e)] * x[nbr(e)]   (normalize)
+// y[i] = sum_{e in row i} x[nbr(e)]                                                  (!normalize)
+// transpose = walk the by-source CSR (A_hat^T).  gate: y *= gate > 0 ? gate_scale : 0.
+struct HopArgs {
+    const float* x;
+    const float* add;
+    float* y;
+    const float* gate;
+    float gate_scale;
+    int ld, normalize, transpose;
+};
+int launch_hop(const GraphView& g, const HopArgs& a, hipStream_t s);
+
+// S[i] = sum_{e -> i} relu(P[i] + Q[src(e)] + sum_f a_e[f] * W1[:, 2Fi + f])
+struct EdgeFwdArgs {
+    const float* P;
+    const float* Q;
+    const float* edge_attr;
+    const float* w1;
+    float* S;
+    int ld, h, fi, fe;
+};
+int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s);
+
+struct EdgeBwdArgs {
+    const float* P;
+    const float* Q;
+    const float* dS;
+    const float* edge_attr;
+    const float* w1;
+    float* dP;
+    float* dQ;
+    float* dWe_partial;   // [nblocks][fe][ld] partial sums of a_e[f] * dh_e
+    float* grad_edge_attr;  // optional [e_stored][fe]
+    int ld, h, fi, fe;
+};
+int edge_bwd_dst_blocks(const GraphView& g, int ld);
+int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t* edge_index_unused, hipStream_t s);
+int launch_edge_attr_grad(const GraphView& g, const EdgeBwdArgs& a, hipStream_t s);
+// sums dWe partials [nblocks][fe][ld] into grad_w1[:, 2Fi + f]
+int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, float* grad_w1, int ldw, int col0,
+                      hipStream_t s);
+
+// ------------------------------------------------------------------------------------ small kernels
+int launch_mask_to_float(const void* mask, int mask_dtype, float* out, int64_t count, hipStream_t s);
+int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t f,
+                    hipStream_t s);
+int launch_rng_advance(uint64_t* rng, hipStream_t s);
+
+// uniform in [0,1) from a counter-based hash (dropout mask; recomputation-free: backward reads y > 0)
+__device__ __forceinline__ float uniform_hash(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (offset * 0x100000001B3ull + ((uint64_t)stream << 40) + idx + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+}  // namespace pfn

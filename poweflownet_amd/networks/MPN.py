@@ -1,0 +1,399 @@
+"""Host-side mirror of the reference's `networks/MPN.py` hot-path classes on the MI355X HIP kernels.
+
+Same constructor signatures, attribute names, `state_dict` keys and `forward` semantics as
+
+  * `EdgeAggregation`   -- networks/MPN.py:6-56
+  * `TAGConv`           -- torch_geometric.nn.TAGConv as used at networks/MPN.py:477-484,:545
+  * `MaskEmbdMultiMPN`  -- networks/MPN.py:456-559
+
+so `train.py` / `utils/training.py` / `utils/evaluation.py`-shaped callers are drop-in.  All arithmetic runs
+in libpfn_hip.so through the C ABI of include/pfn_hip.h; torch supplies device memory, streams and the
+autograd graph edges only.  There is no CPU implementation here: CPU tensors raise RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+
+
+def _padded(f: int) -> int:
+    return (f + 3) // 4 * 4
+
+
+def _capturing() -> bool:
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
+# ================================================================================================ graph
+class GraphCSR:
+    """Device adjacency built by `pfn_graph_build` from a PyG-style `edge_index` (2, E) int64.
+
+    mode -1: the reference's first-edge `is_directed` heuristic decides on device whether the reversed
+    copies are appended (networks/MPN.py:498-523); 0: use the list as given; 1: always undirect.
+    """
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, mode: int = -1, validate: bool = True):
+        lib = L.load()
+        L.require_device(edge_index, what="edge_index")
+        if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise RuntimeError(f"edge_index must be int64 of shape (2, E), got {edge_index.dtype} {tuple(edge_index.shape)}")
+        edge_index = edge_index if edge_index.is_contiguous() else edge_index.contiguous()
+        self.num_nodes, self.e_stored, self.mode = int(num_nodes), int(edge_index.shape[1]), int(mode)
+        self.device = edge_index.device
+        nbytes = lib.pfn_graph_workspace_bytes(self.num_nodes, self.e_stored)
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        self._keepalive = edge_index
+        with torch.cuda.device(self.device):
+            L.check(lib.pfn_graph_build(edge_index.data_ptr(), self.e_stored, self.num_nodes, self.mode,
+                                        self.ws.data_ptr(), nbytes, L.stream_ptr()), "pfn_graph_build")
+        self._keepalive = None
+        if validate and not _capturing():
+            self.info()          # raises on out-of-range ids (one sync per NEW topology only)
+
+    def info(self):
+        """(directed, effective_edge_count); synchronises.  Raises RuntimeError on an out-of-range node id."""
+        lib = L.load()
+        d, e = C.c_int32(0), C.c_int64(0)
+        with torch.cuda.device(self.device):
+            L.check(lib.pfn_graph_info(self.ws.data_ptr(), self.num_nodes, self.e_stored, C.byref(d), C.byref(e),
+                                       L.stream_ptr()), "pfn_graph_info")
+        return bool(d.value), int(e.value)
+
+    def export_edges(self) -> torch.Tensor:
+        """The effective edge list (2, E_eff) int64, in edge-id order (originals first, reverses second)."""
+        lib = L.load()
+        _, e_eff = self.info()
+        out = torch.empty(2, max(2 * self.e_stored, 1), dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            L.check(lib.pfn_graph_export_edges(self.ws.data_ptr(), self.num_nodes, self.e_stored, out.data_ptr(),
+                                               L.stream_ptr()), "pfn_graph_export_edges")
+        return out[:, :e_eff].clone()
+
+
+class _GraphCache:
+    """Reuses the adjacency while the caller hands in the very same, unmodified edge_index tensor
+    (identity + torch's in-place version counter): legitimate because every sample of a reference case shares
+    one topology, and safe because a new or mutated tensor misses."""
+
+    def __init__(self):
+        self._ref, self._key, self._graph = None, None, None
+
+    def get(self, edge_index: torch.Tensor, num_nodes: int, mode: int) -> GraphCSR:
+        key = (edge_index._version, edge_index.data_ptr(), tuple(edge_index.shape), num_nodes, mode)
+        if self._ref is not None and self._ref() is edge_index and self._key == key:
+            return self._graph
+        g = GraphCSR(edge_index, num_nodes, mode)
+        self._ref, self._key, self._graph = weakref.ref(edge_index), key, g
+        return g
+
+
+def _pad_rows(x: torch.Tensor, f: int) -> torch.Tensor:
+    """(N, f) -> (N, roundup(f, 4)) with zero pad columns (no copy when f % 4 == 0)."""
+    ld = _padded(f)
+    if ld == f:
+        return x
+    out = torch.empty(x.shape[0], ld, dtype=torch.float32, device=x.device)
+    L.check(L.load().pfn_pad_rows(x.data_ptr(), f, out.data_ptr(), ld, x.shape[0], f, L.stream_ptr()), "pfn_pad_rows")
+    return out
+
+
+def _unpad_rows(x: torch.Tensor, f: int) -> torch.Tensor:
+    return x if x.shape[1] == f else x[:, :f].contiguous()
+
+
+# ================================================================================= EdgeAggregation layer
+class _EdgeAggrFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph: GraphCSR, dims, x, edge_attr, w1, b1, w2, b2):
+        lib = L.load()
+        fi, fe, h, fo = dims
+        n = x.shape[0]
+        xp = _pad_rows(x, fi)
+        out = torch.empty(n, _padded(fo), dtype=torch.float32, device=x.device)
+        nbytes = lib.pfn_edge_aggr_workspace_bytes(n, graph.e_stored, fi, fe, h, fo)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        L.check(lib.pfn_edge_aggr_forward(graph.ws.data_ptr(), n, graph.e_stored, fi, fe, h, fo, xp.data_ptr(), _padded(fi),
+                                          edge_attr.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                          out.data_ptr(), _padded(fo), ws.data_ptr(), nbytes, L.stream_ptr()),
+                "pfn_edge_aggr_forward")
+        ctx.graph, ctx.dims, ctx.ws = graph, dims, ws
+        ctx.save_for_backward(xp, edge_attr, w1, b1, w2, b2)
+        return _unpad_rows(out, fo)
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        fi, fe, h, fo = ctx.dims
+        xp, edge_attr, w1, b1, w2, b2 = ctx.saved_tensors
+        graph, n = ctx.graph, xp.shape[0]
+        gp = _pad_rows(L.f32c(gout, "grad_out"), fo)
+        gx = torch.empty_like(xp)
+        gea = torch.empty_like(edge_attr) if ctx.needs_input_grad[3] else None
+        gw1, gb1, gw2, gb2 = (torch.empty_like(t) for t in (w1, b1, w2, b2))
+        L.check(lib.pfn_edge_aggr_backward(graph.ws.data_ptr(), n, graph.e_stored, fi, fe, h, fo, xp.data_ptr(), _padded(fi),
+                                           edge_attr.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                                           gp.data_ptr(), _padded(fo), gx.data_ptr(), _padded(fi), L.ptr(gea),
+                                           gw1.data_ptr(), gb1.data_ptr(), gw2.data_ptr(), gb2.data_ptr(),
+                                           ctx.ws.data_ptr(), ctx.ws.numel(), L.stream_ptr()), "pfn_edge_aggr_backward")
+        return None, None, _unpad_rows(gx, fi), gea, gw1, gb1, gw2, gb2
+
+
+class EdgeAggregation(nn.Module):
+    """networks/MPN.py:6-56.  out[i] = sum_{e: dst(e)=i} MLP(cat[x_i, x_src(e), edge_attr_e]), aggr='add';
+    the degree `norm` the reference computes at :43-47 never reaches `message` and is not reproduced."""
+
+    def __init__(self, nfeature_dim, efeature_dim, hidden_dim, output_dim):
+        super().__init__()
+        self.nfeature_dim = nfeature_dim
+        self.efeature_dim = efeature_dim
+        self.output_dim = output_dim
+        self.edge_aggr = nn.Sequential(
+            nn.Linear(nfeature_dim * 2 + efeature_dim, hidden_dim),
+            nn.ReLU(),
+            nn.Linear(hidden_dim, output_dim),
+        )
+        self._graphs = _GraphCache()
+
+    @property
+    def hidden_dim(self):
+        return self.edge_aggr[0].out_features
+
+    def forward(self, x, edge_index, edge_attr):
+        L.require_device(x, edge_index, edge_attr, *self.parameters(), what="EdgeAggregation input")
+        x, edge_attr = L.f32c(x, "x"), L.f32c(edge_attr, "edge_attr")
+        if x.dim() != 2 or x.shape[1] != self.nfeature_dim:
+            raise RuntimeError(f"x must be (N, {self.nfeature_dim}), got {tuple(x.shape)}")
+        if edge_attr.shape != (edge_index.shape[1], self.efeature_dim):
+            raise RuntimeError(f"edge_attr must be ({edge_index.shape[1]}, {self.efeature_dim}), got {tuple(edge_attr.shape)}")
+        with torch.cuda.device(x.device):
+            graph = self._graphs.get(edge_index, x.shape[0], 0)     # the layer takes the list as given
+            l1, l2 = self.edge_aggr[0], self.edge_aggr[2]
+            dims = (self.nfeature_dim, self.efeature_dim, l1.out_features, self.output_dim)
+            return _EdgeAggrFn.apply(graph, dims, x, edge_attr, l1.weight, l1.bias, l2.weight, l2.bias)
+
+
+# ========================================================================================== TAGConv layer
+class _TagConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, graph: GraphCSR, dims, x, bias, *weights):
+        lib = L.load()
+        cin, cout, K = dims
+        n = x.shape[0]
+        xp = _pad_rows(x, cin)
+        out = torch.empty(n, _padded(cout), dtype=torch.float32, device=x.device)
+        nbytes = lib.pfn_tag_conv_workspace_bytes(n, graph.e_stored, cin, cout, K)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        L.check(lib.pfn_tag_conv_forward(graph.ws.data_ptr(), n, graph.e_stored, cin, cout, K, xp.data_ptr(), _padded(cin),
+                                         L.ptr_table(weights), L.ptr(bias), out.data_ptr(), _padded(cout), ws.data_ptr(),
+                                         nbytes, L.stream_ptr()), "pfn_tag_conv_forward")
+        ctx.graph, ctx.dims, ctx.ws, ctx.has_bias = graph, dims, ws, bias is not None
+        ctx.save_for_backward(xp, *weights)
+        return _unpad_rows(out, cout)
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        cin, cout, K = ctx.dims
+        xp, *weights = ctx.saved_tensors
+        graph, n = ctx.graph, xp.shape[0]
+        gp = _pad_rows(L.f32c(gout, "grad_out"), cout)
+        gx = torch.empty_like(xp)
+        gws = [torch.empty_like(w) for w in weights]
+        gb = torch.empty(cout, dtype=torch.float32, device=xp.device) if ctx.has_bias else None
+        L.check(lib.pfn_tag_conv_backward(graph.ws.data_ptr(), n, graph.e_stored, cin, cout, K, xp.data_ptr(), _padded(cin),
+                                          L.ptr_table(weights), gp.data_ptr(), _padded(cout), gx.data_ptr(), _padded(cin),
+                                          L.ptr_table(gws), L.ptr(gb), ctx.ws.data_ptr(), ctx.ws.numel(), L.stream_ptr()),
+                "pfn_tag_conv_backward")
+        return (None, None, _unpad_rows(gx, cin), gb, *gws)
+
+
+class TAGConv(nn.Module):
+    """PyG `TAGConv(in_channels, out_channels, K)` with its defaults (normalize=True, bias=True, no self loops):
+    out = sum_k (A_hat^k x) W_k^T + b.  state_dict keys `lins.{k}.weight`, `bias` (zero-initialised)."""
+
+    def __init__(self, in_channels, out_channels, K=3, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.K = in_channels, out_channels, K
+        self.lins = nn.ModuleList([nn.Linear(in_channels, out_channels, bias=False) for _ in range(K + 1)])
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+        else:
+            self.register_parameter("bias", None)
+        self._graphs = _GraphCache()
+
+    def forward(self, x, edge_index):
+        L.require_device(x, edge_index, *self.parameters(), what="TAGConv input")
+        x = L.f32c(x, "x")
+        if x.dim() != 2 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"x must be (N, {self.in_channels}), got {tuple(x.shape)}")
+        with torch.cuda.device(x.device):
+            graph = self._graphs.get(edge_index, x.shape[0], 0)
+            return _TagConvFn.apply(graph, (self.in_channels, self.out_channels, self.K), x, self.bias,
+                                    *[l.weight for l in self.lins])
+
+
+# ============================================================================================ whole model
+class _MpnFn(torch.autograd.Function):
+    """One autograd node for the whole network: forward = pfn_mpn_forward, backward = pfn_mpn_backward writing
+    every parameter gradient into ONE flat buffer (the data-parallel all-reduce unit)."""
+
+    @staticmethod
+    def forward(ctx, model, graph, x, pred_mask, edge_attr, *params):
+        lib = L.load()
+        cfg = model._config()
+        n = x.shape[0]
+        fo = model.output_dim
+        out = torch.empty(n, _padded(fo), dtype=torch.float32, device=x.device)
+        nbytes = lib.pfn_mpn_workspace_bytes(C.byref(cfg), n, graph.e_stored)
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
+        mask_dtype = 0 if pred_mask.dtype == torch.int64 else 1
+        L.check(lib.pfn_mpn_forward(C.byref(cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params), x.data_ptr(),
+                                    pred_mask.data_ptr(), mask_dtype, edge_attr.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                    nbytes, L.ptr(model._rng_state_on(x.device)), L.stream_ptr()), "pfn_mpn_forward")
+        ctx.model, ctx.graph, ctx.cfg, ctx.ws, ctx.mask_dtype = model, graph, cfg, ws, mask_dtype
+        ctx.save_for_backward(x, pred_mask, edge_attr, *params)
+        return _unpad_rows(out, fo)
+
+    @staticmethod
+    def backward(ctx, gout):
+        lib = L.load()
+        x, pred_mask, edge_attr, *params = ctx.saved_tensors
+        model, graph, n = ctx.model, ctx.graph, x.shape[0]
+        gp = _pad_rows(L.f32c(gout, "grad_out"), model.output_dim)
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
+        grads, off = [], 0
+        for p, sz in zip(params, sizes):
+            grads.append(flat[off:off + sz].view(p.shape))
+            off += sz
+        gx = torch.empty_like(x) if ctx.needs_input_grad[2] else None
+        gea = torch.empty_like(edge_attr) if ctx.needs_input_grad[4] else None
+        L.check(lib.pfn_mpn_backward(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
+                                     L.ptr_table(grads), x.data_ptr(), pred_mask.data_ptr(), ctx.mask_dtype,
+                                     edge_attr.data_ptr(), gp.data_ptr(), L.ptr(gx), L.ptr(gea), ctx.ws.data_ptr(),
+                                     ctx.ws.numel(), L.stream_ptr()), "pfn_mpn_backward")
+        model._last_flat_grad = flat
+        return (None, None, gx, None, gea, *grads)
+
+
+class MaskEmbdMultiMPN(nn.Module):
+    """networks/MPN.py:456-559: mask embedding + (EdgeAggregation, TAGConv) x (L-1) + EdgeAggregation."""
+
+    def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
+        super().__init__()
+        self.nfeature_dim = nfeature_dim
+        self.efeature_dim = efeature_dim
+        self.output_dim = output_dim
+        self.hidden_dim = hidden_dim
+        self.n_gnn_layers = n_gnn_layers
+        self.K = K
+        self.dropout_rate = dropout_rate
+        if n_gnn_layers < 2:
+            # the reference's n_gnn_layers == 1 branch (networks/MPN.py:475-477) builds TAGConv(H, output_dim)
+            # followed by EdgeAggregation(H, ...): shape-broken unless H == output_dim.
+            raise ValueError("MaskEmbdMultiMPN needs n_gnn_layers >= 2 (the reference's L == 1 model cannot run)")
+        self.layers = nn.ModuleList()
+        self.layers.append(EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, hidden_dim))
+        self.layers.append(TAGConv(hidden_dim, hidden_dim, K=K))
+        for _ in range(n_gnn_layers - 2):
+            self.layers.append(EdgeAggregation(hidden_dim, efeature_dim, hidden_dim, hidden_dim))
+            self.layers.append(TAGConv(hidden_dim, hidden_dim, K=K))
+        self.layers.append(EdgeAggregation(hidden_dim, efeature_dim, hidden_dim, output_dim))
+        self.mask_embd = nn.Sequential(
+            nn.Linear(nfeature_dim, hidden_dim),
+            nn.ReLU(),
+            nn.Linear(hidden_dim, nfeature_dim),
+        )
+        self.dropout = nn.Dropout(self.dropout_rate, inplace=False)
+        self._graphs = _GraphCache()
+        self._rng_state: Optional[torch.Tensor] = None
+        self._last_flat_grad: Optional[torch.Tensor] = None
+
+    # ------------------------------------------------------------------ helpers the reference exposes
+    def is_directed(self, edge_index):
+        """networks/MPN.py:498-504, evaluated by the same device kernel the forward pass uses."""
+        if edge_index.shape[1] == 0:
+            return False
+        L.require_device(edge_index, what="edge_index")
+        with torch.cuda.device(edge_index.device):
+            n = int(edge_index.max().item()) + 1
+            return GraphCSR(edge_index, n, mode=-1).info()[0]
+
+    def undirect_graph(self, edge_index, edge_attr):
+        """networks/MPN.py:506-523 (originals first, reversed copies second, attributes duplicated)."""
+        if edge_index.shape[1] == 0:
+            return edge_index, edge_attr
+        L.require_device(edge_index, edge_attr, what="edge_index/edge_attr")
+        with torch.cuda.device(edge_index.device):
+            n = int(edge_index.max().item()) + 1
+            g = GraphCSR(edge_index, n, mode=-1)
+            if not g.info()[0]:
+                return edge_index, edge_attr
+            return g.export_edges(), torch.cat([edge_attr, edge_attr], dim=0)
+
+    # ------------------------------------------------------------------------------------- plumbing
+    def _config(self) -> L.MpnConfig:
+        return L.MpnConfig(self.nfeature_dim, self.efeature_dim, self.output_dim, self.hidden_dim, self.n_gnn_layers,
+                           self.K, float(self.dropout_rate), 1 if self.training else 0)
+
+    def _ordered_params(self):
+        """The C ABI's parameter table order (include/pfn_hip.h)."""
+        out = []
+        for layer in self.layers:
+            if isinstance(layer, EdgeAggregation):
+                l1, l2 = layer.edge_aggr[0], layer.edge_aggr[2]
+                out += [l1.weight, l1.bias, l2.weight, l2.bias]
+            else:
+                out += [lin.weight for lin in layer.lins] + [layer.bias]
+        a, b = self.mask_embd[0], self.mask_embd[2]
+        return out + [a.weight, a.bias, b.weight, b.bias]
+
+    def _rng_state_on(self, device):
+        if not (self.training and self.dropout_rate > 0):
+            return None
+        if self._rng_state is None or self._rng_state.device != device:
+            seed = int(torch.initial_seed()) & 0x7FFFFFFFFFFFFFFF
+            self._rng_state = torch.tensor([seed, 0], dtype=torch.int64, device=device)
+        return self._rng_state
+
+    def seed_dropout(self, seed: int):
+        """Re-seed the counter-based dropout stream (device state {seed, offset}; offset advances per forward)."""
+        dev = next(self.parameters()).device
+        self._rng_state = torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+
+    def flat_grad(self) -> Optional[torch.Tensor]:
+        """The flat fp32 buffer the last backward wrote all parameter gradients into (views of it are the
+        `.grad`s autograd handed out) -- the unit poweflownet_amd.dp all-reduces."""
+        return self._last_flat_grad
+
+    # -------------------------------------------------------------------------------------- forward
+    def forward(self, data):
+        assert data.x.shape[-1] == 4                       # networks/MPN.py:528
+        x = data.x
+        bus_type = data.bus_type                           # read like the reference (:531-532), unused
+        batch = data.batch
+        mask = data.pred_mask
+        edge_index = data.edge_index
+        edge_features = data.edge_attr
+        del bus_type, batch
+        if self.nfeature_dim != 4:
+            raise RuntimeError("MaskEmbdMultiMPN.forward asserts 4 node features (networks/MPN.py:528); "
+                               f"this model was built with nfeature_dim={self.nfeature_dim}")
+        L.require_device(x, mask, edge_index, edge_features, *self.parameters(), what="MaskEmbdMultiMPN input")
+        x, edge_features = L.f32c(x, "data.x"), L.f32c(edge_features, "data.edge_attr")
+        if mask.dtype != torch.int64:
+            mask = mask.float()                            # `.float()` of the reference (:533)
+        mask = mask if mask.is_contiguous() else mask.contiguous()
+        if mask.shape != x.shape:
+            raise RuntimeError(f"pred_mask shape {tuple(mask.shape)} != x shape {tuple(x.shape)}")
+        if edge_features.shape != (edge_index.shape[1], self.efeature_dim):
+            raise RuntimeError(f"edge_attr must be ({edge_index.shape[1]}, {self.efeature_dim}), got {tuple(edge_features.shape)}")
+        with torch.cuda.device(x.device):
+            graph = self._graphs.get(edge_index, x.shape[0], -1)     # is_directed + undirect_graph (:539)
+            return _MpnFn.apply(self, graph, x, mask, edge_features, *self._ordered_params())

@@ -1,0 +1,84 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU and exports every symbol
+include/pfn_hip.h declares; pure-host entry points answer; the product has no CPU fallback."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+from poweflownet_amd import _lib as L
+from poweflownet_amd.networks.MPN import EdgeAggregation, MaskEmbdMultiMPN, TAGConv
+from poweflownet_amd.synth import make_batch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pfn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pfn_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = L.load()
+    declared = _declared_symbols()
+    assert set(declared) == set(L.SYMBOLS), (declared, L.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.pfn_abi_version() == 1
+
+
+def test_host_only_entry_points():
+    lib = L.load()
+    assert lib.pfn_padded_ld(129) == 132 and lib.pfn_padded_ld(4) == 4
+    cfg = L.MpnConfig(4, 2, 4, 129, 4, 3, 0.2, 1)
+    assert lib.pfn_mpn_num_params(C.byref(cfg)) == 35
+    cfgw = L.MpnConfig(4, 2, 4, 129, 6, 6, 0.2, 1)
+    assert lib.pfn_mpn_num_params(C.byref(cfgw)) == 68
+    assert lib.pfn_graph_workspace_bytes(15104, 23808) > 4 * (2 * 15104 + 8 * 23808)
+    ws = lib.pfn_mpn_workspace_bytes(C.byref(cfg), 15104, 23808)
+    assert ws > 15104 * 132 * 4 * 20
+    bad = L.MpnConfig(4, 2, 4, 129, 1, 3, 0.2, 1)          # L == 1 is rejected
+    assert lib.pfn_mpn_workspace_bytes(C.byref(bad), 10, 10) == 0
+
+
+def test_argument_errors_are_reported_not_fatal():
+    lib = L.load()
+    rc = lib.pfn_graph_build(None, 5, 4, -1, None, 0, None)
+    assert rc == -1 and b"null" in lib.pfn_last_error()
+
+
+def test_state_dict_contract_matches_reference_keys():
+    from tests.util import load, params_from
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.2)
+    want = params_from(load("g4_params_standard"))
+    assert sorted(m.state_dict().keys()) == sorted(want.keys())
+    for k, v in m.state_dict().items():
+        assert tuple(v.shape) == tuple(want[k].shape), k
+    m.load_state_dict(want)                                 # a reference checkpoint loads as-is
+    assert sum(p.numel() for p in m.parameters()) == 354_500
+    assert len(m._ordered_params()) == 35
+
+
+def test_no_cpu_fallback():
+    m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(make_batch("14", 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        EdgeAggregation(4, 2, 8, 8)(torch.zeros(3, 4), torch.zeros(2, 2, dtype=torch.long), torch.zeros(2, 2))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        TAGConv(4, 4, 2)(torch.zeros(3, 4), torch.zeros(2, 2, dtype=torch.long))
+
+
+def test_constructor_surface():
+    with pytest.raises(ValueError):
+        MaskEmbdMultiMPN(4, 2, 4, 8, 1, 3, 0.0)
+    m = MaskEmbdMultiMPN(nfeature_dim=4, efeature_dim=2, output_dim=4, hidden_dim=8, n_gnn_layers=3, K=2, dropout_rate=0.1)
+    assert [type(l).__name__ for l in m.layers] == ["EdgeAggregation", "TAGConv"] * 2 + ["EdgeAggregation"]
+    for attr in ("nfeature_dim", "efeature_dim", "output_dim", "hidden_dim", "n_gnn_layers", "K", "dropout_rate"):
+        assert hasattr(m, attr)
+    with pytest.raises(AssertionError):                     # networks/MPN.py:528
+        bad = make_batch("14", 1)
+        bad.x = torch.zeros(14, 6)
+        m(bad)

@@ -1,0 +1,252 @@
+"""Parity tests proper (-m gpu): the HIP path, called through the C ABI, against (a) the golden vectors generated
+from the reference and (b) the CPU oracle on seeded inputs.  Tolerance: north_star's 1e-5 relative fp32 (tests/util.RTOL)."""
+import copy
+
+import pytest
+import torch
+
+from oracle import ref_cpu
+from poweflownet_amd.networks.MPN import EdgeAggregation, GraphCSR, MaskEmbdMultiMPN, TAGConv
+from poweflownet_amd.synth import make_batch
+from tests.util import RTOL, assert_close, data_from, load, params_from
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+# ------------------------------------------------------------------------------------------------ graph
+def test_g1_is_directed_and_undirect_on_device():
+    fx = load("g1_is_directed")
+    m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0).to(DEV)
+    for name in fx["names"]:
+        ei, ea = fx[f"{name}.edge_index"].to(DEV), fx[f"{name}.edge_attr"].to(DEV)
+        assert m.is_directed(ei) == bool(fx[f"{name}.directed"]), name
+        ei2, ea2 = m.undirect_graph(ei, ea)
+        assert torch.equal(ei2.cpu(), fx[f"{name}.out_edge_index"]), name
+        assert torch.equal(ea2.cpu(), fx[f"{name}.out_edge_attr"]), name
+
+
+def test_graph_rejects_out_of_range_ids():
+    ei = torch.tensor([[0, 1, 7], [1, 2, 0]], device=DEV)
+    with pytest.raises(RuntimeError, match="outside"):
+        GraphCSR(ei, 5)
+
+
+def test_scatter_add_matches_index_add_bitwise():
+    import ctypes as C
+    from poweflownet_amd import _lib as L
+    b = make_batch("118", 4)
+    ei = b.edge_index.to(DEV)
+    n = b.x.shape[0]
+    g = GraphCSR(ei, n, mode=1)
+    eff = g.export_edges()
+    x = torch.randn(n, 132, device=DEV)
+    x[:, 129:] = 0
+    out = torch.empty_like(x)
+    L.check(L.load().pfn_scatter_add(g.ws.data_ptr(), n, ei.shape[1], x.data_ptr(), out.data_ptr(), 129, L.stream_ptr()), "sa")
+    # sequential CPU scatter in edge-id order == our per-row edge-id-ordered sums, bit for bit
+    want = torch.zeros(n, 132).index_add_(0, eff[1].cpu(), x.cpu()[eff[0].cpu()])
+    assert torch.equal(out.cpu(), want)
+
+
+# ------------------------------------------------------------------------------------------- single layers
+@pytest.mark.parametrize("tag", ["4_8_8", "8_8_4", "129_129_129", "129_129_4"])
+def test_g2_edge_aggregation_layer(tag):
+    fx = load(f"g2_edge_aggregation_{tag}")
+    fi, h, fo = (int(v) for v in tag.split("_"))
+    layer = EdgeAggregation(fi, 2, h, fo).to(DEV)
+    layer.load_state_dict({"edge_aggr.0.weight": fx["w1"], "edge_aggr.0.bias": fx["b1"],
+                           "edge_aggr.2.weight": fx["w2"], "edge_aggr.2.bias": fx["b2"]})
+    x = fx["x"].to(DEV).requires_grad_(True)
+    ea = fx["edge_attr"].to(DEV).requires_grad_(True)
+    out = layer(x, fx["edge_index"].to(DEV), ea)
+    assert_close(out, fx["out"], RTOL, "out")
+    out.backward(fx["grad_out"].to(DEV))
+    assert_close(x.grad, fx["grad_x"], RTOL, "grad_x")
+    assert_close(ea.grad, fx["grad_edge_attr"], RTOL, "grad_edge_attr")
+    l1, l2 = layer.edge_aggr[0], layer.edge_aggr[2]
+    for got, key in ((l1.weight.grad, "grad_w1"), (l1.bias.grad, "grad_b1"), (l2.weight.grad, "grad_w2"), (l2.bias.grad, "grad_b2")):
+        assert_close(got, fx[key], RTOL, key)
+
+
+@pytest.mark.parametrize("tag", ["K1_8_8", "K3_129_129", "K6_129_129", "K3_8_5"])
+def test_g3_tagconv_layer(tag):
+    fx = load(f"g3_tagconv_{tag}")
+    K = int(fx["K"])
+    cout, cin = fx["w0"].shape
+    layer = TAGConv(cin, cout, K=K).to(DEV)
+    sd = {f"lins.{k}.weight": fx[f"w{k}"] for k in range(K + 1)}
+    sd["bias"] = fx["bias"]
+    layer.load_state_dict(sd)
+    x = fx["x"].to(DEV).requires_grad_(True)
+    out = layer(x, fx["edge_index"].to(DEV))
+    assert_close(out, fx["out"], RTOL, "out")
+    out.backward(fx["grad_out"].to(DEV))
+    assert_close(x.grad, fx["grad_x"], RTOL, "grad_x")
+    assert_close(layer.bias.grad, fx["grad_bias"], RTOL, "grad_bias")
+    for k in range(K + 1):
+        assert_close(layer.lins[k].weight.grad, fx[f"grad_w{k}"], RTOL, f"grad_w{k}")
+
+
+# --------------------------------------------------------------------------------------------- whole model
+def _model_from(fx, shared, dropout=0.0):
+    params = params_from(load("g4_params_standard")) if shared else params_from(fx)
+    cfg = [int(v) for v in fx["cfg"]]
+    m = MaskEmbdMultiMPN(*cfg, dropout)
+    m.load_state_dict(params)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("name,shared", [("g4_model_tiny", False), ("g4_model_case14", True),
+                                         ("g4_model_case118", True), ("g4_model_wideK6", False)])
+def test_g4_whole_model_forward_and_grads(name, shared):
+    fx = load(name)
+    m = _model_from(fx, shared).eval()
+    data = data_from(fx, device=DEV)
+    out = m(data)
+    assert out.shape == fx["out"].shape and out.dtype == torch.float32
+    assert_close(out, fx["out"], RTOL, "out")
+    loss = torch.nn.MSELoss()(out, data.y)
+    assert_close(loss, fx["loss"], RTOL, "loss")
+    loss.backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        assert_close(p.grad, fx[f"grad.{k}"], RTOL, f"grad.{k}")
+    flat = m.flat_grad()
+    assert flat is not None and flat.numel() == sum(p.numel() for p in m.parameters())
+
+
+def test_g6_three_adamw_steps():
+    fx = load("g6_train_step")
+    g4 = load("g4_model_case14")
+    m = _model_from(g4, True).train()                     # dropout_rate 0 -> deterministic
+    data = data_from(g4, device=DEV)
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3)
+    loss_fn = torch.nn.MSELoss()
+    for step in range(1, 4):
+        opt.zero_grad()
+        loss = loss_fn(m(data), data.y)
+        loss.backward()
+        opt.step()
+        assert_close(loss, fx[f"loss.{step}"], 1e-4, f"loss.{step}")
+    # AdamW's first steps are ~lr*sign(g): entries whose gradient is rounding noise may flip, so compare the
+    # well-conditioned entries tightly and bound the rest by 2*lr*steps.
+    for k, p in m.named_parameters():
+        ref, g = fx[f"param_after3.{k}"], g4[f"grad.{k}"]
+        err = (p.detach().cpu() - ref).abs()
+        solid = g.abs() > 1e-3 * g.abs().max()
+        assert err.max().item() <= 6.5e-3, k
+        if solid.any():
+            assert err[solid].max().item() <= 2e-5, (k, err[solid].max().item())
+
+
+def test_g7_batch_equals_concat_of_singles():
+    fx = load("g7_collate")
+    m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
+    m.load_state_dict(params_from(fx))
+    m = m.to(DEV).eval()
+    big = data_from(fx, prefix="big.", device=DEV)
+    assert_close(m(big), fx["batch_out"], RTOL, "batch_out")
+    singles = []
+    for b in range(3):
+        d = data_from(fx, prefix=f"g{b}.", device=DEV)
+        singles.append(m(d))
+    assert_close(torch.cat(singles), fx["singles_out"], RTOL, "singles")
+
+
+@pytest.mark.parametrize("case,B,cfg", [("14", 32, (129, 4, 3)), ("118", 16, (129, 4, 3)), ("118", 4, (129, 6, 6)),
+                                        ("118", 3, (64, 2, 3)), ("14", 5, (512, 3, 2))])
+def test_model_vs_oracle_seeded(case, B, cfg):
+    torch.manual_seed(1234)
+    h, L_, K = cfg
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, h, L_, K, 0.0).eval()
+    with torch.no_grad():
+        for mod in ref.layers:
+            if hasattr(mod, "bias") and isinstance(mod.bias, torch.nn.Parameter):
+                mod.bias.normal_(std=0.1)                  # TAGConv bias is zero-initialised: exercise it
+    m = MaskEmbdMultiMPN(4, 2, 4, h, L_, K, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    data = make_batch(case, B, seed=3)
+    out_ref = ref(data)
+    loss_ref = torch.nn.MSELoss()(out_ref, data.y)
+    loss_ref.backward()
+    dd = data.to(DEV)
+    out = m(dd)
+    assert_close(out, out_ref, RTOL, "out")
+    torch.nn.MSELoss()(out, dd.y).backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, 2 * RTOL, f"grad.{k}")
+
+
+def test_edge_cases_empty_edges_and_isolated_nodes():
+    from poweflownet_amd.data import Data
+    torch.manual_seed(0)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    n = 5
+    for ei in (torch.zeros(2, 0, dtype=torch.long), torch.tensor([[0, 3], [1, 3]])):     # no edges; self loop + isolated
+        d = Data(x=torch.randn(n, 4), y=torch.randn(n, 4), bus_type=torch.zeros(n, dtype=torch.long),
+                 pred_mask=torch.randint(0, 2, (n, 4)), edge_index=ei, edge_attr=torch.randn(ei.shape[1], 2),
+                 batch=torch.zeros(n, dtype=torch.long))
+        assert_close(m(d.to(DEV)), ref(d), RTOL, f"E={ei.shape[1]}")
+
+
+def test_float_mask_and_nonsymmetric_input():
+    """explain_epoch-style input: already-bidirectional, asymmetric edge list + float mask."""
+    torch.manual_seed(5)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 16, 3, 2, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 16, 3, 2, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    d = make_batch("14", 2)
+    ei = torch.cat([d.edge_index, d.edge_index.flip(0)[:, :25]], dim=1)   # first edge has its reverse; others may not
+    d.edge_index, d.edge_attr = ei, torch.randn(ei.shape[1], 2)
+    d.pred_mask = torch.rand(d.x.shape)                                    # arbitrary float mask
+    out_ref = ref(d)
+    out_ref.sum().backward()
+    dd = d.to(DEV)
+    out = m(dd)
+    assert_close(out, out_ref, RTOL, "out")
+    out.sum().backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, 2 * RTOL, f"grad.{k}")
+
+
+def test_forward_does_not_mutate_data_and_is_deterministic():
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).to(DEV).eval()
+    d = make_batch("118", 8).to(DEV)
+    before = {k: getattr(d, k).clone() for k in d.keys()}
+    a = m(d)
+    b = m(d)
+    assert torch.equal(a, b)                                # atomics-free segmented sums: bitwise reproducible
+    for k, v in before.items():
+        assert torch.equal(getattr(d, k), v), k
+
+
+def test_dropout_statistics_and_gradient_mask():
+    """Train-mode check is statistical (torch's CPU bernoulli stream cannot be reproduced)."""
+    torch.manual_seed(0)
+    p = 0.2
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 2, 3, p).to(DEV)
+    m.seed_dropout(123)
+    d = make_batch("118", 16).to(DEV)
+    m.eval()
+    ref_out = m(d)
+    m.train()
+    o1 = m(d)
+    o2 = m(d)
+    assert not torch.equal(o1, o2)                          # offset advanced
+    m.seed_dropout(123)
+    assert torch.equal(m(d), o1)                            # same seed/offset -> same mask
+    assert not torch.equal(o1, ref_out)
+    # E[train output] ~ eval output within a loose bound (linear last layer after the dropped activations)
+    outs = torch.stack([m(d) for _ in range(64)]).mean(0)
+    rel = (outs - ref_out).abs().mean() / ref_out.abs().mean()
+    assert rel < 0.25, rel
+    # gradients flow and are finite
+    loss = torch.nn.MSELoss()(m(d), d.y)
+    loss.backward()
+    assert all(torch.isfinite(q.grad).all() for q in m.parameters())
