@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""bench.py -- graphs/sec of the MaskEmbdMultiMPN hot path on MI355X (BASELINE.json's metric).
+
+One "step" = one pass of the hot path over one batch already resident in HBM: forward, MSELoss, backward,
+(DP: one flat-buffer gradient all-reduce) and the AdamW update -- the per-batch body of the reference's
+train_epoch (utils/training.py:55-77) minus the host->device copy and the loss.item() sync.  Default workload:
+case118v2 (118 buses / 186 branches, synthetic topology per SURVEY.md 8d), batch 128 per GPU, standard.json
+(H=129, L=4, K=3, dropout 0.2), fp32, weak scaling across ranks.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  Besides the contract's keys it carries
+  roofline     : dominant kernel class, algorithmic bytes|flops per launch / HIP-event launch duration
+  cpu_baseline : the CPU oracle (oracle/ref_cpu.py, kind "port") timed on this box's host cores, bounded sample
+  kernels      : per-kernel-class table behind `roofline` (count per step, avg us, achieved, fraction of peak)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12        # B/s, MI355X spec (MI355X_MICROARCH.md; ~6.3e12 achievable)
+MFMA_F32_PEAK = 157.3e12  # FLOP/s, v_mfma_f32_16x16x4_f32 (no TF32/xf32 on gfx950)
+CONFIGS = {"standard": (129, 4, 3), "wide": (129, 6, 6), "small": (64, 2, 3), "large": (512, 5, 3)}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--case", default="118v2")
+    ap.add_argument("--batch", type=int, default=128, help="graphs per GPU")
+    ap.add_argument("--config", default="standard", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="train", choices=["train", "infer"])
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--hub-frac", type=float, default=0.0)
+    return ap.parse_args()
+
+
+def alg_bytes(n, e, h, fe):
+    """Algorithmic bytes per launch of the gather/segment-sum kernel classes (4-byte elements and indices; logical
+    inputs once, one gathered row per directed edge, output once -- the convention of SURVEY.md 8d)."""
+    return {
+        "hop_norm": 4.0 * (e * h + e + n * h + (n + 1)),                          # B_sa(H)
+        "scatter_add": 4.0 * (e * h + e + n * h + (n + 1)),
+        "edge_fwd": 4.0 * (n * h + e * h + e * fe + e + (n + 1) + n * h),
+        "edge_bwd_dst": 4.0 * (2 * n * h + e * h + e * fe + e + (n + 1) + n * h),
+        "edge_bwd_src": 4.0 * (n * h + 2 * e * h + e * fe + e + (n + 1) + n * h),
+    }
+
+
+def b_fwd(n, e, h, L, K, f0=4, fo=4, fe=2):
+    """B_fwd = B_EA(F0->H) + (L-2) B_EA(H->H) + B_EA(H->Fo) + (L-1) B_TAG + B_mask."""
+    b_ea = lambda fi, fo_: 4.0 * (n * fi + e * fi + e * fe + e + (n + 1) + n * fo_)
+    b_tag = K * 4.0 * (e * h + e + n * h + (n + 1)) + 4.0 * n * (h + h)
+    return b_ea(f0, h) + (L - 2) * b_ea(h, h) + b_ea(h, fo) + (L - 1) * b_tag + 48.0 * n
+
+
+def cpu_baseline(args, cfg, data_cpu, seconds):
+    from oracle import ref_cpu
+    h, L, K = cfg
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(1234)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, h, L, K, 0.2)
+    B = args.batch
+    if args.mode == "train":
+        ref.train()
+        opt = torch.optim.AdamW(ref.parameters(), lr=1e-3)
+        step = lambda: ref_cpu.train_step(ref, data_cpu, opt)
+    else:
+        ref.eval()
+
+        def step():
+            with torch.no_grad():
+                ref(data_cpu)
+    step()                                            # warm-up
+    t0, n = time.perf_counter(), 0
+    while True:
+        step()
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= seconds or n >= 50:
+            break
+    return {"value": round(B * n / dt, 2), "unit": "graphs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} {args.mode} steps of the same workload (case{args.case} batch={B}, {args.config}) on the "
+                      f"pure-torch CPU restatement of the reference dataflow, {dt:.1f} s, torch threads={cores}",
+            "ms_per_step": round(1e3 * dt / n, 2)}
+
+
+def main():
+    args = parse()
+    from poweflownet_amd import _lib as L
+    from poweflownet_amd import dp
+    from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+    from poweflownet_amd.synth import CASES, make_batch
+
+    rank, local_rank, world = dp.init_from_env()
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a HIP device (poweflownet_amd has no CPU fallback)")
+    if world != args.gpus and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    dev = torch.device("cuda", local_rank)
+    h, Lg, K = CONFIGS[args.config]
+    torch.manual_seed(1234)                           # train.py:70 -> identical replicas on every rank
+    model = MaskEmbdMultiMPN(4, 2, 4, h, Lg, K, 0.2).to(dev)
+    model.seed_dropout(1234 + rank)
+    data_cpu = make_batch(args.case, args.batch, seed=rank, hub_frac=args.hub_frac)
+    data = data_cpu.to(dev)
+    n_nodes = data.x.shape[0]
+    train = args.mode == "train"
+    loss_fn = torch.nn.MSELoss()
+    loss_box = [None]
+
+    if train:
+        model.train()
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, foreach=True)
+
+        def fwd_bwd():
+            opt.zero_grad(set_to_none=True)
+            loss = loss_fn(model(data), data.y)
+            loss.backward()
+            loss_box[0] = loss
+
+        def step_eager():
+            fwd_bwd()
+            dp.allreduce_gradients(model)
+            opt.step()
+    else:
+        model.eval()
+
+        def step_eager():
+            with torch.no_grad():
+                loss_box[0] = model(data)
+
+    # ---- warm-up on a side stream (builds the topology cache, autotunes nothing, primes the allocator)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            step_eager()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    directed, e_eff = model._graphs._graph.info()
+
+    use_graph = not args.no_graph
+    if use_graph:
+        if train:
+            opt.zero_grad(set_to_none=True)
+            g_fb = torch.cuda.CUDAGraph()
+            if world == 1:
+                with torch.cuda.graph(g_fb):
+                    fwd_bwd()
+                    opt.step()
+                step = g_fb.replay
+            else:
+                g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb):
+                    fwd_bwd()
+                with torch.cuda.graph(g_opt):
+                    opt.step()
+
+                def step():
+                    g_fb.replay()
+                    dp.allreduce_gradients(model)     # one RCCL all-reduce of the flat gradient buffer
+                    g_opt.replay()
+        else:
+            g_inf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g_inf):
+                step_eager()
+            step = g_inf.replay
+    else:
+        step = step_eager
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = args.batch * world * args.steps / elapsed
+    final = loss_box[0]
+    final_loss = float(final.float().mean().item()) if final is not None else None
+
+    # ---- per-kernel timing pass (eager, HIP events on the launch stream) -> roofline of the dominant kernel
+    roofline, kernels = None, {}
+    if rank == 0 and args.profile_steps > 0:
+        torch.cuda.synchronize()
+        L.profile_report(reset=True)
+        L.profile_enable(True)
+        for _ in range(args.profile_steps):
+            step_eager()
+        torch.cuda.synchronize()
+        L.profile_enable(False)
+        rep = L.profile_report(reset=True)
+        ab = alg_bytes(n_nodes, e_eff, h, 2)
+        for name, r in rep.items():
+            cnt = max(r["count"], 1)
+            avg_s = 1e-3 * r["ms"] / cnt
+            row = {"launches_per_step": r["count"] / args.profile_steps, "avg_us": round(1e6 * avg_s, 3),
+                   "ms_per_step": round(r["ms"] / args.profile_steps, 4)}
+            if name in ab:
+                row.update(bound="hbm", achieved=round(ab[name] / avg_s / 1e9, 1), unit="GB/s",
+                           frac=round(ab[name] / avg_s / HBM_PEAK, 4), per_launch=ab[name])
+            elif r["flops"] > 0:
+                fl = r["flops"] / cnt
+                row.update(bound="mfma", achieved=round(fl / avg_s / 1e12, 2), unit="TFLOP/s",
+                           frac=round(fl / avg_s / MFMA_F32_PEAK, 4), per_launch=fl)
+            kernels[name] = row
+        rated = {k: v for k, v in kernels.items() if "bound" in v}
+        if rated:
+            dom = max(rated, key=lambda k: rated[k]["ms_per_step"])
+            d = rated[dom]
+            roofline = {"kernel": dom, "bound": d["bound"], "achieved": d["achieved"],
+                        "peak": HBM_PEAK / 1e9 if d["bound"] == "hbm" else MFMA_F32_PEAK / 1e12, "unit": d["unit"],
+                        "frac": d["frac"], "traffic": None, "avg_launch_us": d["avg_us"],
+                        "launches_per_step": d["launches_per_step"],
+                        "algorithmic_per_launch": d["per_launch"]}
+            tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tfile):
+                try:
+                    t = json.load(open(tfile)).get(f"{dom}:{args.case}:{args.batch}:{args.mode}")
+                    if t is not None:
+                        roofline["traffic"] = t      # HBM bytes per launch from rocprofv3 --pmc (profiles/)
+                except Exception:
+                    pass
+
+    bytes_step = b_fwd(n_nodes, e_eff, h, Lg, K) * (3.0 if train else 1.0)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, (h, Lg, K), data_cpu, args.cpu_seconds)
+
+    if rank == 0:
+        n_case, e_case = CASES[str(args.case)]
+        out = {
+            "metric": f"graphs/sec {'fwd+bwd (train step incl. AdamW)' if train else 'inference fwd'}, "
+                      f"case{args.case} batch={args.batch}",
+            "value": round(value, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"case{args.case} ({n_case} buses, {e_case} branches, synthetic topology) "
+                                   f"MaskEmbdMultiMPN {args.config}.json (H{h} L{Lg} K{K} dropout 0.2) "
+                                   f"{'training step fwd+MSELoss+bwd+AdamW' if train else 'eval forward'}, fp32",
+                       "graphs_per_gpu": args.batch, "global_batch": args.batch * world, "nodes_per_gpu": n_nodes,
+                       "directed_edges_per_gpu": e_eff, "parallelism": f"dp{world}",
+                       "launch": "eager" if not use_graph else "hipGraph replay", "undirected_on_device": directed},
+            "step_algorithmic_bytes": bytes_step,
+            "step_hbm_frac": round(bytes_step / (1e-3 * ms_per_step) / HBM_PEAK, 4),
+            "final_loss": final_loss,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        if cpu:
+            out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

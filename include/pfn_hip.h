@@ -148,6 +148,13 @@ int pfn_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
                    void* stream);
 
+/* --------------------------------------------------------------------------------------- profiling
+ * Optional HIP-event bracket around every kernel launch (same stream), aggregated per kernel class with
+ * the launch's algorithmic bytes / flops.  Inactive during hipGraph capture.
+ * pfn_profile_report synchronises the device and writes a JSON object into `buf`.                  */
+int pfn_profile_enable(int on);
+int pfn_profile_report(char* buf, size_t buf_bytes, int reset);
+
 #ifdef __cplusplus
 }
 #endif

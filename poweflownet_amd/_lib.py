@@ -22,6 +22,7 @@ SYMBOLS = (
     "pfn_edge_aggr_workspace_bytes", "pfn_edge_aggr_forward", "pfn_edge_aggr_backward",
     "pfn_tag_conv_workspace_bytes", "pfn_tag_conv_forward", "pfn_tag_conv_backward",
     "pfn_scatter_add", "pfn_pad_rows", "pfn_mse_loss", "pfn_adamw_step",
+    "pfn_profile_enable", "pfn_profile_report",
 )
 
 
@@ -70,6 +71,8 @@ def load() -> C.CDLL:
         "pfn_pad_rows": (C.c_int, [p, i64, p, i64, i64, i64, p]),
         "pfn_mse_loss": (C.c_int, [p, p, i64, p, p, p, sz, p]),
         "pfn_adamw_step": (C.c_int, [p, p, p, p, i64, f32, f32, f32, f32, f32, p, p]),
+        "pfn_profile_enable": (C.c_int, [i32]),
+        "pfn_profile_report": (C.c_int, [C.c_char_p, sz, i32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name)          # AttributeError here = header/library mismatch
@@ -124,3 +127,15 @@ def f32c(t: torch.Tensor, what: str) -> torch.Tensor:
     if t.dtype != torch.float32:
         raise RuntimeError(f"poweflownet_amd: {what} must be float32 (got {t.dtype})")
     return t if t.is_contiguous() else t.contiguous()
+
+
+def profile_enable(on: bool) -> None:
+    check(load().pfn_profile_enable(1 if on else 0), "pfn_profile_enable")
+
+
+def profile_report(reset: bool = True) -> dict:
+    """{kernel class: {count, ms, bytes, flops}} from the HIP-event brackets (synchronises)."""
+    import json
+    buf = C.create_string_buffer(1 << 16)
+    check(load().pfn_profile_report(buf, len(buf), 1 if reset else 0), "pfn_profile_report")
+    return json.loads(buf.value.decode())

@@ -76,6 +76,9 @@ int launch_hop(const GraphView& g, const HopArgs& a, hipStream_t s) {
     const int blocks = (int)((items + 255) / 256);
     const int* rp = a.transpose ? g.rowptr_out : g.rowptr_in;
     const int* nb = a.transpose ? g.out_dst : g.in_src;
+    // algorithmic bytes B_sa(F) need the effective edge count, which lives on the device: bench.py applies
+    // SURVEY 8(d)'s formula to the measured duration itself.
+    ProfScope ps(a.normalize ? "hop_norm" : "scatter_add", 0.0, 0.0, s);
     if (a.normalize)
         hop_kernel<true><<<blocks, 256, 0, s>>>(g.n, nchunk, rp, nb, g.dinv, a.x, a.add, a.y, a.gate, a.gate_scale, a.ld);
     else
@@ -136,6 +139,7 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
     const long items = (long)g.n * nchunk;
     const int blocks = (int)((items + 255) / 256);
     const size_t lds = (size_t)a.fe * a.ld * sizeof(float);
+    ProfScope ps("edge_fwd", 0.0, 0.0, s);
     if (a.fe == 2)
         edge_fwd_kernel<2><<<blocks, 256, lds, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q,
                                                     a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe);
@@ -269,10 +273,14 @@ static int launch_edge_bwd_fe(const GraphView& g, const EdgeBwdArgs& a, hipStrea
     const int nchunk = a.ld / 4;
     const int blocks = edge_bwd_dst_blocks(g, a.ld);
     const size_t lds_dst = (size_t)FE * a.ld * sizeof(float) + (size_t)256 * FE * sizeof(float4);
+    {
+    ProfScope ps("edge_bwd_dst", 0.0, 0.0, s);
     edge_bwd_dst_kernel<FE><<<blocks, 256, lds_dst, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P,
                                                          a.Q, a.dS, a.edge_attr, a.w1, a.dP, a.dWe_partial, a.ld, a.h,
                                                          a.fi);
+    }
     PFN_CHECK_LAUNCH();
+    ProfScope ps2("edge_bwd_src", 0.0, 0.0, s);
     edge_bwd_src_kernel<FE><<<blocks, 256, (size_t)FE * a.ld * sizeof(float), s>>>(
         g.n, nchunk, g.e_stored, g.rowptr_out, g.out_dst, g.out_eid, a.P, a.Q, a.dS, a.edge_attr, a.w1, a.dQ, a.ld, a.h,
         a.fi);

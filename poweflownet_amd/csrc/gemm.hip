@@ -144,6 +144,12 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
         }
     }
     dim3 grid((a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, a.ncb * a.ngroup);
+    double flops = 0.0, bytes = (double)a.ngroup * a.M * a.ncols * 4.0;
+    for (int t = 0; t < a.nterm; ++t) {
+        flops += 2.0 * a.M * a.term[t].K * a.ncols;
+        bytes += (double)a.M * a.term[t].K * 4.0;
+    }
+    ProfScope ps("gemm_nt", bytes, flops, s);
     gemm_nt_kernel<<<grid, 256, 0, s>>>(a);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
@@ -361,16 +367,24 @@ int launch_weight_grads(const TnPair* pairs, int npairs, const ColsumJob* jobs, 
         }
         if (ta.nblocks > 0) {
             if (M > 0) {
+                double flops = 0.0, bytes = 0.0;
+                for (int q = 0; q < ta.npairs; ++q) {
+                    flops += 2.0 * (double)M * ta.pair[q].na * ta.pair[q].nb;
+                    bytes += 4.0 * (double)M * (ta.pair[q].na + ta.pair[q].nb);
+                }
+                ProfScope ps("gemm_tn", bytes, flops, s);
                 gemm_tn_kernel<<<dim3(ta.nsplit, ta.nblocks), TN_THREADS, 0, s>>>(ta);
                 PFN_CHECK_LAUNCH();
             } else {
                 ta.nsplit = 0;
             }
+            ProfScope ps("tn_reduce", 0.0, 0.0, s);
             tn_reduce_kernel<<<dim3((CB * CB + 255) / 256, ta.nblocks), 256, 0, s>>>(ta);
             PFN_CHECK_LAUNCH();
         }
     }
     if (njobs > 0 && ca.maxcols > 0) {
+        ProfScope ps("colsum", 0.0, 0.0, s);
         if (M > 0) {
             colsum_kernel<<<dim3(ca.nsplit, njobs), 256, 0, s>>>(ca);
             PFN_CHECK_LAUNCH();

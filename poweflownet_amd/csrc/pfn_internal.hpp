@@ -32,6 +32,15 @@ void set_error(const char* fmt, ...);
         if (rc__ != PFN_OK) return rc__; \
     } while (0)
 
+// RAII event bracket around one kernel launch (prof.hip); `bytes`/`flops` are the ALGORITHMIC figures of
+// SURVEY.md 8(d) for that launch, so bench.py can turn measured durations into roofline fractions.
+struct ProfScope {
+    ProfScope(const char* name, double bytes, double flops, hipStream_t s);
+    ~ProfScope();
+    long idx_;
+    hipStream_t s_;
+};
+
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 static inline int ld_of(int f) { return (int)round_up(f, 4); }
 

@@ -1,0 +1,101 @@
+// Optional per-kernel timing with HIP events on the launching stream (bench.py's live roofline measurement).
+// Off by default; never active while the stream is being captured into a hipGraph.
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "pfn_internal.hpp"
+
+namespace pfn {
+
+struct ProfRec {
+    const char* name;
+    hipEvent_t a, b;
+    double bytes, flops;
+};
+static std::mutex g_mu;
+static bool g_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_pool;
+constexpr size_t kMaxRecs = 1 << 17;
+
+ProfScope::ProfScope(const char* name, double bytes, double flops, hipStream_t s) : idx_(-1), s_(s) {
+    if (!g_on) return;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_recs.size() >= kMaxRecs) return;
+    ProfRec r{name, nullptr, nullptr, bytes, flops};
+    if (!g_pool.empty()) {
+        r.a = g_pool.back().first;
+        r.b = g_pool.back().second;
+        g_pool.pop_back();
+    } else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+        return;
+    }
+    (void)hipEventRecord(r.a, s);
+    idx_ = (long)g_recs.size();
+    g_recs.push_back(r);
+}
+ProfScope::~ProfScope() {
+    if (idx_ < 0) return;
+    std::lock_guard<std::mutex> lk(g_mu);
+    (void)hipEventRecord(g_recs[idx_].b, s_);
+}
+
+}  // namespace pfn
+
+using namespace pfn;
+
+extern "C" {
+
+int pfn_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_on = on != 0;
+    return PFN_OK;
+}
+
+// JSON object {"kernel": {"count": n, "ms": total_ms, "bytes": total_alg_bytes, "flops": total_flops}, ...}
+int pfn_profile_report(char* buf, size_t n, int reset) {
+    PFN_CHECK_ARG(buf && n > 2, "pfn_profile_report: bad buffer");
+    PFN_CHECK_HIP(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lk(g_mu);
+    struct Agg { long count = 0; double ms = 0, bytes = 0, flops = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& r : g_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            Agg& a = agg[r.name];
+            a.count += 1;
+            a.ms += ms;
+            a.bytes += r.bytes;
+            a.flops += r.flops;
+        }
+    }
+    std::string out = "{";
+    bool first = true;
+    for (auto& kv : agg) {
+        char line[256];
+        snprintf(line, sizeof(line), "%s\"%s\": {\"count\": %ld, \"ms\": %.6f, \"bytes\": %.1f, \"flops\": %.1f}",
+                 first ? "" : ", ", kv.first.c_str(), kv.second.count, kv.second.ms, kv.second.bytes, kv.second.flops);
+        out += line;
+        first = false;
+    }
+    out += "}";
+    if (reset) {
+        for (auto& r : g_recs) g_pool.emplace_back(r.a, r.b);
+        g_recs.clear();
+    }
+    if (out.size() + 1 > n) {
+        set_error("pfn_profile_report: buffer too small (%zu needed)", out.size() + 1);
+        return PFN_ENOSPACE;
+    }
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return PFN_OK;
+}
+
+}  // extern "C"
