@@ -129,7 +129,8 @@ def main():
 
     if train:
         model.train()
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, foreach=True)
+        from poweflownet_amd.optim import FlatAdamW
+        opt = FlatAdamW(model, lr=1e-3)               # AdamW (train.py:123) as one HIP kernel on the flat buffers
 
         def fwd_bwd():
             opt.zero_grad(set_to_none=True)

@@ -158,13 +158,16 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
 #define PFN_MAX_FE 8
 
 template <int FE>
-__global__ __launch_bounds__(256) void edge_bwd_dst_kernel(int n, int nchunk, int e_stored,
+__global__ __launch_bounds__(256) void edge_bwd_dst_kernel(int n, int nchunk, int bdx, int bdy, int e_stored,
                                                            const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                            const int* __restrict__ eid, const float* __restrict__ P,
                                                            const float* __restrict__ Q, const float* __restrict__ dS,
                                                            const float* __restrict__ ea, const float* __restrict__ w1,
                                                            float* __restrict__ dP, float* __restrict__ dWe_partial,
                                                            int ld, int h, int fi) {
+    // Block = bdx column chunks x bdy rows (bdx * bdy <= 256, lanes run along the columns of one row, then the
+    // next row); a thread keeps ONE column chunk for every row it visits, so the dWe partial sums stay in
+    // registers across the block's whole row range and each block emits a single ordered partial.
     extern __shared__ __attribute__((aligned(16))) float smem[];   // we[FE][ld] | part[256][FE] float4
     float* we = smem;
     float4* part = reinterpret_cast<float4*>(smem + FE * ld);
@@ -174,55 +177,63 @@ __global__ __launch_bounds__(256) void edge_bwd_dst_kernel(int n, int nchunk, in
         we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
     }
     __syncthreads();
-    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = (int)(item / nchunk);
-    const int col = (int)(item - (long)row * nchunk) * 4;
-    float4 dwe[FE];
+    const int ty = threadIdx.x / bdx, tx = threadIdx.x - ty * bdx;
+    const bool active = ty < bdy;
+    for (int c0 = 0; c0 < nchunk; c0 += bdx) {
+        const int c = c0 + tx, col = 4 * c;
+        float4 dwe[FE];
 #pragma unroll
-    for (int f = 0; f < FE; ++f) dwe[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < n) {
-        const float4 p4 = ld4(P + (size_t)row * ld + col);
-        const float4 g4 = ld4(dS + (size_t)row * ld + col);
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        const int beg = rowptr[row], end = rowptr[row + 1];
-        for (int p = beg; p < end; ++p) {
-            const int s = nbr[p];
-            int id = eid[p];
-            id = id >= e_stored ? id - e_stored : id;
-            float4 v = add4(p4, ld4(Q + (size_t)s * ld + col));
-            float a[FE];
+        for (int f = 0; f < FE; ++f) dwe[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active && c < nchunk) {
+            float4 w4[FE];
 #pragma unroll
-            for (int f = 0; f < FE; ++f) {
-                a[f] = ea[(size_t)id * FE + f];
-                v = fma4(a[f], ld4(we + f * ld + col), v);
+            for (int f = 0; f < FE; ++f) w4[f] = ld4(we + f * ld + col);
+            for (int row = blockIdx.x * bdy + ty; row < n; row += gridDim.x * bdy) {
+                const float4 p4 = ld4(P + (size_t)row * ld + col);
+                const float4 g4 = ld4(dS + (size_t)row * ld + col);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int beg = rowptr[row], end = rowptr[row + 1];
+                for (int p = beg; p < end; ++p) {
+                    const int s = nbr[p];
+                    int id = eid[p];
+                    id = id >= e_stored ? id - e_stored : id;
+                    float4 v = add4(p4, ld4(Q + (size_t)s * ld + col));
+                    float a[FE];
+#pragma unroll
+                    for (int f = 0; f < FE; ++f) {
+                        a[f] = ea[(size_t)id * FE + f];
+                        v = fma4(a[f], w4[f], v);
+                    }
+                    float4 dh;
+                    dh.x = v.x > 0.f ? g4.x : 0.f;
+                    dh.y = v.y > 0.f ? g4.y : 0.f;
+                    dh.z = v.z > 0.f ? g4.z : 0.f;
+                    dh.w = v.w > 0.f ? g4.w : 0.f;
+                    acc = add4(acc, dh);
+#pragma unroll
+                    for (int f = 0; f < FE; ++f) dwe[f] = fma4(a[f], dh, dwe[f]);
+                }
+                st4(dP + (size_t)row * ld + col, acc);
             }
-            float4 dh;
-            dh.x = v.x > 0.f ? g4.x : 0.f;
-            dh.y = v.y > 0.f ? g4.y : 0.f;
-            dh.z = v.z > 0.f ? g4.z : 0.f;
-            dh.w = v.w > 0.f ? g4.w : 0.f;
-            acc = add4(acc, dh);
-#pragma unroll
-            for (int f = 0; f < FE; ++f) dwe[f] = fma4(a[f], dh, dwe[f]);
         }
-        st4(dP + (size_t)row * ld + col, acc);
-    }
-    // ordered in-block reduction over the rows this block touched, per column chunk
+        // ordered in-block reduction over the bdy row lanes of each column chunk
+        if (active) {
 #pragma unroll
-    for (int f = 0; f < FE; ++f) part[threadIdx.x * FE + f] = dwe[f];
-    __syncthreads();
-    const long item0 = (long)blockIdx.x * blockDim.x;
-    for (int c = threadIdx.x; c < nchunk; c += blockDim.x) {
-        int t = (int)(((long)c - item0 % nchunk + nchunk) % nchunk);   // first thread of this block on chunk c
-        float4 sum[FE];
-#pragma unroll
-        for (int f = 0; f < FE; ++f) sum[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (; t < (int)blockDim.x; t += nchunk) {
-#pragma unroll
-            for (int f = 0; f < FE; ++f) sum[f] = add4(sum[f], part[t * FE + f]);
+            for (int f = 0; f < FE; ++f) part[threadIdx.x * FE + f] = dwe[f];
         }
+        __syncthreads();
+        if (ty == 0 && c < nchunk) {
+            float4 sum[FE];
 #pragma unroll
-        for (int f = 0; f < FE; ++f) st4(dWe_partial + ((size_t)blockIdx.x * FE + f) * ld + c * 4, sum[f]);
+            for (int f = 0; f < FE; ++f) sum[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int y = 0; y < bdy; ++y) {
+#pragma unroll
+                for (int f = 0; f < FE; ++f) sum[f] = add4(sum[f], part[(y * bdx + tx) * FE + f]);
+            }
+#pragma unroll
+            for (int f = 0; f < FE; ++f) st4(dWe_partial + ((size_t)blockIdx.x * FE + f) * ld + col, sum[f]);
+        }
+        __syncthreads();
     }
 }
 
@@ -263,23 +274,33 @@ __global__ __launch_bounds__(256) void edge_bwd_src_kernel(int n, int nchunk, in
     st4(dQ + (size_t)row * ld + col, acc);
 }
 
+static void dst_block_shape(int ld, int& bdx, int& bdy) {
+    const int nchunk = ld / 4;
+    bdx = nchunk < 256 ? nchunk : 256;
+    bdy = 256 / bdx;
+}
 int edge_bwd_dst_blocks(const GraphView& g, int ld) {
-    const long items = (long)g.n * (ld / 4);
-    return (int)((items + 255) / 256);
+    int bdx, bdy;
+    dst_block_shape(ld, bdx, bdy);
+    const int want = (g.n + bdy - 1) / bdy;
+    return want < 512 ? (want > 0 ? want : 1) : 512;
 }
 
 template <int FE>
 static int launch_edge_bwd_fe(const GraphView& g, const EdgeBwdArgs& a, hipStream_t s) {
     const int nchunk = a.ld / 4;
-    const int blocks = edge_bwd_dst_blocks(g, a.ld);
+    int bdx, bdy;
+    dst_block_shape(a.ld, bdx, bdy);
     const size_t lds_dst = (size_t)FE * a.ld * sizeof(float) + (size_t)256 * FE * sizeof(float4);
     {
-    ProfScope ps("edge_bwd_dst", 0.0, 0.0, s);
-    edge_bwd_dst_kernel<FE><<<blocks, 256, lds_dst, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P,
-                                                         a.Q, a.dS, a.edge_attr, a.w1, a.dP, a.dWe_partial, a.ld, a.h,
-                                                         a.fi);
+        ProfScope ps("edge_bwd_dst", 0.0, 0.0, s);
+        edge_bwd_dst_kernel<FE><<<edge_bwd_dst_blocks(g, a.ld), 256, lds_dst, s>>>(
+            g.n, nchunk, bdx, bdy, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.dS, a.edge_attr, a.w1, a.dP,
+            a.dWe_partial, a.ld, a.h, a.fi);
     }
     PFN_CHECK_LAUNCH();
+    const long items = (long)g.n * nchunk;
+    const int blocks = (int)((items + 255) / 256);
     ProfScope ps2("edge_bwd_src", 0.0, 0.0, s);
     edge_bwd_src_kernel<FE><<<blocks, 256, (size_t)FE * a.ld * sizeof(float), s>>>(
         g.n, nchunk, g.e_stored, g.rowptr_out, g.out_dst, g.out_eid, a.P, a.Q, a.dS, a.edge_attr, a.w1, a.dQ, a.ld, a.h,
@@ -301,20 +322,25 @@ int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t*, hi
     }
 }
 
-// dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered sum over blocks)
+// dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered: 4 interleaved lanes, then a fixed tree)
 __global__ __launch_bounds__(256) void dwe_reduce_kernel(const float* __restrict__ partial, int nblocks, int fe, int ld,
                                                          int h, float* __restrict__ gw1, int ldw, int col0) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= fe * h) return;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
     const int f = i / h, k = i - f * h;
     float acc = 0.f;
-    for (int b = 0; b < nblocks; ++b) acc += partial[((size_t)b * fe + f) * ld + k];
-    gw1[(size_t)k * ldw + col0 + f] = acc;
+    if (i < fe * h)
+        for (int b = ty; b < nblocks; b += 4) acc += partial[((size_t)b * fe + f) * ld + k];
+    red[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && i < fe * h) gw1[(size_t)k * ldw + col0 + f] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
 int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, float* gw1, int ldw, int col0,
                       hipStream_t s) {
-    dwe_reduce_kernel<<<(fe * h + 255) / 256, 256, 0, s>>>(partial, nblocks, fe, ld, h, gw1, ldw, col0);
+    ProfScope ps("dwe_reduce", 0.0, 0.0, s);
+    dwe_reduce_kernel<<<(fe * h + 63) / 64, 256, 0, s>>>(partial, nblocks, fe, ld, h, gw1, ldw, col0);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

@@ -5,15 +5,21 @@
 // products.  All shapes are "tall-skinny": M = nodes (1e4..1e6), K and N <= a few hundred,
 // exact fp32 via v_mfma_f32_16x16x4_f32 (there is no TF32/xf32 on gfx950).
 //
+//  pack    : once per forward, every weight is copied into zero-padded "LDS images" (tiles of <=132 k-rows x
+//            148 floats, one per 144-column block and k chunk, for both orientations W and W^T).  nn.Linear rows
+//            of 129 floats are not 16-byte aligned, so this is what makes the weight stream DMA-able.
 //  gemm_nt : C = sum_t A_t * B_t (+ epilogue).  One wave owns 16 rows x up to 144 columns (9 accumulator
-//            tiles); its A fragment comes straight from global memory as float4 (rows are private to the
-//            wave, so LDS staging would buy nothing), using a k-permutation inside each 16-wide k chunk:
-//            lane group c = lane>>4 supplies k = 16j + 4c + i at MFMA step i, so one 16-byte load feeds four
-//            steps.  The weight tile B (shared by the 4 waves of a block) is staged through LDS with a row
-//            stride of 148 floats (= 4 mod 8), which makes the permuted B fragment reads bank-conflict free.
+//            tiles).  A whole k unit of B (<= 132 x 148 floats = 76 KiB) is resident in LDS, filled by
+//            global_load_lds (16 B/lane, no VGPR round trip) into the other half of a 2 x 77 KiB ring while
+//            the current unit is being multiplied; the wave's A fragment for a unit (9 x float4 per lane,
+//            straight from global: rows are private to the wave) is prefetched one unit ahead.  Inside a
+//            16-wide k chunk lane group c = lane>>4 supplies k = 16j + 4c + i at MFMA step i, so one 16-byte
+//            A load feeds four steps; the 148-float B row stride (= 4 mod 8) makes the matching B reads
+//            bank-conflict free.  One barrier per k unit.
 //  gemm_tn : weight gradients dW = dY^T X (reduction over the node dimension), 9 waves x (48 x 48) output
-//            tiles per block, operands staged through LDS as whole rows, split over M and reduced in a
-//            second, ordered pass (deterministic; no atomics).
+//            tiles per block, operands staged through LDS as whole rows with register prefetch of the next
+//            stage, split over M and reduced in a second, ordered pass (deterministic; no atomics).  Bias
+//            gradients ride along as a virtual ones-column of X.
 #include <algorithm>
 
 #include "pfn_internal.hpp"
@@ -22,15 +28,75 @@ namespace pfn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 9;            // 16-column tiles per wave  -> 144 columns per column block
-constexpr int CB = NT * 16;      // 144
-constexpr int BK = 32;           // k rows of B per LDS stage
-constexpr int LDB = CB + 4;      // 148: (4 * LDB) % 32 == 16 -> the 4 lane groups hit disjoint banks
+constexpr int NT = 9;                 // 16-column tiles per wave  -> 144 columns per column block
+constexpr int CB = GEMM_CB;           // 144
+constexpr int LDB = GEMM_LDB;         // 148: (4 * LDB) % 32 == 16 -> the 4 lane groups hit disjoint banks
+constexpr int KC = GEMM_KC;           // 132 k rows per LDS-resident unit
+constexpr int NCHUNK = (KC + 15) / 16;            // 9 sixteen-wide k chunks per unit
+constexpr int BUF_FLOATS = 77 * 256;              // 77 KiB ring slot (>= KC * LDB floats, whole 1 KiB DMA pieces)
 constexpr int ROWS_PER_BLOCK = 64;
 
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float ldsB[2][BK * LDB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ------------------------------------------------------------------------------------------------ pack
+__global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
+    const PackJob jb = a.job[blockIdx.y];
+    const int ncb = (jb.ld_out + CB - 1) / CB;
+    const int K4 = (jb.K + 3) & ~3;
+    const long total = (long)ncb * K4 * LDB;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // tiles are laid out [cb][k chunk][row][LDB]; because every chunk but the last has KC rows, the flat
+        // index decomposes as cb-major, then absolute k row, then column.
+        const int cb = (int)(i / ((long)K4 * LDB));
+        const long rem = i - (long)cb * K4 * LDB;
+        const int k = (int)(rem / LDB), n = (int)(rem - (long)k * LDB);
+        const int gn = cb * CB + n;
+        float v = 0.f;
+        if (k < jb.K && n < CB && gn < jb.ncols)
+            v = jb.trans ? jb.src[(size_t)(jb.wn0 + gn) * jb.ldw + jb.wk0 + k] : jb.src[(size_t)(jb.wk0 + k) * jb.ldw + jb.wn0 + gn];
+        jb.dst[i] = v;
+    }
+}
+
+size_t packed_floats(int K, int ld_out) {
+    const int ncb = (ld_out + CB - 1) / CB;
+    const int K4 = (K + 3) & ~3;
+    return (size_t)round_up((int64_t)ncb * K4 * LDB, 256);   // whole KiB: DMA pieces never run off the allocation
+}
+
+int launch_pack(const PackJob* jobs, int njobs, hipStream_t s) {
+    for (int j0 = 0; j0 < njobs; j0 += PACK_MAX_JOBS) {
+        PackArgs a;
+        a.njobs = std::min(PACK_MAX_JOBS, njobs - j0);
+        long biggest = 0;
+        for (int j = 0; j < a.njobs; ++j) {
+            a.job[j] = jobs[j0 + j];
+            biggest = std::max<long>(biggest, (long)packed_floats(jobs[j0 + j].K, jobs[j0 + j].ld_out));
+        }
+        const int bx = (int)std::min<long>(std::max<long>(1, (biggest + 255) / 256), 64);
+        ProfScope ps("pack_weights", 0.0, 0.0, s);
+        pack_weights_kernel<<<dim3(bx, a.njobs), 256, 0, s>>>(a);
+        PFN_CHECK_LAUNCH();
+    }
+    return PFN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------- NT
+__device__ __forceinline__ void dma_unit(const float* __restrict__ src, float* lds_dst, int nbytes, int wave, int lane) {
+    // 1 KiB pieces, round-robin over the 4 waves; the last piece is clamped to the tile's final 16 bytes for the
+    // lanes that would run past it (their LDS bytes land in the slot's unused tail).
+    const int npieces = (nbytes + 1023) >> 10;
+    const char* base = reinterpret_cast<const char*>(src);
+    for (int p = wave; p < npieces; p += 4) {
+        int off = (p << 10) + lane * 16;
+        off = off < nbytes ? off : nbytes - 16;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                         (__attribute__((address_space(3))) void*)(lds_dst + (p << 8)), 16, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(256, 1) void gemm_nt_kernel(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF_FLOATS
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, c = lane >> 4;
     const int group = blockIdx.y / a.ncb, cb = blockIdx.y - group * a.ncb;
     const int n0 = cb * CB;
@@ -44,54 +110,78 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int stage = 0;
-    for (int ti = 0; ti < a.nterm; ++ti) {
-        const GemmTerm tm = a.term[ti];
-        if (tm.group != group) continue;
-        const float* Arow = tm.A + (size_t)arow * tm.lda;
+    // ---- unit iterator over (term of this group, k chunk)
+    int ti = -1, kc = 0, nkc = 0;
+    auto next_unit = [&](int& o_ti, int& o_kc) -> bool {
+        int t2 = ti, k2 = kc + 1;
+        if (t2 < 0 || k2 >= nkc) {
+            k2 = 0;
+            do { ++t2; } while (t2 < a.nterm && a.term[t2].group != group);
+            if (t2 >= a.nterm) return false;
+        }
+        o_ti = t2;
+        o_kc = k2;
+        return true;
+    };
+    auto unit_rows = [&](int t2, int k2) { const int K4 = (a.term[t2].K + 3) & ~3; return min(KC, K4 - k2 * KC); };
+    auto issue = [&](int t2, int k2, float4 (&areg)[NCHUNK], float* slot) {
+        const GemmTerm& tm = a.term[t2];
         const int K4 = (tm.K + 3) & ~3;
-        for (int k0 = 0; k0 < tm.K; k0 += BK, ++stage) {
-            float* B = ldsB[stage & 1];
-            // ---- stage the weight tile: rows k0..k0+31, columns n0..n0+143 (zero outside the weight)
-            if (tm.trans) {
-                for (int i = tid; i < BK * CB; i += 256) {
-                    const int k = i & (BK - 1), n = i >> 5;
-                    const int gk = k0 + k, gn = n0 + n;
-                    B[k * LDB + n] = (gk < tm.K && gn < a.ncols) ? tm.W[(size_t)(tm.wn0 + gn) * tm.ldw + tm.wk0 + gk] : 0.f;
-                }
-            } else {
-                for (int i = tid; i < BK * CB; i += 256) {
-                    const int k = i / CB, n = i - k * CB;
-                    const int gk = k0 + k, gn = n0 + n;
-                    B[k * LDB + n] = (gk < tm.K && gn < a.ncols) ? tm.W[(size_t)(tm.wk0 + gk) * tm.ldw + tm.wn0 + gn] : 0.f;
-                }
-            }
-            // ---- this wave's A fragment for the stage: two 16-wide k chunks, 16 B per lane each
-            float4 a4[2];
+        const int rows = min(KC, K4 - k2 * KC);
+        const float* tile = tm.Bp + ((size_t)cb * K4 + (size_t)k2 * KC) * LDB;
+        dma_unit(tile, slot, rows * LDB * 4, wave, lane);
+        const float* Arow = tm.A + (size_t)arow * tm.lda + k2 * KC;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int kk = k0 + 16 * j + 4 * c;
-                a4[j] = (arow_ok && kk < K4) ? *reinterpret_cast<const float4*>(Arow + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-            __syncthreads();
-            const float* Bl = B + (4 * c) * LDB + r;
+        for (int j = 0; j < NCHUNK; ++j) {
+            const int kk = 16 * j + 4 * c;
+            areg[j] = (arow_ok && kk < rows) ? *reinterpret_cast<const float4*>(Arow + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+
+    float4 a_cur[NCHUNK], a_nxt[NCHUNK];
+    int cur_t, cur_k;
+    bool have = next_unit(cur_t, cur_k);
+    if (have) {
+        ti = cur_t; kc = cur_k; nkc = (((a.term[ti].K + 3) & ~3) + KC - 1) / KC;
+        issue(cur_t, cur_k, a_cur, lds);
+    }
+    __syncthreads();   // waits for the DMA (vmcnt) and publishes the slot
+    int slot = 0;
+    while (have) {
+        int nt_, nk_;
+        const bool more = next_unit(nt_, nk_);
+        if (more) issue(nt_, nk_, a_nxt, lds + (slot ^ 1) * BUF_FLOATS);
+        // ---- multiply the resident unit
+        const int rows = unit_rows(cur_t, cur_k);
+        const int kvalid = a.term[cur_t].K - cur_k * KC;   // real (unpadded) k's left in this term
+        const float* Bl = lds + slot * BUF_FLOATS + (4 * c) * LDB + r;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const float av[4] = {a4[j].x, a4[j].y, a4[j].z, a4[j].w};
+        for (int j = 0; j < NCHUNK; ++j) {
+            const float av[4] = {a_cur[j].x, a_cur[j].y, a_cur[j].z, a_cur[j].w};
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (k0 + 16 * j + i < tm.K) {   // block-uniform: skip MFMA steps that only see zero padding
+            for (int i = 0; i < 4; ++i) {
+                if (16 * j + i < kvalid) {                 // block-uniform: skip steps that only see zero padding
+                    const bool lane_in = 16 * j + 4 * c + i < rows;   // beyond the unit the slot holds stale bytes
 #pragma unroll
-                        for (int t = 0; t < NT; ++t) {
-                            if (t < ntile) {
-                                const float b = Bl[(16 * j + i) * LDB + 16 * t];
-                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b, acc[t], 0, 0, 0);
-                            }
+                    for (int t = 0; t < NT; ++t) {
+                        if (t < ntile) {
+                            float b = Bl[(16 * j + i) * LDB + 16 * t];
+                            b = lane_in ? b : 0.f;
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b, acc[t], 0, 0, 0);
                         }
                     }
                 }
             }
         }
+        __syncthreads();   // next unit landed (vmcnt(0) precedes the barrier) and this slot is free again
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NCHUNK; ++j) a_cur[j] = a_nxt[j];
+            ti = nt_; kc = nk_; nkc = (((a.term[ti].K + 3) & ~3) + KC - 1) / KC;
+            cur_t = nt_; cur_k = nk_;
+            slot ^= 1;
+        }
+        have = more;
     }
 
     // ---- epilogue.  Lane holds D[row = 4c + reg][col = r] of every tile.
@@ -132,25 +222,35 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmArgs a) {
     }
 }
 
+static bool g_nt_attr_set = false;
+
 int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
     if (a_in.M == 0) return PFN_OK;
     GemmArgs a = a_in;
     a.ncb = (a.ldc + CB - 1) / CB;
+    double flops = 0.0, bytes = (double)a.ngroup * a.M * a.ncols * 4.0;
     for (int t = 0; t < a.nterm; ++t) {
         if (a.term[t].lda % 4 != 0 || a.term[t].lda < ((a.term[t].K + 3) & ~3)) {
             set_error("gemm_nt: operand row stride %d must be a multiple of 4 and >= roundup(K=%d, 4)", a.term[t].lda,
                       a.term[t].K);
             return PFN_EINVAL;
         }
-    }
-    dim3 grid((a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, a.ncb * a.ngroup);
-    double flops = 0.0, bytes = (double)a.ngroup * a.M * a.ncols * 4.0;
-    for (int t = 0; t < a.nterm; ++t) {
+        if (a.term[t].Bp == nullptr) {
+            set_error("gemm_nt: term %d has no packed weight", t);
+            return PFN_EINVAL;
+        }
         flops += 2.0 * a.M * a.term[t].K * a.ncols;
         bytes += (double)a.M * a.term[t].K * 4.0;
     }
+    const size_t lds_bytes = 2 * BUF_FLOATS * sizeof(float);
+    if (!g_nt_attr_set) {
+        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        g_nt_attr_set = true;
+    }
+    dim3 grid((a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, a.ncb * a.ngroup);
     ProfScope ps("gemm_nt", bytes, flops, s);
-    gemm_nt_kernel<<<grid, 256, 0, s>>>(a);
+    gemm_nt_kernel<<<grid, 256, lds_bytes, s>>>(a);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
@@ -160,15 +260,22 @@ constexpr int TN_MB = 32;          // node rows per LDS stage
 constexpr int TN_LD = CB + 4;      // 148
 constexpr int TN_THREADS = 576;    // 9 waves: 3 x 3 macro tiles of 48 x 48
 constexpr int TN_MAX_PAIRS = 8;
-constexpr int TN_MAX_JOBS = 4;
+constexpr int TN_MAX_BLOCKS = 64;  // output macro blocks (144 x 144) per launch
+constexpr int TN_Q = CB / 4;       // float4 per staged row (36)
 
-constexpr int TN_MAX_BLOCKS = 64;   // output macro blocks (144 x 144) per launch
 struct TnArgs {
     TnPair pair[TN_MAX_PAIRS];
     int npairs, M, rows_per_split, nsplit, nblocks;
     float* partial;   // [nsplit][nblocks][CB*CB]
     unsigned short blk_pair[TN_MAX_BLOCKS], blk_a0[TN_MAX_BLOCKS], blk_b0[TN_MAX_BLOCKS];
 };
+
+// column of the macro block that carries the bias gradient (virtual ones-column), or -1
+__device__ __host__ __forceinline__ int tn_bias_col(const TnPair& pr, int b0) {
+    if (!pr.bias_out) return -1;
+    const int j = pr.nb - b0;              // first column past the real ones
+    return (j >= 0 && j < CB) ? j : -1;
+}
 
 __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs a) {
     __shared__ __attribute__((aligned(16))) float ldsA[TN_MB * TN_LD];
@@ -179,7 +286,9 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs a) {
     const TnPair pr = a.pair[a.blk_pair[by]];
     const int a0 = a.blk_a0[by], b0 = a.blk_b0[by];
     const int wo = wave / 3, wi = wave - 3 * wo;
-    const int na_here = min(CB, pr.na - a0), nb_here = min(CB, pr.nb - b0);
+    const int bcol = tn_bias_col(pr, b0);
+    const int na_here = min(CB, pr.na - a0);
+    const int nb_here = min(CB, pr.nb - b0) + (bcol >= 0 ? 1 : 0);
     const bool wave_active = (48 * wo < na_here) && (48 * wi < nb_here);
     const int lda4 = (pr.na + 3) & ~3, ldb4 = (pr.nb + 3) & ~3;
 
@@ -191,20 +300,42 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs a) {
 
     const int m_beg = blockIdx.x * a.rows_per_split;
     const int m_end = min(a.M, m_beg + a.rows_per_split);
+    // each thread stages two float4 of A and two of B per 32-row stage (32 * 36 = 1152 = 2 * 576)
+    float4 pa[2], pb[2];
+    auto fetch = [&](int m0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = tid + h * TN_THREADS;
+            const int m = i / TN_Q, q = i - m * TN_Q;
+            const int gm = m0 + m;
+            pa[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            pb[h] = pa[h];
+            if (gm < m_end) {
+                if (a0 + 4 * q < lda4) pa[h] = *reinterpret_cast<const float4*>(pr.A + (size_t)gm * pr.lda + a0 + 4 * q);
+                if (b0 + 4 * q < ldb4) pb[h] = *reinterpret_cast<const float4*>(pr.B + (size_t)gm * pr.ldb + b0 + 4 * q);
+                if (bcol >= 0 && (bcol >> 2) == q) {
+                    const float one = pr.bias_rowscale ? pr.bias_rowscale[gm] : 1.0f;
+                    const int bi = bcol & 3;   // selects, not a runtime-indexed store (that would go to scratch)
+                    pb[h].x = bi == 0 ? one : pb[h].x;
+                    pb[h].y = bi == 1 ? one : pb[h].y;
+                    pb[h].z = bi == 2 ? one : pb[h].z;
+                    pb[h].w = bi == 3 ? one : pb[h].w;
+                }
+            }
+        }
+    };
+    if (m_beg < m_end) fetch(m_beg);
     for (int m0 = m_beg; m0 < m_end; m0 += TN_MB) {
         __syncthreads();   // previous stage fully consumed
-        for (int i = tid; i < TN_MB * (CB / 4); i += TN_THREADS) {
-            const int m = i / (CB / 4), q = i - m * (CB / 4);
-            const int gm = m0 + m;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-            if (gm < m_end) {
-                if (a0 + 4 * q < lda4) va = *reinterpret_cast<const float4*>(pr.A + (size_t)gm * pr.lda + a0 + 4 * q);
-                if (b0 + 4 * q < ldb4) vb = *reinterpret_cast<const float4*>(pr.B + (size_t)gm * pr.ldb + b0 + 4 * q);
-            }
-            *reinterpret_cast<float4*>(ldsA + m * TN_LD + 4 * q) = va;
-            *reinterpret_cast<float4*>(ldsB + m * TN_LD + 4 * q) = vb;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int i = tid + h * TN_THREADS;
+            const int m = i / TN_Q, q = i - m * TN_Q;
+            *reinterpret_cast<float4*>(ldsA + m * TN_LD + 4 * q) = pa[h];
+            *reinterpret_cast<float4*>(ldsB + m * TN_LD + 4 * q) = pb[h];
         }
         __syncthreads();
+        if (m0 + TN_MB < m_end) fetch(m0 + TN_MB);   // next stage's loads fly under this stage's MFMAs
         if (wave_active) {
 #pragma unroll
             for (int g = 0; g < TN_MB / 16; ++g) {
@@ -239,108 +370,80 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs a) {
             }
 }
 
-// second stage: ordered sum over splits, scatter into the nn.Linear gradient layout
+// second stage: ordered sum over splits, scatter into the nn.Linear gradient layout (+ bias column)
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const TnArgs a) {
     const int by = blockIdx.y;
     const TnPair pr = a.pair[a.blk_pair[by]];
     const int a0 = a.blk_a0[by], b0 = a.blk_b0[by];
-    const int na_here = min(CB, pr.na - a0), nb_here = min(CB, pr.nb - b0);
+    const int bcol = tn_bias_col(pr, b0);
+    const int na_here = min(CB, pr.na - a0);
+    const int nb_real = min(CB, pr.nb - b0);
+    const int nb_here = nb_real + (bcol >= 0 ? 1 : 0);
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= na_here * nb_here) return;
     const int i = idx / nb_here, j = idx - i * nb_here;
-    float acc = 0.f;
-    for (int sp = 0; sp < a.nsplit; ++sp) acc += a.partial[((size_t)sp * a.nblocks + by) * (CB * CB) + i * CB + j];
-    pr.G[(size_t)(pr.gn0 + a0 + i) * pr.ldg + pr.gk0 + b0 + j] = acc;
+    const float* p = a.partial + (size_t)by * (CB * CB) + i * CB + j;
+    const size_t stride = (size_t)a.nblocks * (CB * CB);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int sp = 0;
+    for (; sp + 4 <= a.nsplit; sp += 4) {
+        s0 += p[(size_t)sp * stride];
+        s1 += p[(size_t)(sp + 1) * stride];
+        s2 += p[(size_t)(sp + 2) * stride];
+        s3 += p[(size_t)(sp + 3) * stride];
+    }
+    for (; sp < a.nsplit; ++sp) s0 += p[(size_t)sp * stride];
+    const float acc = (s0 + s1) + (s2 + s3);
+    if (j < nb_real) pr.G[(size_t)(pr.gn0 + a0 + i) * pr.ldg + pr.gk0 + b0 + j] = acc;
+    else pr.bias_out[a0 + i] = acc;
 }
 
-// column sums (bias gradients), optionally row-weighted: out[n] = sum_m rowscale[m] * A[m][n]
+// fallback column sums for the (rare) case where the bias column has no room in its macro block
 struct ColsumArgs {
-    ColsumJob job[TN_MAX_JOBS];
-    int njobs, M, rows_per_split, nsplit;
-    float* partial;   // [njobs][nsplit][maxcols]
-    int maxcols;
+    const float* A;
+    const float* rowscale;
+    float* out;
+    int lda, ncols, M;
 };
-__global__ __launch_bounds__(256) void colsum_kernel(const ColsumArgs a) {
-    __shared__ float red[4][64];
-    const ColsumJob jb = a.job[blockIdx.y];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int m_beg = blockIdx.x * a.rows_per_split, m_end = min(a.M, m_beg + a.rows_per_split);
-    for (int c0 = 0; c0 < jb.ncols; c0 += 64) {
-        const int col = c0 + tx;
-        float acc = 0.f;
-        if (col < jb.ncols) {
-            for (int m = m_beg + ty; m < m_end; m += 4) {
-                const float v = jb.A[(size_t)m * jb.lda + col];
-                acc += jb.rowscale ? jb.rowscale[m] * v : v;
-            }
-        }
-        red[ty][tx] = acc;
-        __syncthreads();
-        if (ty == 0 && col < jb.ncols)
-            a.partial[((size_t)blockIdx.y * a.nsplit + blockIdx.x) * a.maxcols + col] =
-                (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+__global__ __launch_bounds__(256) void colsum_fallback_kernel(const ColsumArgs a) {
+    __shared__ float red[256];
+    const int col = blockIdx.x;
+    float acc = 0.f;
+    for (int m = threadIdx.x; m < a.M; m += 256) {
+        const float v = a.A[(size_t)m * a.lda + col];
+        acc += a.rowscale ? a.rowscale[m] * v : v;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-}
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const ColsumArgs a) {
-    const ColsumJob jb = a.job[blockIdx.y];
-    const int col = blockIdx.x * blockDim.x + threadIdx.x;
-    if (col >= jb.ncols) return;
-    float acc = 0.f;
-    for (int sp = 0; sp < a.nsplit; ++sp) acc += a.partial[((size_t)blockIdx.y * a.nsplit + sp) * a.maxcols + col];
-    jb.out[col] = acc;
+    if (threadIdx.x == 0) a.out[col] = red[0];
 }
 
-static int tn_nsplit(int64_t M) {
-    int64_t s = (M + 4 * TN_MB - 1) / (4 * TN_MB);   // >= 128 node rows per split
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return (int)s;
+static void tn_split(int64_t M, int nblocks, int& rows_per_split, int& nsplit) {
+    // aim for ~512 resident blocks of 9 waves; at least 4 stages (128 rows) per split
+    int64_t want = std::max<int64_t>(1, 512 / std::max(1, nblocks));
+    int64_t s = std::min<int64_t>(want, (M + 4 * TN_MB - 1) / (4 * TN_MB));
+    s = std::max<int64_t>(1, std::min<int64_t>(s, 128));
+    rows_per_split = (int)round_up((M + s - 1) / s, TN_MB);
+    nsplit = rows_per_split > 0 ? (int)std::max<int64_t>(1, (M + rows_per_split - 1) / rows_per_split) : 1;
 }
-constexpr int COLSUM_SPLIT = 128;
 
 size_t reduce_ws_floats(int64_t M, int max_na, int max_nb, int max_pairs) {
-    (void)max_pairs;
-    const size_t tn = (size_t)tn_nsplit(M) * TN_MAX_BLOCKS * CB * CB;   // one launch's worth of partials
-    const size_t cs = (size_t)TN_MAX_JOBS * COLSUM_SPLIT * (size_t)round_up(std::max(max_na, max_nb), 64);
-    return tn + cs + 1024;
+    (void)M; (void)max_na; (void)max_nb; (void)max_pairs;
+    // nsplit * nblocks <= max(512, 64) macro blocks of partials for every split choice of tn_split
+    return (size_t)(512 + TN_MAX_BLOCKS) * CB * CB + 1024;
 }
 
-int launch_weight_grads(const TnPair* pairs, int npairs, const ColsumJob* jobs, int njobs, int64_t M, ReduceWs ws,
-                        hipStream_t s) {
-    if (njobs > TN_MAX_JOBS) {
-        set_error("launch_weight_grads: too many column-sum jobs (%d)", njobs);
-        return PFN_EINVAL;
-    }
-    const int nsplit0 = tn_nsplit(M);
-    const int rows_per_split = (int)round_up((M + nsplit0 - 1) / nsplit0, TN_MB);
-    const int nsplit = rows_per_split > 0 ? (int)std::max<int64_t>(1, (M + rows_per_split - 1) / rows_per_split) : 1;
-    const size_t tn_floats = (size_t)nsplit * TN_MAX_BLOCKS * CB * CB;
-    ColsumArgs ca;
-    ca.njobs = njobs;
-    ca.M = (int)M;
-    ca.nsplit = (int)std::min<int64_t>(COLSUM_SPLIT, std::max<int64_t>(1, (M + 63) / 64));
-    ca.rows_per_split = (int)((M + ca.nsplit - 1) / ca.nsplit);
-    ca.maxcols = 0;
-    for (int j = 0; j < njobs; ++j) {
-        ca.job[j] = jobs[j];
-        ca.maxcols = std::max(ca.maxcols, jobs[j].ncols);
-    }
-    ca.partial = ws.partial + tn_floats;
-    const size_t need = tn_floats + (size_t)njobs * ca.nsplit * ca.maxcols;
-    if (need > ws.floats) {
-        set_error("launch_weight_grads: reduction workspace %zu < %zu floats", ws.floats, need);
-        return PFN_ENOSPACE;
-    }
-    // pairs are batched so that one launch covers at most TN_MAX_BLOCKS output macro blocks / TN_MAX_PAIRS pairs
+int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s) {
     int p = 0;
     while (p < npairs) {
         TnArgs ta;
         ta.npairs = 0;
         ta.nblocks = 0;
         ta.M = (int)M;
-        ta.rows_per_split = rows_per_split;
-        ta.nsplit = nsplit;
         ta.partial = ws.partial;
         while (p < npairs && ta.npairs < TN_MAX_PAIRS) {
             const TnPair& pr = pairs[p];
@@ -365,34 +468,38 @@ int launch_weight_grads(const TnPair* pairs, int npairs, const ColsumJob* jobs, 
             ta.pair[ta.npairs++] = pr;
             ++p;
         }
-        if (ta.nblocks > 0) {
-            if (M > 0) {
-                double flops = 0.0, bytes = 0.0;
-                for (int q = 0; q < ta.npairs; ++q) {
-                    flops += 2.0 * (double)M * ta.pair[q].na * ta.pair[q].nb;
-                    bytes += 4.0 * (double)M * (ta.pair[q].na + ta.pair[q].nb);
-                }
-                ProfScope ps("gemm_tn", bytes, flops, s);
-                gemm_tn_kernel<<<dim3(ta.nsplit, ta.nblocks), TN_THREADS, 0, s>>>(ta);
-                PFN_CHECK_LAUNCH();
-            } else {
-                ta.nsplit = 0;
-            }
-            ProfScope ps("tn_reduce", 0.0, 0.0, s);
-            tn_reduce_kernel<<<dim3((CB * CB + 255) / 256, ta.nblocks), 256, 0, s>>>(ta);
-            PFN_CHECK_LAUNCH();
+        if (ta.nblocks == 0) continue;
+        tn_split(M, ta.nblocks, ta.rows_per_split, ta.nsplit);
+        if ((size_t)ta.nsplit * ta.nblocks * CB * CB > ws.floats) {
+            set_error("launch_weight_grads: reduction workspace %zu < %zu floats", ws.floats,
+                      (size_t)ta.nsplit * ta.nblocks * CB * CB);
+            return PFN_ENOSPACE;
         }
-    }
-    if (njobs > 0 && ca.maxcols > 0) {
-        ProfScope ps("colsum", 0.0, 0.0, s);
         if (M > 0) {
-            colsum_kernel<<<dim3(ca.nsplit, njobs), 256, 0, s>>>(ca);
+            double flops = 0.0, bytes = 0.0;
+            for (int q = 0; q < ta.npairs; ++q) {
+                flops += 2.0 * (double)M * ta.pair[q].na * ta.pair[q].nb;
+                bytes += 4.0 * (double)M * (ta.pair[q].na + ta.pair[q].nb);
+            }
+            ProfScope ps("gemm_tn", bytes, flops, s);
+            gemm_tn_kernel<<<dim3(ta.nsplit, ta.nblocks), TN_THREADS, 0, s>>>(ta);
             PFN_CHECK_LAUNCH();
         } else {
-            ca.nsplit = 0;
+            ta.nsplit = 0;
         }
-        colsum_reduce_kernel<<<dim3((ca.maxcols + 255) / 256, njobs), 256, 0, s>>>(ca);
-        PFN_CHECK_LAUNCH();
+        {
+            ProfScope ps("tn_reduce", 0.0, 0.0, s);
+            tn_reduce_kernel<<<dim3((CB * (CB + 1) + 255) / 256, ta.nblocks), 256, 0, s>>>(ta);
+            PFN_CHECK_LAUNCH();
+        }
+        for (int q = 0; q < ta.npairs; ++q) {   // bias column without room in its macro block (nb % 144 == 0)
+            const TnPair& pr = ta.pair[q];
+            if (pr.bias_out && pr.nb % CB == 0) {
+                ColsumArgs ca{pr.A, pr.bias_rowscale, pr.bias_out, pr.lda, pr.na, (int)M};
+                colsum_fallback_kernel<<<pr.na, 256, 0, s>>>(ca);
+                PFN_CHECK_LAUNCH();
+            }
+        }
     }
     return PFN_OK;
 }

@@ -25,12 +25,38 @@ static GemmArgs gemm_defaults(int M, int ncols, int ldc) {
     a.bias_group = -1;
     return a;
 }
-static GemmTerm term(const float* A, int lda, int K, const float* W, int ldw, int wk0, int wn0, int trans, int group) {
+static GemmTerm term(const float* A, int lda, int K, const float* Bp, int group) {
     GemmTerm t;
-    t.A = A; t.W = W; t.lda = lda; t.K = K; t.ldw = ldw; t.wk0 = wk0; t.wn0 = wn0; t.trans = trans; t.group = group;
-    t.pad_ = 0;
+    t.A = A; t.Bp = Bp; t.lda = lda; t.K = K; t.group = group; t.pad_ = 0;
     return t;
 }
+static TnPair tn_pair(const float* A, int lda, int na, const float* B, int ldb, int nb, float* G, int ldg, int gk0,
+                      float* bias_out, const float* bias_rowscale) {
+    TnPair p;
+    p.A = A; p.B = B; p.G = G; p.bias_out = bias_out; p.bias_rowscale = bias_rowscale;
+    p.lda = lda; p.ldb = ldb; p.na = na; p.nb = nb; p.ldg = ldg; p.gn0 = 0; p.gk0 = gk0; p.pad_ = 0;
+    return p;
+}
+
+// Collects the weight re-layout jobs of a forward pass (gemm.hip: pack) and hands out the packed addresses.
+// With base == nullptr it only measures.
+struct Packer {
+    float* base;
+    size_t off = 0;
+    std::vector<PackJob> jobs;
+    explicit Packer(float* b) : base(b) {}
+    // B[k][n] = trans ? W[(wn0+n)*ldw + wk0+k] : W[(wk0+k)*ldw + wn0+n],  k < K, n < ncols, for an output of ld_out columns
+    const float* add(const float* W, int ldw, int trans, int wk0, int wn0, int K, int ncols, int ld_out) {
+        float* dst = base ? base + off : nullptr;
+        off += packed_floats(K, ld_out);
+        PackJob j;
+        j.src = W; j.dst = dst; j.ldw = ldw; j.wk0 = wk0; j.wn0 = wn0; j.trans = trans; j.K = K; j.ncols = ncols;
+        j.ld_out = ld_out; j.pad_ = 0;
+        jobs.push_back(j);
+        return dst ? dst : reinterpret_cast<const float*>(0x10);   // non-null sentinel while measuring
+    }
+    int flush(hipStream_t s) { return launch_pack(jobs.data(), (int)jobs.size(), s); }
+};
 
 struct Act {
     int act = ACT_NONE;
@@ -47,19 +73,32 @@ struct Gate {
 // ---------------------------------------------------------------------------------- EdgeAggregation
 struct EaSaved { float *P, *Q, *S; };
 struct EaScratch { float *dS, *dP, *dQ, *dWe; ReduceWs red; };
+struct EaPack { const float *w1i_t, *w1j_t, *w2_t, *w2_d, *w1i_d, *w1j_d; };
+
+static EaPack ea_pack(Packer& pk, int fi, int fe, int h, int fo, const float* w1, const float* w2) {
+    const int ldw1 = 2 * fi + fe, ld = ld_of(h);
+    EaPack p;
+    p.w1i_t = pk.add(w1, ldw1, 1, 0, 0, fi, h, ld);           // x (N x Fi) -> P
+    p.w1j_t = pk.add(w1, ldw1, 1, fi, 0, fi, h, ld);          // x -> Q
+    p.w2_t = pk.add(w2, h, 1, 0, 0, h, fo, ld_of(fo));        // S (N x H) -> out
+    p.w2_d = pk.add(w2, h, 0, 0, 0, fo, h, ld);               // gout (N x Fo) -> dS
+    p.w1i_d = pk.add(w1, ldw1, 0, 0, 0, h, fi, ld_of(fi));    // dP (N x H) -> dx
+    p.w1j_d = pk.add(w1, ldw1, 0, 0, fi, h, fi, ld_of(fi));   // dQ -> dx
+    return p;
+}
 
 static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
-                      const float* w1, const float* b1, const float* w2, const float* b2, float* out, int ldo,
+                      const float* w1, const float* b1, const float* b2, const EaPack& pw, float* out, int ldo,
                       const Act& act, const EaSaved& sv, hipStream_t s) {
-    const int ld = ld_of(h), ldw1 = 2 * fi + fe;
+    const int ld = ld_of(h);
     {   // P = x W1[:, :Fi]^T + b1 ; Q = x W1[:, Fi:2Fi]^T
         GemmArgs a = gemm_defaults(g.n, h, ld);
         a.ngroup = 2;
         a.C[0] = sv.P;
         a.C[1] = sv.Q;
         a.nterm = 2;
-        a.term[0] = term(x, ldx, fi, w1, ldw1, 0, 0, 1, 0);
-        a.term[1] = term(x, ldx, fi, w1, ldw1, fi, 0, 1, 1);
+        a.term[0] = term(x, ldx, fi, pw.w1i_t, 0);
+        a.term[1] = term(x, ldx, fi, pw.w1j_t, 1);
         a.bias = b1;
         a.bias_group = 0;
         PFN_TRY(launch_gemm_nt(a, s));
@@ -72,7 +111,7 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
         GemmArgs a = gemm_defaults(g.n, fo, ldo);
         a.C[0] = out;
         a.nterm = 1;
-        a.term[0] = term(sv.S, ld, h, w2, h, 0, 0, 1, 0);
+        a.term[0] = term(sv.S, ld, h, pw.w2_t, 0);
         a.rowscale = g.deg;
         a.rowbias = b2;
         a.act = act.act;
@@ -85,7 +124,7 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
 }
 
 static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
-                       const float* w1, const float* w2, const float* gout, int ldgo, const Gate& gate, float* gx,
+                       const float* w1, const EaPack& pw, const float* gout, int ldgo, const Gate& gate, float* gx,
                        int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
                        const EaScratch& sc, hipStream_t s) {
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
@@ -93,39 +132,45 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         GemmArgs a = gemm_defaults(g.n, h, ld);
         a.C[0] = sc.dS;
         a.nterm = 1;
-        a.term[0] = term(gout, ldgo, fo, w2, h, 0, 0, 0, 0);
+        a.term[0] = term(gout, ldgo, fo, pw.w2_d, 0);
         PFN_TRY(launch_gemm_nt(a, s));
     }
     EdgeBwdArgs e{sv.P, sv.Q, sc.dS, ea, w1, sc.dP, sc.dQ, sc.dWe, gea, ld, h, fi, fe};
     PFN_TRY(launch_edge_bwd(g, e, nullptr, s));
-    if (g.n > 0) PFN_TRY(launch_dwe_reduce(sc.dWe, edge_bwd_dst_blocks(g, ld), fe, ld, h, gw1, ldw1, 2 * fi, s));
-    else PFN_TRY(launch_dwe_reduce(sc.dWe, 0, fe, ld, h, gw1, ldw1, 2 * fi, s));
+    PFN_TRY(launch_dwe_reduce(sc.dWe, g.n > 0 ? edge_bwd_dst_blocks(g, ld) : 0, fe, ld, h, gw1, ldw1, 2 * fi, s));
     if (gea) PFN_TRY(launch_edge_attr_grad(g, e, s));
     if (gx) {   // dx = dP W1[:, :Fi] + dQ W1[:, Fi:2Fi], gated by the producing layer's activation
         GemmArgs a = gemm_defaults(g.n, fi, ldgx);
         a.C[0] = gx;
         a.nterm = 2;
-        a.term[0] = term(sc.dP, ld, h, w1, ldw1, 0, 0, 0, 0);
-        a.term[1] = term(sc.dQ, ld, h, w1, ldw1, 0, fi, 0, 0);
+        a.term[0] = term(sc.dP, ld, h, pw.w1i_d, 0);
+        a.term[1] = term(sc.dQ, ld, h, pw.w1j_d, 0);
         a.gate = gate.y;
         a.ldg = gate.ld;
         a.gate_scale = gate.scale;
         PFN_TRY(launch_gemm_nt(a, s));
     }
     TnPair pairs[3] = {
-        {gout, sv.S, gw2, ldgo, ld, fo, h, h, 0, 0, 0},
-        {sc.dP, x, gw1, ld, ldx, h, fi, ldw1, 0, 0, 0},
-        {sc.dQ, x, gw1, ld, ldx, h, fi, ldw1, 0, fi, 0},
+        tn_pair(gout, ldgo, fo, sv.S, ld, h, gw2, h, 0, gb2, g.deg),      // dW2 ; db2 = sum_i deg_i gout_i
+        tn_pair(sc.dP, ld, h, x, ldx, fi, gw1, ldw1, 0, gb1, nullptr),    // dW1[:, :Fi] ; db1 = sum_i dP_i
+        tn_pair(sc.dQ, ld, h, x, ldx, fi, gw1, ldw1, fi, nullptr, nullptr),
     };
-    ColsumJob jobs[2] = {{gout, g.deg, gb2, ldgo, fo}, {sc.dP, nullptr, gb1, ld, h}};
-    PFN_TRY(launch_weight_grads(pairs, 3, jobs, 2, g.n, sc.red, s));
-    return PFN_OK;
+    return launch_weight_grads(pairs, 3, g.n, sc.red, s);
 }
 
 // ------------------------------------------------------------------------------------------ TAGConv
-static int tag_forward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx,
-                       const float* const* w, const float* bias, float* out, int ldo, const Act& act, float* xk,
-                       hipStream_t s) {
+struct TagPack { const float* wt[8]; const float* wd[8]; };
+static TagPack tag_pack(Packer& pk, int cin, int cout, int K, const float* const* w) {
+    TagPack p;
+    for (int k = 0; k <= K; ++k) {
+        p.wt[k] = pk.add(w[k], cin, 1, 0, 0, cin, cout, ld_of(cout));   // x^(k) (N x cin) -> out
+        p.wd[k] = pk.add(w[k], cin, 0, 0, 0, cout, cin, ld_of(cin));    // gout (N x cout) -> G_k
+    }
+    return p;
+}
+
+static int tag_forward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
+                       const float* bias, float* out, int ldo, const Act& act, float* xk, hipStream_t s) {
     // xk: K buffers of n * ldx floats holding A_hat^k x, k = 1..K
     const size_t stride = (size_t)g.n * ldx;
     const float* prev = x;
@@ -136,13 +181,8 @@ static int tag_forward(const GraphView& g, int cin, int cout, int K, const float
     }
     GemmArgs a = gemm_defaults(g.n, cout, ldo);
     a.C[0] = out;
-    if (K + 1 > 8) {
-        set_error("TAGConv: K = %d unsupported (max 7)", K);
-        return PFN_EINVAL;
-    }
     a.nterm = K + 1;
-    for (int k = 0; k <= K; ++k)
-        a.term[k] = term(k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, w[k], cin, 0, 0, 1, 0);
+    for (int k = 0; k <= K; ++k) a.term[k] = term(k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, pw.wt[k], 0);
     a.bias = bias;
     a.act = act.act;
     a.p_drop = act.p;
@@ -153,9 +193,9 @@ static int tag_forward(const GraphView& g, int cin, int cout, int K, const float
 
 struct TagScratch { float* G; float *z0, *z1; ReduceWs red; };
 
-static int tag_backward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx,
-                        const float* const* w, const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx,
-                        float* const* gw, float* gbias, const float* xk, const TagScratch& sc, hipStream_t s) {
+static int tag_backward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
+                        const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx, float* const* gw,
+                        float* gbias, const float* xk, const TagScratch& sc, hipStream_t s) {
     const size_t stride = (size_t)g.n * ldx;
     if (gx) {
         if (ldgx != ldx) {
@@ -168,7 +208,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
         a.nterm = K + 1;
         for (int k = 0; k <= K; ++k) {
             a.C[k] = (K == 0) ? gx : sc.G + (size_t)k * stride;
-            a.term[k] = term(gout, ldgo, cout, w[k], cin, 0, 0, 0, k);
+            a.term[k] = term(gout, ldgo, cout, pw.wd[k], k);
         }
         if (K == 0) {
             a.gate = gate.y;
@@ -186,9 +226,9 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
     }
     std::vector<TnPair> pairs;
     for (int k = 0; k <= K; ++k)
-        pairs.push_back({gout, k == 0 ? x : xk + (size_t)(k - 1) * stride, gw[k], ldgo, ldx, cout, cin, cin, 0, 0, 0});
-    ColsumJob job{gout, nullptr, gbias, ldgo, cout};
-    return launch_weight_grads(pairs.data(), (int)pairs.size(), &job, gbias ? 1 : 0, g.n, sc.red, s);
+        pairs.push_back(tn_pair(gout, ldgo, cout, k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, gw[k], cin, 0,
+                                k == 0 ? gbias : nullptr, nullptr));
+    return launch_weight_grads(pairs.data(), (int)pairs.size(), g.n, sc.red, s);
 }
 
 // -------------------------------------------------------------------------------------- whole model
@@ -196,7 +236,8 @@ struct Layout {
     // dims
     int n, e, f0, fe, fo, h, L, K, ld, ld0, ldo, nlayers;
     // forward-saved
-    float *maskf, *me_h, *x0;
+    float *maskf, *me_h, *x0, *packed;
+    size_t packed_floats;
     std::vector<float*> y;       // per layer output (post-activation); last = nullptr (caller's out)
     std::vector<EaSaved> ea;     // per EA layer
     std::vector<float*> xk;      // per TAG layer: K * n * ld
@@ -207,6 +248,36 @@ struct Layout {
     size_t bytes;
 };
 static bool is_ea(int i) { return (i & 1) == 0; }
+
+// packed-weight plan of the whole network (identical walk in forward, which fills it, and backward, which reads it)
+struct ModelPack {
+    std::vector<EaPack> ea;
+    std::vector<TagPack> tag;
+    const float *wa_t, *wb_t, *wb_d;
+};
+static void plan_pack(Packer& pk, int f0, int fe, int fo, int h, int L, int K, const float* const* params,
+                      ModelPack& mp) {
+    const int nlayers = 2 * L - 1;
+    mp.ea.assign(nlayers, EaPack{});
+    mp.tag.assign(nlayers, TagPack{});
+    int pi = 0;
+    for (int i = 0; i < nlayers; ++i) {
+        if (is_ea(i)) {
+            const int fi = i == 0 ? f0 : h, fo_ = (i + 1 == nlayers) ? fo : h;
+            mp.ea[i] = ea_pack(pk, fi, fe, h, fo_, params ? params[pi] : nullptr, params ? params[pi + 2] : nullptr);
+            pi += 4;
+        } else {
+            const float* none[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+            mp.tag[i] = tag_pack(pk, h, h, K, params ? params + pi : none);
+            pi += K + 2;
+        }
+    }
+    const float* wa = params ? params[pi] : nullptr;
+    const float* wb = params ? params[pi + 2] : nullptr;
+    mp.wa_t = pk.add(wa, f0, 1, 0, 0, f0, h, ld_of(h));      // maskf (N x F0) -> me_h
+    mp.wb_t = pk.add(wb, h, 1, 0, 0, h, f0, ld_of(f0));      // me_h (N x H) -> x0
+    mp.wb_d = pk.add(wb, h, 0, 0, 0, f0, h, ld_of(h));       // g (N x F0) -> dh
+}
 
 static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, Layout& lo) {
     PFN_CHECK_ARG(c.n_gnn_layers >= 2, "n_gnn_layers must be >= 2 (L == 1 is shape-broken in the reference)");
@@ -221,6 +292,13 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     lo.nlayers = 2 * lo.L - 1;   // E T E T ... E
     Carver cv(ws);
     const size_t nld = (size_t)n * lo.ld;
+    {
+        Packer measure(nullptr);
+        ModelPack mp;
+        plan_pack(measure, lo.f0, lo.fe, lo.fo, lo.h, lo.L, lo.K, nullptr, mp);
+        lo.packed_floats = measure.off;
+    }
+    lo.packed = cv.take<float>(lo.packed_floats);
     lo.maskf = cv.take<float>((size_t)n * lo.ld0);
     lo.me_h = cv.take<float>(nld);
     lo.x0 = cv.take<float>((size_t)n * lo.ld0);
@@ -243,8 +321,7 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     lo.eas.dS = cv.take<float>(nld);
     lo.eas.dP = cv.take<float>(nld);
     lo.eas.dQ = cv.take<float>(nld);
-    const size_t dwe_blocks = (size_t)((n * (lo.ld / 4) + 255) / 256) + 1;
-    lo.eas.dWe = cv.take<float>(dwe_blocks * lo.fe * lo.ld);
+    lo.eas.dWe = cv.take<float>((size_t)513 * lo.fe * lo.ld);
     lo.tags.G = cv.take<float>(nld * (lo.K + 1));
     lo.tags.z0 = cv.take<float>(nld);
     lo.tags.z1 = cv.take<float>(nld);
@@ -257,14 +334,6 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     return PFN_OK;
 }
 
-// parameter table cursor (order documented in pfn_hip.h)
-struct ParamCursor {
-    const float* const* p;
-    float* const* g;
-    int i = 0;
-    const float* next() { return p[i++]; }
-};
-
 static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
                          const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr, float* out,
                          uint64_t* rng, hipStream_t s) {
@@ -272,13 +341,18 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     PFN_CHECK_ARG(!drop || rng != nullptr, "training with dropout needs rng_state");
     const int nparams = pfn_mpn_num_params(&c);
     const float* const* me = params + (nparams - 4);   // Wa, ba, Wb, bb
+    // every weight -> its packed LDS images (both orientations; backward reuses them)
+    Packer pk(lo.packed);
+    ModelPack mp;
+    plan_pack(pk, lo.f0, lo.fe, lo.fo, lo.h, lo.L, lo.K, params, mp);
+    PFN_TRY(pk.flush(s));
     // mask_embd(mask) + x   (networks/MPN.py:533,:537)
     PFN_TRY(launch_mask_to_float(pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0, s));
     {
         GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
         a.C[0] = lo.me_h;
         a.nterm = 1;
-        a.term[0] = term(lo.maskf, lo.ld0, lo.f0, me[0], lo.f0, 0, 0, 1, 0);
+        a.term[0] = term(lo.maskf, lo.ld0, lo.f0, mp.wa_t, 0);
         a.bias = me[1];
         a.act = ACT_RELU;
         PFN_TRY(launch_gemm_nt(a, s));
@@ -287,7 +361,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         GemmArgs a = gemm_defaults(lo.n, lo.f0, lo.ld0);
         a.C[0] = lo.x0;
         a.nterm = 1;
-        a.term[0] = term(lo.me_h, lo.ld, lo.h, me[2], lo.h, 0, 0, 1, 0);
+        a.term[0] = term(lo.me_h, lo.ld, lo.h, mp.wb_t, 0);
         a.bias = me[3];
         a.resid = x;
         a.ldr = lo.ld0;
@@ -308,12 +382,12 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         const int ldy = last ? lo.ldo : lo.ld;
         if (is_ea(i)) {
             const int fo = last ? lo.fo : lo.h;
-            PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
-                               params[pi + 3], y, ldy, act, lo.ea[i], s));
+            PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 3],
+                               mp.ea[i], y, ldy, act, lo.ea[i], s));
             pi += 4;
             fcur = fo;
         } else {
-            PFN_TRY(tag_forward(g, lo.h, lo.h, lo.K, cur, ldc, params + pi, params[pi + lo.K + 1], y, ldy, act, lo.xk[i], s));
+            PFN_TRY(tag_forward(g, lo.h, lo.h, lo.K, cur, ldc, mp.tag[i], params[pi + lo.K + 1], y, ldy, act, lo.xk[i], s));
             pi += lo.K + 2;
         }
         cur = y;
@@ -326,10 +400,13 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
 static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
                           float* const* grads, const float* x, const float* edge_attr, const float* gout, float* gx,
                           float* gea, hipStream_t s) {
+    (void)x;
     const bool drop = c.training && c.dropout_rate > 0.f;
     const float gscale = drop ? 1.f / (1.f - c.dropout_rate) : 1.f;
     const int nparams = pfn_mpn_num_params(&c);
-    // parameter offsets per layer
+    Packer pk(lo.packed);                      // same walk as forward: addresses only, the images are already filled
+    ModelPack mp;
+    plan_pack(pk, lo.f0, lo.fe, lo.fo, lo.h, lo.L, lo.K, params, mp);
     std::vector<int> poff(lo.nlayers);
     int pi = 0;
     for (int i = 0; i < lo.nlayers; ++i) {
@@ -353,34 +430,31 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         const int p0 = poff[i];
         if (is_ea(i)) {
             const int fi = i == 0 ? lo.f0 : lo.h, fo = last ? lo.fo : lo.h;
-            PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], params[p0 + 2], gcur, ldg, gate,
-                                gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2], grads[p0 + 3], gea, lo.ea[i],
-                                lo.eas, s));
+            PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], mp.ea[i], gcur, ldg, gate, gnext, ldi,
+                                grads[p0], grads[p0 + 1], grads[p0 + 2], grads[p0 + 3], gea, lo.ea[i], lo.eas, s));
         } else {
-            PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, params + p0, gcur, ldg, gate, gnext, ldi, grads + p0,
+            PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
                                  grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s));
         }
         gcur = gnext;
         ldg = ldi;
     }
     // mask_embd backward: x0 = me_h Wb^T + bb + x ; me_h = relu(maskf Wa^T + ba)
-    const float* const* me = params + (nparams - 4);
     float* const* gme = grads + (nparams - 4);
     {
         GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
         a.C[0] = lo.dh;
         a.nterm = 1;
-        a.term[0] = term(gcur, lo.ld0, lo.f0, me[2], lo.h, 0, 0, 0, 0);
+        a.term[0] = term(gcur, lo.ld0, lo.f0, mp.wb_d, 0);
         a.gate = lo.me_h;
         a.ldg = lo.ld;
         PFN_TRY(launch_gemm_nt(a, s));
     }
     TnPair pairs[2] = {
-        {gcur, lo.me_h, gme[2], lo.ld0, lo.ld, lo.f0, lo.h, lo.h, 0, 0, 0},
-        {lo.dh, lo.maskf, gme[0], lo.ld, lo.ld0, lo.h, lo.f0, lo.f0, 0, 0, 0},
+        tn_pair(gcur, lo.ld0, lo.f0, lo.me_h, lo.ld, lo.h, gme[2], lo.h, 0, gme[3], nullptr),     // dWb, dbb
+        tn_pair(lo.dh, lo.ld, lo.h, lo.maskf, lo.ld0, lo.f0, gme[0], lo.f0, 0, gme[1], nullptr),  // dWa, dba
     };
-    ColsumJob jobs[2] = {{gcur, nullptr, gme[3], lo.ld0, lo.f0}, {lo.dh, nullptr, gme[1], lo.ld, lo.h}};
-    PFN_TRY(launch_weight_grads(pairs, 2, jobs, 2, lo.n, lo.eas.red, s));
+    PFN_TRY(launch_weight_grads(pairs, 2, lo.n, lo.eas.red, s));
     if (gx) PFN_CHECK_HIP(hipMemcpyAsync(gx, gcur, (size_t)lo.n * lo.ld0 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return PFN_OK;
 }
@@ -498,19 +572,24 @@ int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_
 }
 
 // ------------------------------------------------------------------------------------- single layers
-struct EaLayerWs { EaSaved sv; EaScratch sc; size_t bytes; };
+struct EaLayerWs { EaSaved sv; EaScratch sc; float* packed; size_t bytes; };
 static EaLayerWs ea_layer_ws(void* ws, int64_t n, int fi, int fe, int h, int fo) {
     Carver cv(ws);
     EaLayerWs w;
     const int ld = ld_of(h);
     const size_t nld = (size_t)n * ld;
+    {
+        Packer measure(nullptr);
+        ea_pack(measure, fi, fe, h, fo, nullptr, nullptr);
+        w.packed = cv.take<float>(measure.off);
+    }
     w.sv.P = cv.take<float>(nld);
     w.sv.Q = cv.take<float>(nld);
     w.sv.S = cv.take<float>(nld);
     w.sc.dS = cv.take<float>(nld);
     w.sc.dP = cv.take<float>(nld);
     w.sc.dQ = cv.take<float>(nld);
-    w.sc.dWe = cv.take<float>(((size_t)((n * (ld / 4) + 255) / 256) + 1) * fe * ld);
+    w.sc.dWe = cv.take<float>((size_t)513 * fe * ld);
     const int maxf = std::max(std::max(h, fi), fo);
     w.sc.red.floats = reduce_ws_floats(n, maxf, maxf, 3);
     w.sc.red.partial = cv.take<float>(w.sc.red.floats);
@@ -535,8 +614,11 @@ int pfn_edge_aggr_forward(const void* gws, int64_t n, int64_t e, int fi, int fe,
         return PFN_ENOSPACE;
     }
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
-    return ea_forward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, b1, w2, b2, out, (int)ldo, Act{}, w.sv,
-                      static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Packer pk(w.packed);
+    const EaPack pw = ea_pack(pk, fi, fe, h, fo, w1, w2);
+    PFN_TRY(pk.flush(s));
+    return ea_forward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, b1, b2, pw, out, (int)ldo, Act{}, w.sv, s);
 }
 
 int pfn_edge_aggr_backward(const void* gws, int64_t n, int64_t e, int fi, int fe, int h, int fo, const float* x,
@@ -556,15 +638,23 @@ int pfn_edge_aggr_backward(const void* gws, int64_t n, int64_t e, int fi, int fe
     hipStream_t s = static_cast<hipStream_t>(stream);
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
     if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)e * fe * sizeof(float), s));
-    return ea_backward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, w2, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gw1, gb1, gw2,
+    Packer pk(w.packed);                       // images were filled by the forward call on the same workspace
+    const EaPack pw = ea_pack(pk, fi, fe, h, fo, w1, w2);
+    return ea_backward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, pw, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gw1, gb1, gw2,
                        gb2, gea, w.sv, w.sc, s);
 }
 
-struct TagLayerWs { float* xk; TagScratch sc; size_t bytes; };
+struct TagLayerWs { float* xk; TagScratch sc; float* packed; size_t bytes; };
 static TagLayerWs tag_layer_ws(void* ws, int64_t n, int cin, int cout, int K) {
     Carver cv(ws);
     TagLayerWs w;
     const size_t nld = (size_t)n * ld_of(cin);
+    {
+        Packer measure(nullptr);
+        const float* none[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        tag_pack(measure, cin, cout, K, none);
+        w.packed = cv.take<float>(measure.off);
+    }
     w.xk = cv.take<float>(nld * std::max(1, K));
     w.sc.G = cv.take<float>(nld * (K + 1));
     w.sc.z0 = cv.take<float>(nld);
@@ -593,8 +683,11 @@ int pfn_tag_conv_forward(const void* gws, int64_t n, int64_t e, int cin, int cou
         return PFN_ENOSPACE;
     }
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
-    return tag_forward(g, cin, cout, K, x, (int)ldx, weights, bias, out, (int)ldo, Act{}, w.xk,
-                       static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    Packer pk(w.packed);
+    const TagPack pw = tag_pack(pk, cin, cout, K, weights);
+    PFN_TRY(pk.flush(s));
+    return tag_forward(g, cin, cout, K, x, (int)ldx, pw, bias, out, (int)ldo, Act{}, w.xk, s);
 }
 
 int pfn_tag_conv_backward(const void* gws, int64_t n, int64_t e, int cin, int cout, int K, const float* x, int64_t ldx,
@@ -609,8 +702,10 @@ int pfn_tag_conv_backward(const void* gws, int64_t n, int64_t e, int cin, int co
         return PFN_ENOSPACE;
     }
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
-    return tag_backward(g, cin, cout, K, x, (int)ldx, weights, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gweights, gbias,
-                        w.xk, w.sc, static_cast<hipStream_t>(stream));
+    Packer pk(w.packed);                       // images were filled by the forward call on the same workspace
+    const TagPack pw = tag_pack(pk, cin, cout, K, weights);
+    return tag_backward(g, cin, cout, K, x, (int)ldx, pw, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gweights, gbias, w.xk,
+                        w.sc, static_cast<hipStream_t>(stream));
 }
 
 // ----------------------------------------------------------------------------------------- utilities

@@ -80,13 +80,32 @@ struct GraphView {
 GraphView graph_view(void* ws, int64_t n, int64_t e_stored);
 
 // ------------------------------------------------------------------------------------------- GEMMs
-// C[g] (M x ldc) = sum over terms t with t.group == g of  A_t (M x K_t) * B_t (K_t x ncols)  + epilogue.
-// B_t[k][n] = trans ? W[(wn0 + n) * ldw + wk0 + k] : W[(wk0 + k) * ldw + wn0 + n]   (weights stay in
-// their nn.Linear layout; nothing is repacked).
+constexpr int GEMM_CB = 144;    // output columns per column block (9 MFMA tiles of 16)
+constexpr int GEMM_LDB = 148;   // packed weight row stride in floats (= 4 mod 8: conflict-free permuted reads)
+constexpr int GEMM_KC = 132;    // k rows per LDS-resident unit (covers H = 129 in one unit)
+
+// Weights are re-laid out once per forward into zero-padded LDS images (gemm.hip: pack):
+// packed[cb][k][GEMM_LDB] with B[k][n] = trans ? W[(wn0 + n) * ldw + wk0 + k] : W[(wk0 + k) * ldw + wn0 + n],
+// k < K4 = roundup(K, 4), n < 144 per column block cb, zero outside [0,K) x [0,ncols).
+struct PackJob {
+    const float* src;
+    float* dst;
+    int ldw, wk0, wn0, trans, K, ncols, ld_out, pad_;
+};
+constexpr int PACK_MAX_JOBS = 64;
+struct PackArgs {
+    PackJob job[PACK_MAX_JOBS];
+    int njobs;
+};
+size_t packed_floats(int K, int ld_out);
+int launch_pack(const PackJob* jobs, int njobs, hipStream_t s);
+
+// C[g] (M x ldc) = sum over terms t with t.group == g of  A_t (M x K_t) * B_t (K_t x ncols)  + epilogue,
+// B_t given as a packed image (Bp).
 struct GemmTerm {
     const float* A;
-    const float* W;
-    int lda, K, ldw, wk0, wn0, trans, group, pad_;
+    const float* Bp;
+    int lda, K, group, pad_;
 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_DROPOUT_RELU = 2 };
 struct GemmArgs {
@@ -109,27 +128,23 @@ struct GemmArgs {
 };
 int launch_gemm_nt(const GemmArgs& a, hipStream_t s);
 
-// dW[(gn0 + i) * ldg + gk0 + j] = sum_m A[m][a0 + i] * B[m][b0 + j],  i < na, j < nb  (A = grad of the
-// layer output, B = the layer input: the nn.Linear weight gradient), reduced deterministically in two stages.
+// dW[(gn0 + i) * ldg + gk0 + j] = sum_m A[m][i] * B[m][j],  i < na, j < nb  (A = grad of the layer output,
+// B = the layer input: the nn.Linear weight gradient), reduced deterministically in two stages.  When bias_out
+// is set, bias_out[i] = sum_m bias_rowscale[m] * A[m][i] rides along as a virtual extra column of B.
 struct TnPair {
     const float* A;
     const float* B;
     float* G;
+    float* bias_out;
+    const float* bias_rowscale;
     int lda, ldb, na, nb, ldg, gn0, gk0, pad_;
-};
-struct ColsumJob {
-    const float* A;         // [M x lda]
-    const float* rowscale;  // [M] or null
-    float* out;             // [ncols]
-    int lda, ncols;
 };
 struct ReduceWs {
     float* partial;   // scratch for split partials
     size_t floats;
 };
 size_t reduce_ws_floats(int64_t M, int max_na, int max_nb, int max_pairs);
-int launch_weight_grads(const TnPair* pairs, int npairs, const ColsumJob* jobs, int njobs, int64_t M,
-                        ReduceWs ws, hipStream_t s);
+int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s);
 
 // ------------------------------------------------------------------------------------- edge kernels
 // y[i] = (add ? add[i] : 0) + dinv[i] * sum_{e in row i} dinv[nbr(e)] * x[nbr(e)]   (normalize)
@@ -164,11 +179,11 @@ struct EdgeBwdArgs {
     const float* w1;
     float* dP;
     float* dQ;
-    float* dWe_partial;   // [nblocks][fe][ld] partial sums of a_e[f] * dh_e
+    float* dWe_partial;   // [edge_bwd_dst_blocks][fe][ld] partial sums of a_e[f] * dh_e
     float* grad_edge_attr;  // optional [e_stored][fe]
     int ld, h, fi, fe;
 };
-int edge_bwd_dst_blocks(const GraphView& g, int ld);
+int edge_bwd_dst_blocks(const GraphView& g, int ld);   // number of dWe partials the dst walk emits (<= 512)
 int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t* edge_index_unused, hipStream_t s);
 int launch_edge_attr_grad(const GraphView& g, const EdgeBwdArgs& a, hipStream_t s);
 // sums dWe partials [nblocks][fe][ld] into grad_w1[:, 2Fi + f]

@@ -140,6 +140,32 @@ def test_g6_three_adamw_steps():
             assert err[solid].max().item() <= 2e-5, (k, err[solid].max().item())
 
 
+def test_g6_flat_adamw_matches_reference_steps():
+    """Same fixture, the flat single-kernel AdamW (poweflownet_amd.optim) instead of torch.optim.AdamW."""
+    from poweflownet_amd.optim import FlatAdamW
+    fx = load("g6_train_step")
+    g4 = load("g4_model_case14")
+    m = _model_from(g4, True).train()
+    data = data_from(g4, device=DEV)
+    opt = FlatAdamW(m, lr=1e-3)
+    loss_fn = torch.nn.MSELoss()
+    for step in range(1, 4):
+        opt.zero_grad()
+        loss = loss_fn(m(data), data.y)
+        loss.backward()
+        opt.step()
+        assert_close(loss, fx[f"loss.{step}"], 1e-4, f"loss.{step}")
+    assert int(opt.step_count.item()) == 3
+    for k, p in m.named_parameters():
+        ref, g = fx[f"param_after3.{k}"], g4[f"grad.{k}"]
+        err = (p.detach().cpu() - ref).abs()
+        solid = g.abs() > 1e-3 * g.abs().max()
+        assert err.max().item() <= 6.5e-3, k
+        if solid.any():
+            assert err[solid].max().item() <= 2e-5, (k, err[solid].max().item())
+    assert sorted(m.state_dict().keys()) == sorted(params_from(load("g4_params_standard")).keys())
+
+
 def test_g7_batch_equals_concat_of_singles():
     fx = load("g7_collate")
     m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
