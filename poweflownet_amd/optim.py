@@ -1,0 +1,64 @@
+"""AdamW over ONE flat fp32 buffer (a single HIP kernel launch per step).
+
+Counterpart of `torch.optim.AdamW(model.parameters(), lr=lr)` at train.py:123 of the reference (torch defaults:
+betas (0.9, 0.999), eps 1e-8, weight_decay 1e-2, decoupled decay).  The model's parameters are re-pointed at
+views of one flat buffer (same order as the C ABI's parameter table), the HIP backward already writes all
+gradients into one flat buffer in that order, so the update is `pfn_adamw_step(flat_param, flat_grad, m, v)`:
+hipGraph-capturable (the step counter lives on the device), no per-tensor kernels.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .dp import _grads_are_views_of
+
+
+class FlatAdamW(torch.optim.Optimizer):
+    def __init__(self, model, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        params = model._ordered_params() if hasattr(model, "_ordered_params") else list(model.parameters())
+        if not params or not params[0].is_cuda:
+            raise RuntimeError("FlatAdamW: move the model to its HIP device first (there is no CPU path)")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._model, self._params = model, params
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in params]).contiguous()
+            off = 0
+            for p in params:
+                p.data = flat[off:off + p.numel()].view(p.shape)     # parameters become views of the flat buffer
+                off += p.numel()
+        self.flat_param = flat
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.step_count = torch.zeros(1, dtype=torch.int64, device=flat.device)
+        self._gather = None
+
+    def _flat_grad(self) -> torch.Tensor:
+        fg = self._model.flat_grad() if hasattr(self._model, "flat_grad") else None
+        if fg is not None and _grads_are_views_of(fg, self._params):
+            return fg
+        # generic path (gradients accumulated elsewhere): gather into a scratch buffer
+        if self._gather is None:
+            self._gather = torch.empty_like(self.flat_param)
+        off = 0
+        for p in self._params:
+            n = p.numel()
+            if p.grad is None:
+                self._gather[off:off + n].zero_()
+            else:
+                self._gather[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        return self._gather
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
+        grad = self._flat_grad()
+        with torch.cuda.device(self.flat_param.device):
+            L.check(L.load().pfn_adamw_step(self.flat_param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
+                                            self.exp_avg_sq.data_ptr(), self.flat_param.numel(), float(g["lr"]),
+                                            float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
+                                            float(g["weight_decay"]), self.step_count.data_ptr(), L.stream_ptr()),
+                    "pfn_adamw_step")
+        return loss
