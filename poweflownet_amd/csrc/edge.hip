@@ -283,7 +283,7 @@ int edge_bwd_dst_blocks(const GraphView& g, int ld) {
     int bdx, bdy;
     dst_block_shape(ld, bdx, bdy);
     const int want = (g.n + bdy - 1) / bdy;
-    return want < 512 ? (want > 0 ? want : 1) : 512;
+    return want < 1024 ? (want > 0 ? want : 1) : 1024;
 }
 
 template <int FE>
@@ -323,24 +323,29 @@ int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t*, hi
 }
 
 // dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered: 4 interleaved lanes, then a fixed tree)
-__global__ __launch_bounds__(256) void dwe_reduce_kernel(const float* __restrict__ partial, int nblocks, int fe, int ld,
-                                                         int h, float* __restrict__ gw1, int ldw, int col0) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void dwe_reduce_kernel(const float* __restrict__ partial, int nblocks, int fe, int ld,
+                                                          int h, float* __restrict__ gw1, int ldw, int col0) {
+    __shared__ float red[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int i = blockIdx.x * 64 + tx;
     const int f = i / h, k = i - f * h;
     float acc = 0.f;
     if (i < fe * h)
-        for (int b = ty; b < nblocks; b += 4) acc += partial[((size_t)b * fe + f) * ld + k];
+        for (int b = ty; b < nblocks; b += 16) acc += partial[((size_t)b * fe + f) * ld + k];
     red[ty][tx] = acc;
     __syncthreads();
-    if (ty == 0 && i < fe * h) gw1[(size_t)k * ldw + col0 + f] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (ty == 0 && i < fe * h) {
+        float s = 0.f;
+#pragma unroll
+        for (int y = 0; y < 16; ++y) s += red[y][tx];
+        gw1[(size_t)k * ldw + col0 + f] = s;
+    }
 }
 
 int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, float* gw1, int ldw, int col0,
                       hipStream_t s) {
     ProfScope ps("dwe_reduce", 0.0, 0.0, s);
-    dwe_reduce_kernel<<<(fe * h + 63) / 64, 256, 0, s>>>(partial, nblocks, fe, ld, h, gw1, ldw, col0);
+    dwe_reduce_kernel<<<(fe * h + 63) / 64, 1024, 0, s>>>(partial, nblocks, fe, ld, h, gw1, ldw, col0);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

@@ -93,8 +93,11 @@ __device__ __forceinline__ void dma_unit(const float* __restrict__ src, float* l
     }
 }
 
+constexpr int ZROW_FLOATS = 4 * LDB + 64;       // a zero region every out-of-unit lane reads instead of stale LDS
+
+template <int NTILE>   // accumulator tiles per wave: 9 (full 144-column block) or 1 (outputs of <= 16 columns)
 __global__ __launch_bounds__(256, 1) void gemm_nt_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF_FLOATS
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF_FLOATS + ZROW_FLOATS
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, c = lane >> 4;
@@ -103,12 +106,11 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel(const GemmArgs a) {
     const int row0 = blockIdx.x * ROWS_PER_BLOCK + wave * 16;
     const int arow = row0 + r;
     const bool arow_ok = arow < a.M;
-    int ntile = (a.ldc - n0 + 15) / 16;
-    ntile = ntile > NT ? NT : ntile;
-
-    f32x4 acc[NT];
+    f32x4 acc[NTILE];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float* zrow = lds + 2 * BUF_FLOATS;
+    for (int i = tid; i < ZROW_FLOATS; i += 256) zrow[i] = 0.f;
 
     // ---- unit iterator over (term of this group, k chunk)
     int ti = -1, kc = 0, nkc = 0;
@@ -157,17 +159,31 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel(const GemmArgs a) {
         const float* Bl = lds + slot * BUF_FLOATS + (4 * c) * LDB + r;
 #pragma unroll
         for (int j = 0; j < NCHUNK; ++j) {
-            const float av[4] = {a_cur[j].x, a_cur[j].y, a_cur[j].z, a_cur[j].w};
+            const int kleft = kvalid - 16 * j;             // block-uniform: real k's from this chunk on
+            if (kleft > 0) {
+                // a lane group whose 4 k rows lie beyond the unit reads zeros (rows % 4 == 0: all four or none)
+                const float* Bj = (16 * j + 4 * c < rows) ? Bl + 16 * j * LDB : zrow + r;
+                const float av[4] = {a_cur[j].x, a_cur[j].y, a_cur[j].z, a_cur[j].w};
+                if (kleft >= 4) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if (16 * j + i < kvalid) {                 // block-uniform: skip steps that only see zero padding
-                    const bool lane_in = 16 * j + 4 * c + i < rows;   // beyond the unit the slot holds stale bytes
+                    for (int i = 0; i < 4; ++i) {
+                        float b[NTILE];
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        if (t < ntile) {
-                            float b = Bl[(16 * j + i) * LDB + 16 * t];
-                            b = lane_in ? b : 0.f;
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b, acc[t], 0, 0, 0);
+                        for (int t = 0; t < NTILE; ++t) b[t] = Bj[i * LDB + 16 * t];
+#pragma unroll
+                        for (int t = 0; t < NTILE; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b[t], acc[t], 0, 0, 0);
+                    }
+                } else {                                   // ragged tail of the term: 1..3 steps
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        if (i < kleft) {
+                            float b[NTILE];
+#pragma unroll
+                            for (int t = 0; t < NTILE; ++t) b[t] = Bj[i * LDB + 16 * t];
+#pragma unroll
+                            for (int t = 0; t < NTILE; ++t)
+                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b[t], acc[t], 0, 0, 0);
                         }
                     }
                 }
@@ -193,8 +209,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel(const GemmArgs a) {
     }
     const float keep_scale = a.act == ACT_DROPOUT_RELU ? 1.0f / (1.0f - a.p_drop) : 1.0f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        if (t >= ntile) continue;
+    for (int t = 0; t < NTILE; ++t) {
         const int col = n0 + 16 * t + r;
         if (col >= a.ldc) continue;
         const bool real = col < a.ncols;
@@ -242,15 +257,18 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
         flops += 2.0 * a.M * a.term[t].K * a.ncols;
         bytes += (double)a.M * a.term[t].K * 4.0;
     }
-    const size_t lds_bytes = 2 * BUF_FLOATS * sizeof(float);
+    const size_t lds_bytes = (2 * BUF_FLOATS + ZROW_FLOATS) * sizeof(float);
     if (!g_nt_attr_set) {
-        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
+        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<9>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         g_nt_attr_set = true;
     }
     dim3 grid((a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, a.ncb * a.ngroup);
     ProfScope ps("gemm_nt", bytes, flops, s);
-    gemm_nt_kernel<<<grid, 256, lds_bytes, s>>>(a);
+    if (a.ldc <= 16) gemm_nt_kernel<1><<<grid, 256, lds_bytes, s>>>(a);
+    else gemm_nt_kernel<9><<<grid, 256, lds_bytes, s>>>(a);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

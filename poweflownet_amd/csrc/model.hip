@@ -321,7 +321,7 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     lo.eas.dS = cv.take<float>(nld);
     lo.eas.dP = cv.take<float>(nld);
     lo.eas.dQ = cv.take<float>(nld);
-    lo.eas.dWe = cv.take<float>((size_t)513 * lo.fe * lo.ld);
+    lo.eas.dWe = cv.take<float>((size_t)1025 * lo.fe * lo.ld);
     lo.tags.G = cv.take<float>(nld * (lo.K + 1));
     lo.tags.z0 = cv.take<float>(nld);
     lo.tags.z1 = cv.take<float>(nld);
@@ -589,7 +589,7 @@ static EaLayerWs ea_layer_ws(void* ws, int64_t n, int fi, int fe, int h, int fo)
     w.sc.dS = cv.take<float>(nld);
     w.sc.dP = cv.take<float>(nld);
     w.sc.dQ = cv.take<float>(nld);
-    w.sc.dWe = cv.take<float>((size_t)513 * fe * ld);
+    w.sc.dWe = cv.take<float>((size_t)1025 * fe * ld);
     const int maxf = std::max(std::max(h, fi), fo);
     w.sc.red.floats = reduce_ws_floats(n, maxf, maxf, 3);
     w.sc.red.partial = cv.take<float>(w.sc.red.floats);

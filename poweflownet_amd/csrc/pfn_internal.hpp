@@ -183,7 +183,7 @@ struct EdgeBwdArgs {
     float* grad_edge_attr;  // optional [e_stored][fe]
     int ld, h, fi, fe;
 };
-int edge_bwd_dst_blocks(const GraphView& g, int ld);   // number of dWe partials the dst walk emits (<= 512)
+int edge_bwd_dst_blocks(const GraphView& g, int ld);   // number of dWe partials the dst walk emits (<= 1024)
 int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t* edge_index_unused, hipStream_t s);
 int launch_edge_attr_grad(const GraphView& g, const EdgeBwdArgs& a, hipStream_t s);
 // sums dWe partials [nblocks][fe][ld] into grad_w1[:, 2Fi + f]
