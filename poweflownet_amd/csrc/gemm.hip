@@ -28,7 +28,6 @@ namespace pfn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 9;                 // 16-column tiles per wave  -> 144 columns per column block
 constexpr int CB = GEMM_CB;           // 144
 constexpr int LDB = GEMM_LDB;         // 148: (4 * LDB) % 32 == 16 -> the 4 lane groups hit disjoint banks
 constexpr int KC = GEMM_KC;           // 132 k rows per LDS-resident unit
@@ -80,12 +79,15 @@ int launch_pack(const PackJob* jobs, int njobs, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------- NT
+constexpr int NT_THREADS = 512;                 // 8 waves: 4 row groups (16 rows each) x 2 column halves (5 + 4 tiles)
+constexpr int ZROW_FLOATS = 4 * LDB + 64;       // a zero region every out-of-unit lane reads instead of stale LDS
+
 __device__ __forceinline__ void dma_unit(const float* __restrict__ src, float* lds_dst, int nbytes, int wave, int lane) {
-    // 1 KiB pieces, round-robin over the 4 waves; the last piece is clamped to the tile's final 16 bytes for the
+    // 1 KiB pieces, round-robin over the 8 waves; the last piece is clamped to the tile's final 16 bytes for the
     // lanes that would run past it (their LDS bytes land in the slot's unused tail).
     const int npieces = (nbytes + 1023) >> 10;
     const char* base = reinterpret_cast<const char*>(src);
-    for (int p = wave; p < npieces; p += 4) {
+    for (int p = wave; p < npieces; p += NT_THREADS / 64) {
         int off = (p << 10) + lane * 16;
         off = off < nbytes ? off : nbytes - 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
@@ -93,24 +95,73 @@ __device__ __forceinline__ void dma_unit(const float* __restrict__ src, float* l
     }
 }
 
-constexpr int ZROW_FLOATS = 4 * LDB + 64;       // a zero region every out-of-unit lane reads instead of stale LDS
+// Multiply one LDS-resident k unit into this wave's NTW accumulator tiles.  B reads of step s+1 are issued
+// before the MFMAs of step s (software pipeline), so together with the partner wave on the same SIMD the
+// matrix pipe always has work while an LDS read is in flight.
+template <int NTW>
+__device__ __forceinline__ void mfma_unit(const float* Bl, const float* zrow_r, const float4 (&a_cur)[NCHUNK], int c,
+                                          int rows, int kvalid, f32x4 (&acc)[5]) {
+#pragma unroll
+    for (int j = 0; j < NCHUNK; ++j) {
+        const int kleft = kvalid - 16 * j;             // block-uniform: real k's from this chunk on
+        if (kleft > 0) {
+            // a lane group whose 4 k rows lie beyond the unit reads zeros (rows % 4 == 0: all four or none)
+            const float* Bj = (16 * j + 4 * c < rows) ? Bl + 16 * j * LDB : zrow_r;
+            const float av[4] = {a_cur[j].x, a_cur[j].y, a_cur[j].z, a_cur[j].w};
+            if (kleft >= 4) {
+                float b0[NTW], b1[NTW];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) b0[t] = Bj[16 * t];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) b1[t] = Bj[LDB + 16 * t];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b0[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) b0[t] = Bj[2 * LDB + 16 * t];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b1[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) b1[t] = Bj[3 * LDB + 16 * t];
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b0[t], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b1[t], acc[t], 0, 0, 0);
+            } else {                                   // ragged tail of the term: 1..3 steps
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (i < kleft) {
+                        float b[NTW];
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) b[t] = Bj[i * LDB + 16 * t];
+#pragma unroll
+                        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b[t], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
 
-template <int NTILE>   // accumulator tiles per wave: 9 (full 144-column block) or 1 (outputs of <= 16 columns)
-__global__ __launch_bounds__(256, 1) void gemm_nt_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF_FLOATS + ZROW_FLOATS
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wave & 3, ch = wave >> 2;       // waves w and w+4 share a SIMD: same rows, the two column halves
     const int r = lane & 15, c = lane >> 4;
     const int group = blockIdx.y / a.ncb, cb = blockIdx.y - group * a.ncb;
     const int n0 = cb * CB;
-    const int row0 = blockIdx.x * ROWS_PER_BLOCK + wave * 16;
+    const int tile0 = ch * 5;                      // column tiles [0,5) or [5,9) of the 144-column block
+    const int row0 = blockIdx.x * ROWS_PER_BLOCK + rg * 16;
     const int arow = row0 + r;
     const bool arow_ok = arow < a.M;
-    f32x4 acc[NTILE];
+    // tiles this wave really has to produce (narrow outputs leave the second half, or most of the first, idle)
+    int ntile_w = (a.ldc - n0 - 16 * tile0 + 15) / 16;
+    ntile_w = ntile_w < 0 ? 0 : (ntile_w > (ch ? 4 : 5) ? (ch ? 4 : 5) : ntile_w);
+    f32x4 acc[5];
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 5; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float* zrow = lds + 2 * BUF_FLOATS;
-    for (int i = tid; i < ZROW_FLOATS; i += 256) zrow[i] = 0.f;
+    for (int i = tid; i < ZROW_FLOATS; i += NT_THREADS) zrow[i] = 0.f;
 
     // ---- unit iterator over (term of this group, k chunk)
     int ti = -1, kc = 0, nkc = 0;
@@ -136,7 +187,8 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel(const GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < NCHUNK; ++j) {
             const int kk = 16 * j + 4 * c;
-            areg[j] = (arow_ok && kk < rows) ? *reinterpret_cast<const float4*>(Arow + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            areg[j] = (arow_ok && ntile_w > 0 && kk < rows) ? *reinterpret_cast<const float4*>(Arow + kk)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -156,38 +208,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel(const GemmArgs a) {
         // ---- multiply the resident unit
         const int rows = unit_rows(cur_t, cur_k);
         const int kvalid = a.term[cur_t].K - cur_k * KC;   // real (unpadded) k's left in this term
-        const float* Bl = lds + slot * BUF_FLOATS + (4 * c) * LDB + r;
-#pragma unroll
-        for (int j = 0; j < NCHUNK; ++j) {
-            const int kleft = kvalid - 16 * j;             // block-uniform: real k's from this chunk on
-            if (kleft > 0) {
-                // a lane group whose 4 k rows lie beyond the unit reads zeros (rows % 4 == 0: all four or none)
-                const float* Bj = (16 * j + 4 * c < rows) ? Bl + 16 * j * LDB : zrow + r;
-                const float av[4] = {a_cur[j].x, a_cur[j].y, a_cur[j].z, a_cur[j].w};
-                if (kleft >= 4) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        float b[NTILE];
-#pragma unroll
-                        for (int t = 0; t < NTILE; ++t) b[t] = Bj[i * LDB + 16 * t];
-#pragma unroll
-                        for (int t = 0; t < NTILE; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b[t], acc[t], 0, 0, 0);
-                    }
-                } else {                                   // ragged tail of the term: 1..3 steps
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        if (i < kleft) {
-                            float b[NTILE];
-#pragma unroll
-                            for (int t = 0; t < NTILE; ++t) b[t] = Bj[i * LDB + 16 * t];
-#pragma unroll
-                            for (int t = 0; t < NTILE; ++t)
-                                acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b[t], acc[t], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+        const float* Bl = lds + slot * BUF_FLOATS + (4 * c) * LDB + r + 16 * tile0;
+        if (ntile_w > 1) {
+            if (ch == 0) mfma_unit<5>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
+            else mfma_unit<4>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
+        } else if (ntile_w == 1) {
+            mfma_unit<1>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
         }
         __syncthreads();   // next unit landed (vmcnt(0) precedes the barrier) and this slot is free again
         if (more) {
@@ -209,8 +235,9 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_kernel(const GemmArgs a) {
     }
     const float keep_scale = a.act == ACT_DROPOUT_RELU ? 1.0f / (1.0f - a.p_drop) : 1.0f;
 #pragma unroll
-    for (int t = 0; t < NTILE; ++t) {
-        const int col = n0 + 16 * t + r;
+    for (int t = 0; t < 5; ++t) {
+        if (t >= ntile_w) continue;
+        const int col = n0 + 16 * (tile0 + t) + r;
         if (col >= a.ldc) continue;
         const bool real = col < a.ncols;
         const float bias = (real && a.bias && (a.bias_group < 0 || a.bias_group == group)) ? a.bias[col] : 0.f;
@@ -259,16 +286,13 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
     }
     const size_t lds_bytes = (2 * BUF_FLOATS + ZROW_FLOATS) * sizeof(float);
     if (!g_nt_attr_set) {
-        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<9>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1>),
+        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         g_nt_attr_set = true;
     }
     dim3 grid((a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, a.ncb * a.ngroup);
     ProfScope ps("gemm_nt", bytes, flops, s);
-    if (a.ldc <= 16) gemm_nt_kernel<1><<<grid, 256, lds_bytes, s>>>(a);
-    else gemm_nt_kernel<9><<<grid, 256, lds_bytes, s>>>(a);
+    gemm_nt_kernel<<<grid, NT_THREADS, lds_bytes, s>>>(a);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
