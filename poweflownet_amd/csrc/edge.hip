@@ -325,27 +325,39 @@ int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t*, hi
 // dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered: 4 interleaved lanes, then a fixed tree)
 __global__ __launch_bounds__(1024) void dwe_reduce_kernel(const float* __restrict__ partial, int nblocks, int fe, int ld,
                                                           int h, float* __restrict__ gw1, int ldw, int col0) {
-    __shared__ float red[16][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int i = blockIdx.x * 64 + tx;
-    const int f = i / h, k = i - f * h;
-    float acc = 0.f;
-    if (i < fe * h)
-        for (int b = ty; b < nblocks; b += 16) acc += partial[((size_t)b * fe + f) * ld + k];
-    red[ty][tx] = acc;
-    __syncthreads();
-    if (ty == 0 && i < fe * h) {
-        float s = 0.f;
-#pragma unroll
-        for (int y = 0; y < 16; ++y) s += red[y][tx];
-        gw1[(size_t)k * ldw + col0 + f] = s;
+    // block = 16 output elements x 64 partial lanes; every lane sums its stride-64 subset with four independent
+    // chains, then a fixed-order tree over the lanes -> deterministic
+    __shared__ float red[64][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + tx;
+    const bool ok = i < fe * h;
+    const int f = ok ? i / h : 0, k = ok ? i - f * h : 0;
+    const float* p = partial + (size_t)f * ld + k;
+    const size_t stride = (size_t)fe * ld;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ok) {
+        int b = ty;
+        for (; b + 192 < nblocks; b += 256) {
+            s0 += p[(size_t)b * stride];
+            s1 += p[(size_t)(b + 64) * stride];
+            s2 += p[(size_t)(b + 128) * stride];
+            s3 += p[(size_t)(b + 192) * stride];
+        }
+        for (; b < nblocks; b += 64) s0 += p[(size_t)b * stride];
     }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int off = 32; off > 0; off >>= 1) {
+        if (ty < off) red[ty][tx] += red[ty + off][tx];
+        __syncthreads();
+    }
+    if (ty == 0 && ok) gw1[(size_t)k * ldw + col0 + f] = red[0][tx];
 }
 
 int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, float* gw1, int ldw, int col0,
                       hipStream_t s) {
     ProfScope ps("dwe_reduce", 0.0, 0.0, s);
-    dwe_reduce_kernel<<<(fe * h + 63) / 64, 1024, 0, s>>>(partial, nblocks, fe, ld, h, gw1, ldw, col0);
+    dwe_reduce_kernel<<<(fe * h + 15) / 16, 1024, 0, s>>>(partial, nblocks, fe, ld, h, gw1, ldw, col0);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

@@ -20,6 +20,8 @@
 //            tiles per block, operands staged through LDS as whole rows with register prefetch of the next
 //            stage, split over M and reduced in a second, ordered pass (deterministic; no atomics).  Bias
 //            gradients ride along as a virtual ones-column of X.
+#include <stdlib.h>
+
 #include <algorithm>
 
 #include "pfn_internal.hpp"
@@ -148,11 +150,11 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wave & 3, ch = wave >> 2;       // waves w and w+4 share a SIMD: same rows, the two column halves
     const int r = lane & 15, c = lane >> 4;
-    const int group = blockIdx.y / a.ncb, cb = blockIdx.y - group * a.ncb;
+    const int cb = blockIdx.y;
     const int n0 = cb * CB;
     const int tile0 = ch * 5;                      // column tiles [0,5) or [5,9) of the 144-column block
-    const int row0 = blockIdx.x * ROWS_PER_BLOCK + rg * 16;
-    const int arow = row0 + r;
+    const int brow0 = blockIdx.x * ROWS_PER_BLOCK;
+    const int arow = brow0 + rg * 16 + r;
     const bool arow_ok = arow < a.M;
     // tiles this wave really has to produce (narrow outputs leave the second half, or most of the first, idle)
     int ntile_w = (a.ldc - n0 - 16 * tile0 + 15) / 16;
@@ -163,13 +165,14 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
     float* zrow = lds + 2 * BUF_FLOATS;
     for (int i = tid; i < ZROW_FLOATS; i += NT_THREADS) zrow[i] = 0.f;
 
-    // ---- unit iterator over (term of this group, k chunk)
-    int ti = -1, kc = 0, nkc = 0;
-    auto next_unit = [&](int& o_ti, int& o_kc) -> bool {
-        int t2 = ti, k2 = kc + 1;
-        if (t2 < 0 || k2 >= nkc) {
+    // ---- unit iterator over (term, k chunk); terms arrive sorted by output group and the block walks ALL groups,
+    // flushing its accumulators whenever the group changes, so the weight DMA stays pipelined across groups.
+    auto nkc_of = [&](int t2) { return (((a.term[t2].K + 3) & ~3) + KC - 1) / KC; };
+    auto next_unit = [&](int t1, int k1, int& o_ti, int& o_kc) -> bool {
+        int t2 = t1, k2 = k1 + 1;
+        if (t2 < 0 || k2 >= nkc_of(t2)) {
             k2 = 0;
-            do { ++t2; } while (t2 < a.nterm && a.term[t2].group != group);
+            ++t2;
             if (t2 >= a.nterm) return false;
         }
         o_ti = t2;
@@ -182,85 +185,108 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         const int K4 = (tm.K + 3) & ~3;
         const int rows = min(KC, K4 - k2 * KC);
         const float* tile = tm.Bp + ((size_t)cb * K4 + (size_t)k2 * KC) * LDB;
-        dma_unit(tile, slot, rows * LDB * 4, wave, lane);
+        if (!(a.dbg & 1)) dma_unit(tile, slot, rows * LDB * 4, wave, lane);
         const float* Arow = tm.A + (size_t)arow * tm.lda + k2 * KC;
 #pragma unroll
         for (int j = 0; j < NCHUNK; ++j) {
             const int kk = 16 * j + 4 * c;
-            areg[j] = (arow_ok && ntile_w > 0 && kk < rows) ? *reinterpret_cast<const float4*>(Arow + kk)
+            areg[j] = (arow_ok && ntile_w > 0 && kk < rows && !(a.dbg & 8)) ? *reinterpret_cast<const float4*>(Arow + kk)
                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
-    float4 a_cur[NCHUNK], a_nxt[NCHUNK];
-    int cur_t, cur_k;
-    bool have = next_unit(cur_t, cur_k);
-    if (have) {
-        ti = cur_t; kc = cur_k; nkc = (((a.term[ti].K + 3) & ~3) + KC - 1) / KC;
-        issue(cur_t, cur_k, a_cur, lds);
-    }
-    __syncthreads();   // waits for the DMA (vmcnt) and publishes the slot
-    int slot = 0;
-    while (have) {
-        int nt_, nk_;
-        const bool more = next_unit(nt_, nk_);
-        if (more) issue(nt_, nk_, a_nxt, lds + (slot ^ 1) * BUF_FLOATS);
-        // ---- multiply the resident unit
-        const int rows = unit_rows(cur_t, cur_k);
-        const int kvalid = a.term[cur_t].K - cur_k * KC;   // real (unpadded) k's left in this term
-        const float* Bl = lds + slot * BUF_FLOATS + (4 * c) * LDB + r + 16 * tile0;
-        if (ntile_w > 1) {
-            if (ch == 0) mfma_unit<5>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
-            else mfma_unit<4>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
-        } else if (ntile_w == 1) {
-            mfma_unit<1>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
-        }
-        __syncthreads();   // next unit landed (vmcnt(0) precedes the barrier) and this slot is free again
-        if (more) {
-#pragma unroll
-            for (int j = 0; j < NCHUNK; ++j) a_cur[j] = a_nxt[j];
-            ti = nt_; kc = nk_; nkc = (((a.term[ti].K + 3) & ~3) + KC - 1) / KC;
-            cur_t = nt_; cur_k = nk_;
-            slot ^= 1;
-        }
-        have = more;
-    }
-
-    // ---- epilogue.  Lane holds D[row = 4c + reg][col = r] of every tile.
-    float* C = a.C[group];
     uint64_t seed = 0, offset = 0;
     if (a.act == ACT_DROPOUT_RELU) {
         seed = a.rng[0];
         offset = a.rng[1];
     }
     const float keep_scale = a.act == ACT_DROPOUT_RELU ? 1.0f / (1.0f - a.p_drop) : 1.0f;
-#pragma unroll
-    for (int t = 0; t < 5; ++t) {
-        if (t >= ntile_w) continue;
-        const int col = n0 + 16 * (tile0 + t) + r;
-        if (col >= a.ldc) continue;
-        const bool real = col < a.ncols;
-        const float bias = (real && a.bias && (a.bias_group < 0 || a.bias_group == group)) ? a.bias[col] : 0.f;
-        const float rbias = (real && a.rowscale) ? a.rowbias[col] : 0.f;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int row = row0 + 4 * c + reg;
-            if (row >= a.M) continue;
-            float v = 0.f;
-            if (real) {
-                v = acc[t][reg] + bias;
-                if (a.rowscale) v = fmaf(a.rowscale[row], rbias, v);
-                if (a.resid) v += a.resid[(size_t)row * a.ldr + col];
-                if (a.act == ACT_RELU) {
-                    v = fmaxf(v, 0.f);
-                } else if (a.act == ACT_DROPOUT_RELU) {
-                    const float u = uniform_hash(seed, offset, a.rng_stream, (uint64_t)row * a.ncols + col);
-                    v = (u >= a.p_drop && v > 0.f) ? v * keep_scale : 0.f;
-                }
-                if (a.gate) v = a.gate[(size_t)row * a.ldg + col] > 0.f ? v * a.gate_scale : 0.f;
-            }
-            C[(size_t)row * a.ldc + col] = v;
+    const int ncol4 = min(CB, a.ldc - n0) >> 2;    // float4 columns of this block's output
+
+    float4 a_cur[NCHUNK], a_nxt[NCHUNK];
+    int cur_t = -1, cur_k = 0;
+    bool have = next_unit(-1, 0, cur_t, cur_k);
+    if (have) issue(cur_t, cur_k, a_cur, lds);
+    __syncthreads();   // waits for the DMA (vmcnt) and publishes the slot
+    int slot = 0;
+    while (have) {
+        int nt_ = 0, nk_ = 0;
+        const bool more = next_unit(cur_t, cur_k, nt_, nk_);
+        if (more) issue(nt_, nk_, a_nxt, lds + (slot ^ 1) * BUF_FLOATS);
+        // ---- multiply the resident unit
+        const int rows = unit_rows(cur_t, cur_k);
+        const int kvalid = a.term[cur_t].K - cur_k * KC;   // real (unpadded) k's left in this term
+        const float* Bl = lds + slot * BUF_FLOATS + (4 * c) * LDB + r + 16 * tile0;
+        if (a.dbg & 2) {
+        } else if (ntile_w > 1) {
+            if (ch == 0) mfma_unit<5>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
+            else mfma_unit<4>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
+        } else if (ntile_w == 1) {
+            mfma_unit<1>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
         }
+        __syncthreads();   // next unit landed (vmcnt(0) precedes the barrier) and this slot is free again
+        const int group = a.term[cur_t].group;
+        if ((!more || a.term[nt_].group != group) && !(a.dbg & 4)) {
+            // ---- flush this group's 64 x 144 tile: accumulators -> LDS (the slot just freed) -> whole-row float4
+            // stores with the fused epilogue.  Lane holds D[row = 4c + reg][col = r] of every tile.
+            float* stage = lds + slot * BUF_FLOATS;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) {
+                if (t < ntile_w) {
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg)
+                        stage[(rg * 16 + 4 * c + reg) * LDB + 16 * (tile0 + t) + r] = acc[t][reg];
+                }
+                acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            __syncthreads();
+            float* C = a.C[group];
+            const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
+            for (int idx = tid; idx < ROWS_PER_BLOCK * ncol4; idx += NT_THREADS) {
+                const int lr = idx / ncol4, q = idx - lr * ncol4;
+                const int row = brow0 + lr, col = n0 + 4 * q;
+                if (row >= a.M) continue;
+                const float4 v4 = *reinterpret_cast<const float4*>(stage + lr * LDB + 4 * q);
+                float v[4] = {v4.x, v4.y, v4.z, v4.w};
+                float g4[4] = {1.f, 1.f, 1.f, 1.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+                if (a.gate) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(a.gate + (size_t)row * a.ldg + col);
+                    g4[0] = t4.x; g4[1] = t4.y; g4[2] = t4.z; g4[3] = t4.w;
+                }
+                if (a.resid) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(a.resid + (size_t)row * a.ldr + col);
+                    r4[0] = t4.x; r4[1] = t4.y; r4[2] = t4.z; r4[3] = t4.w;
+                }
+                const float rs = a.rowscale ? a.rowscale[row] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int cc = col + e;
+                    float x = 0.f;
+                    if (cc < a.ncols) {
+                        x = v[e] + (use_bias ? a.bias[cc] : 0.f);
+                        if (a.rowscale) x = fmaf(rs, a.rowbias[cc], x);
+                        x += r4[e];
+                        if (a.act == ACT_RELU) {
+                            x = fmaxf(x, 0.f);
+                        } else if (a.act == ACT_DROPOUT_RELU) {
+                            const float u = uniform_hash(seed, offset, a.rng_stream, (uint64_t)row * a.ncols + cc);
+                            x = (u >= a.p_drop && x > 0.f) ? x * keep_scale : 0.f;
+                        }
+                        if (a.gate) x = g4[e] > 0.f ? x * a.gate_scale : 0.f;
+                    }
+                    v[e] = x;
+                }
+                *reinterpret_cast<float4*>(C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (more) __syncthreads();   // the staged tile is consumed before the unit after next overwrites this slot
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NCHUNK; ++j) a_cur[j] = a_nxt[j];
+            cur_t = nt_; cur_k = nk_;
+            slot ^= 1;
+        }
+        have = more;
     }
 }
 
@@ -290,7 +316,14 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         g_nt_attr_set = true;
     }
-    dim3 grid((a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, a.ncb * a.ngroup);
+    for (int t = 1; t < a.nterm; ++t)
+        if (a.term[t].group < a.term[t - 1].group) {
+            set_error("gemm_nt: terms must be sorted by output group");
+            return PFN_EINVAL;
+        }
+    dim3 grid((a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, a.ncb);
+    static const int dbg = getenv("PFN_GEMM_DBG") ? atoi(getenv("PFN_GEMM_DBG")) : 0;   // timing dissection only
+    a.dbg = dbg;
     ProfScope ps("gemm_nt", bytes, flops, s);
     gemm_nt_kernel<<<grid, NT_THREADS, lds_bytes, s>>>(a);
     PFN_CHECK_LAUNCH();

@@ -125,6 +125,7 @@ struct GemmArgs {
     const float* gate;      // [M x ldg] or null : out *= gate > 0 ? gate_scale : 0
     int ldg;
     float gate_scale;
+    int dbg;                // PFN_GEMM_DBG bits (timing dissection; results invalid when non-zero)
 };
 int launch_gemm_nt(const GemmArgs& a, hipStream_t s);
 
