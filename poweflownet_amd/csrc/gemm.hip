@@ -153,9 +153,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
     const int cb = blockIdx.y;
     const int n0 = cb * CB;
     const int tile0 = ch * 5;                      // column tiles [0,5) or [5,9) of the 144-column block
-    const int brow0 = blockIdx.x * ROWS_PER_BLOCK;
-    const int arow = brow0 + rg * 16 + r;
-    const bool arow_ok = arow < a.M;
+    const int nrb = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;   // row blocks; this block takes bx, bx + gridDim.x, ...
     // tiles this wave really has to produce (narrow outputs leave the second half, or most of the first, idle)
     int ntile_w = (a.ldc - n0 - 16 * tile0 + 15) / 16;
     ntile_w = ntile_w < 0 ? 0 : (ntile_w > (ch ? 4 : 5) ? (ch ? 4 : 5) : ntile_w);
@@ -165,23 +163,31 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
     float* zrow = lds + 2 * BUF_FLOATS;
     for (int i = tid; i < ZROW_FLOATS; i += NT_THREADS) zrow[i] = 0.f;
 
-    // ---- unit iterator over (term, k chunk); terms arrive sorted by output group and the block walks ALL groups,
-    // flushing its accumulators whenever the group changes, so the weight DMA stays pipelined across groups.
+    // ---- unit iterator over (row block, term, k chunk).  The block is persistent: it walks its row blocks and,
+    // inside each, ALL output groups (terms arrive sorted by group), flushing the accumulators whenever the group
+    // or the row block changes -- so the weight DMA and the A prefetch stay pipelined across groups and row blocks.
     auto nkc_of = [&](int t2) { return (((a.term[t2].K + 3) & ~3) + KC - 1) / KC; };
-    auto next_unit = [&](int t1, int k1, int& o_ti, int& o_kc) -> bool {
-        int t2 = t1, k2 = k1 + 1;
+    auto next_unit = [&](int rb1, int t1, int k1, int& o_rb, int& o_ti, int& o_kc) -> bool {
+        int rb2 = rb1, t2 = t1, k2 = k1 + 1;
         if (t2 < 0 || k2 >= nkc_of(t2)) {
             k2 = 0;
             ++t2;
-            if (t2 >= a.nterm) return false;
+            if (t2 >= a.nterm) {
+                t2 = 0;
+                rb2 += gridDim.x;
+            }
         }
+        if (rb2 >= nrb) return false;
+        o_rb = rb2;
         o_ti = t2;
         o_kc = k2;
         return true;
     };
     auto unit_rows = [&](int t2, int k2) { const int K4 = (a.term[t2].K + 3) & ~3; return min(KC, K4 - k2 * KC); };
-    auto issue = [&](int t2, int k2, float4 (&areg)[NCHUNK], float* slot) {
+    auto issue = [&](int rb2, int t2, int k2, float4 (&areg)[NCHUNK], float* slot) {
         const GemmTerm& tm = a.term[t2];
+        const int arow = rb2 * ROWS_PER_BLOCK + rg * 16 + r;
+        const bool arow_ok = arow < a.M;
         const int K4 = (tm.K + 3) & ~3;
         const int rows = min(KC, K4 - k2 * KC);
         const float* tile = tm.Bp + ((size_t)cb * K4 + (size_t)k2 * KC) * LDB;
@@ -204,15 +210,15 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
     const int ncol4 = min(CB, a.ldc - n0) >> 2;    // float4 columns of this block's output
 
     float4 a_cur[NCHUNK], a_nxt[NCHUNK];
-    int cur_t = -1, cur_k = 0;
-    bool have = next_unit(-1, 0, cur_t, cur_k);
-    if (have) issue(cur_t, cur_k, a_cur, lds);
+    int cur_rb = blockIdx.x, cur_t = -1, cur_k = 0;
+    bool have = next_unit(blockIdx.x, -1, 0, cur_rb, cur_t, cur_k);
+    if (have) issue(cur_rb, cur_t, cur_k, a_cur, lds);
     __syncthreads();   // waits for the DMA (vmcnt) and publishes the slot
     int slot = 0;
     while (have) {
-        int nt_ = 0, nk_ = 0;
-        const bool more = next_unit(cur_t, cur_k, nt_, nk_);
-        if (more) issue(nt_, nk_, a_nxt, lds + (slot ^ 1) * BUF_FLOATS);
+        int nrb_ = 0, nt_ = 0, nk_ = 0;
+        const bool more = next_unit(cur_rb, cur_t, cur_k, nrb_, nt_, nk_);
+        if (more) issue(nrb_, nt_, nk_, a_nxt, lds + (slot ^ 1) * BUF_FLOATS);
         // ---- multiply the resident unit
         const int rows = unit_rows(cur_t, cur_k);
         const int kvalid = a.term[cur_t].K - cur_k * KC;   // real (unpadded) k's left in this term
@@ -226,7 +232,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         }
         __syncthreads();   // next unit landed (vmcnt(0) precedes the barrier) and this slot is free again
         const int group = a.term[cur_t].group;
-        if ((!more || a.term[nt_].group != group) && !(a.dbg & 4)) {
+        if ((!more || a.term[nt_].group != group || nrb_ != cur_rb) && !(a.dbg & 4)) {
             // ---- flush this group's 64 x 144 tile: accumulators -> LDS (the slot just freed) -> whole-row float4
             // stores with the fused epilogue.  Lane holds D[row = 4c + reg][col = r] of every tile.
             float* stage = lds + slot * BUF_FLOATS;
@@ -242,6 +248,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
             __syncthreads();
             float* C = a.C[group];
             const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
+            const int brow0 = cur_rb * ROWS_PER_BLOCK;
             for (int idx = tid; idx < ROWS_PER_BLOCK * ncol4; idx += NT_THREADS) {
                 const int lr = idx / ncol4, q = idx - lr * ncol4;
                 const int row = brow0 + lr, col = n0 + 4 * q;
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         if (more) {
 #pragma unroll
             for (int j = 0; j < NCHUNK; ++j) a_cur[j] = a_nxt[j];
-            cur_t = nt_; cur_k = nk_;
+            cur_rb = nrb_; cur_t = nt_; cur_k = nk_;
             slot ^= 1;
         }
         have = more;
@@ -321,7 +328,16 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
             set_error("gemm_nt: terms must be sorted by output group");
             return PFN_EINVAL;
         }
-    dim3 grid((a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK, a.ncb);
+    static int ncu = 0;
+    if (ncu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
+        if (ncu <= 0) ncu = 256;
+    }
+    const int nrb = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    // one 160 KiB-LDS block per CU: persistent blocks stride over the row blocks
+    dim3 grid(std::min(nrb, std::max(1, ncu / a.ncb)), a.ncb);
     static const int dbg = getenv("PFN_GEMM_DBG") ? atoi(getenv("PFN_GEMM_DBG")) : 0;   // timing dissection only
     a.dbg = dbg;
     ProfScope ps("gemm_nt", bytes, flops, s);
