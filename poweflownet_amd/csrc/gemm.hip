@@ -81,15 +81,17 @@ int launch_pack(const PackJob* jobs, int njobs, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------- NT
-constexpr int NT_THREADS = 512;                 // 8 waves: 4 row groups (16 rows each) x 2 column halves (5 + 4 tiles)
+// two shapes: CS = 2 -> 8 waves: 4 row groups (16 rows each) x 2 column halves (5 + 4 tiles), 64-row blocks (small M);
+//             CS = 1 -> 4 waves x 2 row tiles x all 9 column tiles, 128-row blocks, one wave per SIMD (large M)
 constexpr int ZROW_FLOATS = 4 * LDB + 64;       // a zero region every out-of-unit lane reads instead of stale LDS
 
+template <int NWAVES>
 __device__ __forceinline__ void dma_unit(const float* __restrict__ src, float* lds_dst, int nbytes, int wave, int lane) {
-    // 1 KiB pieces, round-robin over the 8 waves; the last piece is clamped to the tile's final 16 bytes for the
+    // 1 KiB pieces, round-robin over the block's waves; the last piece is clamped to the tile's final 16 bytes for the
     // lanes that would run past it (their LDS bytes land in the slot's unused tail).
     const int npieces = (nbytes + 1023) >> 10;
     const char* base = reinterpret_cast<const char*>(src);
-    for (int p = wave; p < npieces; p += NT_THREADS / 64) {
+    for (int p = wave; p < npieces; p += NWAVES) {
         int off = (p << 10) + lane * 16;
         off = off < nbytes ? off : nbytes - 16;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
@@ -97,37 +99,40 @@ __device__ __forceinline__ void dma_unit(const float* __restrict__ src, float* l
     }
 }
 
-// Multiply one LDS-resident k unit into this wave's NTW accumulator tiles.  B reads of step s+1 are issued
-// before the MFMAs of step s (software pipeline), so together with the partner wave on the same SIMD the
-// matrix pipe always has work while an LDS read is in flight.
-template <int NTW>
-__device__ __forceinline__ void mfma_unit(const float* Bl, const float* zrow_r, const float4 (&a_cur)[NCHUNK], int c,
-                                          int rows, int kvalid, f32x4 (&acc)[5]) {
+// Multiply one LDS-resident k unit into this wave's RT x NTW accumulator tiles (RT row tiles of 16 rows share every
+// B fragment).  B reads of step s+1 are issued before the MFMAs of step s (software pipeline), so together with the
+// partner wave on the same SIMD the matrix pipe always has work while an LDS read is in flight.
+template <int RT, int NTW, int NTWMAX>
+__device__ __forceinline__ void mfma_unit(const float* Bl, const float* zrow_r, const float4 (&a_cur)[RT][NCHUNK], int c,
+                                          int rows, int kvalid, f32x4 (&acc)[RT][NTWMAX]) {
 #pragma unroll
     for (int j = 0; j < NCHUNK; ++j) {
         const int kleft = kvalid - 16 * j;             // block-uniform: real k's from this chunk on
         if (kleft > 0) {
             // a lane group whose 4 k rows lie beyond the unit reads zeros (rows % 4 == 0: all four or none)
             const float* Bj = (16 * j + 4 * c < rows) ? Bl + 16 * j * LDB : zrow_r;
-            const float av[4] = {a_cur[j].x, a_cur[j].y, a_cur[j].z, a_cur[j].w};
+            float av[RT][4];
+#pragma unroll
+            for (int q = 0; q < RT; ++q) {
+                av[q][0] = a_cur[q][j].x; av[q][1] = a_cur[q][j].y; av[q][2] = a_cur[q][j].z; av[q][3] = a_cur[q][j].w;
+            }
             if (kleft >= 4) {
                 float b0[NTW], b1[NTW];
 #pragma unroll
                 for (int t = 0; t < NTW; ++t) b0[t] = Bj[16 * t];
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) b1[t] = Bj[LDB + 16 * t];
+                for (int i = 0; i < 4; ++i) {
+                    // ping-pong: fetch step i+1 into the other register set, then spend step i
+                    if (i < 3) {
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], b0[t], acc[t], 0, 0, 0);
+                        for (int t = 0; t < NTW; ++t) (i & 1 ? b0 : b1)[t] = Bj[(i + 1) * LDB + 16 * t];
+                    }
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) b0[t] = Bj[2 * LDB + 16 * t];
+                    for (int q = 0; q < RT; ++q)
 #pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], b1[t], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) b1[t] = Bj[3 * LDB + 16 * t];
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], b0[t], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], b1[t], acc[t], 0, 0, 0);
+                        for (int t = 0; t < NTW; ++t)
+                            acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][i], (i & 1 ? b1 : b0)[t], acc[q][t], 0, 0, 0);
+                }
             } else {                                   // ragged tail of the term: 1..3 steps
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -136,7 +141,10 @@ __device__ __forceinline__ void mfma_unit(const float* Bl, const float* zrow_r, 
 #pragma unroll
                         for (int t = 0; t < NTW; ++t) b[t] = Bj[i * LDB + 16 * t];
 #pragma unroll
-                        for (int t = 0; t < NTW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b[t], acc[t], 0, 0, 0);
+                        for (int q = 0; q < RT; ++q)
+#pragma unroll
+                            for (int t = 0; t < NTW; ++t)
+                                acc[q][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q][i], b[t], acc[q][t], 0, 0, 0);
                     }
                 }
             }
@@ -144,22 +152,32 @@ __device__ __forceinline__ void mfma_unit(const float* Bl, const float* zrow_r, 
     }
 }
 
-__global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a) {
+// RT = row tiles per wave: 1 -> 64-row blocks (small problems: more blocks), 2 -> 128-row blocks (large problems: every
+// weight byte DMA'd into LDS and every B fragment read from it feeds twice the MFMAs).
+template <int RT, int CS>
+__global__ __launch_bounds__(CS * 256, 1) void gemm_nt_kernel(const GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x BUF_FLOATS + ZROW_FLOATS
+    constexpr int NT_THREADS = CS * 256;
+    constexpr int NTWMAX = CS == 2 ? 5 : 9;        // accumulator tiles per wave and row tile
+    constexpr int RPB = ROWS_PER_BLOCK * RT;       // rows per block
+    constexpr int NIT = (RPB * (CB / 4) + NT_THREADS - 1) / NT_THREADS;   // float4 items per thread in a flush
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rg = wave & 3, ch = wave >> 2;       // waves w and w+4 share a SIMD: same rows, the two column halves
+    const int rg = wave & 3, ch = CS == 2 ? wave >> 2 : 0;   // CS = 2: waves w and w+4 share a SIMD (two column halves)
     const int r = lane & 15, c = lane >> 4;
     const int cb = blockIdx.y;
     const int n0 = cb * CB;
     const int tile0 = ch * 5;                      // column tiles [0,5) or [5,9) of the 144-column block
-    const int nrb = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;   // row blocks; this block takes bx, bx + gridDim.x, ...
+    const int nrb = (a.M + RPB - 1) / RPB;         // row blocks; this block takes bx, bx + gridDim.x, ...
     // tiles this wave really has to produce (narrow outputs leave the second half, or most of the first, idle)
     int ntile_w = (a.ldc - n0 - 16 * tile0 + 15) / 16;
-    ntile_w = ntile_w < 0 ? 0 : (ntile_w > (ch ? 4 : 5) ? (ch ? 4 : 5) : ntile_w);
-    f32x4 acc[5];
+    const int ntile_cap = CS == 2 ? (ch ? 4 : 5) : 9;
+    ntile_w = ntile_w < 0 ? 0 : (ntile_w > ntile_cap ? ntile_cap : ntile_w);
+    f32x4 acc[RT][NTWMAX];
 #pragma unroll
-    for (int t = 0; t < 5; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < RT; ++q)
+#pragma unroll
+        for (int t = 0; t < NTWMAX; ++t) acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float* zrow = lds + 2 * BUF_FLOATS;
     for (int i = tid; i < ZROW_FLOATS; i += NT_THREADS) zrow[i] = 0.f;
 
@@ -184,20 +202,22 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         return true;
     };
     auto unit_rows = [&](int t2, int k2) { const int K4 = (a.term[t2].K + 3) & ~3; return min(KC, K4 - k2 * KC); };
-    auto issue = [&](int rb2, int t2, int k2, float4 (&areg)[NCHUNK], float* slot) {
+    auto issue = [&](int rb2, int t2, int k2, float4 (&areg)[RT][NCHUNK], float* slot) {
         const GemmTerm& tm = a.term[t2];
-        const int arow = rb2 * ROWS_PER_BLOCK + rg * 16 + r;
-        const bool arow_ok = arow < a.M;
         const int K4 = (tm.K + 3) & ~3;
         const int rows = min(KC, K4 - k2 * KC);
         const float* tile = tm.Bp + ((size_t)cb * K4 + (size_t)k2 * KC) * LDB;
-        if (!(a.dbg & 1)) dma_unit(tile, slot, rows * LDB * 4, wave, lane);
-        const float* Arow = tm.A + (size_t)arow * tm.lda + k2 * KC;
+        if (!(a.dbg & 1)) dma_unit<NT_THREADS / 64>(tile, slot, rows * LDB * 4, wave, lane);
 #pragma unroll
-        for (int j = 0; j < NCHUNK; ++j) {
-            const int kk = 16 * j + 4 * c;
-            areg[j] = (arow_ok && ntile_w > 0 && kk < rows && !(a.dbg & 8)) ? *reinterpret_cast<const float4*>(Arow + kk)
-                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < RT; ++q) {
+            const int arow = rb2 * RPB + q * ROWS_PER_BLOCK + rg * 16 + r;
+            const bool ok = arow < a.M && ntile_w > 0 && !(a.dbg & 8);
+            const float* Arow = tm.A + (size_t)(ok ? arow : 0) * tm.lda + k2 * KC;
+#pragma unroll
+            for (int j = 0; j < NCHUNK; ++j) {
+                const int kk = 16 * j + 4 * c;
+                areg[q][j] = (ok && kk < rows) ? *reinterpret_cast<const float4*>(Arow + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
 
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
     const float keep_scale = a.act == ACT_DROPOUT_RELU ? 1.0f / (1.0f - a.p_drop) : 1.0f;
     const int ncol4 = min(CB, a.ldc - n0) >> 2;    // float4 columns of this block's output
 
-    float4 a_cur[NCHUNK], a_nxt[NCHUNK];
+    float4 a_cur[RT][NCHUNK], a_nxt[RT][NCHUNK];
     int cur_rb = blockIdx.x, cur_t = -1, cur_k = 0;
     bool have = next_unit(blockIdx.x, -1, 0, cur_rb, cur_t, cur_k);
     if (have) issue(cur_rb, cur_t, cur_k, a_cur, lds);
@@ -225,71 +245,91 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         const float* Bl = lds + slot * BUF_FLOATS + (4 * c) * LDB + r + 16 * tile0;
         if (a.dbg & 2) {
         } else if (ntile_w > 1) {
-            if (ch == 0) mfma_unit<5>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
-            else mfma_unit<4>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
+            if (CS == 1) mfma_unit<RT, 9, NTWMAX>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
+            else if (ch == 0) mfma_unit<RT, 5, NTWMAX>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
+            else mfma_unit<RT, 4, NTWMAX>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
         } else if (ntile_w == 1) {
-            mfma_unit<1>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
+            mfma_unit<RT, 1, NTWMAX>(Bl, zrow + r, a_cur, c, rows, kvalid, acc);
         }
         __syncthreads();   // next unit landed (vmcnt(0) precedes the barrier) and this slot is free again
         const int group = a.term[cur_t].group;
         if ((!more || a.term[nt_].group != group || nrb_ != cur_rb) && !(a.dbg & 4)) {
-            // ---- flush this group's 64 x 144 tile: accumulators -> LDS (the slot just freed) -> whole-row float4
+            // ---- flush this group's RPB x 144 tile: accumulators -> LDS (the slot just freed) -> whole-row float4
             // stores with the fused epilogue.  Lane holds D[row = 4c + reg][col = r] of every tile.
             float* stage = lds + slot * BUF_FLOATS;
+            const int brow0 = cur_rb * RPB;
 #pragma unroll
-            for (int t = 0; t < 5; ++t) {
-                if (t < ntile_w) {
+            for (int q = 0; q < RT; ++q)
 #pragma unroll
-                    for (int reg = 0; reg < 4; ++reg)
-                        stage[(rg * 16 + 4 * c + reg) * LDB + 16 * (tile0 + t) + r] = acc[t][reg];
+                for (int t = 0; t < NTWMAX; ++t) {
+                    if (t < ntile_w) {
+#pragma unroll
+                        for (int reg = 0; reg < 4; ++reg)
+                            stage[(q * ROWS_PER_BLOCK + rg * 16 + 4 * c + reg) * LDB + 16 * (tile0 + t) + r] = acc[q][t][reg];
+                    }
+                    acc[q][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
-                acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
             __syncthreads();
             float* C = a.C[group];
             const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
-            const int brow0 = cur_rb * ROWS_PER_BLOCK;
-            for (int idx = tid; idx < ROWS_PER_BLOCK * ncol4; idx += NT_THREADS) {
-                const int lr = idx / ncol4, q = idx - lr * ncol4;
-                const int row = brow0 + lr, col = n0 + 4 * q;
-                if (row >= a.M) continue;
-                const float4 v4 = *reinterpret_cast<const float4*>(stage + lr * LDB + 4 * q);
-                float v[4] = {v4.x, v4.y, v4.z, v4.w};
-                float g4[4] = {1.f, 1.f, 1.f, 1.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
-                if (a.gate) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(a.gate + (size_t)row * a.ldg + col);
-                    g4[0] = t4.x; g4[1] = t4.y; g4[2] = t4.z; g4[3] = t4.w;
-                }
-                if (a.resid) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(a.resid + (size_t)row * a.ldr + col);
-                    r4[0] = t4.x; r4[1] = t4.y; r4[2] = t4.z; r4[3] = t4.w;
-                }
-                const float rs = a.rowscale ? a.rowscale[row] : 0.f;
+            const float* extra = a.gate ? a.gate : a.resid;
+            const int ldx = a.gate ? a.ldg : a.ldr;
+            constexpr int FB = 4;                     // items per batch: FB epilogue-operand loads in flight, then FB stores
+#pragma unroll 1
+            for (int it0 = 0; it0 < NIT; it0 += FB) {
+                float4 ex[FB], v4[FB];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int cc = col + e;
-                    float x = 0.f;
-                    if (cc < a.ncols) {
-                        x = v[e] + (use_bias ? a.bias[cc] : 0.f);
-                        if (a.rowscale) x = fmaf(rs, a.rowbias[cc], x);
-                        x += r4[e];
-                        if (a.act == ACT_RELU) {
-                            x = fmaxf(x, 0.f);
-                        } else if (a.act == ACT_DROPOUT_RELU) {
-                            const float u = uniform_hash(seed, offset, a.rng_stream, (uint64_t)row * a.ncols + cc);
-                            x = (u >= a.p_drop && x > 0.f) ? x * keep_scale : 0.f;
-                        }
-                        if (a.gate) x = g4[e] > 0.f ? x * a.gate_scale : 0.f;
-                    }
-                    v[e] = x;
+                for (int u = 0; u < FB; ++u) {
+                    const int idx = tid + (it0 + u) * NT_THREADS;
+                    const int lr = idx / ncol4, q4 = idx - lr * ncol4;
+                    const int row = brow0 + lr;
+                    const bool ok = lr < RPB && row < a.M;
+                    ex[u] = (ok && extra) ? *reinterpret_cast<const float4*>(extra + (size_t)row * ldx + n0 + 4 * q4)
+                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v4[u] = ok ? *reinterpret_cast<const float4*>(stage + lr * LDB + 4 * q4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
-                *reinterpret_cast<float4*>(C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+                for (int u = 0; u < FB; ++u) {
+                    const int idx = tid + (it0 + u) * NT_THREADS;
+                    const int lr = idx / ncol4, q4 = idx - lr * ncol4;
+                    const int row = brow0 + lr, col = n0 + 4 * q4;
+                    if (lr >= RPB || row >= a.M) continue;
+                    float v[4] = {v4[u].x, v4[u].y, v4[u].z, v4[u].w};
+                    const float e4[4] = {ex[u].x, ex[u].y, ex[u].z, ex[u].w};
+                    const float rs = a.rowscale ? a.rowscale[row] : 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int cc = col + e;
+                        float x = 0.f;
+                        if (cc < a.ncols) {
+                            x = v[e] + (use_bias ? a.bias[cc] : 0.f);
+                            if (a.rowscale) x = fmaf(rs, a.rowbias[cc], x);
+                            if (a.resid) x += e4[e];
+                            if (a.act == ACT_RELU) {
+                                x = fmaxf(x, 0.f);
+                            } else if (a.act == ACT_DROPOUT_RELU) {
+                                const float uu = uniform_hash(seed, offset, a.rng_stream, (uint64_t)row * a.ncols + cc);
+                                x = (uu >= a.p_drop && x > 0.f) ? x * keep_scale : 0.f;
+                            }
+                            if (a.gate) x = e4[e] > 0.f ? x * a.gate_scale : 0.f;
+                        }
+                        v[e] = x;
+                    }
+                    *reinterpret_cast<float4*>(C + (size_t)row * a.ldc + col) = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
-            if (more) __syncthreads();   // the staged tile is consumed before the unit after next overwrites this slot
+            if (more) {
+                // the staged tile must be fully READ before the unit after next is DMA'd over it; the stores
+                // themselves may stay in flight (no vmcnt wait: that would stall the next MFMA phase on HBM acks)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
         }
         if (more) {
 #pragma unroll
-            for (int j = 0; j < NCHUNK; ++j) a_cur[j] = a_nxt[j];
+            for (int q = 0; q < RT; ++q)
+#pragma unroll
+                for (int j = 0; j < NCHUNK; ++j) a_cur[q][j] = a_nxt[q][j];
             cur_rb = nrb_; cur_t = nt_; cur_k = nk_;
             slot ^= 1;
         }
@@ -314,20 +354,25 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
             set_error("gemm_nt: term %d has no packed weight", t);
             return PFN_EINVAL;
         }
-        flops += 2.0 * a.M * a.term[t].K * a.ncols;
-        bytes += (double)a.M * a.term[t].K * 4.0;
-    }
-    const size_t lds_bytes = (2 * BUF_FLOATS + ZROW_FLOATS) * sizeof(float);
-    if (!g_nt_attr_set) {
-        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        g_nt_attr_set = true;
-    }
-    for (int t = 1; t < a.nterm; ++t)
-        if (a.term[t].group < a.term[t - 1].group) {
+        if (t > 0 && a.term[t].group < a.term[t - 1].group) {
             set_error("gemm_nt: terms must be sorted by output group");
             return PFN_EINVAL;
         }
+        flops += 2.0 * a.M * a.term[t].K * a.ncols;
+        bytes += (double)a.M * a.term[t].K * 4.0;
+    }
+    if ((a.gate && a.resid) || (a.gate && a.ldg % 4) || (a.resid && a.ldr % 4)) {
+        set_error("gemm_nt: epilogue takes a gate OR a residual, with a row stride that is a multiple of 4");
+        return PFN_EINVAL;
+    }
+    const size_t lds_bytes = (2 * BUF_FLOATS + ZROW_FLOATS) * sizeof(float);
+    if (!g_nt_attr_set) {
+        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<1, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<2, 1>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        g_nt_attr_set = true;
+    }
     static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
@@ -335,13 +380,19 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
     }
-    const int nrb = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    // one 160 KiB-LDS block per CU: persistent blocks stride over the row blocks
-    dim3 grid(std::min(nrb, std::max(1, ncu / a.ncb)), a.ncb);
     static const int dbg = getenv("PFN_GEMM_DBG") ? atoi(getenv("PFN_GEMM_DBG")) : 0;   // timing dissection only
     a.dbg = dbg;
+    // one 160 KiB-LDS block per CU; persistent blocks stride over the row blocks.  128-row blocks once there are at
+    // least two of them per CU (halves the weight DMA and the LDS fragment reads per MFMA), 64-row blocks otherwise.
+    const int slots = std::max(1, ncu / a.ncb);
+    const int nrb64 = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     ProfScope ps("gemm_nt", bytes, flops, s);
-    gemm_nt_kernel<<<grid, NT_THREADS, lds_bytes, s>>>(a);
+    if (nrb64 >= 4 * slots) {
+        const int nrb = (a.M + 2 * ROWS_PER_BLOCK - 1) / (2 * ROWS_PER_BLOCK);
+        gemm_nt_kernel<2, 1><<<dim3(std::min(nrb, slots), a.ncb), 256, lds_bytes, s>>>(a);
+    } else {
+        gemm_nt_kernel<1, 2><<<dim3(std::min(nrb64, slots), a.ncb), 512, lds_bytes, s>>>(a);
+    }
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
