@@ -72,10 +72,12 @@ def b_fwd(n, e, h, L, K, f0=4, fo=4, fe=2):
 
 
 def cpu_baseline(args, cfg, data_cpu, seconds):
+    """The CPU oracle (pure-torch restatement of the reference dataflow) timed on this box's host cores.  torch's
+    intra-op pool over-subscribes badly on many-core hosts (256 threads: ~70 s/step on this workload), so the thread
+    count is the best of a short sweep -- the most favourable setting for the CPU side; `cores` reports it."""
     from oracle import ref_cpu
     h, L, K = cfg
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     torch.manual_seed(1234)
     ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, h, L, K, 0.2)
     B = args.batch
@@ -89,7 +91,18 @@ def cpu_baseline(args, cfg, data_cpu, seconds):
         def step():
             with torch.no_grad():
                 ref(data_cpu)
-    step()                                            # warm-up
+    best_t, best_n = None, 1
+    for nt in sorted({n for n in (4, 8, 16, 32, 64) if n <= ncpu} | ({ncpu} if ncpu <= 64 else set())):
+        torch.set_num_threads(nt)
+        step()                                        # warm-up at this thread count
+        t0 = time.perf_counter()
+        step()
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best_t, best_n = dt, nt
+        if dt > 30:                                   # keep the default run within minutes
+            break
+    torch.set_num_threads(best_n)
     t0, n = time.perf_counter(), 0
     while True:
         step()
@@ -97,10 +110,11 @@ def cpu_baseline(args, cfg, data_cpu, seconds):
         dt = time.perf_counter() - t0
         if dt >= seconds or n >= 50:
             break
-    return {"value": round(B * n / dt, 2), "unit": "graphs/s", "cores": cores, "kind": "port",
+    return {"value": round(B * n / dt, 2), "unit": "graphs/s", "cores": best_n, "kind": "port",
             "sample": f"{n} {args.mode} steps of the same workload (case{args.case} batch={B}, {args.config}) on the "
-                      f"pure-torch CPU restatement of the reference dataflow, {dt:.1f} s, torch threads={cores}",
-            "ms_per_step": round(1e3 * dt / n, 2)}
+                      f"pure-torch CPU restatement of the reference dataflow, {dt:.1f} s, torch threads={best_n} "
+                      f"(best of a 4..64 sweep; host has {ncpu} logical cores)",
+            "host_logical_cores": ncpu, "ms_per_step": round(1e3 * dt / n, 2)}
 
 
 def main():

@@ -371,6 +371,8 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<2, 1>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<2, 2>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         g_nt_attr_set = true;
     }
     static int ncu = 0;
@@ -387,9 +389,11 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
     const int slots = std::max(1, ncu / a.ncb);
     const int nrb64 = (a.M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
     ProfScope ps("gemm_nt", bytes, flops, s);
-    if (nrb64 >= 4 * slots) {
+    static const int wide_rows = getenv("PFN_GEMM_RT2") ? atoi(getenv("PFN_GEMM_RT2")) : 0;   // experiments
+    if (wide_rows && nrb64 >= 4 * slots) {
         const int nrb = (a.M + 2 * ROWS_PER_BLOCK - 1) / (2 * ROWS_PER_BLOCK);
-        gemm_nt_kernel<2, 1><<<dim3(std::min(nrb, slots), a.ncb), 256, lds_bytes, s>>>(a);
+        if (wide_rows == 1) gemm_nt_kernel<2, 1><<<dim3(std::min(nrb, slots), a.ncb), 256, lds_bytes, s>>>(a);
+        else gemm_nt_kernel<2, 2><<<dim3(std::min(nrb, slots), a.ncb), 512, lds_bytes, s>>>(a);
     } else {
         gemm_nt_kernel<1, 2><<<dim3(std::min(nrb64, slots), a.ncb), 512, lds_bytes, s>>>(a);
     }

@@ -1,0 +1,42 @@
+"""`evaluate_epoch` / `load_model` / `num_params` counterparts of the reference's utils/evaluation.py:20-104."""
+from typing import Callable, Optional
+
+import torch
+import torch.nn as nn
+
+from .custom_loss_functions import Masked_L2_loss, MixedMSEPoweImbalance, PowerImbalance
+
+
+def load_model(model: nn.Module, run_id: str, device, models_dir: str = "models"):
+    """utils/evaluation.py:20-36: load `model_state_dict` of the best-validation checkpoint of a run."""
+    import os
+    path = os.path.join(models_dir, f"model_{run_id}.pt")
+    saved = torch.load(path, map_location=device)
+    model.load_state_dict(saved["model_state_dict"])
+    return model, saved
+
+
+def num_params(model: nn.Module) -> int:
+    return sum(p.numel() for p in model.parameters() if p.requires_grad)
+
+
+@torch.no_grad()
+def evaluate_epoch(model: nn.Module, loader, loss_fn: Callable, device="cpu", pre_loss_fn: Optional[Callable] = None) -> float:
+    pre = pre_loss_fn or (lambda x: x)
+    model.eval()
+    total_loss, num_samples = 0.0, 0
+    for data in loader:
+        data = data.to(device)
+        out = model(data)
+        if isinstance(loss_fn, Masked_L2_loss):
+            loss = loss_fn(pre(out), pre(data.y), data.pred_mask)
+        elif isinstance(loss_fn, PowerImbalance):
+            masked_out = out * data.pred_mask + data.pred_mask * (1 - data.pred_mask)
+            loss = loss_fn(pre(masked_out), data.edge_index, data.edge_attr)
+        elif isinstance(loss_fn, MixedMSEPoweImbalance):
+            loss = loss_fn(pre(out), data.edge_index, data.edge_attr, data.y)
+        else:
+            loss = loss_fn(pre(out), pre(data.y))
+        num_samples += len(data)
+        total_loss += loss.item() * len(data)
+    return total_loss / max(num_samples, 1)

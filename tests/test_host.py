@@ -1,0 +1,97 @@
+"""Host logic without a GPU: argument parser precedence, loss dispatch helpers, train/eval loop semantics (driven with
+the CPU oracle model, which is allowed in tests), and the world-size-2 gloo data-parallel step."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ref_cpu
+from poweflownet_amd import dp
+from poweflownet_amd.data import DataLoader
+from poweflownet_amd.synth import make_dataset
+from poweflownet_amd.utils.argument_parser import argument_parser
+from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss, PowerImbalance
+from poweflownet_amd.utils.evaluation import evaluate_epoch, num_params
+from poweflownet_amd.utils.training import train_epoch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_argument_parser_precedence():
+    a = argument_parser(["--cfg_json", os.path.join(ROOT, "configs", "wide.json"), "--case", "6470rte", "--K", "5"])
+    assert (a.hidden_dim, a.n_gnn_layers, a.K, a.case) == (129, 6, 5, "6470rte")      # defaults < JSON < CLI
+    b = argument_parser([])
+    assert (b.hidden_dim, b.train_loss_fn, b.batch_size) == (128, "masked_l2", 128)
+
+
+def test_masked_l2_loss_matches_definition():
+    torch.manual_seed(0)
+    out, y = torch.randn(10, 4), torch.randn(10, 4)
+    mask = torch.randint(0, 2, (10, 4))
+    m = mask.bool()
+    want = ((out - y)[m] ** 2).mean() + 0.5 * ((out - y)[~m] ** 2).mean()
+    assert torch.allclose(Masked_L2_loss(regularize=True, regcoeff=0.5)(out, y, mask), want)
+    assert torch.allclose(Masked_L2_loss(regularize=False)(out, y, mask), ((out - y)[m] ** 2).mean())
+    with pytest.raises(NotImplementedError):
+        PowerImbalance()
+
+
+def test_train_and_eval_epoch_semantics_on_oracle_model():
+    torch.manual_seed(0)
+    ds = make_dataset("14", 12)
+    loader = DataLoader(ds, batch_size=4)
+    model = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 16, 2, 2, 0.0)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+    before = evaluate_epoch(model, loader, Masked_L2_loss(regularize=False), "cpu")
+    l1 = train_epoch(model, loader, torch.nn.MSELoss(), opt, "cpu")
+    l2 = train_epoch(model, loader, Masked_L2_loss(), opt, "cpu")
+    for _ in range(20):
+        l2 = train_epoch(model, loader, Masked_L2_loss(), opt, "cpu")
+    after = evaluate_epoch(model, loader, Masked_L2_loss(regularize=False), "cpu")
+    assert l1 > 0 and l2 > 0 and after < before
+    assert num_params(model) == sum(p.numel() for p in model.parameters())
+
+
+def _dp_worker(rank, world, port, ret):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    r, _, w = dp.init_from_env(backend="gloo")
+    ds = make_dataset("14", 8)
+    torch.manual_seed(1234 + rank)                       # deliberately different init: broadcast must fix it
+    model = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
+    dp.broadcast_parameters(model)
+    loader = DataLoader(ds, batch_size=8, shard=(r, w))
+    batch = next(iter(loader))
+    loss = torch.nn.MSELoss()(model(batch), batch.y)
+    loss.backward()
+    dp.allreduce_gradients(model, ordered_params=list(model.parameters()))
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    if rank == 0:
+        ret["grad"], ret["params"] = flat.clone(), params.clone()
+    gathered = [torch.zeros_like(flat) for _ in range(w)]
+    dist.all_gather(gathered, flat)
+    assert all(torch.equal(g, gathered[0]) for g in gathered)
+    dist.destroy_process_group()
+
+
+def test_dp_world2_gloo_equals_single_process_global_batch():
+    """Mean of the two ranks' gradients on their shards == gradient on the global batch (MSELoss mean, equal node counts)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    torch.set_num_threads(1)
+    ds = make_dataset("14", 8)
+    torch.manual_seed(1234)
+    model = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
+    assert torch.equal(torch.cat([p.detach().reshape(-1) for p in model.parameters()]), ret["params"])
+    batch = next(iter(DataLoader(ds, batch_size=8)))
+    torch.nn.MSELoss()(model(batch), batch.y).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    got = ret["grad"]
+    assert (got - want).abs().max().item() <= 1e-6 * want.abs().max().item() + 1e-9

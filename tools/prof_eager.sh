@@ -7,3 +7,4 @@ rm -rf /tmp/prof_$tag; mkdir -p /tmp/prof_$tag $R/gpurun_out
 env "$@" timeout 300 rocprofv3 --kernel-trace -d /tmp/prof_$tag -o t -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --profile-steps 0 --no-graph $BENCH_ARGS > /tmp/prof_$tag/bench.out 2>&1
 python $R/tools/kstats.py /tmp/prof_$tag/t_results.db "$like" 11 > $R/gpurun_out/$tag.txt 2>&1
 grep -o '"ms_per_step": [0-9.]*' /tmp/prof_$tag/bench.out | head -1 >> $R/gpurun_out/$tag.txt
+if [ -n "$KSEQ" ]; then python $R/tools/kseq.py /tmp/prof_$tag/t_results.db "$KSEQ" ${KSEQ_N:-25} >> $R/gpurun_out/$tag.txt; fi

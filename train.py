@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Training entry counterpart of the reference's train.py (same CLI: `python3 train.py --cfg_json configs/standard.json
+--case 118v2 --model MaskEmbdMultiMPN --train_loss_fn mse_loss --batch-size 128 --lr 0.001 --num-epochs N`).
+
+Differences forced by the image: no dataset files and no pandapower -> samples are synthetic grids with the tensor
+layout of datasets/PowerFlowData.py (poweflownet_amd/synth.py); no wandb.  Like the reference, the three model
+dims come from the data (4/2/4), not from the JSON (train.py:106-117).  Under torchrun every rank trains on its shard of
+each global batch and gradients are averaged with one flat all-reduce (poweflownet_amd/dp.py)."""
+import os
+import time
+
+import numpy as np
+import torch
+
+from poweflownet_amd import dp
+from poweflownet_amd.data import DataLoader
+from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+from poweflownet_amd.optim import FlatAdamW
+from poweflownet_amd.synth import make_dataset
+from poweflownet_amd.utils.argument_parser import argument_parser
+from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss
+from poweflownet_amd.utils.evaluation import evaluate_epoch
+from poweflownet_amd.utils.training import append_to_json, train_epoch
+
+
+def main():
+    args = argument_parser()
+    if args.model != "MaskEmbdMultiMPN":
+        raise SystemExit("only --model MaskEmbdMultiMPN (the hot path) is built; see DESIGN.md 'out of scope'")
+    rank, local_rank, world = dp.init_from_env()
+    if not torch.cuda.is_available():
+        raise SystemExit("train.py needs a HIP device: poweflownet_amd has no CPU fallback")
+    device = torch.device("cuda", local_rank)
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    n = args.synthetic_samples
+    full = make_dataset(args.case, n, seed=0)
+    n_tr, n_va = int(0.5 * n), int(0.2 * n)                      # split [.5, .2, .3] (train.py:76)
+    trainset, valset = full[:n_tr], full[n_tr:n_tr + n_va]
+    shard = (rank, world) if world > 1 else None
+    train_loader = DataLoader(trainset, batch_size=args.batch_size * world, shuffle=True,
+                              generator=torch.Generator().manual_seed(1234), shard=shard)
+    val_loader = DataLoader(valset, batch_size=args.batch_size, shuffle=False)
+    if args.train_loss_fn == "masked_l2":
+        loss_fn = Masked_L2_loss(regularize=args.regularize, regcoeff=args.regularization_coeff)
+    elif args.train_loss_fn == "mse_loss":
+        loss_fn = torch.nn.MSELoss()
+    else:
+        raise SystemExit(f"--train_loss_fn {args.train_loss_fn} is out of this round's scope (SURVEY.md 8f N4)")
+    eval_loss_fn = Masked_L2_loss(regularize=False)
+    model = MaskEmbdMultiMPN(nfeature_dim=4, efeature_dim=2, output_dim=4, hidden_dim=args.hidden_dim,
+                             n_gnn_layers=args.n_gnn_layers, K=args.K, dropout_rate=args.dropout_rate).to(device)
+    dp.broadcast_parameters(model)
+    if rank == 0:
+        print("Total number of parameters: ", sum(p.numel() for p in model.parameters()))
+    optimizer = FlatAdamW(model, lr=args.lr)
+    scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=args.lr, steps_per_epoch=len(train_loader),
+                                                    epochs=args.num_epochs)
+    run_id = time.strftime("%Y%m%d-%H%M%S")
+    best_val = float("inf")
+    for epoch in range(args.num_epochs):
+        t0 = time.time()
+        train_loss = train_epoch(model, train_loader, loss_fn, optimizer, device)
+        val_loss = evaluate_epoch(model, val_loader, eval_loss_fn, device)
+        scheduler.step()                                          # once per epoch, like train.py:145
+        if rank == 0:
+            print(f"Epoch {epoch + 1} / {args.num_epochs}, train={train_loss:.4f}, val={val_loss:.4f}, "
+                  f"{len(trainset) / max(time.time() - t0, 1e-9):.0f} graphs/s")
+            if args.save and val_loss < best_val:
+                best_val = val_loss
+                os.makedirs("models", exist_ok=True)
+                torch.save({"epoch": epoch, "args": vars(args), "val_loss": best_val,
+                            "model_state_dict": model.state_dict()}, os.path.join("models", f"model_{run_id}.pt"))
+                append_to_json(os.path.join("logs", "save_logs.json"), run_id,
+                               {"val_loss": f"{best_val:.4f}", "train_loss": f"{train_loss:.4f}", "epoch": epoch})
+
+
+if __name__ == "__main__":
+    main()
