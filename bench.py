@@ -138,7 +138,8 @@ def main():
     data = data_cpu.to(dev)
     n_nodes = data.x.shape[0]
     train = args.mode == "train"
-    loss_fn = torch.nn.MSELoss()
+    from poweflownet_amd.loss import MSELoss
+    loss_fn = MSELoss()                               # torch.nn.MSELoss semantics (train.py:103), fwd+bwd in one pass
     loss_box = [None]
 
     if train:

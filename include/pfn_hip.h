@@ -86,7 +86,8 @@ size_t pfn_mpn_workspace_bytes(const pfn_mpn_config* cfg, int64_t n_nodes, int64
 /* MaskEmbdMultiMPN.forward (networks/MPN.py:525-559), including EdgeAggregation.forward/message
  * (:23-56) and TAGConv.forward.  x [N, F0] f32, pred_mask [N, F0] (mask_dtype 0: int64, the dataset
  * layout of datasets/PowerFlowData.py:193; 1: float32), edge_attr [e_stored, Fe] f32, out [N, output_dim] f32.  `ws` receives the activations backward needs.  `rng_state`: device
- * uint64[2] {seed, offset}; read when training && dropout_rate > 0 and advanced by one per call.   */
+ * uint64[2] {seed, offset}; when training && dropout_rate > 0 the offset is advanced by one at the start of the call
+ * and then read by the dropout epilogues.                                                          */
 int pfn_mpn_forward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
                     const float* const* params, const float* x, const void* pred_mask,
                     int mask_dtype, const float* edge_attr, float* out, void* ws, size_t ws_bytes,
@@ -143,7 +144,8 @@ int pfn_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, i
 int pfn_mse_loss(const float* out, const float* y, int64_t count, float* loss, float* grad, void* ws,
                  size_t ws_bytes, void* stream);
 /* AdamW on one flat buffer (train.py:123; torch defaults betas (0.9,0.999), eps 1e-8, wd 0.01).
- * `step` is a device int64 counter incremented by the call (capturable).                           */
+ * `step` is a device int64[2] {completed steps, arrival scratch (zero)}; the call increments step[0] itself,
+ * so one launch per update and the whole step stays hipGraph-replayable.                           */
 int pfn_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
                    void* stream);

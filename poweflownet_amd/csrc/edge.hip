@@ -451,11 +451,5 @@ int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst
     return PFN_OK;
 }
 
-__global__ void rng_advance_kernel(uint64_t* rng) { rng[1] += 1; }
-int launch_rng_advance(uint64_t* rng, hipStream_t s) {
-    rng_advance_kernel<<<1, 1, 0, s>>>(rng);
-    PFN_CHECK_LAUNCH();
-    return PFN_OK;
-}
 
 }  // namespace pfn

@@ -39,6 +39,8 @@ constexpr int ROWS_PER_BLOCK = 64;
 
 // ------------------------------------------------------------------------------------------------ pack
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
+    // the dropout stream advances once per forward, before any kernel of that forward reads it
+    if (a.rng_advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.rng_advance[1] += 1;
     const PackJob jb = a.job[blockIdx.y];
     const int ncb = (jb.ld_out + CB - 1) / CB;
     const int K4 = (jb.K + 3) & ~3;
@@ -63,10 +65,11 @@ size_t packed_floats(int K, int ld_out) {
     return (size_t)round_up((int64_t)ncb * K4 * LDB, 256);   // whole KiB: DMA pieces never run off the allocation
 }
 
-int launch_pack(const PackJob* jobs, int njobs, hipStream_t s) {
+int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s) {
     for (int j0 = 0; j0 < njobs; j0 += PACK_MAX_JOBS) {
         PackArgs a;
         a.njobs = std::min(PACK_MAX_JOBS, njobs - j0);
+        a.rng_advance = j0 == 0 ? rng_advance : nullptr;
         long biggest = 0;
         for (int j = 0; j < a.njobs; ++j) {
             a.job[j] = jobs[j0 + j];
@@ -569,8 +572,9 @@ __global__ __launch_bounds__(256) void colsum_fallback_kernel(const ColsumArgs a
 }
 
 static void tn_split(int64_t M, int nblocks, int& rows_per_split, int& nsplit) {
-    // aim for ~512 resident blocks of 9 waves; at least 4 stages (128 rows) per split
-    int64_t want = std::max<int64_t>(1, 512 / std::max(1, nblocks));
+    // aim for ~one 9-wave block per CU: fewer, longer splits keep the partial-sum traffic (83 KB per block, written
+    // then re-read by tn_reduce) below the operand traffic; at least 4 stages (128 rows) per split
+    int64_t want = std::max<int64_t>(1, 256 / std::max(1, nblocks));
     int64_t s = std::min<int64_t>(want, (M + 4 * TN_MB - 1) / (4 * TN_MB));
     s = std::max<int64_t>(1, std::min<int64_t>(s, 128));
     rows_per_split = (int)round_up((M + s - 1) / s, TN_MB);

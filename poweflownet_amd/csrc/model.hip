@@ -55,7 +55,7 @@ struct Packer {
         jobs.push_back(j);
         return dst ? dst : reinterpret_cast<const float*>(0x10);   // non-null sentinel while measuring
     }
-    int flush(hipStream_t s) { return launch_pack(jobs.data(), (int)jobs.size(), s); }
+    int flush(hipStream_t s, uint64_t* rng_advance = nullptr) { return launch_pack(jobs.data(), (int)jobs.size(), rng_advance, s); }
 };
 
 struct Act {
@@ -345,7 +345,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     Packer pk(lo.packed);
     ModelPack mp;
     plan_pack(pk, lo.f0, lo.fe, lo.fo, lo.h, lo.L, lo.K, params, mp);
-    PFN_TRY(pk.flush(s));
+    PFN_TRY(pk.flush(s, drop ? rng : nullptr));   // also advances the dropout stream for this forward
     // mask_embd(mask) + x   (networks/MPN.py:533,:537)
     PFN_TRY(launch_mask_to_float(pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0, s));
     {
@@ -393,7 +393,6 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         cur = y;
         ldc = ldy;
     }
-    if (drop) PFN_TRY(launch_rng_advance(rng, s));
     return PFN_OK;
 }
 
@@ -494,8 +493,9 @@ __global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
-                                                    float b1, float b2, float eps, float wd,
-                                                    const int64_t* __restrict__ step) {
+                                                    float b1, float b2, float eps, float wd, int64_t* step) {
+    // step[0] = completed steps, step[1] = arrival counter: the last block to finish bumps the step and re-arms the
+    // counter, so the whole update is ONE launch and stays hipGraph-replayable
     const float t = (float)(step[0] + 1);
     const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
     const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
@@ -509,8 +509,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
         p[i] = pi - step_size * (mi / denom);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(step + 1), 1ull);
+        if (prev == (unsigned long long)gridDim.x - 1) {
+            step[1] = 0;
+            step[0] += 1;
+        }
+    }
 }
-__global__ void step_inc_kernel(int64_t* step) { step[0] += 1; }
 
 }  // namespace pfn
 
@@ -745,8 +752,6 @@ int pfn_adamw_step(float* p, const float* g, float* m, float* v, int64_t count, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 2048));
     adamw_kernel<<<nb, 256, 0, s>>>(p, g, m, v, count, lr, b1, b2, eps, wd, step);
-    PFN_CHECK_LAUNCH();
-    step_inc_kernel<<<1, 1, 0, s>>>(step);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

@@ -96,9 +96,10 @@ constexpr int PACK_MAX_JOBS = 64;
 struct PackArgs {
     PackJob job[PACK_MAX_JOBS];
     int njobs;
+    uint64_t* rng_advance;   // device {seed, offset}: offset += 1 (dropout stream), or null
 };
 size_t packed_floats(int K, int ld_out);
-int launch_pack(const PackJob* jobs, int njobs, hipStream_t s);
+int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s);
 
 // C[g] (M x ldc) = sum over terms t with t.group == g of  A_t (M x K_t) * B_t (K_t x ncols)  + epilogue,
 // B_t given as a packed image (Bp).
@@ -195,7 +196,6 @@ int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, 
 int launch_mask_to_float(const void* mask, int mask_dtype, float* out, int64_t count, hipStream_t s);
 int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t f,
                     hipStream_t s);
-int launch_rng_advance(uint64_t* rng, hipStream_t s);
 
 // uniform in [0,1) from a counter-based hash (dropout mask; recomputation-free: backward reads y > 0)
 __device__ __forceinline__ float uniform_hash(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {

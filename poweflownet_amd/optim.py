@@ -30,7 +30,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_param = flat
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self.step_count = torch.zeros(1, dtype=torch.int64, device=flat.device)
+        self.step_count = torch.zeros(2, dtype=torch.int64, device=flat.device)   # {steps done, arrival scratch}
         self._gather = None
 
     def _flat_grad(self) -> torch.Tensor:
