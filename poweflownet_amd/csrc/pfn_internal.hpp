@@ -80,13 +80,13 @@ struct GraphView {
 GraphView graph_view(void* ws, int64_t n, int64_t e_stored);
 
 // ------------------------------------------------------------------------------------------- GEMMs
-constexpr int GEMM_CB = 144;    // output columns per column block (9 MFMA tiles of 16)
-constexpr int GEMM_LDB = 148;   // packed weight row stride in floats (= 4 mod 8: conflict-free permuted reads)
+constexpr int GEMM_CB = 128;    // main output columns per column block (4 MFMA quarters of 32)
+constexpr int GEMM_LDB = 132;   // packed weight row stride in floats: 128 main + 4 trailing (VALU) columns
 constexpr int GEMM_KC = 132;    // k rows per LDS-resident unit (covers H = 129 in one unit)
 
 // Weights are re-laid out once per forward into zero-padded LDS images (gemm.hip: pack):
 // packed[cb][k][GEMM_LDB] with B[k][n] = trans ? W[(wn0 + n) * ldw + wk0 + k] : W[(wk0 + k) * ldw + wn0 + n],
-// k < K4 = roundup(K, 4), n < 144 per column block cb, zero outside [0,K) x [0,ncols).
+// k < K4 = roundup(K, 4), n < 132 per 128-column block cb, zero outside [0,K) x [0,ncols).
 struct PackJob {
     const float* src;
     float* dst;
