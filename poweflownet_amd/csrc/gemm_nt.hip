@@ -31,6 +31,7 @@
 namespace pfn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int LDB = GEMM_LDB;                   // 132 floats per packed row
 constexpr int KC = GEMM_KC;                     // 132 k rows per LDS-resident unit
@@ -100,15 +101,32 @@ int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream
 __device__ __forceinline__ void dma_unit(const float* __restrict__ src, float* lds_dst, int nbytes, int wave, int lane) {
     // 1 KiB pieces, round-robin over the 8 waves; the last piece is clamped to the tile's final 16 bytes for the
     // lanes that would run past it (their LDS bytes land in the slot's unused tail).
+    //
+    // Issued as inline asm on purpose: hipcc, when it can see an LDS-DMA in flight, drains vmcnt(0) in front of the next
+    // ds_read it cannot disambiguate from the DMA target -- which here is the very first B read of the MFMA phase, i.e.
+    // it serialises the weight stream and the A prefetch with the multiply.  Hidden from the compiler, the DMA is
+    // waited for by hand (dma_wait) right before the barrier that hands the slot to the readers.
     const int npieces = (nbytes + 1023) >> 10;
     const char* base = reinterpret_cast<const char*>(src);
     for (int p = wave; p < npieces; p += NT_THREADS / 64) {
         int off = (p << 10) + lane * 16;
         off = off < nbytes ? off : nbytes - 16;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                         (__attribute__((address_space(3))) void*)(lds_dst + (p << 8)), 16, 0, 0);
+        const char* g = base + off;
+        const uint32_t m0v = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)(lds_dst + (p << 8))));
+        uint32_t keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(g), "s"(m0v)
+            : "memory");
     }
 }
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // cheap counter-based uniform in [0,1) for the dropout mask (32-bit mixing; the 64-bit state is folded once per launch)
 __device__ __forceinline__ float uniform32(uint32_t key0, uint32_t key1, uint32_t idx) {
@@ -127,19 +145,22 @@ struct Epi {   // everything the per-element epilogue needs, resolved once per f
     uint32_t key0, key1;
     float keep_scale;
 };
-__device__ __forceinline__ float epilogue(const Epi& e, float v, int row, int col) {
+// `aux` = rowscale[row] (when the GEMM has a row-scaled bias) or gate/resid[row][col] (otherwise), `cb`/`crb` = bias[col] /
+// rowbias[col]: all loaded by the caller BEFORE its first store, in one batch (loads cannot be hoisted over the stores
+// by the compiler, and one dependent load per element costs a memory latency each).
+__device__ __forceinline__ float epilogue(const Epi& e, float v, float aux, float cb, float crb, int row, int col) {
     const GemmArgs& a = *e.a;
     if (col >= a.ncols) return 0.f;
-    if (e.use_bias) v += a.bias[col];
-    if (a.rowscale) v = fmaf(a.rowscale[row], a.rowbias[col], v);
-    if (a.resid) v += a.resid[(size_t)row * a.ldr + col];
+    v += cb;
+    if (a.rowscale) v = fmaf(aux, crb, v);
+    if (a.resid) v += aux;
     if (a.act == ACT_RELU) {
         v = fmaxf(v, 0.f);
     } else if (a.act == ACT_DROPOUT_RELU) {
         const float u = uniform32(e.key0, e.key1, (uint32_t)row * (uint32_t)a.ncols + (uint32_t)col);
         v = (u >= a.p_drop && v > 0.f) ? v * e.keep_scale : 0.f;
     }
-    if (a.gate) v = a.gate[(size_t)row * a.ldg + col] > 0.f ? v * a.gate_scale : 0.f;
+    if (a.gate) v = aux > 0.f ? v * a.gate_scale : 0.f;
     return v;
 }
 
@@ -185,19 +206,26 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         return true;
     };
     auto unit_rows = [&](int t2, int k2) { const int K4 = (a.term[t2].K + 3) & ~3; return min(KC, K4 - k2 * KC); };
-    auto issue = [&](int rb2, int t2, int k2, float4 (&areg)[NCH], float* slot) {
+    auto issue = [&](int rb2, int t2, int k2, f32x4 (&areg)[NCH], float* slot) {
         const GemmTerm& tm = a.term[t2];
         const int K4 = (tm.K + 3) & ~3;
         const int rows = min(KC, K4 - k2 * KC);
         const float* tile = tm.Bp + ((size_t)cb * K4 + (size_t)k2 * KC) * LDB;
         if (!(a.dbg & 1)) dma_unit(tile, slot, rows * LDB * 4, wave, lane);
-        const int arow = rb2 * RPB + rgrp * 32 + r32;
-        const bool ok = arow < a.M && (mfma_on || rem_on) && !(a.dbg & 8);
-        const float* Arow = tm.A + (size_t)(ok ? arow : 0) * tm.lda + k2 * KC;
+        // The A prefetch is hidden from the compiler as well (asm loads; the hand-over after the barrier names every
+        // destination register): hipcc otherwise rotates a_cur/a_nxt through a 2x-unrolled loop and, not knowing about
+        // dma_wait(), re-waits on the prefetch with counted vmcnt in the middle of the multiply.  Loads are unconditional
+        // from clamped (always valid) addresses: rows past M are clamped to the last row (their results are never
+        // stored); k past the row is clamped into the row and zeroed at use time.
+        int arow = rb2 * RPB + rgrp * 32 + r32;
+        arow = arow < a.M ? arow : a.M - 1;
+        const float* Arow = tm.A + (size_t)arow * tm.lda;
+        const int kmax = tm.lda - 4;
 #pragma unroll
         for (int m = 0; m < NCH; ++m) {
-            const int kk = 8 * m + 4 * kh;
-            areg[m] = (ok && kk < rows) ? *reinterpret_cast<const float4*>(Arow + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            int kk = k2 * KC + 8 * m + 4 * kh;
+            kk = kk < kmax ? kk : kmax;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[m]) : "v"(Arow + kk) : "memory");
         }
     };
 
@@ -216,11 +244,14 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         ep.keep_scale = 1.0f / (1.0f - a.p_drop);
     }
 
-    float4 a_cur[NCH], a_nxt[NCH];
+    f32x4 a_cur[NCH], a_nxt[NCH];
     int cur_rb = blockIdx.x, cur_t = -1, cur_k = 0;
     bool have = next_unit(blockIdx.x, -1, 0, cur_rb, cur_t, cur_k);
     if (have) issue(cur_rb, cur_t, cur_k, a_cur, lds);
-    __syncthreads();   // waits for the DMA (vmcnt) and publishes the slot
+    dma_wait();
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) asm volatile("" : "+v"(a_cur[m]));   // loaded values become visible to the compiler here
+    __syncthreads();   // publishes the slot (every wave has waited for its own DMA pieces)
     int slot = 0;
     while (have) {
         int nrb_ = 0, nt_ = 0, nk_ = 0;
@@ -237,7 +268,8 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
                 if (kleft > 0) {
                     // a lane half whose 4 k rows lie beyond the unit reads zeros (rows % 4 == 0: all four or none)
                     const bool lane_in = 8 * m + 4 * kh < rows;
-                    const float av[4] = {a_cur[m].x, a_cur[m].y, a_cur[m].z, a_cur[m].w};
+                    const float av[4] = {lane_in ? a_cur[m][0] : 0.f, lane_in ? a_cur[m][1] : 0.f, lane_in ? a_cur[m][2] : 0.f,
+                                         lane_in ? a_cur[m][3] : 0.f};
                     if (mfma_on) {
                         const float* Bj = lane_in ? S + (8 * m + 4 * kh) * LDB + 32 * cq + r32 : zrow + r32;
                         float b[4];
@@ -267,13 +299,25 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
             float* C = a.C[group];
             ep.use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
             const int rbase = cur_rb * RPB + rgrp * 32;
+            const float* extra = a.gate ? a.gate : a.resid;       // at most one of rowscale / gate / resid per GEMM
+            const int ldx = a.gate ? a.ldg : a.ldr;
             if (mfma_on) {
                 const int col = n0 + 32 * cq + r32;
                 if (col < a.ldc) {
+                    const bool real = col < a.ncols;
+                    const float cbias = (real && ep.use_bias) ? a.bias[col] : 0.f;
+                    const float crb = (real && a.rowscale) ? a.rowbias[col] : 0.f;
+                    float aux[16];
 #pragma unroll
                     for (int q = 0; q < 16; ++q) {
                         const int row = rbase + (q & 3) + 8 * (q >> 2) + 4 * kh;
-                        if (row < a.M) C[(size_t)row * a.ldc + col] = epilogue(ep, acc[q], row, col);
+                        const int rowc = row < a.M ? row : a.M - 1;
+                        aux[q] = a.rowscale ? a.rowscale[rowc] : ((extra && real) ? extra[(size_t)rowc * ldx + col] : 0.f);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = rbase + (q & 3) + 8 * (q >> 2) + 4 * kh;
+                        if (row < a.M) C[(size_t)row * a.ldc + col] = epilogue(ep, acc[q], aux[q], cbias, crb, row, col);
                     }
                 }
             }
@@ -283,8 +327,17 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
                 for (int e = 0; e < 4; ++e) v[e] = racc[e] + __shfl_xor(racc[e], 32);   // the two k halves
                 const int row = rbase + r32;
                 if (kh == 0 && row < a.M) {
+                    float aux[4], cbias[4], crb[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = epilogue(ep, v[e], row, rem_col + e);
+                    for (int e = 0; e < 4; ++e) {
+                        const int col = rem_col + e;
+                        const bool real = col < a.ncols;
+                        cbias[e] = (real && ep.use_bias) ? a.bias[col] : 0.f;
+                        crb[e] = (real && a.rowscale) ? a.rowbias[col] : 0.f;
+                        aux[e] = a.rowscale ? a.rowscale[row] : ((extra && real) ? extra[(size_t)row * ldx + col] : 0.f);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = epilogue(ep, v[e], aux[e], cbias[e], crb[e], row, rem_col + e);
                     *reinterpret_cast<float4*>(C + (size_t)row * a.ldc + rem_col) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
@@ -294,10 +347,15 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
             racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
         }
-        __syncthreads();   // next unit landed (vmcnt(0) precedes the barrier) and this slot may be refilled
+        dma_wait();        // this wave's pieces of the next unit have landed ...
+        __syncthreads();   // ... so after the barrier the whole next unit is readable and this slot may be refilled
         if (more) {
 #pragma unroll
-            for (int m = 0; m < NCH; ++m) a_cur[m] = a_nxt[m];
+            for (int m = 0; m < NCH; ++m) {
+                // hand-over AFTER dma_wait() + barrier: the asm-loaded registers become ordinary values here
+                asm volatile("" : "+v"(a_nxt[m]));
+                a_cur[m] = a_nxt[m];
+            }
             cur_rb = nrb_; cur_t = nt_; cur_k = nk_;
             slot ^= 1;
         }
