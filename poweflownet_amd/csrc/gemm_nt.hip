@@ -102,10 +102,11 @@ __device__ __forceinline__ void dma_unit(const float* __restrict__ src, float* l
     // 1 KiB pieces, round-robin over the 8 waves; the last piece is clamped to the tile's final 16 bytes for the
     // lanes that would run past it (their LDS bytes land in the slot's unused tail).
     //
-    // Issued as inline asm on purpose: hipcc, when it can see an LDS-DMA in flight, drains vmcnt(0) in front of the next
-    // ds_read it cannot disambiguate from the DMA target -- which here is the very first B read of the MFMA phase, i.e.
-    // it serialises the weight stream and the A prefetch with the multiply.  Hidden from the compiler, the DMA is
-    // waited for by hand (dma_wait) right before the barrier that hands the slot to the readers.
+    // Inline asm on purpose: while hipcc can see an LDS-DMA in flight it waits vmcnt(0) -- not a counted vmcnt -- for
+    // every ordinary load it later needs (here: the epilogue operands), which drains the whole prefetch of the next unit in
+    // the middle of a flush (measured: 3 us per flush).  Hidden from the compiler, the DMA is waited for by hand
+    // (dma_wait) right before the barrier that hands the slot to its readers; the compiler's own counted waits stay
+    // correct because VMEM returns in issue order.
     const int npieces = (nbytes + 1023) >> 10;
     const char* base = reinterpret_cast<const char*>(src);
     for (int p = wave; p < npieces; p += NT_THREADS / 64) {
@@ -139,29 +140,50 @@ __device__ __forceinline__ float uniform32(uint32_t key0, uint32_t key1, uint32_
     return (float)(h >> 8) * (1.0f / 16777216.0f);
 }
 
-struct Epi {   // everything the per-element epilogue needs, resolved once per flush
-    const GemmArgs* a;
-    bool use_bias;
-    uint32_t key0, key1;
-    float keep_scale;
-};
-// `aux` = rowscale[row] (when the GEMM has a row-scaled bias) or gate/resid[row][col] (otherwise), `cb`/`crb` = bias[col] /
-// rowbias[col]: all loaded by the caller BEFORE its first store, in one batch (loads cannot be hoisted over the stores
-// by the compiler, and one dependent load per element costs a memory latency each).
-__device__ __forceinline__ float epilogue(const Epi& e, float v, float aux, float cb, float crb, int row, int col) {
-    const GemmArgs& a = *e.a;
-    if (col >= a.ncols) return 0.f;
-    v += cb;
-    if (a.rowscale) v = fmaf(aux, crb, v);
-    if (a.resid) v += aux;
-    if (a.act == ACT_RELU) {
-        v = fmaxf(v, 0.f);
-    } else if (a.act == ACT_DROPOUT_RELU) {
-        const float u = uniform32(e.key0, e.key1, (uint32_t)row * (uint32_t)a.ncols + (uint32_t)col);
-        v = (u >= a.p_drop && v > 0.f) ? v * e.keep_scale : 0.f;
+// 4 x 4 transpose across the four lanes of a quad (DPP quad_perm, no LDS): on entry lane j of the quad holds v[i] =
+// M[i][j], on exit v[i] = M[j][i].  Turns the 32x32 accumulator layout (one column per lane) into four consecutive
+// columns of ONE row per lane, so the epilogue stores 16 bytes per lane (whole 128-byte lines per 8 lanes) instead of
+// sixteen 4-byte stores -- dword stores are issue-bound and took ~3 us per 64x132 tile.
+__device__ __forceinline__ float dpp_xor1(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+}
+__device__ __forceinline__ float dpp_xor2(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+}
+__device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
+    const bool o1 = lane & 1, o2 = lane & 2;
+    {   // exchange across lane ^ 1: (v0,v1) and (v2,v3)
+        const float s01 = dpp_xor1(o1 ? v[0] : v[1]), s23 = dpp_xor1(o1 ? v[2] : v[3]);
+        if (o1) { v[0] = s01; v[2] = s23; } else { v[1] = s01; v[3] = s23; }
     }
-    if (a.gate) v = aux > 0.f ? v * a.gate_scale : 0.f;
-    return v;
+    {   // exchange across lane ^ 2: (v0,v2) and (v1,v3)
+        const float s02 = dpp_xor2(o2 ? v[0] : v[2]), s13 = dpp_xor2(o2 ? v[1] : v[3]);
+        if (o2) { v[0] = s02; v[1] = s13; } else { v[2] = s02; v[3] = s13; }
+    }
+}
+
+// Per-element epilogue.  Every operand arrives BY VALUE (kernel-uniform scalars live in SGPRs; `aux` = rowscale[row] when
+// the GEMM has a row-scaled bias, else gate/resid[row][col]; `cb`/`crb` = bias[col] / rowbias[col], zero when absent):
+// reaching them through a pointer to the kernel-argument struct made hipcc emit per-lane waterfall loops -- ~2000
+// instructions per flush.  All loads are done by the caller in one batch BEFORE its first store.
+struct EpiCfg {
+    int ncols, act;
+    bool has_rowscale, has_resid, has_gate;
+    float p_drop, keep_scale, gate_scale;
+    uint32_t key0, key1;
+};
+__device__ __forceinline__ float epilogue(const EpiCfg c, float v, float aux, float cb, float crb, int row, int col) {
+    v += cb;
+    if (c.has_rowscale) v = fmaf(aux, crb, v);
+    if (c.has_resid) v += aux;
+    if (c.act == ACT_RELU) {
+        v = fmaxf(v, 0.f);
+    } else if (c.act == ACT_DROPOUT_RELU) {
+        const float u = uniform32(c.key0, c.key1, (uint32_t)row * (uint32_t)c.ncols + (uint32_t)col);
+        v = (u >= c.p_drop && v > 0.f) ? v * c.keep_scale : 0.f;
+    }
+    if (c.has_gate) v = aux > 0.f ? v * c.gate_scale : 0.f;
+    return col < c.ncols ? v : 0.f;
 }
 
 __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a) {
@@ -206,31 +228,36 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         return true;
     };
     auto unit_rows = [&](int t2, int k2) { const int K4 = (a.term[t2].K + 3) & ~3; return min(KC, K4 - k2 * KC); };
-    auto issue = [&](int rb2, int t2, int k2, f32x4 (&areg)[NCH], float* slot) {
+    // weight DMA of a unit, and the A fragment loads of a unit (one 16-byte load per 8-wide k chunk).  A loads are
+    // unconditional from clamped, always valid addresses (a `cond ? load : 0` select would make the compiler wait for the
+    // load on the spot): rows past M are clamped to the last row (their results are never stored), k past the row is
+    // clamped into the row (those lanes multiply zero B rows).
+    auto issue_dma = [&](int t2, int k2, float* slot) {
         const GemmTerm& tm = a.term[t2];
         const int K4 = (tm.K + 3) & ~3;
         const int rows = min(KC, K4 - k2 * KC);
         const float* tile = tm.Bp + ((size_t)cb * K4 + (size_t)k2 * KC) * LDB;
         if (!(a.dbg & 1)) dma_unit(tile, slot, rows * LDB * 4, wave, lane);
-        // The A prefetch is hidden from the compiler as well (asm loads; the hand-over after the barrier names every
-        // destination register): hipcc otherwise rotates a_cur/a_nxt through a 2x-unrolled loop and, not knowing about
-        // dma_wait(), re-waits on the prefetch with counted vmcnt in the middle of the multiply.  Loads are unconditional
-        // from clamped (always valid) addresses: rows past M are clamped to the last row (their results are never
-        // stored); k past the row is clamped into the row and zeroed at use time.
+    };
+    auto a_row_ptr = [&](int rb2, int t2) -> const float* {
         int arow = rb2 * RPB + rgrp * 32 + r32;
         arow = arow < a.M ? arow : a.M - 1;
-        const float* Arow = tm.A + (size_t)arow * tm.lda;
-        const int kmax = tm.lda - 4;
-#pragma unroll
-        for (int m = 0; m < NCH; ++m) {
-            int kk = k2 * KC + 8 * m + 4 * kh;
-            kk = kk < kmax ? kk : kmax;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(areg[m]) : "v"(Arow + kk) : "memory");
-        }
+        return a.term[t2].A + (size_t)arow * a.term[t2].lda;
+    };
+    auto load_a = [&](const float* Arow, int kmax, int k0, int m) -> f32x4 {
+        int kk = k0 + 8 * m + 4 * kh;
+        kk = kk < kmax ? kk : kmax;
+        return *reinterpret_cast<const f32x4*>(Arow + kk);
     };
 
-    Epi ep;
-    ep.a = &a;
+    EpiCfg ep;
+    ep.ncols = a.ncols;
+    ep.act = a.act;
+    ep.has_rowscale = a.rowscale != nullptr;
+    ep.has_resid = a.resid != nullptr;
+    ep.has_gate = a.gate != nullptr;
+    ep.p_drop = a.p_drop;
+    ep.gate_scale = a.gate_scale;
     ep.key0 = ep.key1 = 0;
     ep.keep_scale = 1.f;
     if (a.act == ACT_DROPOUT_RELU) {
@@ -244,32 +271,141 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         ep.keep_scale = 1.0f / (1.0f - a.p_drop);
     }
 
-    f32x4 a_cur[NCH], a_nxt[NCH];
+    f32x4 a_cur[NCH];   // ONE register set: chunk m of the NEXT unit is loaded into a_cur[m] right after chunk m is consumed
     int cur_rb = blockIdx.x, cur_t = -1, cur_k = 0;
     bool have = next_unit(blockIdx.x, -1, 0, cur_rb, cur_t, cur_k);
-    if (have) issue(cur_rb, cur_t, cur_k, a_cur, lds);
-    dma_wait();
+    if (have) {
+        issue_dma(cur_t, cur_k, lds);
+        const float* Ar = a_row_ptr(cur_rb, cur_t);
 #pragma unroll
-    for (int m = 0; m < NCH; ++m) asm volatile("" : "+v"(a_cur[m]));   // loaded values become visible to the compiler here
+        for (int m = 0; m < NCH; ++m) a_cur[m] = load_a(Ar, a.term[cur_t].lda - 4, cur_k * KC, m);
+    }
+    dma_wait();
     __syncthreads();   // publishes the slot (every wave has waited for its own DMA pieces)
     int slot = 0;
+    int unit_no = 0;
+#define PFN_STAMP(i) do { if (a.timing && blockIdx.x == 0 && tid == 0 && unit_no < 64) a.timing[unit_no * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
     while (have) {
+        PFN_STAMP(0);
         int nrb_ = 0, nt_ = 0, nk_ = 0;
         const bool more = next_unit(cur_rb, cur_t, cur_k, nrb_, nt_, nk_);
-        if (more) issue(nrb_, nt_, nk_, a_nxt, lds + (slot ^ 1) * SLOT_FLOATS);
+        const float* nxA = nullptr;
+        int nx_kmax = 0, nx_k0 = 0;
+        const float* nx_tile = nullptr;
+        float* nx_slot = lds + (slot ^ 1) * SLOT_FLOATS;
+        int nx_bytes = 0;
+        bool dma_done = false;
+        if (more) {
+            const GemmTerm& tn = a.term[nt_];
+            const int K4n = (tn.K + 3) & ~3;
+            nx_bytes = min(KC, K4n - nk_ * KC) * LDB * 4;
+            nx_tile = tn.Bp + ((size_t)cb * K4n + (size_t)nk_ * KC) * LDB;
+            nxA = a_row_ptr(nrb_, nt_);
+            nx_kmax = a.term[nt_].lda - 4;
+            nx_k0 = nk_ * KC;
+        }
+        const bool pf = more && !(a.dbg & 8);
+        // ---- epilogue operands of the flush that follows this unit (if it ends a group / row block): loaded NOW, so
+        // they are older than the A refills issued inside the multiply loop and the flush never waits on the prefetch
+        const int group = a.term[cur_t].group;
+        const bool flush_after = !more || a.term[nt_].group != group || nrb_ != cur_rb;
+        const int rbase = cur_rb * RPB + rgrp * 32;
+        const int col0 = n0 + 32 * cq + (r32 & ~3);                 // after the quad transpose: 4 columns per lane
+        const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
+        const float* extra = a.gate ? a.gate : a.resid;           // at most one of rowscale / gate / resid per GEMM
+        const int ldx = a.gate ? a.ldg : a.ldr;
+        float4 aux[4], raux;
+        float cbias[4], crb[4], rcb[4], rcrb[4];
+        if (flush_after) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool real = col0 + e < a.ncols, rreal = rem_col + e < a.ncols;
+                cbias[e] = (mfma_on && real && use_bias) ? a.bias[col0 + e] : 0.f;
+                crb[e] = (mfma_on && real && a.rowscale) ? a.rowbias[col0 + e] : 0.f;
+                rcb[e] = (rem_on && rreal && use_bias) ? a.bias[rem_col + e] : 0.f;
+                rcrb[e] = (rem_on && rreal && a.rowscale) ? a.rowbias[rem_col + e] : 0.f;
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
+                const int rowc = row < a.M ? row : a.M - 1;
+                aux[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mfma_on && col0 < a.ldc) {
+                    if (a.rowscale) {
+                        const float rs = a.rowscale[rowc];
+                        aux[g] = make_float4(rs, rs, rs, rs);
+                    } else if (extra) {
+                        aux[g] = *reinterpret_cast<const float4*>(extra + (size_t)rowc * ldx + col0);
+                    }
+                }
+            }
+            raux = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (rem_on) {
+                const int row = rbase + r32;
+                const int rowc = row < a.M ? row : a.M - 1;
+                if (a.rowscale) {
+                    const float rs = a.rowscale[rowc];
+                    raux = make_float4(rs, rs, rs, rs);
+                } else if (extra) {
+                    raux = *reinterpret_cast<const float4*>(extra + (size_t)rowc * ldx + rem_col);
+                }
+            }
+        }
+        // small-K units (the slow generic path below) issue the whole DMA up front; the fast path trickles it
+        if (more && !(a.dbg & 1)) {
+            dma_unit(nx_tile, nx_slot, nx_bytes, wave, lane);
+            dma_done = true;
+        }
+        PFN_STAMP(1);
         // ---- multiply the resident unit
         const int rows = unit_rows(cur_t, cur_k);
         const int kvalid = a.term[cur_t].K - cur_k * KC;   // real (unpadded) k's left in this term
         const float* S = lds + slot * SLOT_FLOATS;
         if (!(a.dbg & 2)) {
+            const int nreal_rem = a.ncols - rem_col;           // real trailing columns (1 for H = 129); the rest is padding
+            // chunks whose 8 k's are all real and inside the unit run as straight-line code (no per-step branches, no
+            // zero-row redirect): the compiler can then pipeline the LDS reads of later chunks under earlier MFMAs
+            const int nfull = min(rows, kvalid) >> 3;
+            constexpr int FAST = 16;                           // H = 129: 16 full chunks + one ragged chunk
+            int m_done = 0;
+            if (nfull >= FAST) {
+                const float* Bj = S + (4 * kh) * LDB + 32 * cq + r32;
+                const float* Rj = S + (4 * kh) * LDB + (rem_col - n0);
+#pragma unroll
+                for (int m = 0; m < FAST; ++m) {
+                    if (mfma_on) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float bv = (a.dbg & 16) ? 1.0f : Bj[(8 * m + i) * LDB];
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][i], bv, acc, 0, 0, 0);
+                        }
+                    }
+                    if (rem_on && !(a.dbg & 64)) {
+                        if (nreal_rem <= 1) {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) racc[0] = fmaf(a_cur[m][i], Rj[(8 * m + i) * LDB], racc[0]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {
+                                const float4 rb4 = *reinterpret_cast<const float4*>(Rj + (8 * m + i) * LDB);
+                                racc[0] = fmaf(a_cur[m][i], rb4.x, racc[0]);
+                                racc[1] = fmaf(a_cur[m][i], rb4.y, racc[1]);
+                                racc[2] = fmaf(a_cur[m][i], rb4.z, racc[2]);
+                                racc[3] = fmaf(a_cur[m][i], rb4.w, racc[3]);
+                            }
+                        }
+                    }
+                    if (pf && !(a.dbg & 32)) a_cur[m] = load_a(nxA, nx_kmax, nx_k0, m);   // chunk m consumed: refill it for the next unit
+                }
+                m_done = FAST;
+            }
 #pragma unroll
             for (int m = 0; m < NCH; ++m) {
                 const int kleft = kvalid - 8 * m;              // block-uniform: real k's from this chunk on
-                if (kleft > 0) {
+                if (m >= m_done && kleft > 0) {
                     // a lane half whose 4 k rows lie beyond the unit reads zeros (rows % 4 == 0: all four or none)
                     const bool lane_in = 8 * m + 4 * kh < rows;
-                    const float av[4] = {lane_in ? a_cur[m][0] : 0.f, lane_in ? a_cur[m][1] : 0.f, lane_in ? a_cur[m][2] : 0.f,
-                                         lane_in ? a_cur[m][3] : 0.f};
+                    const float av[4] = {a_cur[m][0], a_cur[m][1], a_cur[m][2], a_cur[m][3]};
                     if (mfma_on) {
                         const float* Bj = lane_in ? S + (8 * m + 4 * kh) * LDB + 32 * cq + r32 : zrow + r32;
                         float b[4];
@@ -291,34 +427,33 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
                         }
                     }
                 }
+                if (m >= m_done && pf) a_cur[m] = load_a(nxA, nx_kmax, nx_k0, m);
             }
+        } else if (pf) {
+#pragma unroll
+            for (int m = 0; m < NCH; ++m) a_cur[m] = load_a(nxA, nx_kmax, nx_k0, m);
         }
-        const int group = a.term[cur_t].group;
-        if ((!more || a.term[nt_].group != group || nrb_ != cur_rb) && !(a.dbg & 4)) {
-            // ---- flush straight from registers: acc[q] of lane (r32, kh) is D[row (q&3) + 8 (q>>2) + 4 kh][col r32]
+        if (more && !dma_done && !(a.dbg & 1)) dma_unit(nx_tile, nx_slot, nx_bytes, wave, lane);
+        PFN_STAMP(2);
+        // The next unit's DMA pieces (and A refills) have had the whole multiply to land: wait for them HERE, before the
+        // flush issues its stores -- vmcnt counts stores too, so a vmcnt(0) in front of the barrier would also wait for
+        // the HBM write acknowledgements of the tile just flushed (measured: ~3 us per flush).
+        dma_wait();
+        if (flush_after && !(a.dbg & 4)) {
+            // ---- flush straight from registers: acc[q] of lane (r32, kh) is D[row (q&3) + 8 (q>>2) + 4 kh][col r32];
+            // after the quad transpose lane (u = r32 >> 2, j = r32 & 3) holds, for register group g, row
+            // rbase + j + 8 g + 4 kh and the four columns col0 .. col0 + 3
             float* C = a.C[group];
-            ep.use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
-            const int rbase = cur_rb * RPB + rgrp * 32;
-            const float* extra = a.gate ? a.gate : a.resid;       // at most one of rowscale / gate / resid per GEMM
-            const int ldx = a.gate ? a.ldg : a.ldr;
-            if (mfma_on) {
-                const int col = n0 + 32 * cq + r32;
-                if (col < a.ldc) {
-                    const bool real = col < a.ncols;
-                    const float cbias = (real && ep.use_bias) ? a.bias[col] : 0.f;
-                    const float crb = (real && a.rowscale) ? a.rowbias[col] : 0.f;
-                    float aux[16];
+            if (mfma_on && col0 < a.ldc) {
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int row = rbase + (q & 3) + 8 * (q >> 2) + 4 * kh;
-                        const int rowc = row < a.M ? row : a.M - 1;
-                        aux[q] = a.rowscale ? a.rowscale[rowc] : ((extra && real) ? extra[(size_t)rowc * ldx + col] : 0.f);
-                    }
+                for (int g = 0; g < 4; ++g) {
+                    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
+                    quad_transpose(v, lane);
+                    const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
+                    const float ax[4] = {aux[g].x, aux[g].y, aux[g].z, aux[g].w};
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) {
-                        const int row = rbase + (q & 3) + 8 * (q >> 2) + 4 * kh;
-                        if (row < a.M) C[(size_t)row * a.ldc + col] = epilogue(ep, acc[q], aux[q], cbias, crb, row, col);
-                    }
+                    for (int e = 0; e < 4; ++e) v[e] = epilogue(ep, v[e], ax[e], cbias[e], crb[e], row, col0 + e);
+                    if (row < a.M) *reinterpret_cast<float4*>(C + (size_t)row * a.ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
             if (rem_on) {
@@ -327,35 +462,26 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
                 for (int e = 0; e < 4; ++e) v[e] = racc[e] + __shfl_xor(racc[e], 32);   // the two k halves
                 const int row = rbase + r32;
                 if (kh == 0 && row < a.M) {
-                    float aux[4], cbias[4], crb[4];
+                    const float ax[4] = {raux.x, raux.y, raux.z, raux.w};
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int col = rem_col + e;
-                        const bool real = col < a.ncols;
-                        cbias[e] = (real && ep.use_bias) ? a.bias[col] : 0.f;
-                        crb[e] = (real && a.rowscale) ? a.rowbias[col] : 0.f;
-                        aux[e] = a.rowscale ? a.rowscale[row] : ((extra && real) ? extra[(size_t)row * ldx + col] : 0.f);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = epilogue(ep, v[e], aux[e], cbias[e], crb[e], row, rem_col + e);
+                    for (int e = 0; e < 4; ++e) v[e] = epilogue(ep, v[e], ax[e], rcb[e], rcrb[e], row, rem_col + e);
                     *reinterpret_cast<float4*>(C + (size_t)row * a.ldc + rem_col) = make_float4(v[0], v[1], v[2], v[3]);
                 }
             }
         }
-        if (!more || a.term[nt_].group != group || nrb_ != cur_rb) {
+        if (flush_after) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] = 0.f;
             racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
         }
-        dma_wait();        // this wave's pieces of the next unit have landed ...
-        __syncthreads();   // ... so after the barrier the whole next unit is readable and this slot may be refilled
+        PFN_STAMP(3);
+        // raw barrier (LDS reads done, no vmcnt drain: the flush's stores stay in flight across it); every wave waited for
+        // its own DMA pieces above, so after the barrier the whole next unit is readable and this slot may be refilled
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PFN_STAMP(4);
+        ++unit_no;
         if (more) {
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) {
-                // hand-over AFTER dma_wait() + barrier: the asm-loaded registers become ordinary values here
-                asm volatile("" : "+v"(a_nxt[m]));
-                a_cur[m] = a_nxt[m];
-            }
             cur_rb = nrb_; cur_t = nt_; cur_k = nk_;
             slot ^= 1;
         }

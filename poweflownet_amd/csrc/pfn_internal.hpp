@@ -127,6 +127,7 @@ struct GemmArgs {
     int ldg;
     float gate_scale;
     int dbg;                // PFN_GEMM_DBG bits (timing dissection; results invalid when non-zero)
+    unsigned long long* timing;   // optional [units][8] s_memtime stamps of block 0 / wave 0 (tools/ubench only)
 };
 int launch_gemm_nt(const GemmArgs& a, hipStream_t s);
 

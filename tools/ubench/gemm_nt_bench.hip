@@ -1,0 +1,59 @@
+// Standalone timing harness for launch_gemm_nt (links libpfn_hip.so): isolates the tall-skinny GEMM from the model.
+//   gemm_nt_bench M K N nterm ngroup [iters]
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include <stdlib.h>
+#include <vector>
+#include "../../poweflownet_amd/csrc/pfn_internal.hpp"
+using namespace pfn;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+int main(int argc, char** argv) {
+    const int M = argc > 1 ? atoi(argv[1]) : 15104, K = argc > 2 ? atoi(argv[2]) : 129, N = argc > 3 ? atoi(argv[3]) : 129;
+    const int nterm = argc > 4 ? atoi(argv[4]) : 1, ngroup = argc > 5 ? atoi(argv[5]) : 1, iters = argc > 6 ? atoi(argv[6]) : 20;
+    const int lda = ld_of(K), ldc = ld_of(N);
+    std::vector<float> hA((size_t)M * lda), hW((size_t)N * K);
+    for (auto& v : hA) v = (rand() % 2001 - 1000) * 1e-3f;
+    for (size_t i = 0; i < hA.size(); ++i) if ((int)(i % lda) >= K) hA[i] = 0.f;
+    for (auto& v : hW) v = (rand() % 2001 - 1000) * 1e-3f;
+    float *dA, *dW, *dP, *dC;
+    CK(hipMalloc(&dA, hA.size() * 4 * nterm)); CK(hipMalloc(&dW, hW.size() * 4));
+    for (int t = 0; t < nterm; ++t) CK(hipMemcpy(dA + (size_t)t * hA.size(), hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
+    const size_t pf = packed_floats(K, ldc);
+    CK(hipMalloc(&dP, pf * 4)); CK(hipMalloc(&dC, (size_t)M * ldc * 4 * ngroup));
+    PackJob pj; pj.src = dW; pj.dst = dP; pj.ldw = K; pj.wk0 = 0; pj.wn0 = 0; pj.trans = 1; pj.K = K; pj.ncols = N; pj.ld_out = ldc; pj.pad_ = 0;
+    if (launch_pack(&pj, 1, nullptr, 0) != 0) { printf("pack failed: %s\n", pfn_last_error()); return 1; }
+    GemmArgs a; memset(&a, 0, sizeof(a));
+    a.M = M; a.ncols = N; a.ldc = ldc; a.ngroup = ngroup; a.gate_scale = 1.f; a.bias_group = -1; a.nterm = nterm;
+    for (int g = 0; g < ngroup; ++g) a.C[g] = dC + (size_t)g * M * ldc;
+    for (int t = 0; t < nterm; ++t) { a.term[t].A = dA + (size_t)t * hA.size(); a.term[t].Bp = dP; a.term[t].lda = lda; a.term[t].K = K; a.term[t].group = ngroup > 1 ? t * ngroup / nterm : 0; }
+    unsigned long long* dT; CK(hipMalloc(&dT, 64 * 8 * 8)); CK(hipMemset(dT, 0, 64 * 8 * 8));
+    if (getenv("PFN_NT_TIMING")) a.timing = dT;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) if (launch_gemm_nt(a, 0) != 0) { printf("gemm failed: %s\n", pfn_last_error()); return 1; }
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < iters; ++i) launch_gemm_nt(a, 0);
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double us = 1e3 * ms / iters, flops = 2.0 * M * K * N * nterm;
+    // spot check a few entries against a host dot product (first group, first term only meaningful when nterm == ngroup == 1)
+    std::vector<float> hC((size_t)64 * ldc);
+    CK(hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0;
+    for (int r = 0; r < 64 && r < M; r += 7) for (int c = 0; c < N; c += 5) {
+        double ref = 0; for (int k = 0; k < K; ++k) ref += (double)hA[(size_t)r * lda + k] * hW[(size_t)c * K + k];
+        ref *= (ngroup > 1 ? 1 : nterm);
+        const double err = fabs(ref - hC[(size_t)r * ldc + c]); if (err > maxerr) maxerr = err;
+    }
+    printf("M=%d K=%d N=%d nterm=%d ngroup=%d : %.2f us  %.1f TFLOP/s  (spot max err %.2e)\n", M, K, N, nterm, ngroup, us, flops / us * 1e-6, maxerr);
+    if (a.timing) {
+        unsigned long long hT[64 * 8]; CK(hipMemcpy(hT, dT, sizeof(hT), hipMemcpyDeviceToHost));
+        printf("  unit: top->issued  issued->mfma_done  mfma_done->flushed  flushed->barrier_passed | total   (s_memtime ticks, block 0 wave 0)\n");
+        for (int u = 0; u < 12 && hT[u * 8 + 4]; ++u)
+            printf("  %3d: %8llu %8llu %8llu %8llu | %8llu\n", u, hT[u*8+1]-hT[u*8+0], hT[u*8+2]-hT[u*8+1], hT[u*8+3]-hT[u*8+2], hT[u*8+4]-hT[u*8+3], hT[u*8+4]-hT[u*8+0]);
+    }
+    return 0;
+}
