@@ -5,6 +5,7 @@
 // (call sites :477-484,:545), plus their autograd, as sequences of the HIP kernels in graph.hip /
 // edge.hip / gemm.hip.  Nothing here synchronises or allocates: every buffer is carved out of the
 // caller's workspace, so a whole training step can be captured into one hipGraph.
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -70,6 +71,48 @@ struct Gate {
     float scale = 1.f;
 };
 
+// ------------------------------------------------------------------------------------------ side stream
+// Weight-gradient work (dW GEMMs, their reductions) only feeds the optimizer: it is forked onto a second HIP stream and
+// overlaps the latency-bound chain that propagates the input gradient to the previous layer.  Under hipGraph capture
+// the fork/join events become graph edges, so the replayed step keeps the overlap.  mark(i) = "layer i's side work is
+// enqueued"; the main stream waits for a mark before it overwrites a buffer that side work still reads.
+struct SideQ {
+    hipStream_t main_s = nullptr, side_s = nullptr;
+    hipEvent_t fork_ev = nullptr;
+    hipEvent_t marks[64];
+    bool marked[64];
+    int fork() {            // side stream starts after everything enqueued on main so far
+        PFN_CHECK_HIP(hipEventRecord(fork_ev, main_s));
+        PFN_CHECK_HIP(hipStreamWaitEvent(side_s, fork_ev, 0));
+        return PFN_OK;
+    }
+    int mark(int i) {
+        PFN_CHECK_HIP(hipEventRecord(marks[i], side_s));
+        marked[i] = true;
+        return PFN_OK;
+    }
+    int main_wait(int i) {
+        if (i >= 0 && i < 64 && marked[i]) PFN_CHECK_HIP(hipStreamWaitEvent(main_s, marks[i], 0));
+        return PFN_OK;
+    }
+};
+static SideQ* side_queue(hipStream_t main_s) {
+    static SideQ q;
+    static bool ready = false, failed = false;
+    if (failed) return nullptr;
+    if (!ready) {
+        if (getenv("PFN_NO_SIDE_STREAM")) { failed = true; return nullptr; }
+        bool ok = hipStreamCreateWithFlags(&q.side_s, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&q.fork_ev, hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; ok && i < 64; ++i) ok = hipEventCreateWithFlags(&q.marks[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) { failed = true; return nullptr; }
+        ready = true;
+    }
+    q.main_s = main_s;
+    for (int i = 0; i < 64; ++i) q.marked[i] = false;
+    return &q;
+}
+
 // ---------------------------------------------------------------------------------- EdgeAggregation
 struct EaSaved { float *P, *Q, *S; };
 struct EaScratch { float *dS, *dP, *dQ, *dWe; ReduceWs red; };
@@ -126,8 +169,9 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
 static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
                        const float* w1, const EaPack& pw, const float* gout, int ldgo, const Gate& gate, float* gx,
                        int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
-                       const EaScratch& sc, hipStream_t s) {
+                       const EaScratch& sc, hipStream_t s, SideQ* sq = nullptr, int layer = 0) {
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
+    if (sq) PFN_TRY(sq->main_wait(layer + 2));   // the previous EA layer's side work still reads dP / dQ / dWe
     {   // dS = gout W2
         GemmArgs a = gemm_defaults(g.n, h, ld);
         a.C[0] = sc.dS;
@@ -137,7 +181,25 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
     }
     EdgeBwdArgs e{sv.P, sv.Q, sc.dS, ea, w1, sc.dP, sc.dQ, sc.dWe, gea, ld, h, fi, fe};
     PFN_TRY(launch_edge_bwd(g, e, nullptr, s));
-    PFN_TRY(launch_dwe_reduce(sc.dWe, g.n > 0 ? edge_bwd_dst_blocks(g, ld) : 0, fe, ld, h, gw1, ldw1, 2 * fi, s));
+    // everything the weight gradients need (gout, S, dP, dQ, dWe partials) exists now: fork them off
+    hipStream_t ws = s;
+    if (sq) {
+        PFN_TRY(sq->fork());
+        ws = sq->side_s;
+    }
+    PFN_TRY(launch_dwe_reduce(sc.dWe, g.n > 0 ? edge_bwd_dst_blocks(g, ld) : 0, fe, ld, h, gw1, ldw1, 2 * fi, ws));
+    {
+        TnPair pairs[3] = {
+            tn_pair(gout, ldgo, fo, sv.S, ld, h, gw2, h, 0, gb2, g.deg),      // dW2 ; db2 = sum_i deg_i gout_i
+            tn_pair(sc.dP, ld, h, x, ldx, fi, gw1, ldw1, 0, gb1, nullptr),    // dW1[:, :Fi] ; db1 = sum_i dP_i
+            tn_pair(sc.dQ, ld, h, x, ldx, fi, gw1, ldw1, fi, nullptr, nullptr),
+        };
+        PFN_TRY(launch_weight_grads(pairs, 3, g.n, sc.red, ws));
+    }
+    if (sq) {
+        PFN_TRY(sq->mark(layer));
+        PFN_TRY(sq->main_wait(layer + 1));   // gx below overwrites the buffer the next-outer layer's side work reads as gout
+    }
     if (gea) PFN_TRY(launch_edge_attr_grad(g, e, s));
     if (gx) {   // dx = dP W1[:, :Fi] + dQ W1[:, Fi:2Fi], gated by the producing layer's activation
         GemmArgs a = gemm_defaults(g.n, fi, ldgx);
@@ -150,12 +212,7 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         a.gate_scale = gate.scale;
         PFN_TRY(launch_gemm_nt(a, s));
     }
-    TnPair pairs[3] = {
-        tn_pair(gout, ldgo, fo, sv.S, ld, h, gw2, h, 0, gb2, g.deg),      // dW2 ; db2 = sum_i deg_i gout_i
-        tn_pair(sc.dP, ld, h, x, ldx, fi, gw1, ldw1, 0, gb1, nullptr),    // dW1[:, :Fi] ; db1 = sum_i dP_i
-        tn_pair(sc.dQ, ld, h, x, ldx, fi, gw1, ldw1, fi, nullptr, nullptr),
-    };
-    return launch_weight_grads(pairs, 3, g.n, sc.red, s);
+    return PFN_OK;
 }
 
 // ------------------------------------------------------------------------------------------ TAGConv
@@ -195,8 +252,22 @@ struct TagScratch { float* G; float *z0, *z1; ReduceWs red; };
 
 static int tag_backward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
                         const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx, float* const* gw,
-                        float* gbias, const float* xk, const TagScratch& sc, hipStream_t s) {
+                        float* gbias, const float* xk, const TagScratch& sc, hipStream_t s, SideQ* sq = nullptr,
+                        int layer = 0) {
     const size_t stride = (size_t)g.n * ldx;
+    {   // weight gradients need only gout and the saved hops: fork them off first
+        hipStream_t ws = s;
+        if (sq) {
+            PFN_TRY(sq->fork());
+            ws = sq->side_s;
+        }
+        std::vector<TnPair> pairs;
+        for (int k = 0; k <= K; ++k)
+            pairs.push_back(tn_pair(gout, ldgo, cout, k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, gw[k], cin, 0,
+                                    k == 0 ? gbias : nullptr, nullptr));
+        PFN_TRY(launch_weight_grads(pairs.data(), (int)pairs.size(), g.n, sc.red, ws));
+        if (sq) PFN_TRY(sq->mark(layer));
+    }
     if (gx) {
         if (ldgx != ldx) {
             set_error("TAGConv backward: grad_x stride %d != x stride %d", ldgx, ldx);
@@ -214,21 +285,19 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             a.gate = gate.y;
             a.ldg = gate.ld;
             a.gate_scale = gate.scale;
+            if (sq) PFN_TRY(sq->main_wait(layer + 1));
         }
         PFN_TRY(launch_gemm_nt(a, s));
         const float* z = sc.G + (size_t)K * stride;
         for (int k = K - 1; k >= 0; --k) {
             float* dst = (k == 0) ? gx : ((k & 1) ? sc.z1 : sc.z0);
+            if (k == 0 && sq) PFN_TRY(sq->main_wait(layer + 1));   // gx overwrites what the outer layer's side work reads
             HopArgs hp{z, sc.G + (size_t)k * stride, dst, k == 0 ? gate.y : nullptr, k == 0 ? gate.scale : 1.f, ldx, 1, 1};
             PFN_TRY(launch_hop(g, hp, s));
             z = dst;
         }
     }
-    std::vector<TnPair> pairs;
-    for (int k = 0; k <= K; ++k)
-        pairs.push_back(tn_pair(gout, ldgo, cout, k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, gw[k], cin, 0,
-                                k == 0 ? gbias : nullptr, nullptr));
-    return launch_weight_grads(pairs.data(), (int)pairs.size(), g.n, sc.red, s);
+    return PFN_OK;
 }
 
 // -------------------------------------------------------------------------------------- whole model
@@ -413,6 +482,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         pi += is_ea(i) ? 4 : lo.K + 2;
     }
     if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)lo.e * lo.fe * sizeof(float), s));
+    SideQ* sq = lo.nlayers + 2 <= 64 ? side_queue(s) : nullptr;
     const float* gcur = gout;
     int ldg = lo.ldo;
     for (int i = lo.nlayers - 1; i >= 0; --i) {
@@ -430,10 +500,10 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         if (is_ea(i)) {
             const int fi = i == 0 ? lo.f0 : lo.h, fo = last ? lo.fo : lo.h;
             PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], mp.ea[i], gcur, ldg, gate, gnext, ldi,
-                                grads[p0], grads[p0 + 1], grads[p0 + 2], grads[p0 + 3], gea, lo.ea[i], lo.eas, s));
+                                grads[p0], grads[p0 + 1], grads[p0 + 2], grads[p0 + 3], gea, lo.ea[i], lo.eas, s, sq, i + 1));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
-                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s));
+                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, sq, i + 1));
         }
         gcur = gnext;
         ldg = ldi;
@@ -453,7 +523,14 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         tn_pair(gcur, lo.ld0, lo.f0, lo.me_h, lo.ld, lo.h, gme[2], lo.h, 0, gme[3], nullptr),     // dWb, dbb
         tn_pair(lo.dh, lo.ld, lo.h, lo.maskf, lo.ld0, lo.f0, gme[0], lo.f0, 0, gme[1], nullptr),  // dWa, dba
     };
-    PFN_TRY(launch_weight_grads(pairs, 2, lo.n, lo.eas.red, s));
+    if (sq) {
+        PFN_TRY(sq->fork());
+        PFN_TRY(launch_weight_grads(pairs, 2, lo.n, lo.eas.red, sq->side_s));
+        PFN_TRY(sq->mark(0));
+        PFN_TRY(sq->main_wait(0));   // join: the side stream is in order, its last mark covers all earlier side work
+    } else {
+        PFN_TRY(launch_weight_grads(pairs, 2, lo.n, lo.eas.red, s));
+    }
     if (gx) PFN_CHECK_HIP(hipMemcpyAsync(gx, gcur, (size_t)lo.n * lo.ld0 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return PFN_OK;
 }
