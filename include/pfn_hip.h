@@ -68,6 +68,11 @@ int pfn_graph_build(const int64_t* edge_index /* [2, e_stored] */, int64_t e_sto
  * error flag (non-zero when an id was out of range -> PFN_EINDEX).                               */
 int pfn_graph_info(const void* graph_ws, int64_t n_nodes, int64_t e_stored, int32_t* directed,
                    int64_t* e_effective, void* stream);
+/* Synchronising check (once per topology): *ok = 1 iff n_nodes % seg_nodes == 0 and no effective edge crosses a multiple
+ * of seg_nodes, i.e. the batch is a disjoint union of index-contiguous graphs of seg_nodes nodes (what PyG's Batch of one
+ * reference case is).  A caller that got ok may pass seg_nodes to the model / TAGConv entry points, which then keep the K
+ * propagation hops of a TAGConv resident in LDS per graph instead of running K gather kernels over HBM/L2.            */
+int pfn_graph_segments(void* graph_ws, int64_t n_nodes, int64_t e_stored, int64_t seg_nodes, int32_t* ok, void* stream);
 /* Copies the effective (post-undirect) edge list back out as int64 [2, 2*e_stored] (tests). */
 int pfn_graph_export_edges(const void* graph_ws, int64_t n_nodes, int64_t e_stored,
                            int64_t* edge_index_out, void* stream);
@@ -91,7 +96,7 @@ size_t pfn_mpn_workspace_bytes(const pfn_mpn_config* cfg, int64_t n_nodes, int64
 int pfn_mpn_forward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
                     const float* const* params, const float* x, const void* pred_mask,
                     int mask_dtype, const float* edge_attr, float* out, void* ws, size_t ws_bytes,
-                    uint64_t* rng_state, void* stream);
+                    uint64_t* rng_state, int64_t seg_nodes /* 0, or a value pfn_graph_segments accepted */, void* stream);
 
 /* Autograd of the above (what loss.backward() runs, utils/training.py:74): grad_out [N, output_dim];
  * writes every entry of `grads` (overwrites, does not accumulate); grad_x [N, F0] and
@@ -99,7 +104,7 @@ int pfn_mpn_forward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_n
 int pfn_mpn_backward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
                      const float* const* params, float* const* grads, const float* x,
                      const void* pred_mask, int mask_dtype, const float* edge_attr, const float* grad_out,
-                     float* grad_x, float* grad_edge_attr, void* ws, size_t ws_bytes, void* stream);
+                     float* grad_x, float* grad_edge_attr, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream);
 
 /* ------------------------------------------------------------------------------------- single layers
  * EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, output_dim).forward (networks/MPN.py:30-56):
@@ -125,11 +130,11 @@ int pfn_edge_aggr_backward(const void* graph_ws, int64_t n_nodes, int64_t e_stor
 size_t pfn_tag_conv_workspace_bytes(int64_t n_nodes, int64_t e_stored, int cin, int cout, int K);
 int pfn_tag_conv_forward(const void* graph_ws, int64_t n_nodes, int64_t e_stored, int cin, int cout, int K,
                          const float* x, int64_t ldx, const float* const* weights, const float* bias,
-                         float* out, int64_t ldo, void* ws, size_t ws_bytes, void* stream);
+                         float* out, int64_t ldo, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream);
 int pfn_tag_conv_backward(const void* graph_ws, int64_t n_nodes, int64_t e_stored, int cin, int cout, int K,
                           const float* x, int64_t ldx, const float* const* weights, const float* grad_out,
                           int64_t ldgo, float* grad_x, int64_t ldgx, float* const* grad_weights,
-                          float* grad_bias, void* ws, size_t ws_bytes, void* stream);
+                          float* grad_bias, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream);
 
 /* ----------------------------------------------------------------------------------------- utilities
  * The segmented scatter-add in isolation (PyG SumAggregation / scatter_add_ under propagate):

@@ -87,6 +87,84 @@ int launch_hop(const GraphView& g, const HopArgs& a, hipStream_t s) {
     return PFN_OK;
 }
 
+// ------------------------------------------------------------------------------------ LDS-resident hops
+// PyG batches are block diagonal: when every graph's node rows fit in LDS (118 buses x 528 B = 62 KB) the K hops of a
+// TAGConv need no trip through L2/HBM between hops: a workgroup stages the rows of its graph(s) once, then ping-pongs
+// between two LDS tiles, gathering neighbour rows with ds_read_b128.  Forward writes every hop result out (they are
+// GEMM operands and saved for the weight gradients); backward keeps the Horner iterates on chip and writes only the end.
+constexpr int FH_THREADS = 512;
+constexpr int FH_LDS_BYTES = 156 * 1024;
+
+bool fused_hops_fit(int seg, int ld) { return seg > 0 && (size_t)2 * seg * ld * sizeof(float) <= (size_t)FH_LDS_BYTES; }
+
+__global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_pb, const int* __restrict__ rowptr,
+                                                                const int* __restrict__ nbr, const float* __restrict__ dinv,
+                                                                const FusedHopsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tiles[];   // 2 x rows_pb x ld
+    const int r0 = blockIdx.x * rows_pb;
+    const int rows = min(rows_pb, n - r0);
+    const int nchunk = a.ld >> 2;
+    const int items = rows * nchunk;
+    float* cur = tiles;
+    float* nxt = tiles + (size_t)rows_pb * a.ld;
+    const float* first = a.transpose ? a.G + (size_t)a.K * a.stride : a.x0;
+    for (int i = threadIdx.x; i < items; i += FH_THREADS)   // rows are contiguous in memory: a linear float4 copy
+        st4(cur + 4 * i, ld4(first + (size_t)r0 * a.ld + 4 * i));
+    __syncthreads();
+    for (int k = 1; k <= a.K; ++k) {
+        const bool last = k == a.K;
+        const float* addp = a.transpose ? a.G + (size_t)(a.K - k) * a.stride : nullptr;
+        float* gout = a.transpose ? (last ? a.out : nullptr) : a.xk + (size_t)(k - 1) * a.stride;
+        for (int i = threadIdx.x; i < items; i += FH_THREADS) {
+            const int lr = i / nchunk, col = (i - lr * nchunk) * 4;
+            const int row = r0 + lr;
+            const int beg = rowptr[row], end = rowptr[row + 1];
+            const float di = dinv[row];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = beg; p < end; ++p) {
+                const int s = nbr[p];
+                acc = fma4(dinv[s] * di, ld4(cur + (size_t)(s - r0) * a.ld + col), acc);
+            }
+            const size_t o = (size_t)row * a.ld + col;
+            if (addp) acc = add4(acc, ld4(addp + o));
+            if (last && a.gate) {
+                const float4 g4 = ld4(a.gate + o);
+                acc.x = g4.x > 0.f ? acc.x * a.gate_scale : 0.f;
+                acc.y = g4.y > 0.f ? acc.y * a.gate_scale : 0.f;
+                acc.z = g4.z > 0.f ? acc.z * a.gate_scale : 0.f;
+                acc.w = g4.w > 0.f ? acc.w * a.gate_scale : 0.f;
+            }
+            if (!last) st4(nxt + (size_t)lr * a.ld + col, acc);
+            if (gout) st4(gout + o, acc);
+        }
+        __syncthreads();
+        float* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+}
+
+int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s) {
+    if (g.n == 0 || a.K == 0) return PFN_OK;
+    // whole graphs per block: as many as fit the two LDS tiles, but keep >= ~2 blocks per CU worth of parallelism
+    int gpb = (int)((size_t)FH_LDS_BYTES / ((size_t)2 * a.seg * a.ld * sizeof(float)));
+    const int ngraphs = g.n / a.seg;
+    while (gpb > 1 && (ngraphs + gpb - 1) / gpb < 512) --gpb;
+    const int rows_pb = gpb * a.seg;
+    const size_t lds = (size_t)2 * rows_pb * a.ld * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_hops_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_BYTES));
+        attr_set = true;
+    }
+    ProfScope ps(a.transpose ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
+    fused_hops_kernel<<<(g.n + rows_pb - 1) / rows_pb, FH_THREADS, lds, s>>>(
+        g.n, rows_pb, a.transpose ? g.rowptr_out : g.rowptr_in, a.transpose ? g.out_dst : g.in_src, g.dinv, a);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
 // ------------------------------------------------------------------------------ EdgeAggregation fwd
 // The per-edge Linear(2Fi+Fe -> H) splits into per-node terms P = x W1[:, :Fi]^T + b1, Q = x W1[:, Fi:2Fi]^T
 // (node GEMMs) and a per-edge residue sum_f a_e[f] W1[:, 2Fi+f]; the second Linear commutes with the

@@ -180,6 +180,17 @@ __global__ __launch_bounds__(256) void graph_sort_rows_kernel(int n, const int* 
     }
 }
 
+// Segment check for the LDS-resident multi-hop path: ok iff no effective edge crosses a multiple of `seg` (the batch
+// is then a disjoint union of index-contiguous blocks of `seg` nodes, e.g. the graphs of a PyG batch of one case).
+__global__ __launch_bounds__(256) void graph_segcheck_kernel(int n, int seg, const int* __restrict__ rowptr_in,
+                                                             const int* __restrict__ in_src, int* flags) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    const int sid = row / seg;
+    for (int p = rowptr_in[row]; p < rowptr_in[row + 1]; ++p)
+        if (in_src[p] / seg != sid) atomicOr(&flags[4], 1);
+}
+
 __global__ void graph_export_kernel(int n, const int* __restrict__ rowptr_in, const int* __restrict__ in_src,
                                     const int* __restrict__ in_eid, const int* flags, int cap, int64_t* out) {
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
@@ -255,6 +266,22 @@ int pfn_graph_info(const void* ws, int64_t n, int64_t e, int32_t* directed, int6
         set_error("edge_index holds a node id outside [0, %lld)", (long long)n);
         return PFN_EINDEX;
     }
+    return PFN_OK;
+}
+
+int pfn_graph_segments(void* ws, int64_t n, int64_t e, int64_t seg_nodes, int32_t* ok, void* stream) {
+    PFN_CHECK_ARG(ws != nullptr && ok != nullptr, "pfn_graph_segments: null pointer");
+    *ok = 0;
+    if (seg_nodes <= 0 || n <= 0 || n % seg_nodes != 0 || seg_nodes > (1 << 20)) return PFN_OK;
+    GraphView g = graph_view(ws, n, e);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PFN_CHECK_HIP(hipMemsetAsync(g.flags + 4, 0, sizeof(int), s));
+    graph_segcheck_kernel<<<((int)n + 255) / 256, 256, 0, s>>>((int)n, (int)seg_nodes, g.rowptr_in, g.in_src, g.flags);
+    PFN_CHECK_LAUNCH();
+    int bad = 1;
+    PFN_CHECK_HIP(hipMemcpyAsync(&bad, g.flags + 4, sizeof(int), hipMemcpyDeviceToHost, s));
+    PFN_CHECK_HIP(hipStreamSynchronize(s));
+    *ok = bad ? 0 : 1;
     return PFN_OK;
 }
 

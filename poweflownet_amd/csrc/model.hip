@@ -227,14 +227,19 @@ static TagPack tag_pack(Packer& pk, int cin, int cout, int K, const float* const
 }
 
 static int tag_forward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
-                       const float* bias, float* out, int ldo, const Act& act, float* xk, hipStream_t s) {
+                       const float* bias, float* out, int ldo, const Act& act, float* xk, hipStream_t s, int seg = 0) {
     // xk: K buffers of n * ldx floats holding A_hat^k x, k = 1..K
     const size_t stride = (size_t)g.n * ldx;
-    const float* prev = x;
-    for (int k = 1; k <= K; ++k) {
-        HopArgs hp{prev, nullptr, xk + (size_t)(k - 1) * stride, nullptr, 1.f, ldx, 1, 0};
-        PFN_TRY(launch_hop(g, hp, s));
-        prev = hp.y;
+    if (K > 0 && fused_hops_fit(seg, ldx)) {
+        FusedHopsArgs fh{x, xk, nullptr, nullptr, nullptr, 1.f, stride, ldx, K, 0, seg};
+        PFN_TRY(launch_fused_hops(g, fh, s));
+    } else {
+        const float* prev = x;
+        for (int k = 1; k <= K; ++k) {
+            HopArgs hp{prev, nullptr, xk + (size_t)(k - 1) * stride, nullptr, 1.f, ldx, 1, 0};
+            PFN_TRY(launch_hop(g, hp, s));
+            prev = hp.y;
+        }
     }
     GemmArgs a = gemm_defaults(g.n, cout, ldo);
     a.C[0] = out;
@@ -253,7 +258,7 @@ struct TagScratch { float* G; float *z0, *z1; ReduceWs red; };
 static int tag_backward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
                         const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx, float* const* gw,
                         float* gbias, const float* xk, const TagScratch& sc, hipStream_t s, SideQ* sq = nullptr,
-                        int layer = 0) {
+                        int layer = 0, int seg = 0) {
     const size_t stride = (size_t)g.n * ldx;
     {   // weight gradients need only gout and the saved hops: fork them off first
         hipStream_t ws = s;
@@ -288,13 +293,19 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             if (sq) PFN_TRY(sq->main_wait(layer + 1));
         }
         PFN_TRY(launch_gemm_nt(a, s));
-        const float* z = sc.G + (size_t)K * stride;
-        for (int k = K - 1; k >= 0; --k) {
-            float* dst = (k == 0) ? gx : ((k & 1) ? sc.z1 : sc.z0);
-            if (k == 0 && sq) PFN_TRY(sq->main_wait(layer + 1));   // gx overwrites what the outer layer's side work reads
-            HopArgs hp{z, sc.G + (size_t)k * stride, dst, k == 0 ? gate.y : nullptr, k == 0 ? gate.scale : 1.f, ldx, 1, 1};
-            PFN_TRY(launch_hop(g, hp, s));
-            z = dst;
+        if (K > 0 && fused_hops_fit(seg, ldx)) {
+            if (sq) PFN_TRY(sq->main_wait(layer + 1));   // gx overwrites what the outer layer's side work reads
+            FusedHopsArgs fh{nullptr, nullptr, sc.G, gx, gate.y, gate.scale, stride, ldx, K, 1, seg};
+            PFN_TRY(launch_fused_hops(g, fh, s));
+        } else {
+            const float* z = sc.G + (size_t)K * stride;
+            for (int k = K - 1; k >= 0; --k) {
+                float* dst = (k == 0) ? gx : ((k & 1) ? sc.z1 : sc.z0);
+                if (k == 0 && sq) PFN_TRY(sq->main_wait(layer + 1));   // gx overwrites what the outer layer's side work reads
+                HopArgs hp{z, sc.G + (size_t)k * stride, dst, k == 0 ? gate.y : nullptr, k == 0 ? gate.scale : 1.f, ldx, 1, 1};
+                PFN_TRY(launch_hop(g, hp, s));
+                z = dst;
+            }
         }
     }
     return PFN_OK;
@@ -405,7 +416,7 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
 
 static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
                          const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr, float* out,
-                         uint64_t* rng, hipStream_t s) {
+                         uint64_t* rng, int seg, hipStream_t s) {
     const bool drop = c.training && c.dropout_rate > 0.f;
     PFN_CHECK_ARG(!drop || rng != nullptr, "training with dropout needs rng_state");
     const int nparams = pfn_mpn_num_params(&c);
@@ -456,7 +467,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
             pi += 4;
             fcur = fo;
         } else {
-            PFN_TRY(tag_forward(g, lo.h, lo.h, lo.K, cur, ldc, mp.tag[i], params[pi + lo.K + 1], y, ldy, act, lo.xk[i], s));
+            PFN_TRY(tag_forward(g, lo.h, lo.h, lo.K, cur, ldc, mp.tag[i], params[pi + lo.K + 1], y, ldy, act, lo.xk[i], s, seg));
             pi += lo.K + 2;
         }
         cur = y;
@@ -467,7 +478,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
 
 static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
                           float* const* grads, const float* x, const float* edge_attr, const float* gout, float* gx,
-                          float* gea, hipStream_t s) {
+                          float* gea, int seg, hipStream_t s) {
     (void)x;
     const bool drop = c.training && c.dropout_rate > 0.f;
     const float gscale = drop ? 1.f / (1.f - c.dropout_rate) : 1.f;
@@ -503,7 +514,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
                                 grads[p0], grads[p0 + 1], grads[p0 + 2], grads[p0 + 3], gea, lo.ea[i], lo.eas, s, sq, i + 1));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
-                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, sq, i + 1));
+                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, sq, i + 1, seg));
         }
         gcur = gnext;
         ldg = ldi;
@@ -625,7 +636,7 @@ static int check_common(const pfn_mpn_config* c, const void* gws, int64_t n, int
 
 int pfn_mpn_forward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
                     const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr, float* out, void* ws,
-                    size_t ws_bytes, uint64_t* rng, void* stream) {
+                    size_t ws_bytes, uint64_t* rng, int64_t seg_nodes, void* stream) {
     PFN_TRY(check_common(c, gws, n, e, ws));
     PFN_CHECK_ARG(params && (n == 0 || (x && pred_mask && out)) && (e == 0 || edge_attr), "pfn_mpn_forward: null tensor");
     Layout lo;
@@ -636,12 +647,14 @@ int pfn_mpn_forward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t
     }
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
     PFN_CHECK_ARG(c->nfeature_dim % 4 == 0, "nfeature_dim must be a multiple of 4 (the reference asserts 4, networks/MPN.py:528)");
-    return model_forward(*c, g, lo, params, x, pred_mask, mask_dtype, edge_attr, out, rng, static_cast<hipStream_t>(stream));
+    PFN_CHECK_ARG(seg_nodes >= 0 && (seg_nodes == 0 || n % seg_nodes == 0), "seg_nodes must be 0 or divide n_nodes");
+    return model_forward(*c, g, lo, params, x, pred_mask, mask_dtype, edge_attr, out, rng, (int)seg_nodes,
+                         static_cast<hipStream_t>(stream));
 }
 
 int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
                      float* const* grads, const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr,
-                     const float* gout, float* gx, float* gea, void* ws, size_t ws_bytes, void* stream) {
+                     const float* gout, float* gx, float* gea, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream) {
     (void)pred_mask; (void)mask_dtype;
     PFN_TRY(check_common(c, gws, n, e, ws));
     PFN_CHECK_ARG(params && grads && (n == 0 || (x && gout)), "pfn_mpn_backward: null tensor");
@@ -652,7 +665,8 @@ int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_
         return PFN_ENOSPACE;
     }
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
-    return model_backward(*c, g, lo, params, grads, x, edge_attr, gout, gx, gea, static_cast<hipStream_t>(stream));
+    PFN_CHECK_ARG(seg_nodes >= 0 && (seg_nodes == 0 || n % seg_nodes == 0), "seg_nodes must be 0 or divide n_nodes");
+    return model_backward(*c, g, lo, params, grads, x, edge_attr, gout, gx, gea, (int)seg_nodes, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------- single layers
@@ -757,7 +771,7 @@ size_t pfn_tag_conv_workspace_bytes(int64_t n, int64_t e, int cin, int cout, int
 
 int pfn_tag_conv_forward(const void* gws, int64_t n, int64_t e, int cin, int cout, int K, const float* x, int64_t ldx,
                          const float* const* weights, const float* bias, float* out, int64_t ldo, void* ws,
-                         size_t ws_bytes, void* stream) {
+                         size_t ws_bytes, int64_t seg_nodes, void* stream) {
     PFN_CHECK_ARG(gws && ws && weights, "pfn_tag_conv_forward: null pointer");
     PFN_CHECK_ARG(ldx == ld_of(cin) && ldo == ld_of(cout), "pfn_tag_conv_forward: row strides must be pfn_padded_ld(F)");
     PFN_CHECK_ARG(K >= 0 && K <= 7, "K must be in [0, 7]");
@@ -771,12 +785,13 @@ int pfn_tag_conv_forward(const void* gws, int64_t n, int64_t e, int cin, int cou
     Packer pk(w.packed);
     const TagPack pw = tag_pack(pk, cin, cout, K, weights);
     PFN_TRY(pk.flush(s));
-    return tag_forward(g, cin, cout, K, x, (int)ldx, pw, bias, out, (int)ldo, Act{}, w.xk, s);
+    PFN_CHECK_ARG(seg_nodes >= 0 && (seg_nodes == 0 || n % seg_nodes == 0), "seg_nodes must be 0 or divide n_nodes");
+    return tag_forward(g, cin, cout, K, x, (int)ldx, pw, bias, out, (int)ldo, Act{}, w.xk, s, (int)seg_nodes);
 }
 
 int pfn_tag_conv_backward(const void* gws, int64_t n, int64_t e, int cin, int cout, int K, const float* x, int64_t ldx,
                           const float* const* weights, const float* gout, int64_t ldgo, float* gx, int64_t ldgx,
-                          float* const* gweights, float* gbias, void* ws, size_t ws_bytes, void* stream) {
+                          float* const* gweights, float* gbias, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream) {
     PFN_CHECK_ARG(gws && ws && weights && gout && gweights, "pfn_tag_conv_backward: null pointer");
     PFN_CHECK_ARG(ldx == ld_of(cin) && ldgo == ld_of(cout), "pfn_tag_conv_backward: row strides must be pfn_padded_ld(F)");
     PFN_CHECK_ARG(K >= 0 && K <= 7, "K must be in [0, 7]");
@@ -788,8 +803,9 @@ int pfn_tag_conv_backward(const void* gws, int64_t n, int64_t e, int cin, int co
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
     Packer pk(w.packed);                       // images were filled by the forward call on the same workspace
     const TagPack pw = tag_pack(pk, cin, cout, K, weights);
+    PFN_CHECK_ARG(seg_nodes >= 0 && (seg_nodes == 0 || n % seg_nodes == 0), "seg_nodes must be 0 or divide n_nodes");
     return tag_backward(g, cin, cout, K, x, (int)ldx, pw, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gweights, gbias, w.xk,
-                        w.sc, static_cast<hipStream_t>(stream));
+                        w.sc, static_cast<hipStream_t>(stream), nullptr, 0, (int)seg_nodes);
 }
 
 // ----------------------------------------------------------------------------------------- utilities
@@ -827,7 +843,8 @@ int pfn_adamw_step(float* p, const float* g, float* m, float* v, int64_t count, 
                    float eps, float wd, int64_t* step, void* stream) {
     PFN_CHECK_ARG(p && g && m && v && step, "pfn_adamw_step: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 2048));
+    // one block per CU at most: every block ends with one atomic on the arrival counter (~12 ns each, serialised)
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 256));
     adamw_kernel<<<nb, 256, 0, s>>>(p, g, m, v, count, lr, b1, b2, eps, wd, step);
     PFN_CHECK_LAUNCH();
     return PFN_OK;

@@ -163,6 +163,24 @@ struct HopArgs {
 };
 int launch_hop(const GraphView& g, const HopArgs& a, hipStream_t s);
 
+// K normalised hops with the node rows of `seg_per_block` whole graphs resident in LDS (two ping-pong tiles):
+//   forward  (transpose = 0):  xs[k] = A_hat xs[k-1], xs[0] = x0;  every xs[k] (k = 1..K) is written to `xk + (k-1)*stride`
+//   backward (transpose = 1):  z = G[K]; z = G[k] + A_hat^T z for k = K-1..0; only the final z is written (to `out`), gated
+// Requires the segment property checked by pfn_graph_segments.  Returns false from fused_hops_fit() when a graph's rows
+// do not fit in LDS (the caller then runs K launch_hop passes).
+struct FusedHopsArgs {
+    const float* x0;      // forward: layer input;          backward: unused
+    float* xk;            // forward: K output buffers;     backward: unused
+    const float* G;       // backward: K+1 buffers G[0..K]; forward: unused
+    float* out;           // backward: final gradient
+    const float* gate;
+    float gate_scale;
+    size_t stride;        // floats between consecutive k buffers
+    int ld, K, transpose, seg;
+};
+bool fused_hops_fit(int seg, int ld);
+int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s);
+
 // S[i] = sum_{e -> i} relu(P[i] + Q[src(e)] + sum_f a_e[f] * W1[:, 2Fi + f])
 struct EdgeFwdArgs {
     const float* P;

@@ -38,7 +38,8 @@ class GraphCSR:
     copies are appended (networks/MPN.py:498-523); 0: use the list as given; 1: always undirect.
     """
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, mode: int = -1, validate: bool = True):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, mode: int = -1, validate: bool = True,
+                 seg_hint: int = 0):
         lib = L.load()
         L.require_device(edge_index, what="edge_index")
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
@@ -53,8 +54,15 @@ class GraphCSR:
             L.check(lib.pfn_graph_build(edge_index.data_ptr(), self.e_stored, self.num_nodes, self.mode,
                                         self.ws.data_ptr(), nbytes, L.stream_ptr()), "pfn_graph_build")
         self._keepalive = None
+        self.seg_nodes = 0       # > 0: the batch is a union of index-contiguous graphs of this many nodes (checked on device)
         if validate and not _capturing():
             self.info()          # raises on out-of-range ids (one sync per NEW topology only)
+            if seg_hint > 0 and self.num_nodes % seg_hint == 0:
+                ok = C.c_int32(0)
+                with torch.cuda.device(self.device):
+                    L.check(lib.pfn_graph_segments(self.ws.data_ptr(), self.num_nodes, self.e_stored, int(seg_hint),
+                                                   C.byref(ok), L.stream_ptr()), "pfn_graph_segments")
+                self.seg_nodes = int(seg_hint) if ok.value else 0
 
     def info(self):
         """(directed, effective_edge_count); synchronises.  Raises RuntimeError on an out-of-range node id."""
@@ -84,11 +92,11 @@ class _GraphCache:
     def __init__(self):
         self._ref, self._key, self._graph = None, None, None
 
-    def get(self, edge_index: torch.Tensor, num_nodes: int, mode: int) -> GraphCSR:
-        key = (edge_index._version, edge_index.data_ptr(), tuple(edge_index.shape), num_nodes, mode)
+    def get(self, edge_index: torch.Tensor, num_nodes: int, mode: int, seg_hint: int = 0) -> GraphCSR:
+        key = (edge_index._version, edge_index.data_ptr(), tuple(edge_index.shape), num_nodes, mode, seg_hint)
         if self._ref is not None and self._ref() is edge_index and self._key == key:
             return self._graph
-        g = GraphCSR(edge_index, num_nodes, mode)
+        g = GraphCSR(edge_index, num_nodes, mode, seg_hint=seg_hint)
         self._ref, self._key, self._graph = weakref.ref(edge_index), key, g
         return g
 
@@ -191,7 +199,7 @@ class _TagConvFn(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         L.check(lib.pfn_tag_conv_forward(graph.ws.data_ptr(), n, graph.e_stored, cin, cout, K, xp.data_ptr(), _padded(cin),
                                          L.ptr_table(weights), L.ptr(bias), out.data_ptr(), _padded(cout), ws.data_ptr(),
-                                         nbytes, L.stream_ptr()), "pfn_tag_conv_forward")
+                                         nbytes, graph.seg_nodes, L.stream_ptr()), "pfn_tag_conv_forward")
         ctx.graph, ctx.dims, ctx.ws, ctx.has_bias = graph, dims, ws, bias is not None
         ctx.save_for_backward(xp, *weights)
         return _unpad_rows(out, cout)
@@ -208,8 +216,8 @@ class _TagConvFn(torch.autograd.Function):
         gb = torch.empty(cout, dtype=torch.float32, device=xp.device) if ctx.has_bias else None
         L.check(lib.pfn_tag_conv_backward(graph.ws.data_ptr(), n, graph.e_stored, cin, cout, K, xp.data_ptr(), _padded(cin),
                                           L.ptr_table(weights), gp.data_ptr(), _padded(cout), gx.data_ptr(), _padded(cin),
-                                          L.ptr_table(gws), L.ptr(gb), ctx.ws.data_ptr(), ctx.ws.numel(), L.stream_ptr()),
-                "pfn_tag_conv_backward")
+                                          L.ptr_table(gws), L.ptr(gb), ctx.ws.data_ptr(), ctx.ws.numel(), graph.seg_nodes,
+                                          L.stream_ptr()), "pfn_tag_conv_backward")
         return (None, None, _unpad_rows(gx, cin), gb, *gws)
 
 
@@ -255,7 +263,8 @@ class _MpnFn(torch.autograd.Function):
         mask_dtype = 0 if pred_mask.dtype == torch.int64 else 1
         L.check(lib.pfn_mpn_forward(C.byref(cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params), x.data_ptr(),
                                     pred_mask.data_ptr(), mask_dtype, edge_attr.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                                    nbytes, L.ptr(model._rng_state_on(x.device)), L.stream_ptr()), "pfn_mpn_forward")
+                                    nbytes, L.ptr(model._rng_state_on(x.device)), graph.seg_nodes, L.stream_ptr()),
+                "pfn_mpn_forward")
         ctx.model, ctx.graph, ctx.cfg, ctx.ws, ctx.mask_dtype = model, graph, cfg, ws, mask_dtype
         ctx.save_for_backward(x, pred_mask, edge_attr, *params)
         return _unpad_rows(out, fo)
@@ -277,7 +286,7 @@ class _MpnFn(torch.autograd.Function):
         L.check(lib.pfn_mpn_backward(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
                                      L.ptr_table(grads), x.data_ptr(), pred_mask.data_ptr(), ctx.mask_dtype,
                                      edge_attr.data_ptr(), gp.data_ptr(), L.ptr(gx), L.ptr(gea), ctx.ws.data_ptr(),
-                                     ctx.ws.numel(), L.stream_ptr()), "pfn_mpn_backward")
+                                     ctx.ws.numel(), graph.seg_nodes, L.stream_ptr()), "pfn_mpn_backward")
         model._last_flat_grad = flat
         return (None, None, gx, None, gea, *grads)
 
@@ -395,5 +404,10 @@ class MaskEmbdMultiMPN(nn.Module):
         if edge_features.shape != (edge_index.shape[1], self.efeature_dim):
             raise RuntimeError(f"edge_attr must be ({edge_index.shape[1]}, {self.efeature_dim}), got {tuple(edge_features.shape)}")
         with torch.cuda.device(x.device):
-            graph = self._graphs.get(edge_index, x.shape[0], -1)     # is_directed + undirect_graph (:539)
+            # PyG-style batches carry `ptr` (B+1,): equal-sized graphs let the TAGConv hops stay in LDS per graph; the
+            # hint is verified on device against the actual edge list (pfn_graph_segments) before it is trusted
+            ptr = getattr(data, "ptr", None)
+            nseg = int(ptr.numel()) - 1 if torch.is_tensor(ptr) else 0
+            seg_hint = x.shape[0] // nseg if nseg > 0 and x.shape[0] % nseg == 0 else 0
+            graph = self._graphs.get(edge_index, x.shape[0], -1, seg_hint)   # is_directed + undirect_graph (:539)
             return _MpnFn.apply(self, graph, x, mask, edge_features, *self._ordered_params())

@@ -220,6 +220,38 @@ def test_model_vs_oracle_seeded(case, B, cfg):
         assert_close(p.grad, q.grad, 2 * RTOL, f"grad.{k}")
 
 
+def test_fused_lds_hops_match_generic_path():
+    """Batches with `ptr` take the LDS-resident multi-hop path; without it the per-hop kernels.  Same results."""
+    torch.manual_seed(3)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 3, 0.0).to(DEV).eval()
+    with torch.no_grad():
+        for mod in m.layers:
+            if isinstance(mod, TAGConv):
+                mod.bias.normal_(std=0.1)
+    for case, B in (("118", 6), ("14", 37)):
+        d = make_batch(case, B).to(DEV)
+        out_f = m(d)
+        assert m._graphs._graph.seg_nodes == {"118": 118, "14": 14}[case]
+        loss = out_f.square().mean()
+        m.zero_grad()
+        loss.backward()
+        gf = [p.grad.clone() for p in m.parameters()]
+        d2 = d.clone()
+        del d2.__dict__["ptr"]; d2._keys.remove("ptr")
+        out_g = m(d2)
+        assert m._graphs._graph.seg_nodes == 0
+        m.zero_grad()
+        out_g.square().mean().backward()
+        assert_close(out_f, out_g, 1e-6, "out")
+        for a, p in zip(gf, m.parameters()):
+            assert_close(a, p.grad, 1e-6, "grad")
+    # a hint that the edges contradict is rejected on device: 5 graphs of 14 nodes claimed to be 7 graphs of 10
+    d = make_batch("14", 5).to(DEV)
+    d.ptr = torch.arange(0, 71, 10, device=DEV)
+    m(d)
+    assert m._graphs._graph.seg_nodes == 0
+
+
 def test_edge_cases_empty_edges_and_isolated_nodes():
     from poweflownet_amd.data import Data
     torch.manual_seed(0)
