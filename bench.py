@@ -52,12 +52,15 @@ def parse():
     return ap.parse_args()
 
 
-def alg_bytes(n, e, h, fe):
+def alg_bytes(n, e, h, fe, K=3):
     """Algorithmic bytes per launch of the gather/segment-sum kernel classes (4-byte elements and indices; logical
     inputs once, one gathered row per directed edge, output once -- the convention of SURVEY.md 8d)."""
     return {
         "hop_norm": 4.0 * (e * h + e + n * h + (n + 1)),                          # B_sa(H)
         "scatter_add": 4.0 * (e * h + e + n * h + (n + 1)),
+        # K hops in one launch (rows LDS-resident between hops): the algorithmic work is still K x B_sa(H)
+        "fused_hops_fwd": K * 4.0 * (e * h + e + n * h + (n + 1)),
+        "fused_hops_bwd": K * 4.0 * (e * h + e + n * h + (n + 1)),
         "edge_fwd": 4.0 * (n * h + e * h + e * fe + e + (n + 1) + n * h),
         "edge_bwd_dst": 4.0 * (2 * n * h + e * h + e * fe + e + (n + 1) + n * h),
         "edge_bwd_src": 4.0 * (n * h + 2 * e * h + e * fe + e + (n + 1) + n * h),
@@ -239,7 +242,7 @@ def main():
         torch.cuda.synchronize()
         L.profile_enable(False)
         rep = L.profile_report(reset=True)
-        ab = alg_bytes(n_nodes, e_eff, h, 2)
+        ab = alg_bytes(n_nodes, e_eff, h, 2, K)
         for name, r in rep.items():
             cnt = max(r["count"], 1)
             avg_s = 1e-3 * r["ms"] / cnt

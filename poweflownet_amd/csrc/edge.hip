@@ -8,6 +8,8 @@
 // Work item = (node row, 16-byte column chunk): consecutive lanes read consecutive float4s of the same
 // neighbour row (528 B contiguous for H = 129), every row is reduced by one lane sequentially in edge-id
 // order -> no atomics, deterministic, same summation order as the reference's sequential scatter.
+#include <stdlib.h>
+
 #include "pfn_internal.hpp"
 
 namespace pfn {
@@ -95,18 +97,37 @@ int launch_hop(const GraphView& g, const HopArgs& a, hipStream_t s) {
 constexpr int FH_THREADS = 512;
 constexpr int FH_LDS_BYTES = 156 * 1024;
 
-bool fused_hops_fit(int seg, int ld) { return seg > 0 && (size_t)2 * seg * ld * sizeof(float) <= (size_t)FH_LDS_BYTES; }
+bool fused_hops_fit(int seg, int ld, int n) {
+    // Pays only when there are enough graphs to give every CU several blocks (the per-CU load/store path, ~25-50 GB/s,
+    // bounds a block that streams 4 tiles): measured at 128 graphs (case118 x 128) the fused kernel loses to K generic
+    // hop launches (40 vs 26 us), at 2048 graphs it wins.  PFN_FUSED_HOPS=0/1 forces the choice (experiments).
+    static const char* force = getenv("PFN_FUSED_HOPS");
+    if (seg <= 0 || (size_t)2 * seg * ld * sizeof(float) > (size_t)FH_LDS_BYTES) return false;
+    if (force) return force[0] == '1';
+    return n / seg >= 1024;
+}
 
-__global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_pb, const int* __restrict__ rowptr,
-                                                                const int* __restrict__ nbr, const float* __restrict__ dinv,
-                                                                const FusedHopsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float tiles[];   // 2 x rows_pb x ld
+__global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_pb, int nbr_cap,
+                                                                const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                                const float* __restrict__ dinv, const FusedHopsArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float tiles[];   // 2 x rows_pb x ld | dinv[rows_pb] | rp[rows_pb+1] | nbr[cap]
     const int r0 = blockIdx.x * rows_pb;
     const int rows = min(rows_pb, n - r0);
     const int nchunk = a.ld >> 2;
     const int items = rows * nchunk;
     float* cur = tiles;
     float* nxt = tiles + (size_t)rows_pb * a.ld;
+    float* s_dinv = tiles + (size_t)2 * rows_pb * a.ld;
+    int* s_rp = reinterpret_cast<int*>(s_dinv + rows_pb);
+    int* s_nb = s_rp + rows_pb + 1;
+    // the block's slice of the adjacency goes to LDS once: with ~8 work items per thread and K hops, index loads from
+    // global memory (three dependent latencies per item) would dominate everything else
+    const int e0 = rowptr[r0], e1 = rowptr[r0 + rows];
+    const bool nb_in_lds = e1 - e0 <= nbr_cap;
+    for (int i = threadIdx.x; i <= rows; i += FH_THREADS) s_rp[i] = rowptr[r0 + i] - e0;
+    for (int i = threadIdx.x; i < rows; i += FH_THREADS) s_dinv[i] = dinv[r0 + i];
+    if (nb_in_lds)
+        for (int i = threadIdx.x; i < e1 - e0; i += FH_THREADS) s_nb[i] = nbr[e0 + i] - r0;
     const float* first = a.transpose ? a.G + (size_t)a.K * a.stride : a.x0;
     for (int i = threadIdx.x; i < items; i += FH_THREADS)   // rows are contiguous in memory: a linear float4 copy
         st4(cur + 4 * i, ld4(first + (size_t)r0 * a.ld + 4 * i));
@@ -117,15 +138,14 @@ __global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_
         float* gout = a.transpose ? (last ? a.out : nullptr) : a.xk + (size_t)(k - 1) * a.stride;
         for (int i = threadIdx.x; i < items; i += FH_THREADS) {
             const int lr = i / nchunk, col = (i - lr * nchunk) * 4;
-            const int row = r0 + lr;
-            const int beg = rowptr[row], end = rowptr[row + 1];
-            const float di = dinv[row];
+            const int beg = s_rp[lr], end = s_rp[lr + 1];
+            const float di = s_dinv[lr];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int p = beg; p < end; ++p) {
-                const int s = nbr[p];
-                acc = fma4(dinv[s] * di, ld4(cur + (size_t)(s - r0) * a.ld + col), acc);
+                const int ls = nb_in_lds ? s_nb[p] : nbr[e0 + p] - r0;
+                acc = fma4(s_dinv[ls] * di, ld4(cur + (size_t)ls * a.ld + col), acc);
             }
-            const size_t o = (size_t)row * a.ld + col;
+            const size_t o = (size_t)(r0 + lr) * a.ld + col;
             if (addp) acc = add4(acc, ld4(addp + o));
             if (last && a.gate) {
                 const float4 g4 = ld4(a.gate + o);
@@ -151,16 +171,19 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
     const int ngraphs = g.n / a.seg;
     while (gpb > 1 && (ngraphs + gpb - 1) / gpb < 512) --gpb;
     const int rows_pb = gpb * a.seg;
-    const size_t lds = (size_t)2 * rows_pb * a.ld * sizeof(float);
+    const size_t tile_bytes = (size_t)2 * rows_pb * a.ld * sizeof(float);
+    const size_t fixed = tile_bytes + (size_t)(2 * rows_pb + 1) * sizeof(int);
+    const size_t lds_total = (size_t)160 * 1024;
+    const int nbr_cap = (int)((lds_total - fixed) / sizeof(int));
     static bool attr_set = false;
     if (!attr_set) {
         PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_hops_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, FH_LDS_BYTES));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
         attr_set = true;
     }
     ProfScope ps(a.transpose ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
-    fused_hops_kernel<<<(g.n + rows_pb - 1) / rows_pb, FH_THREADS, lds, s>>>(
-        g.n, rows_pb, a.transpose ? g.rowptr_out : g.rowptr_in, a.transpose ? g.out_dst : g.in_src, g.dinv, a);
+    fused_hops_kernel<<<(g.n + rows_pb - 1) / rows_pb, FH_THREADS, lds_total, s>>>(
+        g.n, rows_pb, nbr_cap, a.transpose ? g.rowptr_out : g.rowptr_in, a.transpose ? g.out_dst : g.in_src, g.dinv, a);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

@@ -230,7 +230,7 @@ static int tag_forward(const GraphView& g, int cin, int cout, int K, const float
                        const float* bias, float* out, int ldo, const Act& act, float* xk, hipStream_t s, int seg = 0) {
     // xk: K buffers of n * ldx floats holding A_hat^k x, k = 1..K
     const size_t stride = (size_t)g.n * ldx;
-    if (K > 0 && fused_hops_fit(seg, ldx)) {
+    if (K > 0 && fused_hops_fit(seg, ldx, g.n)) {
         FusedHopsArgs fh{x, xk, nullptr, nullptr, nullptr, 1.f, stride, ldx, K, 0, seg};
         PFN_TRY(launch_fused_hops(g, fh, s));
     } else {
@@ -293,7 +293,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             if (sq) PFN_TRY(sq->main_wait(layer + 1));
         }
         PFN_TRY(launch_gemm_nt(a, s));
-        if (K > 0 && fused_hops_fit(seg, ldx)) {
+        if (K > 0 && fused_hops_fit(seg, ldx, g.n)) {
             if (sq) PFN_TRY(sq->main_wait(layer + 1));   // gx overwrites what the outer layer's side work reads
             FusedHopsArgs fh{nullptr, nullptr, sc.G, gx, gate.y, gate.scale, stride, ldx, K, 1, seg};
             PFN_TRY(launch_fused_hops(g, fh, s));

@@ -178,7 +178,7 @@ struct FusedHopsArgs {
     size_t stride;        // floats between consecutive k buffers
     int ld, K, transpose, seg;
 };
-bool fused_hops_fit(int seg, int ld);
+bool fused_hops_fit(int seg, int ld, int n);
 int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s);
 
 // S[i] = sum_{e -> i} relu(P[i] + Q[src(e)] + sum_f a_e[f] * W1[:, 2Fi + f])
