@@ -323,3 +323,82 @@ def test_dropout_statistics_and_gradient_mask():
     loss = torch.nn.MSELoss()(m(d), d.y)
     loss.backward()
     assert all(torch.isfinite(q.grad).all() for q in m.parameters())
+
+
+# ------------------------------------------------------------------------------------ BASELINE.json full sizes
+def test_config2_full_size_vs_oracle():
+    """configs[1]: case118v2, batch 128, standard.json -- direct parity with the CPU oracle at the benchmark's size."""
+    torch.manual_seed(1234)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    data = make_batch("118v2", 128, seed=0)
+    torch.set_num_threads(8)
+    out_ref = ref(data)
+    torch.nn.MSELoss()(out_ref, data.y).backward()
+    dd = data.to(DEV)
+    out = m(dd)
+    assert_close(out, out_ref, RTOL, "out")
+    torch.nn.MSELoss()(out, dd.y).backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, 3 * RTOL, f"grad.{k}")
+
+
+def test_config3_inference_batch2048_properties():
+    """configs[2]: case118v2 inference, batch 2048 (takes the LDS-resident hop path).  Size-independent properties:
+    every graph of the batch equals the same graph run alone; the result is bitwise reproducible."""
+    torch.manual_seed(1234)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.2).to(DEV).eval()
+    big = make_batch("118v2", 2048, seed=5)
+    bd = big.to(DEV)
+    with torch.no_grad():
+        out = m(bd)
+        assert m._graphs._graph.seg_nodes == 118
+        assert torch.equal(out, m(bd))
+        assert torch.isfinite(out).all()
+        for gidx in (0, 1, 1023, 2047):
+            single = make_batch("118v2", 1, seed=5, first=gidx).to(DEV)
+            assert torch.equal(single.x.cpu(), big.x[gidx * 118:(gidx + 1) * 118])
+            assert_close(m(single), out[gidx * 118:(gidx + 1) * 118], RTOL, f"graph {gidx}")
+
+
+@pytest.mark.parametrize("hub", [0.0, 0.2])
+def test_config4_case6470_batch64_properties(hub):
+    """configs[3]: case6470rte training batch 64 (and the high-degree 'hub' variant): graphs of the batch equal the same
+    graph run alone (forward), gradients of a 2-graph batch equal the oracle's, permuting the stored edge order leaves the
+    output unchanged up to summation order."""
+    torch.manual_seed(1234)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).to(DEV).eval()
+    big = make_batch("6470rte", 64, seed=2, hub_frac=hub)
+    bd = big.to(DEV)
+    out = m(bd)
+    assert out.shape == (64 * 6470, 4) and torch.isfinite(out).all()
+    for gidx in (0, 63):
+        single = make_batch("6470rte", 1, seed=2, first=gidx, hub_frac=hub).to(DEV)
+        with torch.no_grad():
+            assert_close(m(single), out[gidx * 6470:(gidx + 1) * 6470], RTOL, f"graph {gidx}")
+    loss = torch.nn.MSELoss()(out, bd.y)
+    loss.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+    # edge-order permutation invariance (sums are re-ordered -> tolerance, not bitwise)
+    perm = torch.randperm(big.edge_index.shape[1])
+    pd = big.clone()
+    pd.edge_index, pd.edge_attr = big.edge_index[:, perm].contiguous(), big.edge_attr[perm].contiguous()
+    if bool(ref_cpu.is_directed(pd.edge_index)) == bool(ref_cpu.is_directed(big.edge_index)):
+        with torch.no_grad():
+            assert_close(m(pd.to(DEV)), out, RTOL, "edge permutation")
+    # small direct parity on the same topology: 2 graphs vs the CPU oracle, forward + gradients
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).eval()
+    ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
+    two = make_batch("6470rte", 2, seed=2, hub_frac=hub)
+    torch.set_num_threads(8)
+    o_ref = ref(two)
+    torch.nn.MSELoss()(o_ref, two.y).backward()
+    m.zero_grad()
+    td = two.to(DEV)
+    o = m(td)
+    assert_close(o, o_ref, RTOL, "two-graph out")
+    torch.nn.MSELoss()(o, td.y).backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, 3 * RTOL, f"grad.{k}")
