@@ -130,7 +130,8 @@ class MaskEmbdMultiMPN(nn.Module):
 
     def forward(self, data, return_intermediates: bool = False):
         assert data.x.shape[-1] == 4                                       # :528
-        x = self.mask_embd(data.pred_mask.float()) + data.x               # :533,:537
+        # `.float()` in the reference (:533); cast to x's dtype so the same oracle also runs in float64 as a yardstick
+        x = self.mask_embd(data.pred_mask.to(data.x.dtype)) + data.x      # :533,:537
         edge_index, edge_attr = undirect_graph(data.edge_index, data.edge_attr)   # :539
         inter = [x]
         for layer in self.layers[:-1]:                                     # :541-547
