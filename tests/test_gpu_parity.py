@@ -340,10 +340,13 @@ def _fp64_truth(ref32, data):
 
 def test_config2_full_size_vs_oracle():
     """configs[1]: case118v2, batch 128, standard.json -- direct parity with the CPU oracle at the benchmark's size.
-    Forward: 1e-5 relative, against the fp32 oracle AND against the same oracle in float64.  Parameter gradients are
-    sign-cancelling sums over 15,104 nodes / 47,616 edges accumulated in fp32 (MFMA chains of ~256 rows, then an ordered
-    sum of ~60 partials): measured 1e-5..2e-4 of the largest entry against float64 (tools/dbg_grad.py; the CPU's
-    many-accumulator BLAS sits at 1e-7..3e-5).  Bound: 5e-4 of the largest entry, or 3x the fp32 oracle's own error."""
+    Forward: 1e-5 relative, against the fp32 oracle AND against the same oracle in float64.  Parameter gradients at
+    this size are NOT smooth in the rounding error: of the 6.1M hidden pre-activations per EdgeAggregation (and 1.9M
+    layer outputs per ReLU) about one per layer lies within the fp32 forward error (~1e-6) of zero, and its ReLU mask
+    then differs from float64's -- one flipped mask moves a weight gradient by 1e-5..2e-4 of its largest entry
+    (tools/dbg_chain.py counts them: 1 flip for the HIP path, 0-1 for the fp32 oracle at the same layer; single
+    layers fed identical inputs agree with float64 to 2-8e-7, tools/dbg_layer.py).  Bound: 5e-4 of the largest entry,
+    or 3x the fp32 oracle's own error."""
     torch.manual_seed(1234)
     ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).eval()
     m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0)
