@@ -5,26 +5,31 @@
 // and per node (TAGConv.lins, mask_embd :491-495), restructured to per-NODE products.  M = nodes
 // (1e4..1e6), K and N <= a few hundred; exact fp32 on v_mfma_f32_32x32x2_f32 (there is no TF32/xf32 on gfx950).
 //
-//  pack : once per forward every weight is copied into zero-padded "LDS images": per 128-column block, roundup(K,4)
-//         rows of 132 floats (128 main columns + up to 4 "remainder" columns), for both orientations W and W^T.
-//         nn.Linear rows of 129 floats are not 16-byte aligned; the images are, which makes the weight stream DMA-able.
-//  gemm : block = 64 rows x 128 columns, 8 waves = 2 row groups (32 rows) x 4 column quarters (32 columns): one 32x32
-//         accumulator tile (16 VGPRs) per wave, the two waves of a SIMD hide each other's LDS latency.
-//         H = 129 = 4*32 + 1: the odd column never gets a tile of its own -- up to 4 trailing output columns are
-//         accumulated by VALU dot products from the fragments the wave already holds (B values are LDS broadcasts).
-//         A whole k unit of B (<= 132 x 132 floats = 68 KiB) is resident in LDS, filled by global_load_lds (16 B/lane,
-//         no VGPR round trip) into the other half of a 2 x 69 KiB ring while the current unit is multiplied; the wave's
-//         A fragment for a unit (17 float4 per lane, straight from global: rows are private to a row group) is
-//         prefetched one unit ahead.  Inside an 8-wide k chunk lane half kh = lane>>5 supplies k = 8m + 4kh + i at MFMA
-//         step i, so one 16-byte A load feeds four steps; B reads are software-pipelined one step ahead.
-//         Blocks are persistent (one 160 KiB-LDS block per CU striding over row blocks) and walk ALL output groups of a
-//         launch, so DMA and A prefetch stay pipelined across groups and row blocks.  The 32x32 accumulator layout puts
-//         32 consecutive columns of a row in one register across lanes -> the epilogue (bias, deg*b2, residual,
-//         ReLU / dropout+ReLU, gradient gate) stores whole 128-byte lines straight from registers: no LDS staging, no
-//         flush barrier, stores of one wave overlap the MFMAs of the others.
+//  pack : once per forward every weight is copied into a zero-padded "LDS image", for both orientations W and W^T:
+//         per 32-column quarter q, per group g of four k's, 32 columns x 4 k's  ->  image[q][g][col][k & 3]; then the
+//         up to 4 trailing columns (H = 129 = 4*32 + 1) as rem[g][col][k & 3].  K is padded to a multiple of 8 with
+//         zeros.  A lane's B operands for four consecutive MFMA steps are one aligned 16-byte LDS read, and a quarter's
+//         k range is one contiguous run of whole KiBs -> copied to LDS by global_load_lds, no VGPR round trip.
+//  gemm : WEIGHT-STATIONARY.  The weights of ALL terms of a launch (<= 4 x 129 x 129 floats, for a slice of 128 / 64 /
+//         32 output columns) are loaded into LDS ONCE per block (<= 160 KiB), then the block's 8 waves run free:
+//         NO barrier and no LDS traffic other than B reads in the steady state.  Every wave owns 32-row tiles of A
+//         (and CT = 1 or 2 quarters of 32 output columns), streams its A fragment straight from global into registers
+//         (17 float4 per lane and piece, refilled for the next piece right after each chunk is consumed = a prefetch
+//         distance of one whole piece), and strides over the row tiles persistently.  Inside an 8-wide k chunk lane half
+//         kh = lane>>5 supplies k = 8m + 4kh + i at MFMA step i, so one 16-byte A load and one 16-byte B read feed four
+//         steps.  Up to 4 trailing output columns never get an MFMA tile: they are VALU dot products off the fragments
+//         the wave already holds (B values are LDS broadcasts).  The 32x32 accumulator layout puts 32 consecutive columns
+//         of a row in one register across lanes; a DPP quad transpose turns that into four consecutive columns per lane,
+//         so the fused epilogue (bias, deg*b2, residual, ReLU / dropout+ReLU, gradient gate) stores 16 bytes per lane
+//         straight from registers.  The stores of one wave overlap the MFMAs of the other wave on its SIMD.
+//         A launch whose weights do not fit in LDS even for 32-column slices (hidden_dim >> 129) is split into several
+//         launches that accumulate into C (raw partial sums; the epilogue runs in the last one).
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
+#include <type_traits>
+#include <vector>
 
 #include "pfn_internal.hpp"
 
@@ -33,21 +38,19 @@ namespace pfn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int LDB = GEMM_LDB;                   // 132 floats per packed row
-constexpr int KC = GEMM_KC;                     // 132 k rows per LDS-resident unit
-constexpr int NCH = (KC + 7) / 8;               // 17 eight-wide k chunks per unit
-constexpr int SLOT_FLOATS = 69 * 256;           // 69 KiB ring slot (>= KC * LDB floats, whole 1 KiB DMA pieces)
-constexpr int ZROW_FLOATS = 4 * LDB;            // zero rows every out-of-unit lane reads instead of stale LDS
-constexpr int RPB = 64;                         // rows per block
 constexpr int NT_THREADS = 512;
+constexpr int NT_WAVES = NT_THREADS / 64;
+constexpr int NCH = 17;                         // eight-wide k chunks per piece
+constexpr int KP = 8 * NCH;                     // 136 k's per piece: H = 129 is ONE piece
+constexpr int NT_MAX_PIECES = 16;
+constexpr int NT_LDS_BYTES = 160 * 1024;
 
 // column plan of an output of `ld` (padded) columns: `remv` trailing columns (0 or 4) go to the VALU path when that
-// saves a whole MFMA quarter; `nq` 32-column MFMA quarters; `ncb` 128-column blocks.
-__host__ __device__ inline void col_plan(int ld, int& remv, int& nq, int& ncb) {
+// saves a whole MFMA quarter; `nq` 32-column MFMA quarters.
+__host__ __device__ inline void col_plan(int ld, int& remv, int& nq) {
     const int m = ld & 31;
     remv = (m != 0 && m <= 4) ? m : 0;
     nq = (ld - remv + 31) / 32;
-    ncb = nq > 0 ? (nq + 3) / 4 : 1;
 }
 
 // ------------------------------------------------------------------------------------------------ pack
@@ -55,28 +58,34 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     // the dropout stream advances once per forward, before any kernel of that forward reads it
     if (a.rng_advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.rng_advance[1] += 1;
     const PackJob jb = a.job[blockIdx.y];
-    int remv, nq, ncb;
-    col_plan(jb.ld_out, remv, nq, ncb);
-    const int K4 = (jb.K + 3) & ~3;
-    const long total = (long)ncb * K4 * LDB;
+    int remv, nq;
+    col_plan(jb.ld_out, remv, nq);
+    const int G = ((jb.K + 7) & ~7) >> 2;       // groups of four k's
+    const long main_floats = (long)nq * G * 128, total = main_floats + (long)G * 16;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        // [cb][k][LDB]: every k chunk but the last has KC rows, so the flat index is cb-major, then absolute k row
-        const int cb = (int)(i / ((long)K4 * LDB));
-        const long rem = i - (long)cb * K4 * LDB;
-        const int k = (int)(rem / LDB), n = (int)(rem - (long)k * LDB);
-        const int gn = cb * GEMM_CB + n;
+        int k, n;
+        if (i < main_floats) {
+            const int q = (int)(i / ((long)G * 128));
+            const int r = (int)(i - (long)q * G * 128);
+            k = 4 * (r >> 7) + (r & 3);
+            n = 32 * q + ((r & 127) >> 2);
+        } else {
+            const int r = (int)(i - main_floats);
+            k = 4 * (r >> 4) + (r & 3);
+            n = 32 * nq + ((r & 15) >> 2);
+        }
         float v = 0.f;
-        if (k < jb.K && gn < jb.ncols)
-            v = jb.trans ? jb.src[(size_t)(jb.wn0 + gn) * jb.ldw + jb.wk0 + k] : jb.src[(size_t)(jb.wk0 + k) * jb.ldw + jb.wn0 + gn];
+        if (k < jb.K && n < jb.ncols)
+            v = jb.trans ? jb.src[(size_t)(jb.wn0 + n) * jb.ldw + jb.wk0 + k] : jb.src[(size_t)(jb.wk0 + k) * jb.ldw + jb.wn0 + n];
         jb.dst[i] = v;
     }
 }
 
 size_t packed_floats(int K, int ld_out) {
-    int remv, nq, ncb;
-    col_plan(ld_out, remv, nq, ncb);
-    const int K4 = (K + 3) & ~3;
-    return (size_t)round_up((int64_t)ncb * K4 * LDB, 256);   // whole KiB: DMA pieces never run off the allocation
+    int remv, nq;
+    col_plan(ld_out, remv, nq);
+    const int G = ((K + 7) & ~7) >> 2;
+    return (size_t)round_up((int64_t)nq * G * 128 + (int64_t)G * 16, 256);
 }
 
 int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s) {
@@ -98,34 +107,22 @@ int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream
 }
 
 // ------------------------------------------------------------------------------------------------- NT
-__device__ __forceinline__ void dma_unit(const float* __restrict__ src, float* lds_dst, int nbytes, int wave, int lane) {
-    // 1 KiB pieces, round-robin over the 8 waves; the last piece is clamped to the tile's final 16 bytes for the
-    // lanes that would run past it (their LDS bytes land in the slot's unused tail).
-    //
-    // Inline asm on purpose: while hipcc can see an LDS-DMA in flight it waits vmcnt(0) -- not a counted vmcnt -- for
-    // every ordinary load it later needs (here: the epilogue operands), which drains the whole prefetch of the next unit in
-    // the middle of a flush (measured: 3 us per flush).  Hidden from the compiler, the DMA is waited for by hand
-    // (dma_wait) right before the barrier that hands the slot to its readers; the compiler's own counted waits stay
-    // correct because VMEM returns in issue order.
-    const int npieces = (nbytes + 1023) >> 10;
-    const char* base = reinterpret_cast<const char*>(src);
-    for (int p = wave; p < npieces; p += NT_THREADS / 64) {
-        int off = (p << 10) + lane * 16;
-        off = off < nbytes ? off : nbytes - 16;
-        const char* g = base + off;
-        const uint32_t m0v = __builtin_amdgcn_readfirstlane(
-            (uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)(lds_dst + (p << 8))));
-        uint32_t keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %2\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(g), "s"(m0v)
-            : "memory");
-    }
+// One 1 KiB LDS-DMA (64 lanes x 16 bytes; LDS destination = wave-uniform base + lane * 16).
+// Inline asm on purpose: while hipcc can see an LDS-DMA in flight it waits vmcnt(0) -- not a counted vmcnt -- for every
+// ordinary load it later needs.  Hidden from the compiler, the DMA is waited for by hand (dma_wait) before the barrier
+// that publishes the weights; the compiler's own counted waits stay correct because VMEM returns in issue order.
+__device__ __forceinline__ void dma_1k(const char* g, float* lds_dst) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)lds_dst));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(m0v)
+        : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -172,83 +169,218 @@ struct EpiCfg {
     float p_drop, keep_scale, gate_scale;
     uint32_t key0, key1;
 };
-__device__ __forceinline__ float epilogue(const EpiCfg c, float v, float aux, float cb, float crb, int row, int col) {
-    v += cb;
-    if (c.has_rowscale) v = fmaf(aux, crb, v);
-    if (c.has_resid) v += aux;
-    if (c.act == ACT_RELU) {
-        v = fmaxf(v, 0.f);
-    } else if (c.act == ACT_DROPOUT_RELU) {
-        const float u = uniform32(c.key0, c.key1, (uint32_t)row * (uint32_t)c.ncols + (uint32_t)col);
-        v = (u >= c.p_drop && v > 0.f) ? v * c.keep_scale : 0.f;
-    }
-    if (c.has_gate) v = aux > 0.f ? v * c.gate_scale : 0.f;
-    return col < c.ncols ? v : 0.f;
+struct NtPiece {
+    const float* A;      // operand rows, advanced to this piece's first k
+    const float* Bq;     // image of quarter 0 at this piece's first k group; quarter q lies q * qstride floats further
+    const float* Brem;   // trailing-column image at this piece's first k group
+    int lda;             // row stride of A (floats)
+    int kmax;            // last legal 16-byte read position inside a row, relative to A
+    int klen;            // k's of the piece: a multiple of 8, <= KP (the image is zero beyond the real K)
+    int qstride;         // floats between quarters of the image
+    int group;           // output group
+    int lds_off;         // float offset of the piece's slice image in LDS
+};
+struct NtArgs {
+    int M, ncols, ldc, npiece;
+    int tps, cshift, nq, remv;   // quarters per LDS slice; log2(column groups per block); MFMA quarters; VALU columns (padded)
+    int nrem, bias_group, ldr, ldg;
+    int kuni, pad0_;             // k length shared by every piece of the launch, or 0
+    NtPiece piece[NT_MAX_PIECES];
+    float* C[8];
+    int gflags[8];               // per group: 1 = add the C already in memory, 2 = store raw sums (no epilogue).  int, not
+                                 // char: a byte field of the kernel argument is fetched by a VECTOR load + vmcnt(0)
+    const float *bias, *rowscale, *rowbias, *resid, *gate;
+    const uint64_t* rng;
+    uint32_t rng_stream;
+    int act;
+    float p_drop, gate_scale;
+};
+
+// ---- hand-managed VMEM.  In the steady state EVERY vector-memory instruction of a wave is inline asm, invisible to
+// hipcc's waitcnt insertion, and every wait is a hand-counted `s_waitcnt vmcnt(N)` tied to the registers it protects:
+//   * the A refill writes IN PLACE ("+v"): one 68-register fragment instead of the two sets the register allocator
+//     keeps for a visible load (a spill anywhere in the flush costs a vmcnt(0) drain per reload -- measured 18 us/flush);
+//   * a compiler-inserted wait would be vmcnt(0) (it cannot see the 17 younger prefetch loads) and drain the prefetch.
+// VMEM returns in issue order and vmcnt counts loads and stores alike, so "wait until at most N younger ops are
+// outstanding" is exact when N counts the ops issued after the one needed, and merely early when N is smaller.
+__device__ __forceinline__ void vload_x4(f32x4& dst, const char* sbase, uint32_t voff) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ f32x4 vload_x4_addr(const float* p) {
+    f32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ float vload_x1_addr(const float* p) {
+    float r;
+    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
+    return r;
+}
+__device__ __forceinline__ void vstore_x4(float* p, f32x4 v) {
+    // the s_nop is the ISA's "VMEM store wider than 64 bits -> VALU overwrites its data registers" hazard (2 wait states),
+    // which hipcc fills in for its own stores but cannot see inside inline asm (without it: intermittently wrong elements)
+#if defined(PFN_NT_NOSTORE)
+    asm volatile("; no store %0 %1" : : "v"(p), "v"(v) : "memory");
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+#endif
+}
+template <int N>
+__device__ __forceinline__ void wait_a(f32x4& v) {   // the fragment chunk about to be consumed has landed
+#if defined(PFN_NT_SAFE)
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
+#else
+    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+#endif
 }
 
-__global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // 2 x SLOT_FLOATS + ZROW_FLOATS
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int rgrp = wave & 1, cq = wave >> 1;     // waves w and w+4 share a SIMD: same rows, column quarters cq, cq+2
-    const int r32 = lane & 31, kh = lane >> 5;
-    const int cb = blockIdx.y;
-    const int n0 = cb * GEMM_CB;
-    int remv, nq, ncb;
-    col_plan(a.ldc, remv, nq, ncb);
-    const bool mfma_on = 4 * cb + cq < nq;                       // this wave owns a live 32-column quarter
-    const bool rem_on = cq == 0 && cb == ncb - 1 && remv > 0;    // ... and/or the trailing VALU columns
-    const int rem_col = 32 * nq;                                 // first trailing column (global); local = rem_col - n0
-    const int nrb = (a.M + RPB - 1) / RPB;         // row blocks; this block takes bx, bx + gridDim.x, ...
-    f32x16 acc;
+// Multiply one LDS-resident piece into the accumulators and refill the A fragment for the next piece.
+//   NFAST: 17 / 16 = the piece has exactly that many chunks -> straight-line code; 0 = generic (per-chunk guard).
+//   NR   : trailing VALU columns this wave accumulates (0, 1 or 4).
+// Chunk m waits for a_cur[m] with vmcnt(16): after the load that filled it, the wave issued the 16 other refills of that
+// round (plus, around a flush, a few stores / epilogue operands -- then the wait asks for slightly younger prefetches
+// than strictly needed, never for the stores).
+template <int CT, int NR, int NFAST>
+__device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], float (&racc)[4], f32x4 (&a_cur)[NCH],
+                                            const float* S, int klen, int tps, int tsel, uint32_t kh4, int r32,
+                                            const char* nbase, uint32_t nvoff, int nkmax) {
+    constexpr bool FAST = NFAST != 0;
+    constexpr int CTE = CT > 0 ? CT : 1, NRE = NR > 0 ? NR : 1;
+    const int tile_floats = FAST ? NFAST * 8 * 32 : klen * 32;
+    const float* Bt = S + tsel * tile_floats + (kh4 * 8 + r32) * 4;
+    const float* Rt = S + tps * tile_floats + kh4 * 4;
+    // B operands are software-pipelined ONE chunk ahead by hand, and a scheduling barrier closes every chunk: left to
+    // itself the scheduler hoists the LDS reads of all 17 chunks to the top and spills.
+    f32x4 b_nxt[CTE], r_nxt[NRE];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    float racc[4] = {0.f, 0.f, 0.f, 0.f};
-    float* zrow = lds + 2 * SLOT_FLOATS;
-    for (int i = tid; i < ZROW_FLOATS; i += NT_THREADS) zrow[i] = 0.f;
-
-    // ---- unit iterator over (row block, term, k chunk).  The block is persistent: it walks its row blocks and,
-    // inside each, ALL output groups (terms arrive sorted by group), flushing the accumulators whenever the group
-    // or the row block changes -- so the weight DMA and the A prefetch stay pipelined across groups and row blocks.
-    auto nkc_of = [&](int t2) { return (((a.term[t2].K + 3) & ~3) + KC - 1) / KC; };
-    auto next_unit = [&](int rb1, int t1, int k1, int& o_rb, int& o_ti, int& o_kc) -> bool {
-        int rb2 = rb1, t2 = t1, k2 = k1 + 1;
-        if (t2 < 0 || k2 >= nkc_of(t2)) {
-            k2 = 0;
-            ++t2;
-            if (t2 >= a.nterm) {
-                t2 = 0;
-                rb2 += gridDim.x;
+    for (int ct = 0; ct < CT; ++ct) b_nxt[ct] = *reinterpret_cast<const f32x4*>(Bt + ct * tile_floats);
+#pragma unroll
+    for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + c * 4);
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const bool live = FAST ? m < NFAST : 8 * m < klen;
+        if (live) {
+            f32x4 b[CTE], r[NRE];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) b[ct] = b_nxt[ct];
+#pragma unroll
+            for (int c = 0; c < NR; ++c) r[c] = r_nxt[c];
+            if (m + 1 < NCH && (FAST ? m + 1 < NFAST : 8 * (m + 1) < klen)) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) b_nxt[ct] = *reinterpret_cast<const f32x4*>(Bt + ct * tile_floats + (m + 1) * 256);
+#pragma unroll
+                for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + (m + 1) * 32 + c * 4);
+            }
+            wait_a<NCH - 1>(a_cur[m]);
+            const f32x4 av = a_cur[m];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b[ct][i], acc[ct], 0, 0, 0);
+#pragma unroll
+                for (int c = 0; c < NR; ++c) racc[c] = fmaf(av[i], r[c][i], racc[c]);
             }
         }
-        if (rb2 >= nrb) return false;
-        o_rb = rb2;
-        o_ti = t2;
-        o_kc = k2;
-        return true;
+        // chunk m consumed: refill it IN PLACE for the next piece.  Unconditional (the wait counts rely on exactly 17
+        // refills per piece), from a clamped always-valid address: k's past the row multiply zero B rows.
+        // Address = wave-uniform 64-bit base (SGPRs) + 32-bit per-lane offset.
+        const uint32_t kk = min(kh4 + 8u * m, (uint32_t)nkmax);
+        vload_x4(a_cur[m], nbase, nvoff + 4u * kk);
+#if defined(PFN_NT_SAFE) && PFN_NT_SAFE == 2
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <int CT>
+__global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CTE = CT > 0 ? CT : 1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, kh = lane >> 5;
+    const int slice = blockIdx.y;
+    const int cg = wave & ((1 << a.cshift) - 1);       // column group of this wave inside the slice
+    const int rsub = wave >> a.cshift;                  // its row tile inside the block's step
+    const int rw = NT_WAVES >> a.cshift;                // row tiles per block step
+    const int tile0 = slice * a.tps + cg * CT;          // first 32-column quarter of this wave
+    const bool mfma_on = CT > 0 && tile0 < a.nq;
+    const bool rem_on = a.remv > 0 && slice == (int)gridDim.y - 1 && cg == 0;
+    const int rem_col = 32 * a.nq;
+    const int nrt = (a.M + 31) >> 5;
+    const int rt_step = gridDim.x * rw;
+    int rt = blockIdx.x * rw + rsub;
+
+    // A fragment addresses: uniform base of the row tile (64-bit, SGPRs) + per-lane byte offset of the lane's row inside
+    // the tile (rows past M are clamped to the last row; their results are never stored)
+    auto a_base = [&](int rt2, int p2) -> const char* {
+        return reinterpret_cast<const char*>(a.piece[p2].A + (size_t)rt2 * 32 * a.piece[p2].lda);
     };
-    auto unit_rows = [&](int t2, int k2) { const int K4 = (a.term[t2].K + 3) & ~3; return min(KC, K4 - k2 * KC); };
-    // weight DMA of a unit, and the A fragment loads of a unit (one 16-byte load per 8-wide k chunk).  A loads are
-    // unconditional from clamped, always valid addresses (a `cond ? load : 0` select would make the compiler wait for the
-    // load on the spot): rows past M are clamped to the last row (their results are never stored), k past the row is
-    // clamped into the row (those lanes multiply zero B rows).
-    auto issue_dma = [&](int t2, int k2, float* slot) {
-        const GemmTerm& tm = a.term[t2];
-        const int K4 = (tm.K + 3) & ~3;
-        const int rows = min(KC, K4 - k2 * KC);
-        const float* tile = tm.Bp + ((size_t)cb * K4 + (size_t)k2 * KC) * LDB;
-        if (!(a.dbg & 1)) dma_unit(tile, slot, rows * LDB * 4, wave, lane);
+    auto a_voff = [&](int rt2, int p2) -> uint32_t {
+        const int lrow = min(r32, a.M - 1 - rt2 * 32);
+        return (uint32_t)(lrow * a.piece[p2].lda) * 4u;
     };
-    auto a_row_ptr = [&](int rb2, int t2) -> const float* {
-        int arow = rb2 * RPB + rgrp * 32 + r32;
-        arow = arow < a.M ? arow : a.M - 1;
-        return a.term[t2].A + (size_t)arow * a.term[t2].lda;
-    };
-    auto load_a = [&](const float* Arow, int kmax, int k0, int m) -> f32x4 {
-        int kk = k0 + 8 * m + 4 * kh;
-        kk = kk < kmax ? kk : kmax;
-        return *reinterpret_cast<const f32x4*>(Arow + kk);
-    };
+
+    // ---- first A fragment (in flight while the weights are copied)
+    f32x4 a_cur[NCH];
+    {
+        const int rt0 = rt < nrt ? rt : 0;
+        const char* b0 = a_base(rt0, 0);
+        const uint32_t v0 = a_voff(rt0, 0);
+        const int kmax0 = a.piece[0].kmax;
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            const uint32_t kk = min((uint32_t)(8 * m + 4 * kh), (uint32_t)kmax0);
+            a_cur[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vload_x4(a_cur[m], b0, v0 + 4u * kk);
+        }
+    }
+    // ---- weights of every piece -> LDS, once: 1 KiB DMA pieces dealt round-robin to the 8 waves
+    {
+        int dealt = 0;
+        for (int p = 0; p < a.npiece; ++p) {
+            const int klen = a.piece[p].klen, kib = klen >> 3;
+            for (int j = 0; j < a.tps; ++j) {
+                const int q = slice * a.tps + j;
+                if (q < a.nq) {
+                    const char* src = reinterpret_cast<const char*>(a.piece[p].Bq + (size_t)q * a.piece[p].qstride) + lane * 16;
+                    float* dst = lds + a.piece[p].lds_off + j * klen * 32;
+                    for (int c = (wave - dealt) & 7; c < kib; c += NT_WAVES) dma_1k(src + (c << 10), dst + (c << 8));
+                    dealt += kib;
+                }
+            }
+            if (tid < klen)
+                *reinterpret_cast<float4*>(lds + a.piece[p].lds_off + a.tps * klen * 32 + tid * 4) =
+                    *reinterpret_cast<const float4*>(a.piece[p].Brem + tid * 4);
+        }
+    }
+    // ---- per-column epilogue operands: a wave's columns never change, so bias / rowbias are loaded once
+    float cbias[CTE][4], crb[CTE][4], rcb[4], rcrb[4];
+    {
+        const int clast = a.ncols - 1;
+#pragma unroll
+        for (int ct = 0; ct < CTE; ++ct) {
+            const int col0 = 32 * (tile0 + ct) + (r32 & ~3);   // after the quad transpose: 4 columns per lane
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int cc = min(col0 + e, clast);
+                const float bv = a.bias ? a.bias[cc] : 0.f, rv = a.rowscale ? a.rowbias[cc] : 0.f;
+                cbias[ct][e] = col0 + e <= clast ? bv : 0.f;
+                crb[ct][e] = col0 + e <= clast ? rv : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int cc = min(rem_col + e, clast);
+            const float bv = a.bias ? a.bias[cc] : 0.f, rv = a.rowscale ? a.rowbias[cc] : 0.f;
+            rcb[e] = rem_col + e <= clast ? bv : 0.f;
+            rcrb[e] = rem_col + e <= clast ? rv : 0.f;
+        }
+    }
+    dma_wait();
+    __syncthreads();   // the only barrier: from here on the waves run free
+    if (rt >= nrt || !(mfma_on || rem_on)) return;
 
     EpiCfg ep;
     ep.ncols = a.ncols;
@@ -271,189 +403,182 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
         ep.keep_scale = 1.0f / (1.0f - a.p_drop);
     }
 
-    f32x4 a_cur[NCH];   // ONE register set: chunk m of the NEXT unit is loaded into a_cur[m] right after chunk m is consumed
-    int cur_rb = blockIdx.x, cur_t = -1, cur_k = 0;
-    bool have = next_unit(blockIdx.x, -1, 0, cur_rb, cur_t, cur_k);
-    if (have) {
-        issue_dma(cur_t, cur_k, lds);
-        const float* Ar = a_row_ptr(cur_rb, cur_t);
+    f32x16 acc[CTE];
 #pragma unroll
-        for (int m = 0; m < NCH; ++m) a_cur[m] = load_a(Ar, a.term[cur_t].lda - 4, cur_k * KC, m);
-    }
-    dma_wait();
-    __syncthreads();   // publishes the slot (every wave has waited for its own DMA pieces)
-    int slot = 0;
-    int unit_no = 0;
-#define PFN_STAMP(i) do { if (a.timing && blockIdx.x == 0 && tid == 0 && unit_no < 64) a.timing[unit_no * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-    while (have) {
-        PFN_STAMP(0);
-        int nrb_ = 0, nt_ = 0, nk_ = 0;
-        const bool more = next_unit(cur_rb, cur_t, cur_k, nrb_, nt_, nk_);
-        const float* nxA = nullptr;
-        int nx_kmax = 0, nx_k0 = 0;
-        const float* nx_tile = nullptr;
-        float* nx_slot = lds + (slot ^ 1) * SLOT_FLOATS;
-        int nx_bytes = 0;
-        bool dma_done = false;
-        if (more) {
-            const GemmTerm& tn = a.term[nt_];
-            const int K4n = (tn.K + 3) & ~3;
-            nx_bytes = min(KC, K4n - nk_ * KC) * LDB * 4;
-            nx_tile = tn.Bp + ((size_t)cb * K4n + (size_t)nk_ * KC) * LDB;
-            nxA = a_row_ptr(nrb_, nt_);
-            nx_kmax = a.term[nt_].lda - 4;
-            nx_k0 = nk_ * KC;
+    for (int ct = 0; ct < CTE; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
+    float racc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int nr = rem_on ? (a.nrem > 1 ? 4 : 1) : 0;   // trailing columns this wave owns (the generic path always computes 4)
+    const float* extra = a.gate ? a.gate : a.resid;     // at most one of rowscale / gate / resid per GEMM
+    const int ldx = a.gate ? a.ldg : a.ldr;
+    uint32_t kh4 = 4u * kh;
+    // The round loop is instantiated ONCE per multiply variant and the variant is chosen outside it (all pieces of a
+    // launch normally share one k length): with several variants merging inside the loop, the fragment's loop-carried
+    // registers are copied to working registers and back every round (a second 68-register set, spills in the flush).
+    auto rounds = [&](auto nfast_c, auto nr_c) {
+    constexpr int NFAST = decltype(nfast_c)::value, NR = decltype(nr_c)::value;
+    int p = 0;
+    while (true) {
+        asm volatile("" : "+v"(kh4));   // opaque per round: keeps the 17 refill offsets from being hoisted into 17 VGPRs
+        // ---- the piece after this one: same row tile, next piece -- or the wave's next row tile, first piece
+        int np = p + 1, nrt_ = rt;
+        if (np == a.npiece) {
+            np = 0;
+            nrt_ = rt + rt_step;
         }
-        const bool pf = more && !(a.dbg & 8);
-        // ---- epilogue operands of the flush that follows this unit (if it ends a group / row block): loaded NOW, so
-        // they are older than the A refills issued inside the multiply loop and the flush never waits on the prefetch
-        const int group = a.term[cur_t].group;
-        const bool flush_after = !more || a.term[nt_].group != group || nrb_ != cur_rb;
-        const int rbase = cur_rb * RPB + rgrp * 32;
-        const int col0 = n0 + 32 * cq + (r32 & ~3);                 // after the quad transpose: 4 columns per lane
-        const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
-        const float* extra = a.gate ? a.gate : a.resid;           // at most one of rowscale / gate / resid per GEMM
-        const int ldx = a.gate ? a.ldg : a.ldr;
-        float4 aux[4], raux;
-        float cbias[4], crb[4], rcb[4], rcrb[4];
+        const bool more = nrt_ < nrt;
+        const int group = a.piece[p].group;
+        const bool flush_after = !more || np == 0 || a.piece[np].group != group;
+        const int pi = more ? np : p;                        // no next piece: refill from the current one (harmless)
+        const char* nbase = a_base(more ? nrt_ : rt, pi);
+        const uint32_t nvoff = a_voff(more ? nrt_ : rt, pi);
+        const int nkmax = a.piece[pi].kmax;
+        // ---- per-row epilogue operands of the flush that follows this piece: requested NOW (hidden loads), so they are
+        // older than the 17 refills issued inside the multiply; the flush waits for them with vmcnt(17)
+        const int rbase = rt * 32;
+        f32x4 aux[CTE][4], raux;
+#pragma unroll
+        for (int ct = 0; ct < CTE; ++ct)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) aux[ct][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        raux = f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool has_aux = flush_after && (a.rowscale || extra);
+        if (has_aux) {
+            if (a.rowscale) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
+                    aux[0][g][0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
+                }
+                if (rem_on) {
+                    const int row = rbase + r32;
+                    raux[0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
+                }
+            } else {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int col0 = 32 * (tile0 + ct) + (r32 & ~3);
+                    const int colc = col0 < a.ldc ? col0 : 0;       // lanes past the row read column 0 (never stored)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
+                        aux[ct][g] = vload_x4_addr(extra + (size_t)(row < a.M ? row : a.M - 1) * ldx + colc);
+                    }
+                }
+                if (rem_on) {
+                    const int row = rbase + r32;
+                    raux = vload_x4_addr(extra + (size_t)(row < a.M ? row : a.M - 1) * ldx + rem_col);
+                }
+            }
+        }
+        // ---- multiply
+        {
+            const float* S = lds + a.piece[p].lds_off;
+            const int klen = a.piece[p].klen, tsel = cg * CT;
+            nt_multiply<CT, NR, NFAST>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax);
+        }
         if (flush_after) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool real = col0 + e < a.ncols, rreal = rem_col + e < a.ncols;
-                cbias[e] = (mfma_on && real && use_bias) ? a.bias[col0 + e] : 0.f;
-                crb[e] = (mfma_on && real && a.rowscale) ? a.rowbias[col0 + e] : 0.f;
-                rcb[e] = (rem_on && rreal && use_bias) ? a.bias[rem_col + e] : 0.f;
-                rcrb[e] = (rem_on && rreal && a.rowscale) ? a.rowbias[rem_col + e] : 0.f;
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
-                const int rowc = row < a.M ? row : a.M - 1;
-                aux[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (mfma_on && col0 < a.ldc) {
-                    if (a.rowscale) {
-                        const float rs = a.rowscale[rowc];
-                        aux[g] = make_float4(rs, rs, rs, rs);
-                    } else if (extra) {
-                        aux[g] = *reinterpret_cast<const float4*>(extra + (size_t)rowc * ldx + col0);
-                    }
-                }
-            }
-            raux = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (rem_on) {
-                const int row = rbase + r32;
-                const int rowc = row < a.M ? row : a.M - 1;
-                if (a.rowscale) {
-                    const float rs = a.rowscale[rowc];
-                    raux = make_float4(rs, rs, rs, rs);
-                } else if (extra) {
-                    raux = *reinterpret_cast<const float4*>(extra + (size_t)rowc * ldx + rem_col);
-                }
-            }
-        }
-        // small-K units (the slow generic path below) issue the whole DMA up front; the fast path trickles it
-        if (more && !(a.dbg & 1)) {
-            dma_unit(nx_tile, nx_slot, nx_bytes, wave, lane);
-            dma_done = true;
-        }
-        PFN_STAMP(1);
-        // ---- multiply the resident unit
-        const int rows = unit_rows(cur_t, cur_k);
-        const int kvalid = a.term[cur_t].K - cur_k * KC;   // real (unpadded) k's left in this term
-        const float* S = lds + slot * SLOT_FLOATS;
-        if (!(a.dbg & 2)) {
-            const int nreal_rem = a.ncols - rem_col;           // real trailing columns (1 for H = 129); the rest is padding
-            // chunks whose 8 k's are all real and inside the unit run as straight-line code (no per-step branches, no
-            // zero-row redirect): the compiler can then pipeline the LDS reads of later chunks under earlier MFMAs
-            const int nfull = min(rows, kvalid) >> 3;
-            constexpr int FAST = 16;                           // H = 129: 16 full chunks + one ragged chunk
-            int m_done = 0;
-            if (nfull >= FAST) {
-                const float* Bj = S + (4 * kh) * LDB + 32 * cq + r32;
-                const float* Rj = S + (4 * kh) * LDB + (rem_col - n0);
-#pragma unroll
-                for (int m = 0; m < FAST; ++m) {
-                    if (mfma_on) {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float bv = (a.dbg & 16) ? 1.0f : Bj[(8 * m + i) * LDB];
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[m][i], bv, acc, 0, 0, 0);
-                        }
-                    }
-                    if (rem_on && !(a.dbg & 64)) {
-                        if (nreal_rem <= 1) {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) racc[0] = fmaf(a_cur[m][i], Rj[(8 * m + i) * LDB], racc[0]);
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {
-                                const float4 rb4 = *reinterpret_cast<const float4*>(Rj + (8 * m + i) * LDB);
-                                racc[0] = fmaf(a_cur[m][i], rb4.x, racc[0]);
-                                racc[1] = fmaf(a_cur[m][i], rb4.y, racc[1]);
-                                racc[2] = fmaf(a_cur[m][i], rb4.z, racc[2]);
-                                racc[3] = fmaf(a_cur[m][i], rb4.w, racc[3]);
-                            }
-                        }
-                    }
-                    if (pf && !(a.dbg & 32)) a_cur[m] = load_a(nxA, nx_kmax, nx_k0, m);   // chunk m consumed: refill it for the next unit
-                }
-                m_done = FAST;
-            }
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) {
-                const int kleft = kvalid - 8 * m;              // block-uniform: real k's from this chunk on
-                if (m >= m_done && kleft > 0) {
-                    // a lane half whose 4 k rows lie beyond the unit reads zeros (rows % 4 == 0: all four or none)
-                    const bool lane_in = 8 * m + 4 * kh < rows;
-                    const float av[4] = {a_cur[m][0], a_cur[m][1], a_cur[m][2], a_cur[m][3]};
-                    if (mfma_on) {
-                        const float* Bj = lane_in ? S + (8 * m + 4 * kh) * LDB + 32 * cq + r32 : zrow + r32;
-                        float b[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) b[i] = Bj[i * LDB];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            if (i < kleft) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b[i], acc, 0, 0, 0);
-                    }
-                    if (rem_on) {   // trailing columns: lane-local partial dot products, B values are LDS broadcasts
-                        const float* Rj = lane_in ? S + (8 * m + 4 * kh) * LDB + (rem_col - n0) : zrow;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float4 rb4 = *reinterpret_cast<const float4*>(Rj + i * LDB);
-                            racc[0] = fmaf(av[i], rb4.x, racc[0]);
-                            racc[1] = fmaf(av[i], rb4.y, racc[1]);
-                            racc[2] = fmaf(av[i], rb4.z, racc[2]);
-                            racc[3] = fmaf(av[i], rb4.w, racc[3]);
-                        }
-                    }
-                }
-                if (m >= m_done && pf) a_cur[m] = load_a(nxA, nx_kmax, nx_k0, m);
-            }
-        } else if (pf) {
-#pragma unroll
-            for (int m = 0; m < NCH; ++m) a_cur[m] = load_a(nxA, nx_kmax, nx_k0, m);
-        }
-        if (more && !dma_done && !(a.dbg & 1)) dma_unit(nx_tile, nx_slot, nx_bytes, wave, lane);
-        PFN_STAMP(2);
-        // The next unit's DMA pieces (and A refills) have had the whole multiply to land: wait for them HERE, before the
-        // flush issues its stores -- vmcnt counts stores too, so a vmcnt(0) in front of the barrier would also wait for
-        // the HBM write acknowledgements of the tile just flushed (measured: ~3 us per flush).
-        dma_wait();
-        if (flush_after && !(a.dbg & 4)) {
             // ---- flush straight from registers: acc[q] of lane (r32, kh) is D[row (q&3) + 8 (q>>2) + 4 kh][col r32];
             // after the quad transpose lane (u = r32 >> 2, j = r32 & 3) holds, for register group g, row
             // rbase + j + 8 g + 4 kh and the four columns col0 .. col0 + 3
+            // The last MFMA was issued a few instructions ago and its 16 passes are still writing the accumulators; hipcc's
+            // hazard recognizer does not look past the inline asm that closes the multiply, so the >= 18 wait states an
+            // XDL write needs before a VALU read are spent by hand (without them: intermittently stale accumulator rows).
+            if (CT > 0) {
+                if (CT == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[CTE - 1]));
+                else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]));
+            }
             float* C = a.C[group];
-            if (mfma_on && col0 < a.ldc) {
+            const int gf = a.gflags[group];
+            const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
+            if (has_aux) {   // the operands requested before the multiply: exactly the 17 refills are younger
+                if (CT == 2)
+                    asm volatile("s_waitcnt vmcnt(17)" : "+v"(aux[0][0]), "+v"(aux[0][1]), "+v"(aux[0][2]), "+v"(aux[0][3]),
+                                 "+v"(aux[CTE - 1][0]), "+v"(aux[CTE - 1][1]), "+v"(aux[CTE - 1][2]), "+v"(aux[CTE - 1][3]), "+v"(raux));
+                else
+                    asm volatile("s_waitcnt vmcnt(17)" : "+v"(aux[0][0]), "+v"(aux[0][1]), "+v"(aux[0][2]), "+v"(aux[0][3]), "+v"(raux));
+                if (a.rowscale) {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float v[4] = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-                    quad_transpose(v, lane);
-                    const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
-                    const float ax[4] = {aux[g].x, aux[g].y, aux[g].z, aux[g].w};
+                    for (int g = 0; g < 4; ++g) {
+                        const float rs = aux[0][g][0];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = epilogue(ep, v[e], ax[e], cbias[e], crb[e], row, col0 + e);
-                    if (row < a.M) *reinterpret_cast<float4*>(C + (size_t)row * a.ldc + col0) = make_float4(v[0], v[1], v[2], v[3]);
+                        for (int ct = 0; ct < CTE; ++ct) aux[ct][g] = f32x4{rs, rs, rs, rs};
+                    }
+                    raux = f32x4{raux[0], raux[0], raux[0], raux[0]};
+                }
+            }
+            // Every epilogue stage is ONE kernel-uniform branch around straight-line code for all 16 values of a tile (a
+            // per-element `switch` cost 7 us per flush).  Columns past ncols need no masking: packed weights, bias and
+            // rowbias are zero there and the pad columns of resid / gate are zero by the layout invariant, so every stage
+            // maps 0 to 0.
+            const bool raw = gf & 2;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col0 = 32 * (tile0 + ct) + (r32 & ~3);
+                if (tile0 + ct < a.nq && col0 < a.ldc) {
+                    float v[4][4];
+                    float* dst[4];
+                    int row[4];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float t[4] = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
+                        quad_transpose(t, lane);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = t[e];
+                        row[g] = rbase + (r32 & 3) + 8 * g + 4 * kh;
+                        dst[g] = C + (size_t)(row[g] < a.M ? row[g] : a.M - 1) * a.ldc + col0;
+                    }
+                    if (gf & 1) {   // accumulating launch (weights larger than LDS): rare, visible loads
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 old = *reinterpret_cast<const float4*>(dst[g]);
+                            v[g][0] += old.x; v[g][1] += old.y; v[g][2] += old.z; v[g][3] += old.w;
+                        }
+                    }
+                    if (!raw) {
+                        if (use_bias) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[g][e] += cbias[ct][e];
+                        }
+                        if (ep.has_rowscale) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[g][e] = fmaf(aux[ct][g][e], crb[ct][e], v[g][e]);
+                        }
+                        if (ep.has_resid) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[g][e] += aux[ct][g][e];
+                        }
+                        if (ep.act == ACT_RELU) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+                        } else if (ep.act == ACT_DROPOUT_RELU) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    const float u = uniform32(ep.key0, ep.key1, (uint32_t)row[g] * (uint32_t)ep.ncols + (uint32_t)(col0 + e));
+                                    v[g][e] = (u >= ep.p_drop && v[g][e] > 0.f) ? v[g][e] * ep.keep_scale : 0.f;
+                                }
+                        }
+                        if (ep.has_gate) {
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[g][e] = aux[ct][g][e] > 0.f ? v[g][e] * ep.gate_scale : 0.f;
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        if (row[g] < a.M) vstore_x4(dst[g], f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
                 }
             }
             if (rem_on) {
@@ -462,67 +587,115 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const GemmArgs a
                 for (int e = 0; e < 4; ++e) v[e] = racc[e] + __shfl_xor(racc[e], 32);   // the two k halves
                 const int row = rbase + r32;
                 if (kh == 0 && row < a.M) {
-                    const float ax[4] = {raux.x, raux.y, raux.z, raux.w};
+                    float* dst = C + (size_t)row * a.ldc + rem_col;
+                    if (gf & 1) {
+                        const float4 old = *reinterpret_cast<const float4*>(dst);
+                        v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
+                    }
+                    if (!raw) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = epilogue(ep, v[e], ax[e], rcb[e], rcrb[e], row, rem_col + e);
-                    *reinterpret_cast<float4*>(C + (size_t)row * a.ldc + rem_col) = make_float4(v[0], v[1], v[2], v[3]);
+                        for (int e = 0; e < 4; ++e) {
+                            float x = v[e] + (use_bias ? rcb[e] : 0.f);
+                            if (ep.has_rowscale) x = fmaf(raux[e], rcrb[e], x);
+                            if (ep.has_resid) x += raux[e];
+                            if (ep.act == ACT_RELU) {
+                                x = fmaxf(x, 0.f);
+                            } else if (ep.act == ACT_DROPOUT_RELU) {
+                                const float u = uniform32(ep.key0, ep.key1, (uint32_t)row * (uint32_t)ep.ncols + (uint32_t)(rem_col + e));
+                                x = (u >= ep.p_drop && x > 0.f) ? x * ep.keep_scale : 0.f;
+                            }
+                            if (ep.has_gate) x = raux[e] > 0.f ? x * ep.gate_scale : 0.f;
+                            v[e] = rem_col + e < ep.ncols ? x : 0.f;
+                        }
+                    }
+                    vstore_x4(dst, f32x4{v[0], v[1], v[2], v[3]});
                 }
             }
-        }
-        if (flush_after) {
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+            for (int ct = 0; ct < CTE; ++ct)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
             racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
         }
-        PFN_STAMP(3);
-        // raw barrier (LDS reads done, no vmcnt drain: the flush's stores stay in flight across it); every wave waited for
-        // its own DMA pieces above, so after the barrier the whole next unit is readable and this slot may be refilled
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        PFN_STAMP(4);
-        ++unit_no;
-        if (more) {
-            cur_rb = nrb_; cur_t = nt_; cur_k = nk_;
-            slot ^= 1;
-        }
-        have = more;
+        if (!more) break;
+        p = np;
+        rt = nrt_;
     }
+    };
+    using std::integral_constant;
+    if (a.kuni == KP && nr == 0) rounds(integral_constant<int, NCH>{}, integral_constant<int, 0>{});
+    else if (a.kuni == KP && nr == 1) rounds(integral_constant<int, NCH>{}, integral_constant<int, 1>{});
+    else if (a.kuni == KP - 8 && nr == 0) rounds(integral_constant<int, NCH - 1>{}, integral_constant<int, 0>{});
+    else if constexpr (CT < 2) rounds(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+    // CT == 2 exists only for the straight-line variants (the launcher never pairs it with the generic one: two tiles plus
+    // four trailing columns plus per-chunk guards do not fit the register file without spills)
 }
 
-static bool g_nt_attr_set = false;
-
-int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
-    if (a_in.M == 0) return PFN_OK;
-    GemmArgs a = a_in;
-    int remv, nq;
-    col_plan(a.ldc, remv, nq, a.ncb);
-    double flops = 0.0, bytes = (double)a.ngroup * a.M * a.ncols * 4.0;
-    for (int t = 0; t < a.nterm; ++t) {
-        if (a.term[t].lda % 4 != 0 || a.term[t].lda < ((a.term[t].K + 3) & ~3)) {
-            set_error("gemm_nt: operand row stride %d must be a multiple of 4 and >= roundup(K=%d, 4)", a.term[t].lda,
-                      a.term[t].K);
-            return PFN_EINVAL;
-        }
-        if (a.term[t].Bp == nullptr) {
-            set_error("gemm_nt: term %d has no packed weight", t);
-            return PFN_EINVAL;
-        }
-        if (t > 0 && a.term[t].group < a.term[t - 1].group) {
-            set_error("gemm_nt: terms must be sorted by output group");
-            return PFN_EINVAL;
-        }
-        flops += 2.0 * a.M * a.term[t].K * a.ncols;
-        bytes += (double)a.M * a.term[t].K * 4.0;
+template <int CT>
+static int launch_variant(const NtArgs& k, dim3 grid, size_t lds_bytes, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<CT>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
+        attr_set = true;
     }
+    gemm_nt_kernel<CT><<<grid, NT_THREADS, lds_bytes, s>>>(k);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
+    if (a.M == 0) return PFN_OK;
+    int remv, nq;
+    col_plan(a.ldc, remv, nq);
     if (a.ldc % 4) {
         set_error("gemm_nt: output row stride %d must be a multiple of 4", a.ldc);
         return PFN_EINVAL;
     }
-    const size_t lds_bytes = (2 * SLOT_FLOATS + ZROW_FLOATS) * sizeof(float);
-    if (!g_nt_attr_set) {
-        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        g_nt_attr_set = true;
+    double flops = 0.0, bytes = (double)a.ngroup * a.M * a.ncols * 4.0;
+    std::vector<NtPiece> pieces;
+    for (int t = 0; t < a.nterm; ++t) {
+        const GemmTerm& tm = a.term[t];
+        if (tm.lda % 4 != 0 || tm.lda < ((tm.K + 3) & ~3)) {
+            set_error("gemm_nt: operand row stride %d must be a multiple of 4 and >= roundup(K=%d, 4)", tm.lda, tm.K);
+            return PFN_EINVAL;
+        }
+        if (tm.Bp == nullptr) {
+            set_error("gemm_nt: term %d has no packed weight", t);
+            return PFN_EINVAL;
+        }
+        if (t > 0 && tm.group < a.term[t - 1].group) {
+            set_error("gemm_nt: terms must be sorted by output group");
+            return PFN_EINVAL;
+        }
+        flops += 2.0 * a.M * tm.K * a.ncols;
+        bytes += (double)a.M * tm.K * 4.0;
+        const int K8 = (tm.K + 7) & ~7, qstride = (K8 >> 2) * 128;
+        for (int k0 = 0; k0 < K8; k0 += KP) {
+            NtPiece pc;
+            pc.A = tm.A + k0;
+            pc.Bq = tm.Bp + (size_t)(k0 >> 2) * 128;
+            pc.Brem = tm.Bp + (size_t)nq * qstride + (size_t)(k0 >> 2) * 16;
+            pc.lda = tm.lda;
+            pc.kmax = tm.lda - 4 - k0;
+            pc.klen = std::min(KP, K8 - k0);
+            pc.qstride = qstride;
+            pc.group = tm.group;
+            pc.lds_off = 0;
+            pieces.push_back(pc);
+        }
+    }
+    // ---- how many 32-column quarters of every piece fit in LDS at once (tps), and where the launch has to be cut
+    auto piece_bytes = [](const NtPiece& pc, int tps) { return (size_t)pc.klen * (32 * tps + 4) * sizeof(float); };
+    int tps = 0;
+    if (nq > 0) {
+        const int start = nq >= 3 ? 4 : nq;
+        for (tps = start; tps >= 1; tps >>= 1) {
+            size_t tot = 0;
+            for (const NtPiece& pc : pieces) tot += piece_bytes(pc, tps);
+            if (tot <= (size_t)NT_LDS_BYTES && pieces.size() <= (size_t)NT_MAX_PIECES) break;
+        }
+        if (tps < 1) tps = std::min(start, 2);   // does not fit whole: several accumulating launches
     }
     static int ncu = 0;
     if (ncu == 0) {
@@ -531,14 +704,71 @@ int launch_gemm_nt(const GemmArgs& a_in, hipStream_t s) {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         if (ncu <= 0) ncu = 256;
     }
-    static const int dbg = getenv("PFN_GEMM_DBG") ? atoi(getenv("PFN_GEMM_DBG")) : 0;   // timing dissection only
-    a.dbg = dbg;
-    // one 160 KiB-LDS block per CU; persistent blocks stride over the 64-row blocks
-    const int nrb = (a.M + RPB - 1) / RPB;
-    dim3 grid(std::min(nrb, std::max(1, ncu / a.ncb)), a.ncb);
+    const int nrt = (a.M + 31) / 32;
+    const int nslices = tps > 0 ? (nq + tps - 1) / tps : 1;
+    // wave tile: two quarters per wave halve the A re-reads, but only when there is enough work to fill the chip twice over
+    int CT = tps == 0 ? 0 : 1;
+    if (pieces.empty()) {
+        set_error("gemm_nt: no terms");
+        return PFN_EINVAL;
+    }
+    bool fast = true;
+    for (const NtPiece& pc : pieces) fast &= pc.klen == pieces[0].klen;
+    const int nrem = std::max(0, std::min(remv, a.ncols - 32 * nq));
+    fast = fast && ((pieces[0].klen == KP && nrem <= 1) || (pieces[0].klen == KP - 8 && remv == 0));
+    if (fast && tps >= 2 && (long)nrt * nslices * (tps / 2) >= 2L * ncu * NT_WAVES) CT = 2;
+    static const int force_ct = getenv("PFN_NT_CT") ? atoi(getenv("PFN_NT_CT")) : 0;   // tuning aid: 1 or 2
+    if (force_ct > 0 && CT > 0) CT = std::min(force_ct, (fast && tps >= 2) ? 2 : 1);
+    int cshift = 0;
+    while (CT > 0 && (CT << cshift) < tps) ++cshift;
+    const int rw = NT_WAVES >> cshift;
+    dim3 grid(std::min((nrt + rw - 1) / rw, std::max(8, ncu / nslices / 8 * 8)), nslices);
+
+    NtArgs k;
+    memset(&k, 0, sizeof(k));
+    k.M = a.M; k.ncols = a.ncols; k.ldc = a.ldc;
+    k.tps = tps; k.cshift = cshift; k.nq = nq; k.remv = remv;
+    k.nrem = nrem;
+    k.bias_group = a.bias_group; k.ldr = a.ldr; k.ldg = a.ldg;
+    for (int g = 0; g < 8; ++g) k.C[g] = a.C[g];
+    k.bias = a.bias; k.rowscale = a.rowscale; k.rowbias = a.rowbias; k.resid = a.resid; k.gate = a.gate;
+    k.rng = a.rng; k.rng_stream = a.rng_stream; k.act = a.act; k.p_drop = a.p_drop; k.gate_scale = a.gate_scale;
+
+    bool seen[8] = {false, false, false, false, false, false, false, false};
     ProfScope ps("gemm_nt", bytes, flops, s);
-    gemm_nt_kernel<<<grid, NT_THREADS, lds_bytes, s>>>(a);
-    PFN_CHECK_LAUNCH();
+    for (size_t i0 = 0; i0 < pieces.size();) {
+        size_t i1 = i0, used = 0;
+        while (i1 < pieces.size() && i1 - i0 < (size_t)NT_MAX_PIECES && used + piece_bytes(pieces[i1], tps) <= (size_t)NT_LDS_BYTES) {
+            pieces[i1].lds_off = (int)(used / sizeof(float));
+            used += piece_bytes(pieces[i1], tps);
+            ++i1;
+        }
+        if (i1 == i0) {
+            set_error("gemm_nt: a %d-row weight piece does not fit in LDS", pieces[i0].klen);
+            return PFN_EINVAL;
+        }
+        k.npiece = (int)(i1 - i0);
+        k.kuni = pieces[i0].klen;
+        for (size_t i = i0; i < i1; ++i)
+            if (pieces[i].klen != k.kuni) k.kuni = 0;
+        bool here[8] = {false, false, false, false, false, false, false, false};
+        for (size_t i = i0; i < i1; ++i) {
+            k.piece[i - i0] = pieces[i];
+            here[pieces[i].group] = true;
+        }
+        for (int g = 0; g < 8; ++g) {
+            bool later = false;
+            for (size_t i = i1; i < pieces.size(); ++i) later |= pieces[i].group == g;
+            k.gflags[g] = (seen[g] ? 1 : 0) | (later ? 2 : 0);
+            seen[g] |= here[g];
+        }
+        int rc;
+        if (CT == 0) rc = launch_variant<0>(k, grid, used, s);
+        else if (CT == 1) rc = launch_variant<1>(k, grid, used, s);
+        else rc = launch_variant<2>(k, grid, used, s);
+        if (rc != PFN_OK) return rc;
+        i0 = i1;
+    }
     return PFN_OK;
 }
 

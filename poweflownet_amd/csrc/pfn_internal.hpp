@@ -80,13 +80,10 @@ struct GraphView {
 GraphView graph_view(void* ws, int64_t n, int64_t e_stored);
 
 // ------------------------------------------------------------------------------------------- GEMMs
-constexpr int GEMM_CB = 128;    // main output columns per column block (4 MFMA quarters of 32)
-constexpr int GEMM_LDB = 132;   // packed weight row stride in floats: 128 main + 4 trailing (VALU) columns
-constexpr int GEMM_KC = 132;    // k rows per LDS-resident unit (covers H = 129 in one unit)
-
-// Weights are re-laid out once per forward into zero-padded LDS images (gemm.hip: pack):
-// packed[cb][k][GEMM_LDB] with B[k][n] = trans ? W[(wn0 + n) * ldw + wk0 + k] : W[(wk0 + k) * ldw + wn0 + n],
-// k < K4 = roundup(K, 4), n < 132 per 128-column block cb, zero outside [0,K) x [0,ncols).
+// Weights are re-laid out once per forward into zero-padded LDS images (gemm_nt.hip: pack), K8 = roundup(K, 8):
+//   image[q][g][c][i] = B[4g + i][32q + c]   for the nq 32-column MFMA quarters of an output of ld_out columns, then
+//   rem[g][c][i]      = B[4g + i][32nq + c]  for the up to 4 trailing (VALU) columns,
+// with B[k][n] = trans ? W[(wn0 + n) * ldw + wk0 + k] : W[(wk0 + k) * ldw + wn0 + n], zero outside [0,K) x [0,ncols).
 struct PackJob {
     const float* src;
     float* dst;
@@ -110,7 +107,7 @@ struct GemmTerm {
 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_DROPOUT_RELU = 2 };
 struct GemmArgs {
-    int M, ncols, ldc, nterm, ngroup, ncb;
+    int M, ncols, ldc, nterm, ngroup, pad_;
     float* C[8];            // per group
     GemmTerm term[8];
     const float* bias;      // [ncols] or null
@@ -126,8 +123,6 @@ struct GemmArgs {
     const float* gate;      // [M x ldg] or null : out *= gate > 0 ? gate_scale : 0
     int ldg;
     float gate_scale;
-    int dbg;                // PFN_GEMM_DBG bits (timing dissection; results invalid when non-zero)
-    unsigned long long* timing;   // optional [units][8] s_memtime stamps of block 0 / wave 0 (tools/ubench only)
 };
 int launch_gemm_nt(const GemmArgs& a, hipStream_t s);
 
