@@ -98,30 +98,35 @@ constexpr int FH_THREADS = 512;
 constexpr int FH_LDS_BYTES = 156 * 1024;
 
 bool fused_hops_fit(int seg, int ld, int n) {
-    // Pays only when there are enough graphs to give every CU several blocks (the per-CU load/store path, ~25-50 GB/s,
-    // bounds a block that streams 4 tiles): measured at 128 graphs (case118 x 128) the fused kernel loses to K generic
-    // hop launches (40 vs 26 us), at 2048 graphs it wins.  PFN_FUSED_HOPS=0/1 forces the choice (experiments).
+    // A hop acts on every column independently, so a block may take a COLUMN SLICE of its graph(s): small batches still
+    // fill the chip (case118 x 128: 128 graphs x 3 slices of 11 float4 columns = 384 blocks, 41 KB of LDS each, three per
+    // CU) and the K hops cost one launch instead of K (measured 47 -> ~10 us per TAGConv at 128 graphs).  Needs two
+    // tiles of at least one float4 column of a whole graph in LDS.  PFN_FUSED_HOPS=0/1 forces the choice (experiments).
     static const char* force = getenv("PFN_FUSED_HOPS");
-    if (seg <= 0 || (size_t)2 * seg * ld * sizeof(float) > (size_t)FH_LDS_BYTES) return false;
+    (void)ld;
+    (void)n;
+    if (seg <= 0 || (size_t)2 * seg * 4 * sizeof(float) + (size_t)(2 * seg + 1) * sizeof(int) > (size_t)FH_LDS_BYTES / 2) return false;
     if (force) return force[0] == '1';
-    return n / seg >= 1024;
+    return true;
 }
 
-__global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_pb, int nbr_cap,
+__global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_pb, int cw, int nbr_cap,
                                                                 const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                                 const float* __restrict__ dinv, const FusedHopsArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float tiles[];   // 2 x rows_pb x ld | dinv[rows_pb] | rp[rows_pb+1] | nbr[cap]
+    extern __shared__ __attribute__((aligned(16))) float tiles[];   // 2 x rows_pb x 4cw | dinv[rows_pb] | rp[rows_pb+1] | nbr[cap]
     const int r0 = blockIdx.x * rows_pb;
     const int rows = min(rows_pb, n - r0);
-    const int nchunk = a.ld >> 2;
-    const int items = rows * nchunk;
+    const int c0 = blockIdx.y * cw;                       // first float4 column of this block's slice
+    const int cwh = min(cw, (a.ld >> 2) - c0);            // float4 columns in the slice
+    const int tld = 4 * cw;                               // tile row stride (floats)
+    const int items = rows * cwh;
     float* cur = tiles;
-    float* nxt = tiles + (size_t)rows_pb * a.ld;
-    float* s_dinv = tiles + (size_t)2 * rows_pb * a.ld;
+    float* nxt = tiles + (size_t)rows_pb * tld;
+    float* s_dinv = tiles + (size_t)2 * rows_pb * tld;
     int* s_rp = reinterpret_cast<int*>(s_dinv + rows_pb);
     int* s_nb = s_rp + rows_pb + 1;
-    // the block's slice of the adjacency goes to LDS once: with ~8 work items per thread and K hops, index loads from
-    // global memory (three dependent latencies per item) would dominate everything else
+    // the block's slice of the adjacency goes to LDS once: with several work items per thread and K hops, index loads
+    // from global memory (three dependent latencies per item) would dominate everything else
     const int e0 = rowptr[r0], e1 = rowptr[r0 + rows];
     const bool nb_in_lds = e1 - e0 <= nbr_cap;
     for (int i = threadIdx.x; i <= rows; i += FH_THREADS) s_rp[i] = rowptr[r0 + i] - e0;
@@ -129,23 +134,25 @@ __global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_
     if (nb_in_lds)
         for (int i = threadIdx.x; i < e1 - e0; i += FH_THREADS) s_nb[i] = nbr[e0 + i] - r0;
     const float* first = a.transpose ? a.G + (size_t)a.K * a.stride : a.x0;
-    for (int i = threadIdx.x; i < items; i += FH_THREADS)   // rows are contiguous in memory: a linear float4 copy
-        st4(cur + 4 * i, ld4(first + (size_t)r0 * a.ld + 4 * i));
+    for (int i = threadIdx.x; i < items; i += FH_THREADS) {
+        const int lr = i / cwh, lc = i - lr * cwh;
+        st4(cur + (size_t)lr * tld + 4 * lc, ld4(first + (size_t)(r0 + lr) * a.ld + 4 * (c0 + lc)));
+    }
     __syncthreads();
     for (int k = 1; k <= a.K; ++k) {
         const bool last = k == a.K;
         const float* addp = a.transpose ? a.G + (size_t)(a.K - k) * a.stride : nullptr;
         float* gout = a.transpose ? (last ? a.out : nullptr) : a.xk + (size_t)(k - 1) * a.stride;
         for (int i = threadIdx.x; i < items; i += FH_THREADS) {
-            const int lr = i / nchunk, col = (i - lr * nchunk) * 4;
+            const int lr = i / cwh, lc = i - lr * cwh;
             const int beg = s_rp[lr], end = s_rp[lr + 1];
             const float di = s_dinv[lr];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int p = beg; p < end; ++p) {
                 const int ls = nb_in_lds ? s_nb[p] : nbr[e0 + p] - r0;
-                acc = fma4(s_dinv[ls] * di, ld4(cur + (size_t)ls * a.ld + col), acc);
+                acc = fma4(s_dinv[ls] * di, ld4(cur + (size_t)ls * tld + 4 * lc), acc);
             }
-            const size_t o = (size_t)(r0 + lr) * a.ld + col;
+            const size_t o = (size_t)(r0 + lr) * a.ld + 4 * (c0 + lc);
             if (addp) acc = add4(acc, ld4(addp + o));
             if (last && a.gate) {
                 const float4 g4 = ld4(a.gate + o);
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_
                 acc.z = g4.z > 0.f ? acc.z * a.gate_scale : 0.f;
                 acc.w = g4.w > 0.f ? acc.w * a.gate_scale : 0.f;
             }
-            if (!last) st4(nxt + (size_t)lr * a.ld + col, acc);
+            if (!last) st4(nxt + (size_t)lr * tld + 4 * lc, acc);
             if (gout) st4(gout + o, acc);
         }
         __syncthreads();
@@ -166,24 +173,39 @@ __global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_
 
 int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s) {
     if (g.n == 0 || a.K == 0) return PFN_OK;
+    const int nchunk = a.ld / 4, ngraphs = g.n / a.seg;
+    // column slices: aim for >= 512 blocks; a slice must leave room for two tiles of a whole graph
+    const size_t per_chunk_graph = (size_t)2 * a.seg * 4 * sizeof(float);
+    const int max_cw = (int)std::min<size_t>(nchunk, ((size_t)FH_LDS_BYTES - (size_t)(2 * a.seg + 1) * sizeof(int)) / per_chunk_graph);
+    if (max_cw < 1) {
+        set_error("fused hops: a %d-row graph does not fit in LDS", a.seg);
+        return PFN_EINVAL;
+    }
+    int cs = std::max(1, std::min(nchunk, (512 + ngraphs - 1) / std::max(1, ngraphs)));   // slices wanted
+    int cw = (nchunk + cs - 1) / cs;
+    cw = std::min(cw, max_cw);
+    cs = (nchunk + cw - 1) / cw;
     // whole graphs per block: as many as fit the two LDS tiles, but keep >= ~2 blocks per CU worth of parallelism
-    int gpb = (int)((size_t)FH_LDS_BYTES / ((size_t)2 * a.seg * a.ld * sizeof(float)));
-    const int ngraphs = g.n / a.seg;
-    while (gpb > 1 && (ngraphs + gpb - 1) / gpb < 512) --gpb;
+    int gpb = (int)((size_t)FH_LDS_BYTES / ((size_t)2 * a.seg * cw * 4 * sizeof(float) + (size_t)2 * a.seg * sizeof(int)));
+    gpb = std::max(1, gpb);
+    while (gpb > 1 && (long)((ngraphs + gpb - 1) / gpb) * cs < 512) --gpb;
     const int rows_pb = gpb * a.seg;
-    const size_t tile_bytes = (size_t)2 * rows_pb * a.ld * sizeof(float);
+    const size_t tile_bytes = (size_t)2 * rows_pb * cw * 4 * sizeof(float);
     const size_t fixed = tile_bytes + (size_t)(2 * rows_pb + 1) * sizeof(int);
-    const size_t lds_total = (size_t)160 * 1024;
+    // neighbour list: what the slice's rows need (average degree is small), capped by what is left of 160 KiB / blocks per CU
+    const size_t want_nb = (size_t)rows_pb * 16 * sizeof(int);
+    const size_t lds_cap = (size_t)160 * 1024;
+    const size_t lds_total = std::min(lds_cap, fixed + want_nb);
     const int nbr_cap = (int)((lds_total - fixed) / sizeof(int));
     static bool attr_set = false;
     if (!attr_set) {
         PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_hops_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_total));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         attr_set = true;
     }
     ProfScope ps(a.transpose ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
-    fused_hops_kernel<<<(g.n + rows_pb - 1) / rows_pb, FH_THREADS, lds_total, s>>>(
-        g.n, rows_pb, nbr_cap, a.transpose ? g.rowptr_out : g.rowptr_in, a.transpose ? g.out_dst : g.in_src, g.dinv, a);
+    fused_hops_kernel<<<dim3((g.n + rows_pb - 1) / rows_pb, cs), FH_THREADS, lds_total, s>>>(
+        g.n, rows_pb, cw, nbr_cap, a.transpose ? g.rowptr_out : g.rowptr_in, a.transpose ? g.out_dst : g.in_src, g.dinv, a);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
