@@ -62,8 +62,8 @@ def alg_bytes(n, e, h, fe, K=3):
         "fused_hops_fwd": K * 4.0 * (e * h + e + n * h + (n + 1)),
         "fused_hops_bwd": K * 4.0 * (e * h + e + n * h + (n + 1)),
         "edge_fwd": 4.0 * (n * h + e * h + e * fe + e + (n + 1) + n * h),
-        "edge_bwd_dst": 4.0 * (2 * n * h + e * h + e * fe + e + (n + 1) + n * h),
-        "edge_bwd_src": 4.0 * (n * h + 2 * e * h + e * fe + e + (n + 1) + n * h),
+        # one launch: the by-destination half (dP, dWe) + the by-source half (dQ)
+        "edge_bwd": 4.0 * (2 * n * h + e * h + e * fe + e + (n + 1) + n * h) + 4.0 * (n * h + 2 * e * h + e * fe + e + (n + 1) + n * h),
     }
 
 

@@ -281,7 +281,7 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
 #define PFN_MAX_FE 8
 
 template <int FE>
-__global__ __launch_bounds__(256) void edge_bwd_dst_kernel(int n, int nchunk, int bdx, int bdy, int e_stored,
+__device__ __forceinline__ void edge_bwd_dst_body(int bid, int nblk, int n, int nchunk, int bdx, int bdy, int e_stored,
                                                            const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                            const int* __restrict__ eid, const float* __restrict__ P,
                                                            const float* __restrict__ Q, const float* __restrict__ dS,
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void edge_bwd_dst_kernel(int n, int nchunk, in
             float4 w4[FE];
 #pragma unroll
             for (int f = 0; f < FE; ++f) w4[f] = ld4(we + f * ld + col);
-            for (int row = blockIdx.x * bdy + ty; row < n; row += gridDim.x * bdy) {
+            for (int row = bid * bdy + ty; row < n; row += nblk * bdy) {
                 const float4 p4 = ld4(P + (size_t)row * ld + col);
                 const float4 g4 = ld4(dS + (size_t)row * ld + col);
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -354,14 +354,14 @@ __global__ __launch_bounds__(256) void edge_bwd_dst_kernel(int n, int nchunk, in
                 for (int f = 0; f < FE; ++f) sum[f] = add4(sum[f], part[(y * bdx + tx) * FE + f]);
             }
 #pragma unroll
-            for (int f = 0; f < FE; ++f) st4(dWe_partial + ((size_t)blockIdx.x * FE + f) * ld + col, sum[f]);
+            for (int f = 0; f < FE; ++f) st4(dWe_partial + ((size_t)bid * FE + f) * ld + col, sum[f]);
         }
         __syncthreads();
     }
 }
 
 template <int FE>
-__global__ __launch_bounds__(256) void edge_bwd_src_kernel(int n, int nchunk, int e_stored,
+__device__ __forceinline__ void edge_bwd_src_body(int bid, int n, int nchunk, int e_stored,
                                                            const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                            const int* __restrict__ eid, const float* __restrict__ P,
                                                            const float* __restrict__ Q, const float* __restrict__ dS,
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(256) void edge_bwd_src_kernel(int n, int nchunk, in
         we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
     }
     __syncthreads();
-    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long item = (long)bid * blockDim.x + threadIdx.x;
     const int row = (int)(item / nchunk);
     if (row >= n) return;
     const int col = (int)(item - (long)row * nchunk) * 4;
@@ -397,6 +397,26 @@ __global__ __launch_bounds__(256) void edge_bwd_src_kernel(int n, int nchunk, in
     st4(dQ + (size_t)row * ld + col, acc);
 }
 
+// One launch for both halves of the EdgeAggregation backward: blocks [0, nb_dst) walk the by-destination CSR (dP, dWe
+// partials; block-persistent), the rest walk the by-source CSR (dQ).  Both halves are latency-bound at small batches; in
+// one grid they overlap instead of paying two launch floors.
+template <int FE>
+__global__ __launch_bounds__(256) void edge_bwd_kernel(int nb_dst, int n, int nchunk, int bdx, int bdy, int e_stored,
+                                                       const int* __restrict__ rp_in, const int* __restrict__ in_src,
+                                                       const int* __restrict__ in_eid, const int* __restrict__ rp_out,
+                                                       const int* __restrict__ out_dst, const int* __restrict__ out_eid,
+                                                       const float* __restrict__ P, const float* __restrict__ Q,
+                                                       const float* __restrict__ dS, const float* __restrict__ ea,
+                                                       const float* __restrict__ w1, float* __restrict__ dP,
+                                                       float* __restrict__ dQ, float* __restrict__ dWe_partial, int ld, int h,
+                                                       int fi) {
+    if ((int)blockIdx.x < nb_dst)
+        edge_bwd_dst_body<FE>(blockIdx.x, nb_dst, n, nchunk, bdx, bdy, e_stored, rp_in, in_src, in_eid, P, Q, dS, ea, w1, dP,
+                              dWe_partial, ld, h, fi);
+    else
+        edge_bwd_src_body<FE>(blockIdx.x - nb_dst, n, nchunk, e_stored, rp_out, out_dst, out_eid, P, Q, dS, ea, w1, dQ, ld, h, fi);
+}
+
 static void dst_block_shape(int ld, int& bdx, int& bdy) {
     const int nchunk = ld / 4;
     bdx = nchunk < 256 ? nchunk : 256;
@@ -415,19 +435,13 @@ static int launch_edge_bwd_fe(const GraphView& g, const EdgeBwdArgs& a, hipStrea
     int bdx, bdy;
     dst_block_shape(a.ld, bdx, bdy);
     const size_t lds_dst = (size_t)FE * a.ld * sizeof(float) + (size_t)256 * FE * sizeof(float4);
-    {
-        ProfScope ps("edge_bwd_dst", 0.0, 0.0, s);
-        edge_bwd_dst_kernel<FE><<<edge_bwd_dst_blocks(g, a.ld), 256, lds_dst, s>>>(
-            g.n, nchunk, bdx, bdy, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.dS, a.edge_attr, a.w1, a.dP,
-            a.dWe_partial, a.ld, a.h, a.fi);
-    }
-    PFN_CHECK_LAUNCH();
+    const int nb_dst = edge_bwd_dst_blocks(g, a.ld);
     const long items = (long)g.n * nchunk;
-    const int blocks = (int)((items + 255) / 256);
-    ProfScope ps2("edge_bwd_src", 0.0, 0.0, s);
-    edge_bwd_src_kernel<FE><<<blocks, 256, (size_t)FE * a.ld * sizeof(float), s>>>(
-        g.n, nchunk, g.e_stored, g.rowptr_out, g.out_dst, g.out_eid, a.P, a.Q, a.dS, a.edge_attr, a.w1, a.dQ, a.ld, a.h,
-        a.fi);
+    const int nb_src = (int)((items + 255) / 256);
+    ProfScope ps("edge_bwd", 0.0, 0.0, s);
+    edge_bwd_kernel<FE><<<nb_dst + nb_src, 256, lds_dst, s>>>(nb_dst, g.n, nchunk, bdx, bdy, g.e_stored, g.rowptr_in, g.in_src,
+                                                             g.in_eid, g.rowptr_out, g.out_dst, g.out_eid, a.P, a.Q, a.dS,
+                                                             a.edge_attr, a.w1, a.dP, a.dQ, a.dWe_partial, a.ld, a.h, a.fi);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

@@ -2,9 +2,9 @@
 R=$GRAFT_REPO_ROOT; cd $R
 timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
 for args in "" "--case 6470rte --batch 64 --steps 10 --warmup 3"; do
-python bench.py --no-cpu-baseline --profile-steps 0 $args 2>/dev/null | python -c "
+python bench.py --no-cpu-baseline $args 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('RUN', d['config']['workload'][:12], 'ms/step', d['ms_per_step'], d['value'])
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); ks=d.get('kernels') or {}
+print('RUN', d['config']['workload'][:12], 'ms/step', d['ms_per_step'], ' '.join(f\"{k}:{v['avg_us']:.0f}/{v.get('achieved','')}\" for k,v in ks.items()))
 "
 done
