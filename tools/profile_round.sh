@@ -1,15 +1,16 @@
 #!/bin/bash
 # Round profile (run on the GPU box through gpurun): rocprofv3 kernel-trace stats of the default bench command, plus
 # two separate PMC passes (FETCH_SIZE / WRITE_SIZE) on a short eager run.  Summaries land in gpurun_out/prof_round/.
+#   tools/profile_round.sh [tag]     (BENCH_ARGS="--case ... --batch ..." selects another workload)
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; rm -rf $O /tmp/pr; mkdir -p $O /tmp/pr
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pr/trace -o bench -- python $R/bench.py --no-cpu-baseline $BENCH_ARGS > $O/bench_under_rocprof.json 2> /tmp/pr/trace.err
-find /tmp/pr/trace -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-find /tmp/pr/trace -name "*domain_stats.csv" -exec cp {} $O/domain_stats.csv \;
+TAG=${1:-r01_case118_b128_train}
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; rm -rf /tmp/pr; mkdir -p $O /tmp/pr
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pr/trace -o bench -- python $R/bench.py --no-cpu-baseline $BENCH_ARGS > $O/${TAG}_bench_under_rocprof.json 2> /tmp/pr/trace.err
+find /tmp/pr/trace -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats.csv \;
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace -f csv -d /tmp/pr/$c -o pmc -- python $R/bench.py --no-cpu-baseline --no-graph --steps 3 --warmup 1 --profile-steps 0 $BENCH_ARGS > /tmp/pr/$c.out 2> /tmp/pr/$c.err
   F=$(find /tmp/pr/$c -name "*counter_collection.csv" | head -1)
-  python - "$F" "$c" > $O/pmc_$c.txt <<'PY'
+  python - "$F" "$c" > $O/${TAG}_pmc_$c.txt <<'PY'
 import csv, sys, collections
 path, ctr = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: [0, 0.0])
@@ -18,9 +19,37 @@ with open(path) as f:
         if row.get("Counter_Name") != ctr: continue
         k = row["Kernel_Name"].split("(")[0][:60]
         agg[k][0] += 1; agg[k][1] += float(row["Counter_Value"])
-print(f"# {ctr}: per-kernel launches, total counter value, value per launch (raw counter units as reported by rocprofv3)")
+print(f"# {ctr}: per-kernel launches, total counter value, value per launch (raw counter units as reported by rocprofv3: KiB)")
 for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
     print(f"{k:60s} n={n:5d} total={v:16.1f} per_launch={v / n:14.1f}")
 PY
 done
+# HBM-side bytes per launch of every kernel class: (2 x FETCH_SIZE + WRITE_SIZE) KiB (MI355X_MICROARCH.md: FETCH_SIZE
+# reports half of a wide coalesced read on gfx950; WRITE_SIZE is taken as is)
+python - $O $TAG "$BENCH_ARGS" > $O/${TAG}_pmc_traffic.json <<'PY'
+import sys, re, json
+o, tag, bargs = sys.argv[1], sys.argv[2], sys.argv[3]
+def read(c):
+    d = {}
+    for line in open(f"{o}/{tag}_pmc_{c}.txt"):
+        m = re.match(r"(.*?)\s+n=\s*(\d+) total=\s*([\d.]+) per_launch=\s*([\d.]+)", line)
+        if m: d[m.group(1).strip()] = (int(m.group(2)), float(m.group(3)))
+    return d
+f, w = read("FETCH_SIZE"), read("WRITE_SIZE")
+cls = {"gemm_nt": "gemm_nt_kernel", "gemm_tn": "gemm_tn_kernel", "hop_norm": "hop_kernel<true>", "edge_fwd": "edge_fwd_kernel",
+       "edge_bwd": "edge_bwd_kernel", "fused_hops": "fused_hops_kernel"}
+case = re.search(r"--case (\S+)", bargs); batch = re.search(r"--batch (\d+)", bargs); mode = re.search(r"--mode (\S+)", bargs)
+key = f"{case.group(1) if case else '118v2'}:{batch.group(1) if batch else 128}:{mode.group(1) if mode else 'train'}"
+out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, averaged over all launches of the class in a 3-step "
+                "eager run; separate rocprofv3 --pmc passes.  The counters are fabric-side (L2 <-> Infinity Cache/HBM) and "
+                "include Infinity-Cache hits; at case118v2 x 128 the whole working set sits in the 256 MiB Infinity Cache."}
+for c, pat in cls.items():
+    nf = [v for k, v in f.items() if pat in k]
+    if not nf: continue
+    launches = sum(n for n, _ in nf)                      # all template instantiations of the class, launch-weighted
+    fv = sum(t for _, t in nf) / launches
+    wv = sum(t for k, (n, t) in w.items() if pat in k) / launches
+    out[f"{c}:{key}"] = int((2 * fv + wv) * 1024)
+print(json.dumps(out, indent=1))
+PY
 ls -la $O
