@@ -88,6 +88,57 @@ def test_g3_tagconv_layer(tag):
         assert_close(layer.lins[k].weight.grad, fx[f"grad_w{k}"], RTOL, f"grad_w{k}")
 
 
+@pytest.mark.parametrize("fi,fe,h,fo,nodes", [(7, 3, 65, 5, 300), (64, 2, 64, 64, 257), (33, 1, 193, 130, 1000),
+                                              (1, 2, 128, 1, 64), (129, 2, 300, 129, 513)])
+def test_edge_aggregation_odd_shapes_vs_oracle(fi, fe, h, fo, nodes):
+    """Shapes that exercise every tile / quadrant / remainder path of the GEMMs (64-multiples, 64k+1, >136 k's per
+    piece, single columns) against the oracle layer on a random sparse graph."""
+    torch.manual_seed(fi * 1000 + h)
+    ref = ref_cpu.EdgeAggregation(fi, fe, h, fo)
+    ours = EdgeAggregation(fi, fe, h, fo)
+    ours.load_state_dict(ref.state_dict())
+    ours = ours.to(DEV)
+    e = 3 * nodes
+    ei = torch.randint(0, nodes, (2, e))
+    x, ea, g = torch.randn(nodes, fi), torch.randn(e, fe), torch.randn(nodes, fo)
+
+    def run(mod, x, ei, ea, g):
+        x = x.clone().requires_grad_(True)
+        ea = ea.clone().requires_grad_(True)
+        y = mod(x, ei, ea)
+        y.backward(g)
+        return [y.detach(), x.grad, ea.grad] + [p.grad for p in mod.parameters()]
+
+    want = run(ref, x, ei, ea, g)
+    got = run(ours, x.to(DEV), ei.to(DEV), ea.to(DEV), g.to(DEV))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert_close(a, b, 2 * RTOL, f"tensor {i}")
+
+
+@pytest.mark.parametrize("cin,cout,K,nodes", [(33, 70, 2, 500), (64, 128, 1, 129), (193, 65, 3, 400), (5, 1, 4, 77)])
+def test_tagconv_odd_shapes_vs_oracle(cin, cout, K, nodes):
+    torch.manual_seed(cin * 100 + cout)
+    ref = ref_cpu.TAGConv(cin, cout, K)
+    with torch.no_grad():
+        ref.bias.normal_(std=0.2)
+    ours = TAGConv(cin, cout, K=K)
+    ours.load_state_dict(ref.state_dict())
+    ours = ours.to(DEV)
+    ei = torch.randint(0, nodes, (2, 4 * nodes))
+    x, g = torch.randn(nodes, cin), torch.randn(nodes, cout)
+
+    def run(mod, x, ei, g):
+        x = x.clone().requires_grad_(True)
+        y = mod(x, ei)
+        y.backward(g)
+        return [y.detach(), x.grad] + [p.grad for p in mod.parameters()]
+
+    want = run(ref, x, ei, g)
+    got = run(ours, x.to(DEV), ei.to(DEV), g.to(DEV))
+    for i, (a, b) in enumerate(zip(got, want)):
+        assert_close(a, b, 2 * RTOL, f"tensor {i}")
+
+
 # --------------------------------------------------------------------------------------------- whole model
 def _model_from(fx, shared, dropout=0.0):
     params = params_from(load("g4_params_standard")) if shared else params_from(fx)
