@@ -184,7 +184,7 @@ struct NtArgs {
     int M, ncols, ldc, npiece;
     int tps, cshift, nq, remv;   // quarters per LDS slice; log2(column groups per block); MFMA quarters; VALU columns (padded)
     int nrem, bias_group, ldr, ldg;
-    int kuni, pad0_;             // k length shared by every piece of the launch, or 0
+    int kuni, bias_lds_off;      // k length shared by every piece of the launch, or 0; float offset of the bias image in LDS
     NtPiece piece[NT_MAX_PIECES];
     float* C[8];
     int gflags[8];               // per group: 1 = add the C already in memory, 2 = store raw sums (no epilogue).  int, not
@@ -355,28 +355,12 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                     *reinterpret_cast<const float4*>(a.piece[p].Brem + tid * 4);
         }
     }
-    // ---- per-column epilogue operands: a wave's columns never change, so bias / rowbias are loaded once
-    float cbias[CTE][4], crb[CTE][4], rcb[4], rcrb[4];
+    // ---- per-column epilogue operand (the bias -- or, for a row-scaled bias, the rowbias; a GEMM has one or the other,
+    // checked by the launcher): staged in LDS, zero past ncols, and read back at flush time.  Held in registers for the
+    // whole kernel it cost 8-12 VGPRs, the difference between spilling in the flush and not.
     {
-        const int clast = a.ncols - 1;
-#pragma unroll
-        for (int ct = 0; ct < CTE; ++ct) {
-            const int col0 = 32 * (tile0 + ct) + (r32 & ~3);   // after the quad transpose: 4 columns per lane
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int cc = min(col0 + e, clast);
-                const float bv = a.bias ? a.bias[cc] : 0.f, rv = a.rowscale ? a.rowbias[cc] : 0.f;
-                cbias[ct][e] = col0 + e <= clast ? bv : 0.f;
-                crb[ct][e] = col0 + e <= clast ? rv : 0.f;
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int cc = min(rem_col + e, clast);
-            const float bv = a.bias ? a.bias[cc] : 0.f, rv = a.rowscale ? a.rowbias[cc] : 0.f;
-            rcb[e] = rem_col + e <= clast ? bv : 0.f;
-            rcrb[e] = rem_col + e <= clast ? rv : 0.f;
-        }
+        const float* bsrc = a.rowscale ? a.rowbias : a.bias;
+        for (int i = tid; i < a.ldc; i += NT_THREADS) lds[a.bias_lds_off + i] = (bsrc && i < a.ncols) ? bsrc[i] : 0.f;
     }
     dma_wait();
     __syncthreads();   // the only barrier: from here on the waves run free
@@ -537,17 +521,18 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                         }
                     }
                     if (!raw) {
-                        if (use_bias) {
+                        const f32x4 cb4 = *reinterpret_cast<const f32x4*>(lds + a.bias_lds_off + col0);
+                        if (use_bias && !ep.has_rowscale) {
 #pragma unroll
                             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[g][e] += cbias[ct][e];
+                                for (int e = 0; e < 4; ++e) v[g][e] += cb4[e];
                         }
                         if (ep.has_rowscale) {
 #pragma unroll
                             for (int g = 0; g < 4; ++g)
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) v[g][e] = fmaf(aux[ct][g][e], crb[ct][e], v[g][e]);
+                                for (int e = 0; e < 4; ++e) v[g][e] = fmaf(aux[ct][g][e], cb4[e], v[g][e]);
                         }
                         if (ep.has_resid) {
 #pragma unroll
@@ -593,10 +578,11 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                         v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
                     }
                     if (!raw) {
+                        const f32x4 rcb = *reinterpret_cast<const f32x4*>(lds + a.bias_lds_off + rem_col);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float x = v[e] + (use_bias ? rcb[e] : 0.f);
-                            if (ep.has_rowscale) x = fmaf(raux[e], rcrb[e], x);
+                            float x = v[e] + ((use_bias && !ep.has_rowscale) ? rcb[e] : 0.f);
+                            if (ep.has_rowscale) x = fmaf(raux[e], rcb[e], x);
                             if (ep.has_resid) x += raux[e];
                             if (ep.act == ACT_RELU) {
                                 x = fmaxf(x, 0.f);
@@ -652,6 +638,10 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
         set_error("gemm_nt: output row stride %d must be a multiple of 4", a.ldc);
         return PFN_EINVAL;
     }
+    if (a.bias && a.rowscale) {
+        set_error("gemm_nt: a GEMM takes a bias or a row-scaled bias, not both");
+        return PFN_EINVAL;
+    }
     double flops = 0.0, bytes = (double)a.ngroup * a.M * a.ncols * 4.0;
     std::vector<NtPiece> pieces;
     for (int t = 0; t < a.nterm; ++t) {
@@ -687,13 +677,15 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     }
     // ---- how many 32-column quarters of every piece fit in LDS at once (tps), and where the launch has to be cut
     auto piece_bytes = [](const NtPiece& pc, int tps) { return (size_t)pc.klen * (32 * tps + 4) * sizeof(float); };
+    const size_t bias_bytes = (size_t)round_up((int64_t)a.ldc * sizeof(float), 16);   // the bias image rides behind the pieces
+    const size_t lds_budget = (size_t)NT_LDS_BYTES - bias_bytes;
     int tps = 0;
     if (nq > 0) {
         const int start = nq >= 3 ? 4 : nq;
         for (tps = start; tps >= 1; tps >>= 1) {
             size_t tot = 0;
             for (const NtPiece& pc : pieces) tot += piece_bytes(pc, tps);
-            if (tot <= (size_t)NT_LDS_BYTES && pieces.size() <= (size_t)NT_MAX_PIECES) break;
+            if (tot <= lds_budget && pieces.size() <= (size_t)NT_MAX_PIECES) break;
         }
         if (tps < 1) tps = std::min(start, 2);   // does not fit whole: several accumulating launches
     }
@@ -738,7 +730,7 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     ProfScope ps("gemm_nt", bytes, flops, s);
     for (size_t i0 = 0; i0 < pieces.size();) {
         size_t i1 = i0, used = 0;
-        while (i1 < pieces.size() && i1 - i0 < (size_t)NT_MAX_PIECES && used + piece_bytes(pieces[i1], tps) <= (size_t)NT_LDS_BYTES) {
+        while (i1 < pieces.size() && i1 - i0 < (size_t)NT_MAX_PIECES && used + piece_bytes(pieces[i1], tps) <= lds_budget) {
             pieces[i1].lds_off = (int)(used / sizeof(float));
             used += piece_bytes(pieces[i1], tps);
             ++i1;
@@ -748,6 +740,7 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
             return PFN_EINVAL;
         }
         k.npiece = (int)(i1 - i0);
+        k.bias_lds_off = (int)(used / sizeof(float));
         k.kuni = pieces[i0].klen;
         for (size_t i = i0; i < i1; ++i)
             if (pieces[i].klen != k.kuni) k.kuni = 0;
@@ -763,9 +756,9 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
             seen[g] |= here[g];
         }
         int rc;
-        if (CT == 0) rc = launch_variant<0>(k, grid, used, s);
-        else if (CT == 1) rc = launch_variant<1>(k, grid, used, s);
-        else rc = launch_variant<2>(k, grid, used, s);
+        if (CT == 0) rc = launch_variant<0>(k, grid, used + bias_bytes, s);
+        else if (CT == 1) rc = launch_variant<1>(k, grid, used + bias_bytes, s);
+        else rc = launch_variant<2>(k, grid, used + bias_bytes, s);
         if (rc != PFN_OK) return rc;
         i0 = i1;
     }
