@@ -145,7 +145,9 @@ int pfn_scatter_add(const void* graph_ws, int64_t n_nodes, int64_t e_stored, con
 int pfn_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t n_rows,
                  int64_t features, void* stream);
 /* MSELoss(out, y) forward+backward in one pass (train.py:103; utils/training.py:72-74):
- * loss[0] = mean((out-y)^2), grad[i] = 2 (out[i]-y[i]) / count.                                    */
+ * loss[0] = mean((out-y)^2), grad[i] = 2 (out[i]-y[i]) / count (grad may be NULL).  `ws`: >= 1028 bytes,
+ * 256 float partials + one int32 arrival counter at byte 1024 that must be ZERO before the first call and is
+ * left zero by every call (one launch: the last block to arrive sums the partials in block order).           */
 int pfn_mse_loss(const float* out, const float* y, int64_t count, float* loss, float* grad, void* ws,
                  size_t ws_bytes, void* stream);
 /* AdamW on one flat buffer (train.py:123; torch defaults betas (0.9,0.999), eps 1e-8, wd 0.01).

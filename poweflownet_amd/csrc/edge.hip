@@ -554,24 +554,6 @@ int launch_edge_attr_grad(const GraphView& g, const EdgeBwdArgs& a, hipStream_t 
 }
 
 // ------------------------------------------------------------------------------------ small kernels
-template <typename T>
-__global__ void mask_to_float_kernel(const T* __restrict__ m, float* __restrict__ o, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) o[i] = (float)m[i];
-}
-int launch_mask_to_float(const void* mask, int mask_dtype, float* out, int64_t count, hipStream_t s) {
-    if (count == 0) return PFN_OK;
-    const int blocks = (int)((count + 255) / 256);
-    if (mask_dtype == 0) mask_to_float_kernel<int64_t><<<blocks, 256, 0, s>>>(static_cast<const int64_t*>(mask), out, count);
-    else if (mask_dtype == 1) mask_to_float_kernel<float><<<blocks, 256, 0, s>>>(static_cast<const float*>(mask), out, count);
-    else {
-        set_error("mask_dtype must be 0 (int64) or 1 (float32)");
-        return PFN_EINVAL;
-    }
-    PFN_CHECK_LAUNCH();
-    return PFN_OK;
-}
-
 __global__ void pad_rows_kernel(const float* __restrict__ src, int64_t lds_, float* __restrict__ dst, int64_t ldd,
                                 int64_t rows, int64_t f) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

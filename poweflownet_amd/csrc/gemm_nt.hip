@@ -57,6 +57,12 @@ __host__ __device__ inline void col_plan(int ld, int& remv, int& nq) {
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     // the dropout stream advances once per forward, before any kernel of that forward reads it
     if (a.rng_advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.rng_advance[1] += 1;
+    if (a.mask_count > 0) {   // the rider: pred_mask.float() (networks/MPN.py:533), spread over every block of the launch
+        const int64_t nthr = (int64_t)gridDim.x * gridDim.y * blockDim.x;
+        for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < a.mask_count; i += nthr)
+            a.maskf[i] = a.mask_dtype == 0 ? (float)static_cast<const int64_t*>(a.mask)[i] : static_cast<const float*>(a.mask)[i];
+    }
+    if ((int)blockIdx.y >= a.njobs) return;
     const PackJob jb = a.job[blockIdx.y];
     int remv, nq;
     col_plan(jb.ld_out, remv, nq);
@@ -88,11 +94,21 @@ size_t packed_floats(int K, int ld_out) {
     return (size_t)round_up((int64_t)nq * G * 128 + (int64_t)G * 16, 256);
 }
 
-int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s) {
-    for (int j0 = 0; j0 < njobs; j0 += PACK_MAX_JOBS) {
+int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s, const void* mask, int mask_dtype,
+                float* maskf, int64_t mask_count) {
+    if (mask && mask_dtype != 0 && mask_dtype != 1) {
+        set_error("pred_mask dtype code %d unsupported (0: int64, 1: float32)", mask_dtype);
+        return PFN_EINVAL;
+    }
+    for (int j0 = 0; j0 < njobs || (j0 == 0 && mask); j0 += PACK_MAX_JOBS) {
         PackArgs a;
-        a.njobs = std::min(PACK_MAX_JOBS, njobs - j0);
+        a.njobs = std::max(0, std::min(PACK_MAX_JOBS, njobs - j0));
         a.rng_advance = j0 == 0 ? rng_advance : nullptr;
+        const bool rider = j0 == 0 && mask != nullptr && mask_count > 0;
+        a.mask = rider ? mask : nullptr;
+        a.maskf = maskf;
+        a.mask_count = rider ? mask_count : 0;
+        a.mask_dtype = mask_dtype;
         long biggest = 0;
         for (int j = 0; j < a.njobs; ++j) {
             a.job[j] = jobs[j0 + j];
@@ -100,7 +116,8 @@ int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream
         }
         const int bx = (int)std::min<long>(std::max<long>(1, (biggest + 255) / 256), 64);
         ProfScope ps("pack_weights", 0.0, 0.0, s);
-        pack_weights_kernel<<<dim3(bx, a.njobs), 256, 0, s>>>(a);
+        if (a.njobs == 0 && !rider) continue;
+        pack_weights_kernel<<<dim3(bx, std::max(1, a.njobs)), 256, 0, s>>>(a);
         PFN_CHECK_LAUNCH();
     }
     return PFN_OK;

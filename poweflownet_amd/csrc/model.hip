@@ -56,7 +56,10 @@ struct Packer {
         jobs.push_back(j);
         return dst ? dst : reinterpret_cast<const float*>(0x10);   // non-null sentinel while measuring
     }
-    int flush(hipStream_t s, uint64_t* rng_advance = nullptr) { return launch_pack(jobs.data(), (int)jobs.size(), rng_advance, s); }
+    int flush(hipStream_t s, uint64_t* rng_advance = nullptr, const void* mask = nullptr, int mask_dtype = 0,
+              float* maskf = nullptr, int64_t mask_count = 0) {
+        return launch_pack(jobs.data(), (int)jobs.size(), rng_advance, s, mask, mask_dtype, maskf, mask_count);
+    }
 };
 
 struct Act {
@@ -425,9 +428,9 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     Packer pk(lo.packed);
     ModelPack mp;
     plan_pack(pk, lo.f0, lo.fe, lo.fo, lo.h, lo.L, lo.K, params, mp);
-    PFN_TRY(pk.flush(s, drop ? rng : nullptr));   // also advances the dropout stream for this forward
+    // ... the same launch advances the dropout stream for this forward and converts pred_mask to float32
+    PFN_TRY(pk.flush(s, drop ? rng : nullptr, pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0));
     // mask_embd(mask) + x   (networks/MPN.py:533,:537)
-    PFN_TRY(launch_mask_to_float(pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0, s));
     {
         GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
         a.C[0] = lo.me_h;
@@ -547,10 +550,13 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
 }
 
 // ---------------------------------------------------------------------------------------- utilities
-__global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restrict__ o, const float* __restrict__ y,
-                                                          int64_t n, float inv_n, float* __restrict__ grad,
-                                                          float* __restrict__ partial) {
+// One launch: every block reduces its slice to a partial and takes a ticket; the last arriver sums the partials in
+// block order (not arrival order: deterministic) and re-arms the counter for the next call.
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ o, const float* __restrict__ y, int64_t n,
+                                                  float inv_n, float* __restrict__ grad, float* __restrict__ partial,
+                                                  int* __restrict__ counter, float* __restrict__ loss) {
     __shared__ float red[256];
+    __shared__ int s_last;
     float acc = 0.f;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float d = o[i] - y[i];
@@ -563,20 +569,25 @@ __global__ __launch_bounds__(256) void mse_partial_kernel(const float* __restric
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
-}
-__global__ __launch_bounds__(256) void mse_final_kernel(const float* __restrict__ partial, int nb, float inv_n,
-                                                        float* __restrict__ loss) {
-    __shared__ float red[256];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < nb; i += 256) acc += partial[i];
-    red[threadIdx.x] = acc;
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = red[0];
+        __threadfence();
+        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    red[threadIdx.x] = threadIdx.x < gridDim.x ? __hip_atomic_load(partial + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
         __syncthreads();
     }
-    if (threadIdx.x == 0) loss[0] = red[0] * inv_n;
+    if (threadIdx.x == 0) {
+        loss[0] = red[0] * inv_n;
+        *counter = 0;
+    }
 }
 
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -826,15 +837,14 @@ int pfn_mse_loss(const float* out, const float* y, int64_t count, float* loss, f
                  void* stream) {
     PFN_CHECK_ARG(out && y && loss && ws, "pfn_mse_loss: null pointer");
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 256));
-    if (ws_bytes < nb * sizeof(float)) {
-        set_error("pfn_mse_loss: workspace too small (need %zu bytes)", nb * sizeof(float));
+    if (ws_bytes < 257 * sizeof(float)) {
+        set_error("pfn_mse_loss: workspace too small (need %zu bytes)", 257 * sizeof(float));
         return PFN_ENOSPACE;
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     const float inv_n = count > 0 ? 1.0f / (float)count : 0.f;
-    mse_partial_kernel<<<nb, 256, 0, s>>>(out, y, count, inv_n, grad, static_cast<float*>(ws));
-    PFN_CHECK_LAUNCH();
-    mse_final_kernel<<<1, 256, 0, s>>>(static_cast<float*>(ws), nb, inv_n, loss);
+    mse_kernel<<<nb, 256, 0, s>>>(out, y, count, inv_n, grad, static_cast<float*>(ws),
+                                  reinterpret_cast<int*>(static_cast<float*>(ws) + 256), loss);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

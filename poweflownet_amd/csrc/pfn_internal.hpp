@@ -94,9 +94,15 @@ struct PackArgs {
     PackJob job[PACK_MAX_JOBS];
     int njobs;
     uint64_t* rng_advance;   // device {seed, offset}: offset += 1 (dropout stream), or null
+    // optional rider (one launch floor less per forward): pred_mask -> float32, spread over all blocks of the launch
+    const void* mask;
+    float* maskf;
+    int64_t mask_count;
+    int mask_dtype;          // 0: int64, 1: float32
 };
 size_t packed_floats(int K, int ld_out);
-int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s);
+int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s, const void* mask = nullptr,
+                int mask_dtype = 0, float* maskf = nullptr, int64_t mask_count = 0);
 
 // C[g] (M x ldc) = sum over terms t with t.group == g of  A_t (M x K_t) * B_t (K_t x ncols)  + epilogue,
 // B_t given as a packed image (Bp).
@@ -207,7 +213,6 @@ int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, 
                       hipStream_t s);
 
 // ------------------------------------------------------------------------------------ small kernels
-int launch_mask_to_float(const void* mask, int mask_dtype, float* out, int64_t count, hipStream_t s);
 int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t f,
                     hipStream_t s);
 
