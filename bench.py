@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--hub-frac", type=float, default=0.0)
+    ap.add_argument("--loss", default="mse", choices=["mse", "masked_l2"],
+                    help="mse = BASELINE.json's metric (train.py:103); masked_l2 = the reference's default --train_loss_fn")
     return ap.parse_args()
 
 
@@ -146,7 +148,9 @@ def main():
     n_nodes = data.x.shape[0]
     train = args.mode == "train"
     from poweflownet_amd.loss import MSELoss
-    loss_fn = MSELoss()                               # torch.nn.MSELoss semantics (train.py:103), fwd+bwd in one pass
+    from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss
+    masked = args.loss == "masked_l2"
+    loss_fn = Masked_L2_loss() if masked else MSELoss()   # MSELoss: torch.nn.MSELoss semantics (train.py:103), fwd+bwd in one pass
     loss_box = [None]
 
     if train:
@@ -156,7 +160,7 @@ def main():
 
         def fwd_bwd():
             opt.zero_grad(set_to_none=True)
-            loss = loss_fn(model(data), data.y)
+            loss = loss_fn(model(data), data.y, data.pred_mask) if masked else loss_fn(model(data), data.y)
             loss.backward(loss_fn.unit_grad(loss))     # == loss.backward(), minus autograd's ones_like + mul kernels
             loss_box[0] = loss
 

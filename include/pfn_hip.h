@@ -150,6 +150,16 @@ int pfn_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, i
  * left zero by every call (one launch: the last block to arrive sums the partials in block order).           */
 int pfn_mse_loss(const float* out, const float* y, int64_t count, float* loss, float* grad, void* ws,
                  size_t ws_bytes, void* stream);
+/* Masked_L2_loss(output, target, mask) forward+backward (utils/custom_loss_functions.py:10-46; the reference's default
+ * --train_loss_fn, utils/argument_parser.py:36; dispatch utils/training.py:61-62), d = out - y:
+ *   loss[0] = mean over {mask != 0} of d^2  +  (regularize ? regcoeff * mean over {(1 - mask) != 0} of d^2 : 0)
+ *   grad[i] = 2 d_i ( [mask_i != 0] / n1 + regcoeff [mask_i != 1] / n0 )          (grad may be NULL)
+ * An empty set gives NaN, as torch's mean of nothing does.  mask: `count` entries, mask_dtype 0 = int64, 1 = float32.
+ * `ws`: >= 4128 bytes; its last int32 (byte 4124) is an arrival counter that must be ZERO before the first call and is
+ * left zero by every call.                                                                                          */
+int pfn_masked_l2_loss(const float* out, const float* y, const void* mask, int mask_dtype, int64_t count,
+                       int regularize, float regcoeff, float* loss, float* grad, void* ws, size_t ws_bytes,
+                       void* stream);
 /* AdamW on one flat buffer (train.py:123; torch defaults betas (0.9,0.999), eps 1e-8, wd 0.01).
  * `step` is a device int64[2] {completed steps, arrival scratch (zero)}; the call increments step[0] itself,
  * so one launch per update and the whole step stays hipGraph-replayable.                           */

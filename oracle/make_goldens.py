@@ -12,8 +12,9 @@ Only the vectors are committed; no reference source travels.  Refuses to run wit
   G4 MaskEmbdMultiMPN fwd, per-layer activations, all parameter grads under MSELoss (:456-559)
   G6 three AdamW training steps driven by a restatement of utils/training.py:55-77
   G7 collate fixture (analytic; PyG absent) + batch == concatenation of singles
+  G8 Masked_L2_loss fwd + grad (utils/custom_loss_functions.py:10-46), the reference's default loss
 
-usage:  python oracle/make_goldens.py
+usage:  python oracle/make_goldens.py [g8]      (no argument: every fixture; a name: only that one)
 """
 import os
 import sys
@@ -218,6 +219,39 @@ def g7():
     npz("g7_collate", **arrays)
 
 
+def g8():
+    """Masked_L2_loss of the reference, imported unmodified.  Its module also imports torchvision (absent from the image,
+    unused by the class): an empty placeholder module satisfies the import."""
+    import types
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.datasets = types.ModuleType("torchvision.datasets")
+        tv.transforms = types.ModuleType("torchvision.transforms")
+        sys.modules.update({"torchvision": tv, "torchvision.datasets": tv.datasets, "torchvision.transforms": tv.transforms})
+    from utils.custom_loss_functions import Masked_L2_loss  # the reference
+    torch.manual_seed(8)
+    n = 37
+    table = torch.tensor([[0, 0, 1, 1], [0, 1, 0, 1], [1, 1, 0, 0]])
+    bus = torch.tensor([0] + [1 if i % 3 == 0 else 2 for i in range(1, n)])
+    cases = {}
+    out, y = torch.randn(n, 4), torch.randn(n, 4)
+    masks = {"int": table[bus], "float": table[bus].float(), "allone": torch.ones(n, 4, dtype=torch.long),
+             "odd": torch.randint(0, 3, (n, 4))}            # 'odd': values outside {0, 1} select BOTH terms
+    for mname, mask in masks.items():
+        for reg, coeff in ((True, 1), (True, 0.5), (False, 1)):
+            o = out.clone().requires_grad_(True)
+            loss = Masked_L2_loss(regularize=reg, regcoeff=coeff)(o, y, mask)
+            loss.backward()
+            key = f"{mname}_{int(reg)}_{coeff}"
+            cases[key + ".loss"] = loss.detach()
+            cases[key + ".grad"] = o.grad
+    npz("g8_masked_l2", out=out, y=y, **{f"mask.{k}": v for k, v in masks.items()}, **cases)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    g1(); g2(); g3(); g4_g6(); g7()
+    only = sys.argv[1] if len(sys.argv) > 1 else None
+    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g6, "g7": g7, "g8": g8}
+    for name, fn in todo.items():
+        if only is None or only == name:
+            fn()

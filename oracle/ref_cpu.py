@@ -143,6 +143,19 @@ class MaskEmbdMultiMPN(nn.Module):
         return (x, inter) if return_intermediates else x
 
 
+def masked_l2_loss(output, target, mask, regularize=True, regcoeff=1):
+    """Masked_L2_loss.forward (utils/custom_loss_functions.py:30-46), the reference's default loss
+    (utils/argument_parser.py:36): mean squared error over the entries with mask != 0, plus regcoeff x the mean over the
+    entries with (1 - mask) != 0.  A mask value outside {0, 1} is in both sets; an empty set gives NaN (mean of nothing)."""
+    d2 = (output - target) ** 2
+    sel = mask != 0
+    loss = d2[sel].sum() / sel.sum()
+    if regularize:
+        rest = (1 - mask) != 0
+        loss = loss + regcoeff * (d2[rest].sum() / rest.sum())
+    return loss
+
+
 def train_step(model, data, optimizer, loss_fn=None):
     """The per-batch body of train_epoch (utils/training.py:55-77) for the default-else loss branch
     (:72): zero_grad -> forward -> loss(out, y) -> backward -> step.  Returns the loss tensor."""

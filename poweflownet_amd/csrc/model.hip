@@ -550,6 +550,82 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
 }
 
 // ---------------------------------------------------------------------------------------- utilities
+// ---- Masked_L2_loss (utils/custom_loss_functions.py:10-46): two masked means of (out - y)^2.  Kernel 1 reduces
+// (sum, count) of both sets with an ordered last-arriver combine and writes the loss and the totals; kernel 2 turns the
+// totals into the two gradient scales.
+struct MaskedL2Ws {
+    float s1[256], s0[256];
+    int c1[256], c0[256];
+    float tot_s1, tot_s0;
+    int tot_c1, tot_c0;
+    int pad_[3];
+    int counter;   // byte 4124
+};
+__device__ __forceinline__ float mask_value(const void* m, int dtype, int64_t i) {
+    return dtype == 0 ? (float)static_cast<const int64_t*>(m)[i] : static_cast<const float*>(m)[i];
+}
+__global__ __launch_bounds__(256) void masked_l2_reduce_kernel(const float* __restrict__ o, const float* __restrict__ y,
+                                                               const void* __restrict__ mask, int mask_dtype, int64_t n,
+                                                               int regularize, float regcoeff, MaskedL2Ws* __restrict__ w,
+                                                               float* __restrict__ loss) {
+    __shared__ float rs1[256], rs0[256];
+    __shared__ int rc1[256], rc0[256];
+    __shared__ int s_last;
+    float a1 = 0.f, a0 = 0.f;
+    int k1 = 0, k0 = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = o[i] - y[i], m = mask_value(mask, mask_dtype, i);
+        if (m != 0.f) { a1 = fmaf(d, d, a1); ++k1; }                 // mask.type(bool)
+        if (1.f - m != 0.f) { a0 = fmaf(d, d, a0); ++k0; }           // (1 - mask).type(bool)
+    }
+    const int t = threadIdx.x;
+    rs1[t] = a1; rs0[t] = a0; rc1[t] = k1; rc0[t] = k0;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { rs1[t] += rs1[t + off]; rs0[t] += rs0[t + off]; rc1[t] += rc1[t + off]; rc0[t] += rc0[t + off]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        w->s1[blockIdx.x] = rs1[0]; w->s0[blockIdx.x] = rs0[0]; w->c1[blockIdx.x] = rc1[0]; w->c0[blockIdx.x] = rc0[0];
+        __threadfence();
+        const int tk = __hip_atomic_fetch_add(&w->counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = tk == (int)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    const bool in = t < (int)gridDim.x;
+    rs1[t] = in ? __hip_atomic_load(&w->s1[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    rs0[t] = in ? __hip_atomic_load(&w->s0[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+    rc1[t] = in ? __hip_atomic_load(&w->c1[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    rc0[t] = in ? __hip_atomic_load(&w->c0[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { rs1[t] += rs1[t + off]; rs0[t] += rs0[t + off]; rc1[t] += rc1[t + off]; rc0[t] += rc0[t + off]; }
+        __syncthreads();
+    }
+    if (t == 0) {
+        w->tot_s1 = rs1[0]; w->tot_s0 = rs0[0]; w->tot_c1 = rc1[0]; w->tot_c0 = rc0[0];
+        float l = rs1[0] / (float)rc1[0];                            // 0/0 = NaN: torch's mean of an empty selection
+        if (regularize) l += regcoeff * (rs0[0] / (float)rc0[0]);
+        loss[0] = l;
+        w->counter = 0;
+    }
+}
+__global__ __launch_bounds__(256) void masked_l2_grad_kernel(const float* __restrict__ o, const float* __restrict__ y,
+                                                             const void* __restrict__ mask, int mask_dtype, int64_t n,
+                                                             int regularize, float regcoeff, const MaskedL2Ws* __restrict__ w,
+                                                             float* __restrict__ grad) {
+    const float g1 = 2.f / (float)w->tot_c1, g0 = regularize ? 2.f * regcoeff / (float)w->tot_c0 : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float d = o[i] - y[i], m = mask_value(mask, mask_dtype, i);
+        float g = 0.f;
+        if (m != 0.f) g += g1 * d;
+        if (regularize && 1.f - m != 0.f) g += g0 * d;
+        grad[i] = g;
+    }
+}
+
 // One launch: every block reduces its slice to a partial and takes a ticket; the last arriver sums the partials in
 // block order (not arrival order: deterministic) and re-arms the counter for the next call.
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ o, const float* __restrict__ y, int64_t n,
@@ -846,6 +922,27 @@ int pfn_mse_loss(const float* out, const float* y, int64_t count, float* loss, f
     mse_kernel<<<nb, 256, 0, s>>>(out, y, count, inv_n, grad, static_cast<float*>(ws),
                                   reinterpret_cast<int*>(static_cast<float*>(ws) + 256), loss);
     PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+int pfn_masked_l2_loss(const float* out, const float* y, const void* mask, int mask_dtype, int64_t count, int regularize,
+                       float regcoeff, float* loss, float* grad, void* ws, size_t ws_bytes, void* stream) {
+    PFN_CHECK_ARG(out && y && mask && loss && ws, "pfn_masked_l2_loss: null pointer");
+    PFN_CHECK_ARG(mask_dtype == 0 || mask_dtype == 1, "pfn_masked_l2_loss: mask_dtype must be 0 (int64) or 1 (float32)");
+    if (ws_bytes < sizeof(MaskedL2Ws)) {
+        set_error("pfn_masked_l2_loss: workspace too small (need %zu bytes)", sizeof(MaskedL2Ws));
+        return PFN_ENOSPACE;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MaskedL2Ws* w = static_cast<MaskedL2Ws*>(ws);
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 256));
+    masked_l2_reduce_kernel<<<nb, 256, 0, s>>>(out, y, mask, mask_dtype, count, regularize, regcoeff, w, loss);
+    PFN_CHECK_LAUNCH();
+    if (grad && count > 0) {
+        masked_l2_grad_kernel<<<(int)std::min<int64_t>((count + 255) / 256, 1024), 256, 0, s>>>(out, y, mask, mask_dtype, count,
+                                                                                              regularize, regcoeff, w, grad);
+        PFN_CHECK_LAUNCH();
+    }
     return PFN_OK;
 }
 

@@ -1,4 +1,5 @@
-"""`MSELoss` with forward and backward fused into one pass over (out, y) (`pfn_mse_loss`).
+"""`MSELoss` and `Masked_L2_loss` with forward and backward fused into one pass over (out, y) (`pfn_mse_loss`,
+`pfn_masked_l2_loss`).
 
 Counterpart of `torch.nn.MSELoss()` at train.py:103 as used by the else-branch of train_epoch
 (utils/training.py:72): loss = mean((out - y)^2); the gradient 2 (out - y) / numel is produced by the same
@@ -17,7 +18,8 @@ _WS = {}      # per device: (workspace with the zeroed arrival counter, the cons
 def _state(device):
     key = (device.type, device.index)
     if key not in _WS:
-        _WS[key] = (torch.zeros(264, dtype=torch.float32, device=device), torch.ones((), dtype=torch.float32, device=device))
+        _WS[key] = (torch.zeros(264, dtype=torch.float32, device=device), torch.ones((), dtype=torch.float32, device=device),
+                    torch.zeros(1032, dtype=torch.float32, device=device))
     return _WS[key]
 
 
@@ -30,7 +32,7 @@ class _MseFn(torch.autograd.Function):
             raise RuntimeError(f"MSELoss: shape mismatch {tuple(out.shape)} vs {tuple(y.shape)}")
         loss = torch.empty((), dtype=torch.float32, device=out.device)
         grad = torch.empty_like(out) if ctx.needs_input_grad[0] else None
-        ws, _ = _state(out.device)
+        ws = _state(out.device)[0]
         with torch.cuda.device(out.device):
             L.check(L.load().pfn_mse_loss(out.data_ptr(), y.data_ptr(), out.numel(), loss.data_ptr(), L.ptr(grad),
                                           ws.data_ptr(), ws.numel() * 4, L.stream_ptr()), "pfn_mse_loss")
@@ -57,3 +59,45 @@ class MSELoss(nn.Module):
         """The constant 1 on `loss`'s device.  `loss.backward(MSELoss.unit_grad(loss))` is `loss.backward()` without the
         two tiny kernels autograd spends on creating that 1 and multiplying the gradient by it."""
         return _state(loss.device)[1]
+
+
+class _MaskedL2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, out, y, mask, regularize, regcoeff):
+        L.require_device(out, y, mask, what="Masked_L2_loss input")
+        out, y = L.f32c(out, "output"), L.f32c(y, "target")
+        if out.shape != y.shape or mask.shape != out.shape:
+            raise RuntimeError(f"Masked_L2_loss: shape mismatch {tuple(out.shape)} / {tuple(y.shape)} / {tuple(mask.shape)}")
+        if mask.dtype == torch.int64:
+            code = 0
+        else:
+            mask, code = mask.to(torch.float32), 1
+        mask = mask.contiguous()
+        loss = torch.empty((), dtype=torch.float32, device=out.device)
+        grad = torch.empty_like(out) if ctx.needs_input_grad[0] else None
+        ws = _state(out.device)[2]
+        with torch.cuda.device(out.device):
+            L.check(L.load().pfn_masked_l2_loss(out.data_ptr(), y.data_ptr(), mask.data_ptr(), code, out.numel(), int(bool(regularize)),
+                                                float(regcoeff), loss.data_ptr(), L.ptr(grad), ws.data_ptr(), ws.numel() * 4,
+                                                L.stream_ptr()), "pfn_masked_l2_loss")
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        if ctx.grad is None:
+            return None, None, None, None, None
+        if gloss.data_ptr() == _state(ctx.grad.device)[1].data_ptr():
+            return ctx.grad, None, None, None, None
+        return ctx.grad * gloss, None, None, None, None
+
+
+def masked_l2_loss(output, target, mask, regularize=True, regcoeff=1):
+    """Masked_L2_loss.forward (utils/custom_loss_functions.py:30-46) on HIP tensors: loss and its gradient in two launches
+    instead of four `masked_select` compactions, two means and their autograd graph."""
+    return _MaskedL2Fn.apply(output, target, mask, regularize, regcoeff)
+
+
+def unit_grad(loss):
+    """The constant 1 on `loss`'s device: `loss.backward(unit_grad(loss))` == `loss.backward()` minus two tiny kernels."""
+    return _state(loss.device)[1]

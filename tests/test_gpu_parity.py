@@ -232,6 +232,34 @@ def test_fused_mse_loss_matches_torch():
     assert_close(g1, a.grad, 1e-6, "grad")
 
 
+def test_g8_masked_l2_loss_matches_reference_goldens():
+    """pfn_masked_l2_loss vs outputs of the reference's own Masked_L2_loss (tests/golden/g8_masked_l2.npz), through the
+    dispatching class the train loop uses; then against the oracle on a full-size input."""
+    from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss
+    fx = load("g8_masked_l2")
+    for mname in ("int", "float", "allone", "odd"):
+        for reg, coeff in ((True, 1), (True, 0.5), (False, 1)):
+            o = fx["out"].to(DEV).requires_grad_(True)
+            loss = Masked_L2_loss(regularize=reg, regcoeff=coeff)(o, fx["y"].to(DEV), fx[f"mask.{mname}"].to(DEV))
+            want = fx[f"{mname}_{int(reg)}_{coeff}.loss"]
+            if torch.isnan(want):
+                assert torch.isnan(loss).item()
+            else:
+                assert_close(loss, want, 1e-6, f"loss {mname} {reg} {coeff}")
+            loss.backward()
+            assert_close(o.grad, fx[f"{mname}_{int(reg)}_{coeff}.grad"], 1e-6, f"grad {mname} {reg} {coeff}")
+    d = make_batch("118v2", 128, seed=5)
+    out = torch.randn_like(d.y)
+    o_ref = out.clone().requires_grad_(True)
+    l_ref = ref_cpu.masked_l2_loss(o_ref, d.y, d.pred_mask, True, 1)
+    l_ref.backward()
+    o = out.to(DEV).requires_grad_(True)
+    loss = Masked_L2_loss()(o, d.y.to(DEV), d.pred_mask.to(DEV))
+    loss.backward(Masked_L2_loss.unit_grad(loss))
+    assert_close(loss, l_ref, 1e-6, "loss full size")
+    assert_close(o.grad, o_ref.grad, 1e-6, "grad full size")
+
+
 def test_g7_batch_equals_concat_of_singles():
     fx = load("g7_collate")
     m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
