@@ -13,6 +13,7 @@ Only the vectors are committed; no reference source travels.  Refuses to run wit
   G6 three AdamW training steps driven by a restatement of utils/training.py:55-77
   G7 collate fixture (analytic; PyG absent) + batch == concatenation of singles
   G8 Masked_L2_loss fwd + grad (utils/custom_loss_functions.py:10-46), the reference's default loss
+  G9 PowerFlowData: raw .npy -> split -> masks -> normalised samples (datasets/PowerFlowData.py:44-217)
 
 usage:  python oracle/make_goldens.py [g8]      (no argument: every fixture; a name: only that one)
 """
@@ -248,10 +249,57 @@ def g8():
     npz("g8_masked_l2", out=out, y=y, **{f"mask.{k}": v for k, v in masks.items()}, **cases)
 
 
+def g9():
+    """The reference's PowerFlowData, imported unmodified (torch_geometric.data / .datasets through the stand-in), run on
+    a synthetic raw directory in the reference's file format; the raw arrays travel in the fixture."""
+    import tempfile
+    import torch_geometric  # noqa: F401  (stand-in; PowerFlowData.py does `import torch_geometric`)
+    import torch_geometric.data, torch_geometric.datasets  # noqa: F401,E401
+    from datasets.PowerFlowData import PowerFlowData, denormalize
+    torch.serialization.add_safe_globals([torch_geometric.data.Data])   # torch >= 2.6 defaults torch.load to weights_only
+    rng = np.random.default_rng(9)
+    S, ei = 10, seven_node_multigraph().numpy()
+    n, e = 7, ei.shape[1]
+    node = np.zeros((S, n, 6), dtype=np.float64)
+    node[:, :, 0] = np.arange(n)
+    node[:, :, 1] = np.array([0, 1, 2, 2, 1, 2, 2])              # slack, PV, PQ ...
+    node[:, :, 2:] = rng.normal(size=(S, n, 4)) * np.array([0.05, 10.0, 50.0, 20.0]) + np.array([1.0, 0.0, 30.0, 10.0])
+    edge = np.zeros((S, e, 4), dtype=np.float64)
+    edge[:, :, 0:2] = ei.T
+    edge[:, :, 2:] = np.abs(rng.normal(size=(S, e, 2))) * 0.1 + 0.01
+    out = {"raw_node": node, "raw_edge": edge}
+    with tempfile.TemporaryDirectory() as root:
+        os.makedirs(os.path.join(root, "raw"))
+        np.save(os.path.join(root, "raw", "case7x_edge_features.npy"), edge)
+        np.save(os.path.join(root, "raw", "case7x_node_features.npy"), node)
+        sets = {}
+        for task in ("train", "val", "test"):
+            ds = PowerFlowData(root=root, case="7x", split=[.5, .2, .3], task=task, normalize=True)
+            sets[task] = ds
+            out[f"{task}.len"] = np.int64(len(ds))
+            for k in ("x", "y", "bus_type", "pred_mask", "edge_index", "edge_attr"):
+                out[f"{task}.{k}"] = torch.stack([ds[i][k] for i in range(len(ds))])
+            for k in ("xymean", "xystd", "edgemean", "edgestd"):
+                out[f"{task}.{k}"] = getattr(ds, k)
+        out["dims"] = np.array(sets["train"].get_data_dimensions())
+        ms = sets["train"].get_data_means_stds()
+        out["train.means_stds"] = torch.cat([t.reshape(-1) for t in ms])
+        # a validation set normalised with the TRAIN statistics (the keyword path of the constructor)
+        ds = PowerFlowData(root=root, case="7x", split=[.5, .2, .3], task="val", normalize=True, xymean=sets["train"].xymean,
+                           xystd=sets["train"].xystd, edgemean=sets["train"].edgemean, edgestd=sets["train"].edgestd)
+        out["val_trainstats.x"] = torch.stack([ds[i]["x"] for i in range(len(ds))])
+        out["val_trainstats.edge_attr"] = torch.stack([ds[i]["edge_attr"] for i in range(len(ds))])
+        ds = PowerFlowData(root=root, case="7x", split=[.5, .2, .3], task="test", normalize=False)
+        out["test_raw.x"] = torch.stack([ds[i]["x"] for i in range(len(ds))])
+        out["test_raw.y"] = torch.stack([ds[i]["y"] for i in range(len(ds))])
+        out["denorm.y"] = denormalize(sets["train"][0]["y"], sets["train"].xymean, sets["train"].xystd)
+    npz("g9_powerflowdata", **out)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
-    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g6, "g7": g7, "g8": g8}
+    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g6, "g7": g7, "g8": g8, "g9": g9}
     for name, fn in todo.items():
         if only is None or only == name:
             fn()

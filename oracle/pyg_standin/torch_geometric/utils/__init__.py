@@ -9,3 +9,11 @@ def degree(index, num_nodes=None, dtype=None):
     out = torch.zeros(num_nodes, dtype=dtype if dtype is not None else torch.get_default_dtype(),
                       device=index.device)
     return out.scatter_add_(0, index, torch.ones(index.numel(), dtype=out.dtype, device=index.device))
+
+
+def from_scipy_sparse_matrix(*a, **k):   # importable names only (datasets/PowerFlowData.py:12), never called on the path
+    raise NotImplementedError
+
+
+def dense_to_sparse(*a, **k):
+    raise NotImplementedError

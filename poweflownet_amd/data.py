@@ -123,4 +123,7 @@ class DataLoader:
                 idx = idx[r::w]
                 if not idx:
                     continue
-            yield Batch.from_data_list([self.dataset[i] for i in idx])
+            if hasattr(self.dataset, "collate_indices"):       # device-resident dataset: one gather per field, no host loop
+                yield self.dataset.collate_indices(idx)
+            else:
+                yield Batch.from_data_list([self.dataset[i] for i in idx])

@@ -1,4 +1,5 @@
 """Host-side mini PyG surface: collate rule (G7, analytic) and loader sharding."""
+import pytest
 import torch
 
 from oracle import ref_cpu
@@ -76,3 +77,69 @@ def test_make_batch_offsets():
     b = make_batch("14", 3)
     assert b.edge_index.shape == (2, 60) and int(b.edge_index[:, 20:40].min()) >= 14
     assert b.ptr.tolist() == [0, 14, 28, 42]
+
+
+# ------------------------------------------------------------------------------ PowerFlowData
+def _raw_dir(tmp_path, fx, case="7x"):
+    import numpy as np
+    (tmp_path / "raw").mkdir()
+    np.save(tmp_path / "raw" / f"case{case}_edge_features.npy", fx["raw_edge"].numpy())
+    np.save(tmp_path / "raw" / f"case{case}_node_features.npy", fx["raw_node"].numpy())
+    return str(tmp_path)
+
+
+def test_g9_powerflowdata_matches_reference_class(tmp_path):
+    """Every per-sample field, the statistics and the keyword paths of the constructor against what the reference's own
+    PowerFlowData produced from the same raw files (tests/golden/g9_powerflowdata.npz)."""
+    from poweflownet_amd.datasets import PowerFlowData, denormalize
+    fx = load("g9_powerflowdata")
+    root = _raw_dir(tmp_path, fx)
+    sets = {}
+    for task in ("train", "val", "test"):
+        ds = PowerFlowData(root=root, case="7x", split=[.5, .2, .3], task=task, normalize=True)
+        sets[task] = ds
+        assert len(ds) == int(fx[f"{task}.len"])
+        for k in ("x", "y", "edge_attr"):
+            got = torch.stack([getattr(ds[i], k) for i in range(len(ds))])
+            assert_close(got, fx[f"{task}.{k}"], 1e-6, f"{task}.{k}")
+        for k in ("bus_type", "pred_mask", "edge_index"):
+            got = torch.stack([getattr(ds[i], k) for i in range(len(ds))])
+            assert torch.equal(got, fx[f"{task}.{k}"]), f"{task}.{k}"
+        for k in ("xymean", "xystd", "edgemean", "edgestd"):
+            assert_close(getattr(ds, k), fx[f"{task}.{k}"], 1e-6, f"{task}.{k}")
+    assert list(sets["train"].get_data_dimensions()) == fx["dims"].tolist()
+    assert_close(torch.cat([t.reshape(-1) for t in sets["train"].get_data_means_stds()]), fx["train.means_stds"], 1e-6, "means_stds")
+    tr = sets["train"]
+    ds = PowerFlowData(root=root, case="7x", split=[.5, .2, .3], task="val", xymean=tr.xymean, xystd=tr.xystd,
+                       edgemean=tr.edgemean, edgestd=tr.edgestd)
+    assert_close(torch.stack([ds[i].x for i in range(len(ds))]), fx["val_trainstats.x"], 1e-6, "val with train stats")
+    assert_close(torch.stack([ds[i].edge_attr for i in range(len(ds))]), fx["val_trainstats.edge_attr"], 1e-6, "val ea")
+    ds = PowerFlowData(root=root, case="7x", split=[.5, .2, .3], task="test", normalize=False)
+    assert_close(torch.stack([ds[i].x for i in range(len(ds))]), fx["test_raw.x"], 1e-7, "raw x")
+    assert_close(torch.stack([ds[i].y for i in range(len(ds))]), fx["test_raw.y"], 1e-7, "raw y")
+    assert_close(denormalize(tr[0].y, tr.xymean, tr.xystd), fx["denorm.y"], 1e-6, "denormalize")
+    with pytest.raises(RuntimeError):       # fractions that do not cover the samples: torch.split refuses, as in the reference
+        PowerFlowData(root=root, case="7x", split=[.5, .2, .2], task="train")
+
+
+def test_powerflowdata_device_batches_equal_per_sample_collate(tmp_path):
+    from poweflownet_amd.data import Batch, DataLoader
+    from poweflownet_amd.datasets import PowerFlowData, random_bus_type
+    fx = load("g9_powerflowdata")
+    ds = PowerFlowData(root=_raw_dir(tmp_path, fx), case="7x", split=[.5, .2, .3], task="train")
+    batches = list(DataLoader(ds, batch_size=2, shuffle=False))
+    assert len(batches) == 3 and batches[-1].num_graphs == 1
+    for bi, b in enumerate(batches):
+        want = Batch.from_data_list([ds[i] for i in range(2 * bi, min(2 * bi + 2, len(ds)))])
+        for k in ("x", "y", "bus_type", "pred_mask", "edge_index", "edge_attr", "batch", "ptr"):
+            assert torch.equal(getattr(b, k), getattr(want, k)), k
+    assert batches[0].edge_index is batches[1].edge_index          # static topology: one cached tensor per batch size
+    # a transform switches to the per-sample path and is applied
+    (tmp_path / "t").mkdir()
+    ds_t = PowerFlowData(root=_raw_dir(tmp_path / "t", fx), case="7x", split=[.5, .2, .3], task="train", transform=random_bus_type)
+    b = next(iter(DataLoader(ds_t, batch_size=5)))
+    assert int(b.bus_type.max()) <= 1 and b.x.shape == (35, 4)
+    # rank sharding of a global batch
+    shards = [next(iter(DataLoader(ds, batch_size=4, shard=(r, 2)))) for r in range(2)]
+    assert torch.equal(shards[0].x, Batch.from_data_list([ds[0], ds[2]]).x)
+    assert torch.equal(shards[1].x, Batch.from_data_list([ds[1], ds[3]]).x)

@@ -260,6 +260,43 @@ def test_g8_masked_l2_loss_matches_reference_goldens():
     assert_close(o.grad, o_ref.grad, 1e-6, "grad full size")
 
 
+def test_powerflowdata_on_device_feeds_the_model(tmp_path):
+    """A split resident on the GPU: batches assembled there equal the host collate of the same samples, the model output is
+    identical, and equal-size batches reuse one cached edge_index (topology cache hit: no graph rebuild)."""
+    import numpy as np
+    from poweflownet_amd.data import Batch, DataLoader
+    from poweflownet_amd.datasets import PowerFlowData
+    from poweflownet_amd.synth import make_topology
+    rng = np.random.default_rng(4)
+    S, n = 12, 118
+    ei = make_topology(118, 186).numpy()
+    e = ei.shape[1]
+    node = np.zeros((S, n, 6))
+    node[:, :, 0] = np.arange(n)
+    node[:, :, 1] = np.where(np.arange(n) == 0, 0, np.where(np.arange(n) % 3 == 0, 1, 2))
+    node[:, :, 2:] = rng.normal(size=(S, n, 4))
+    edge = np.zeros((S, e, 4))
+    edge[:, :, :2] = ei.T
+    edge[:, :, 2:] = np.abs(rng.normal(size=(S, e, 2)))
+    (tmp_path / "raw").mkdir()
+    np.save(tmp_path / "raw" / "case118v2_edge_features.npy", edge)
+    np.save(tmp_path / "raw" / "case118v2_node_features.npy", node)
+    host = PowerFlowData(root=str(tmp_path), case="118v2", split=[.5, .25, .25], task="train")
+    dev = PowerFlowData(root=str(tmp_path), case="118v2", split=[.5, .25, .25], task="train", device=DEV)
+    assert len(dev) == 6 and dev.device.type == "cuda"
+    torch.manual_seed(0)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).to(DEV).eval()
+    seen = []
+    for bi, b in enumerate(DataLoader(dev, batch_size=3)):
+        want = Batch.from_data_list([host[i] for i in range(3 * bi, 3 * bi + 3)])
+        for k in ("x", "y", "pred_mask", "edge_index", "edge_attr", "ptr"):
+            assert torch.equal(getattr(b, k).cpu(), getattr(want, k)), k
+        out = m(b)
+        assert_close(out, m(want.to(DEV)), 1e-6, "device batch vs host batch")
+        seen.append(b.edge_index)
+    assert seen[0] is seen[1]
+
+
 def test_g7_batch_equals_concat_of_singles():
     fx = load("g7_collate")
     m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)

@@ -2,8 +2,10 @@
 """Training entry counterpart of the reference's train.py (same CLI: `python3 train.py --cfg_json configs/standard.json
 --case 118v2 --model MaskEmbdMultiMPN --train_loss_fn mse_loss --batch-size 128 --lr 0.001 --num-epochs N`).
 
-Differences forced by the image: no dataset files and no pandapower -> samples are synthetic grids with the tensor
-layout of datasets/PowerFlowData.py (poweflownet_amd/synth.py); no wandb.  Like the reference, the three model
+Data: when `<data-dir>/raw/case<case>_{node,edge}_features.npy` exist they are loaded by the device-resident
+`PowerFlowData` (same splits, masks and normalisation as datasets/PowerFlowData.py; batches are assembled on the GPU);
+otherwise (this image ships no dataset files and no pandapower) samples are synthetic grids with the same tensor layout
+(poweflownet_amd/synth.py).  No wandb.  Like the reference, the three model
 dims come from the data (4/2/4), not from the JSON (train.py:106-117).  Under torchrun every rank trains on its shard of
 each global batch and gradients are averaged with one flat all-reduce (poweflownet_amd/dp.py)."""
 import os
@@ -14,6 +16,7 @@ import torch
 
 from poweflownet_amd import dp
 from poweflownet_amd.data import DataLoader
+from poweflownet_amd.datasets import PowerFlowData, random_bus_type
 from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
 from poweflownet_amd.optim import FlatAdamW
 from poweflownet_amd.synth import make_dataset
@@ -33,10 +36,19 @@ def main():
     device = torch.device("cuda", local_rank)
     torch.manual_seed(1234)
     np.random.seed(1234)
-    n = args.synthetic_samples
-    full = make_dataset(args.case, n, seed=0)
-    n_tr, n_va = int(0.5 * n), int(0.2 * n)                      # split [.5, .2, .3] (train.py:76)
-    trainset, valset = full[:n_tr], full[n_tr:n_tr + n_va]
+    raw = os.path.join(args.data_dir, "raw", f"case{args.case}_node_features.npy")
+    if os.path.exists(raw):                                       # the reference's own files (train.py:76-79)
+        # (the reference applies transform=random_bus_type to the train split; the model never reads bus_type, and
+        #  without the per-sample transform the batches are assembled on the device)
+        trainset = PowerFlowData(root=args.data_dir, case=args.case, split=[.5, .2, .3], task="train",
+                                 normalize=not args.disable_normalize, device=device)
+        valset = PowerFlowData(root=args.data_dir, case=args.case, split=[.5, .2, .3], task="val",
+                               normalize=not args.disable_normalize, device=device)
+    else:
+        n = args.synthetic_samples
+        full = make_dataset(args.case, n, seed=0)
+        n_tr, n_va = int(0.5 * n), int(0.2 * n)                  # split [.5, .2, .3] (train.py:76)
+        trainset, valset = full[:n_tr], full[n_tr:n_tr + n_va]
     shard = (rank, world) if world > 1 else None
     train_loader = DataLoader(trainset, batch_size=args.batch_size * world, shuffle=True,
                               generator=torch.Generator().manual_seed(1234), shard=shard)
