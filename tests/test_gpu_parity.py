@@ -297,6 +297,52 @@ def test_powerflowdata_on_device_feeds_the_model(tmp_path):
     assert seen[0] is seen[1]
 
 
+def test_graphed_train_step_equals_eager_training(tmp_path):
+    """train_epoch with a GraphedTrainStep (one hipGraph replay per batch, eager for the short last batch, re-capture
+    after a learning-rate change) leaves the same parameters and returns the same epoch loss as the eager loop."""
+    import numpy as np
+    from poweflownet_amd.data import DataLoader
+    from poweflownet_amd.datasets import PowerFlowData
+    from poweflownet_amd.optim import FlatAdamW
+    from poweflownet_amd.synth import make_topology
+    from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss
+    from poweflownet_amd.utils.training import GraphedTrainStep, train_epoch
+    rng = np.random.default_rng(11)
+    S, n = 44, 14
+    ei = make_topology(14, 20).numpy()
+    node = np.zeros((S, n, 6))
+    node[:, :, 1] = np.where(np.arange(n) == 0, 0, np.where(np.arange(n) % 3 == 0, 1, 2))
+    node[:, :, 2:] = rng.normal(size=(S, n, 4))
+    edge = np.zeros((S, 20, 4))
+    edge[:, :, :2] = ei.T
+    edge[:, :, 2:] = np.abs(rng.normal(size=(S, 20, 2)))
+    (tmp_path / "raw").mkdir()
+    np.save(tmp_path / "raw" / "case14_edge_features.npy", edge)
+    np.save(tmp_path / "raw" / "case14_node_features.npy", node)
+    ds = PowerFlowData(root=str(tmp_path), case="14", split=[.5, .25, .25], task="train", device=DEV)   # 22 samples
+
+    def run(graphed):
+        torch.manual_seed(5)
+        m = MaskEmbdMultiMPN(4, 2, 4, 32, 3, 2, 0.0).to(DEV)
+        opt = FlatAdamW(m, lr=1e-3)
+        loss_fn = Masked_L2_loss()
+        g = GraphedTrainStep(m, loss_fn, opt) if graphed else None
+        losses = []
+        for epoch in range(3):
+            loader = DataLoader(ds, batch_size=8, shuffle=True, generator=torch.Generator().manual_seed(epoch))   # 8 + 8 + 6
+            losses.append(train_epoch(m, loader, loss_fn, opt, DEV, graph=g))
+            if epoch == 1:
+                opt.param_groups[0]["lr"] = 5e-4                                   # what a scheduler does between epochs
+        return losses, [p.detach().clone() for p in m.parameters()]
+
+    l_e, p_e = run(False)
+    l_g, p_g = run(True)
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (l_e, l_g)
+    for a, b in zip(p_e, p_g):
+        assert_close(b, a, 1e-6, "parameters after 3 epochs")
+
+
 def test_g7_batch_equals_concat_of_singles():
     fx = load("g7_collate")
     m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)

@@ -23,7 +23,7 @@ from poweflownet_amd.synth import make_dataset
 from poweflownet_amd.utils.argument_parser import argument_parser
 from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss
 from poweflownet_amd.utils.evaluation import evaluate_epoch
-from poweflownet_amd.utils.training import append_to_json, train_epoch
+from poweflownet_amd.utils.training import GraphedTrainStep, append_to_json, train_epoch
 
 
 def main():
@@ -56,7 +56,8 @@ def main():
     if args.train_loss_fn == "masked_l2":
         loss_fn = Masked_L2_loss(regularize=args.regularize, regcoeff=args.regularization_coeff)
     elif args.train_loss_fn == "mse_loss":
-        loss_fn = torch.nn.MSELoss()
+        from poweflownet_amd.loss import MSELoss
+        loss_fn = MSELoss()                                       # torch.nn.MSELoss semantics (train.py:103), one kernel
     else:
         raise SystemExit(f"--train_loss_fn {args.train_loss_fn} is out of this round's scope (SURVEY.md 8f N4)")
     eval_loss_fn = Masked_L2_loss(regularize=False)
@@ -70,14 +71,16 @@ def main():
                                                     epochs=args.num_epochs)
     run_id = time.strftime("%Y%m%d-%H%M%S")
     best_val = float("inf")
+    graphed = GraphedTrainStep(model, loss_fn, optimizer) if world == 1 else None   # one hipGraph launch per batch
     for epoch in range(args.num_epochs):
         t0 = time.time()
-        train_loss = train_epoch(model, train_loader, loss_fn, optimizer, device)
+        train_loss = train_epoch(model, train_loader, loss_fn, optimizer, device, graph=graphed)
+        t_train = time.time() - t0
         val_loss = evaluate_epoch(model, val_loader, eval_loss_fn, device)
         scheduler.step()                                          # once per epoch, like train.py:145
         if rank == 0:
             print(f"Epoch {epoch + 1} / {args.num_epochs}, train={train_loss:.4f}, val={val_loss:.4f}, "
-                  f"{len(trainset) / max(time.time() - t0, 1e-9):.0f} graphs/s")
+                  f"{len(trainset) / max(t_train, 1e-9):.0f} train graphs/s")
             if args.save and val_loss < best_val:
                 best_val = val_loss
                 os.makedirs("models", exist_ok=True)
