@@ -160,6 +160,16 @@ int pfn_mse_loss(const float* out, const float* y, int64_t count, float* loss, f
 int pfn_masked_l2_loss(const float* out, const float* y, const void* mask, int mask_dtype, int64_t count,
                        int regularize, float regcoeff, float* loss, float* grad, void* ws, size_t ws_bytes,
                        void* stream);
+/* PowerImbalance(x, edge_index, edge_attr) forward+backward (utils/custom_loss_functions.py:99-286; --train_loss_fn
+ * power_imbalance, train.py:95-97; dispatch utils/training.py:63-67).  `graph_ws`: the adjacency pfn_graph_build made from
+ * the SAME stored-once edge_index with mode -1 (the class undirects by the model's rule, :136-157).  x [N, 4] =
+ * normalised (Vm, Va deg, P, Q), edge_attr [e_stored, 2] = normalised (r, x), stats = 12 host floats
+ * {xymean[4], xystd[4], edgemean[2], edgestd[2]} (de-normalisation x * std + mean, :127-132).
+ *   loss[0] = mean_i (dP_i^2 + dQ_i^2),  grad_x [N, 4] = d loss / d x (NULL to skip).
+ * dpq: scratch [N, 2] floats.  `ws`: >= 1280 bytes whose int32 at byte 1024 is an arrival counter that must be ZERO before
+ * the first call and is left zero by every call.                                                                       */
+int pfn_power_imbalance(const void* graph_ws, int64_t n_nodes, int64_t e_stored, const float* x, const float* edge_attr,
+                        const float* stats, float* loss, float* grad_x, float* dpq, void* ws, size_t ws_bytes, void* stream);
 /* AdamW on one flat buffer (train.py:123; torch defaults betas (0.9,0.999), eps 1e-8, wd 0.01).
  * `step` is a device int64[2] {completed steps, arrival scratch (zero)}; the call increments step[0] itself,
  * so one launch per update and the whole step stays hipGraph-replayable.                           */

@@ -14,6 +14,7 @@ Only the vectors are committed; no reference source travels.  Refuses to run wit
   G7 collate fixture (analytic; PyG absent) + batch == concatenation of singles
   G8 Masked_L2_loss fwd + grad (utils/custom_loss_functions.py:10-46), the reference's default loss
   G9 PowerFlowData: raw .npy -> split -> masks -> normalised samples (datasets/PowerFlowData.py:44-217)
+  G10 PowerImbalance / MixedMSEPoweImbalance fwd + grad (utils/custom_loss_functions.py:99-306)
 
 usage:  python oracle/make_goldens.py [g8]      (no argument: every fixture; a name: only that one)
 """
@@ -249,6 +250,39 @@ def g8():
     npz("g8_masked_l2", out=out, y=y, **{f"mask.{k}": v for k, v in masks.items()}, **cases)
 
 
+def g10():
+    """The physics losses of the reference, imported unmodified (MessagePassing with flow='target_to_source' through the
+    stand-in)."""
+    import types
+    if "torchvision" not in sys.modules:
+        tv = types.ModuleType("torchvision")
+        tv.datasets = types.ModuleType("torchvision.datasets")
+        tv.transforms = types.ModuleType("torchvision.transforms")
+        sys.modules.update({"torchvision": tv, "torchvision.datasets": tv.datasets, "torchvision.transforms": tv.transforms})
+    from utils.custom_loss_functions import MixedMSEPoweImbalance, PowerImbalance  # the reference
+    torch.manual_seed(10)
+    ei = seven_node_multigraph()
+    n, e = 7, ei.shape[1]
+    xymean = torch.tensor([[1.0, -3.0, 20.0, 8.0]])
+    xystd = torch.tensor([[0.05, 9.0, 40.0, 15.0]])
+    edgemean = torch.tensor([[0.04, 0.15]])
+    edgestd = torch.tensor([[0.02, 0.08]])
+    x, y = torch.randn(n, 4), torch.randn(n, 4)
+    ea = torch.randn(e, 2) * 0.5
+    out = dict(edge_index=ei, edge_index_sym=bidir(ei), x=x, y=y, edge_attr=ea, edge_attr_sym=torch.cat([ea, ea]),
+               xymean=xymean, xystd=xystd, edgemean=edgemean, edgestd=edgestd)
+    for tag, (eidx, eattr) in {"dir": (ei, ea), "sym": (bidir(ei), torch.cat([ea, ea]))}.items():
+        xx = x.clone().requires_grad_(True)
+        loss = PowerImbalance(xymean, xystd, edgemean, edgestd)(xx, eidx, eattr)
+        loss.backward()
+        out[f"pi_{tag}.loss"], out[f"pi_{tag}.grad"] = loss.detach(), xx.grad
+        xx = x.clone().requires_grad_(True)
+        loss = MixedMSEPoweImbalance(xymean, xystd, edgemean, edgestd, alpha=0.9)(xx, eidx, eattr, y)
+        loss.backward()
+        out[f"mix_{tag}.loss"], out[f"mix_{tag}.grad"] = loss.detach(), xx.grad
+    npz("g10_power_imbalance", **out)
+
+
 def g9():
     """The reference's PowerFlowData, imported unmodified (torch_geometric.data / .datasets through the stand-in), run on
     a synthetic raw directory in the reference's file format; the raw arrays travel in the fixture."""
@@ -299,7 +333,7 @@ def g9():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
-    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g6, "g7": g7, "g8": g8, "g9": g9}
+    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
     for name, fn in todo.items():
         if only is None or only == name:
             fn()

@@ -12,9 +12,9 @@ import torch.nn as nn
 
 
 class MessagePassing(nn.Module):
-    """flow='source_to_target': *_j <- edge_index[0] (source), *_i <- edge_index[1] (target);
-    messages are summed onto edge_index[1]; kwargs that message() does not name are dropped;
-    update() is the identity."""
+    """flow='source_to_target': *_j <- edge_index[0] (source), *_i <- edge_index[1] (target), messages are summed onto
+    edge_index[1]; flow='target_to_source' swaps the roles (*_i <- edge_index[0], summed onto edge_index[0]).  kwargs that
+    message() does not name are dropped; update() gets the aggregate plus the kwargs it names (default: identity)."""
 
     def __init__(self, aggr='add', flow='source_to_target', node_dim=-2, **kwargs):
         super().__init__()
@@ -46,7 +46,10 @@ class MessagePassing(nn.Module):
         msg = self.message(**margs)
         out = torch.zeros((num_nodes,) + tuple(msg.shape[1:]), dtype=msg.dtype, device=msg.device)
         out = out.index_add(0, edge_index[i], msg)
-        return self.update(out)
+        # PyG hands update() the propagate kwargs its signature names (PowerImbalance.update(aggregated, x),
+        # utils/custom_loss_functions.py:229)
+        uargs = {name: kwargs[name] for name in list(inspect.signature(self.update).parameters)[1:] if name in kwargs}
+        return self.update(out, **uargs)
 
     def message(self, x_j):
         return x_j

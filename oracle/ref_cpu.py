@@ -156,6 +156,36 @@ def masked_l2_loss(output, target, mask, regularize=True, regcoeff=1):
     return loss
 
 
+def power_imbalance(x, edge_index, edge_attr, xymean, xystd, edgemean, edgestd):
+    """PowerImbalance.forward (utils/custom_loss_functions.py:248-281) with its message (:159-228) and update (:229-246):
+    undirect a stored-once list, de-normalise (x * std + mean, no epsilon, :127-132), then with flow='target_to_source'
+    (i = edge_index[0], j = edge_index[1], aggregation onto i):
+        e = Vm cos(Va pi/180), f = Vm sin(Va pi/180), g = r / (r^2 + x^2), b = -x / (r^2 + x^2)
+        Pji = g (e_i e_j - e_i^2 + f_i f_j - f_i^2) + b (f_i e_j - e_i f_j)
+        Qji = g (f_i e_j - e_i f_j) + b (-e_i e_j + e_i^2 - f_i f_j + f_i^2)
+        dP_i = P_i - sum_j Pji,  dQ_i = Q_i - sum_j Qji,  loss = mean_i (dP_i^2 + dQ_i^2)."""
+    edge_index, edge_attr = undirect_graph(edge_index, edge_attr)
+    xd = x * xystd.to(x.dtype) + xymean.to(x.dtype)
+    ed = edge_attr * edgestd.to(x.dtype) + edgemean.to(x.dtype)
+    i, j = edge_index[0], edge_index[1]
+    r, xx = ed[:, 0], ed[:, 1]
+    g, b = r / (r ** 2 + xx ** 2), -xx / (r ** 2 + xx ** 2)
+    vm, va = xd[:, 0], xd[:, 1] * (torch.pi / 180.0)
+    e, f = vm * torch.cos(va), vm * torch.sin(va)
+    ei_, fi_, ej_, fj_ = e[i], f[i], e[j], f[j]
+    pji = g * (ei_ * ej_ - ei_ ** 2 + fi_ * fj_ - fi_ ** 2) + b * (fi_ * ej_ - ei_ * fj_)
+    qji = g * (fi_ * ej_ - ei_ * fj_) + b * (-ei_ * ej_ + ei_ ** 2 - fi_ * fj_ + fi_ ** 2)
+    agg = torch.zeros(x.shape[0], 2, dtype=x.dtype).index_add(0, i, torch.stack([pji, qji], dim=1))
+    dpq = xd[:, 2:4] - agg
+    return dpq.square().sum(dim=-1).mean()
+
+
+def mixed_mse_power_imbalance(x, edge_index, edge_attr, y, xymean, xystd, edgemean, edgestd, alpha=0.5):
+    """MixedMSEPoweImbalance.forward (:300-306): alpha * MSE(x, y) + (1 - alpha) * 0.020 * power_imbalance."""
+    return alpha * F.mse_loss(x, y) + (1 - alpha) * 0.020 * power_imbalance(x, edge_index, edge_attr, xymean, xystd, edgemean,
+                                                                           edgestd)
+
+
 def train_step(model, data, optimizer, loss_fn=None):
     """The per-batch body of train_epoch (utils/training.py:55-77) for the default-else loss branch
     (:72): zero_grad -> forward -> loss(out, y) -> backward -> step.  Returns the loss tensor."""

@@ -21,7 +21,7 @@ SYMBOLS = (
     "pfn_mpn_num_params", "pfn_mpn_workspace_bytes", "pfn_mpn_forward", "pfn_mpn_backward",
     "pfn_edge_aggr_workspace_bytes", "pfn_edge_aggr_forward", "pfn_edge_aggr_backward",
     "pfn_tag_conv_workspace_bytes", "pfn_tag_conv_forward", "pfn_tag_conv_backward",
-    "pfn_scatter_add", "pfn_pad_rows", "pfn_mse_loss", "pfn_masked_l2_loss", "pfn_adamw_step",
+    "pfn_scatter_add", "pfn_pad_rows", "pfn_mse_loss", "pfn_masked_l2_loss", "pfn_power_imbalance", "pfn_adamw_step",
     "pfn_profile_enable", "pfn_profile_report",
 )
 
@@ -72,6 +72,7 @@ def load() -> C.CDLL:
         "pfn_pad_rows": (C.c_int, [p, i64, p, i64, i64, i64, p]),
         "pfn_mse_loss": (C.c_int, [p, p, i64, p, p, p, sz, p]),
         "pfn_masked_l2_loss": (C.c_int, [p, p, p, C.c_int, i64, C.c_int, C.c_float, p, p, p, sz, p]),
+        "pfn_power_imbalance": (C.c_int, [p, i64, i64, p, p, p, p, p, p, p, sz, p]),
         "pfn_adamw_step": (C.c_int, [p, p, p, p, i64, f32, f32, f32, f32, f32, p, p]),
         "pfn_profile_enable": (C.c_int, [i32]),
         "pfn_profile_report": (C.c_int, [C.c_char_p, sz, i32]),

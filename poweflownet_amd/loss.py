@@ -19,7 +19,7 @@ def _state(device):
     key = (device.type, device.index)
     if key not in _WS:
         _WS[key] = (torch.zeros(264, dtype=torch.float32, device=device), torch.ones((), dtype=torch.float32, device=device),
-                    torch.zeros(1032, dtype=torch.float32, device=device))
+                    torch.zeros(1032, dtype=torch.float32, device=device), torch.zeros(320, dtype=torch.float32, device=device))
     return _WS[key]
 
 
@@ -101,3 +101,39 @@ def masked_l2_loss(output, target, mask, regularize=True, regcoeff=1):
 def unit_grad(loss):
     """The constant 1 on `loss`'s device: `loss.backward(unit_grad(loss))` == `loss.backward()` minus two tiny kernels."""
     return _state(loss.device)[1]
+
+
+class _PowerImbalanceFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, graph, edge_attr, stats):
+        L.require_device(x, edge_attr, what="PowerImbalance input")
+        x, edge_attr = L.f32c(x, "x"), L.f32c(edge_attr, "edge_attr")
+        n = x.shape[0]
+        if x.dim() != 2 or x.shape[1] != 4 or edge_attr.shape != (graph.e_stored, 2) or graph.num_nodes != n:
+            raise RuntimeError(f"PowerImbalance: x must be (N, 4) and edge_attr (E, 2); got {tuple(x.shape)}, {tuple(edge_attr.shape)}")
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dpq = torch.empty(max(n, 1), 2, dtype=torch.float32, device=x.device)
+        ws = _state(x.device)[3]
+        import ctypes as C
+        st = (C.c_float * 12)(*stats)
+        with torch.cuda.device(x.device):
+            L.check(L.load().pfn_power_imbalance(graph.ws.data_ptr(), n, graph.e_stored, x.data_ptr(), edge_attr.data_ptr(), st,
+                                                 loss.data_ptr(), L.ptr(grad), dpq.data_ptr(), ws.data_ptr(), ws.numel() * 4,
+                                                 L.stream_ptr()), "pfn_power_imbalance")
+        ctx.grad = grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        if ctx.grad is None:
+            return None, None, None, None
+        if gloss.data_ptr() == _state(ctx.grad.device)[1].data_ptr():
+            return ctx.grad, None, None, None
+        return ctx.grad * gloss, None, None, None
+
+
+def power_imbalance(x, graph, edge_attr, stats):
+    """PowerImbalance.forward on HIP tensors; `graph` = the GraphCSR of the stored-once edge_index (mode -1), `stats` = 12
+    floats {xymean[4], xystd[4], edgemean[2], edgestd[2]}."""
+    return _PowerImbalanceFn.apply(x, graph, edge_attr, stats)

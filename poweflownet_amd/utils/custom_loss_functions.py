@@ -2,9 +2,8 @@
 
 `Masked_L2_loss` (:10-46) is the reference's default loss (utils/argument_parser.py:36-39): two masked MSE means over
 (N, 4).  On HIP tensors it is `pfn_masked_l2_loss` (loss + gradient in two launches); on host tensors
-(metrics on the CPU) plain torch ops.  The physics losses
-(`PowerImbalance`, `MixedMSEPoweImbalance`, :99-306) are row N4 of SURVEY.md 8(f) -- outside the hot path of this
-round -- and exist here only as named placeholders so that `isinstance` dispatch keeps the reference's order.
+(metrics on the CPU) plain torch ops.  The physics losses (`PowerImbalance`, `MixedMSEPoweImbalance`, :99-306; SURVEY.md
+8f row N4) run as `pfn_power_imbalance` (csrc/physics.hip).
 """
 import torch
 import torch.nn as nn
@@ -37,14 +36,54 @@ class Masked_L2_loss(nn.Module):
 
 
 class PowerImbalance(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """Power-imbalance loss (reference :99-286): mean over buses of dP^2 + dQ^2, where dP/dQ are the mismatch between the
+    predicted injections and the branch flows implied by the predicted voltages.  Same constructor and forward signature
+    as the reference class; on HIP tensors the two CSR walks of `pfn_power_imbalance` (csrc/physics.hip; SURVEY.md 8f row
+    N4), the adjacency cached per `edge_index` tensor like the model's."""
+    base_sn = 100        # kva
+    base_voltage = 345   # kv
+    base_ohm = 1190.25   # v**2/sn
+
+    def __init__(self, xymean, xystd, edgemean, edgestd, reduction="mean"):
         super().__init__()
-        raise NotImplementedError("PowerImbalance (utils/custom_loss_functions.py:99-286) is out of this round's scope "
-                                  "(SURVEY.md 8f, row N4)")
+        self.xymean = xymean[0:1] if xymean.shape[0] > 1 else xymean
+        self.xystd = xystd[0:1] if xystd.shape[0] > 1 else xystd
+        self.edgemean, self.edgestd = edgemean, edgestd
+        self._stats = None
+        self._graphs = None
+
+    def forward(self, x, edge_index, edge_attr):
+        if not x.is_cuda:
+            raise RuntimeError("PowerImbalance: there is no CPU path (move the tensors to the HIP device)")
+        from ..loss import power_imbalance
+        from ..networks.MPN import _GraphCache
+        if self._stats is None:      # 12 host floats, read once (the statistics are constants of the dataset)
+            self._stats = [float(v) for t in (self.xymean, self.xystd, self.edgemean, self.edgestd) for v in t.reshape(-1).tolist()]
+            if len(self._stats) != 12:
+                raise RuntimeError("PowerImbalance: expected 4 node and 2 branch statistics")
+        if self._graphs is None:
+            self._graphs = _GraphCache()
+        graph = self._graphs.get(edge_index, x.shape[0], -1)
+        return power_imbalance(x, graph, edge_attr, self._stats)
+
+    @staticmethod
+    def unit_grad(loss):
+        from ..loss import unit_grad
+        return unit_grad(loss)
 
 
 class MixedMSEPoweImbalance(nn.Module):
-    def __init__(self, *args, **kwargs):
+    """alpha * MSE(x, y) + (1 - alpha) * 0.020 * PowerImbalance(x) (reference :289-306)."""
+
+    def __init__(self, xymean, xystd, edgemean, edgestd, alpha=0.5, reduction="mean"):
         super().__init__()
-        raise NotImplementedError("MixedMSEPoweImbalance (utils/custom_loss_functions.py:289-306) is out of this round's "
-                                  "scope (SURVEY.md 8f, row N4)")
+        assert alpha <= 1. and alpha >= 0
+        from ..loss import MSELoss
+        self.power_imbalance = PowerImbalance(xymean, xystd, edgemean, edgestd, reduction)
+        self.mse_loss_fn = MSELoss()
+        self.alpha = alpha
+
+    def forward(self, x, edge_index, edge_attr, y):
+        power_imb_loss = self.power_imbalance(x, edge_index, edge_attr)
+        mse_loss = self.mse_loss_fn(x, y)
+        return self.alpha * mse_loss + (1 - self.alpha) * 0.020 * power_imb_loss

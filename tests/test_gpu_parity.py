@@ -343,6 +343,38 @@ def test_graphed_train_step_equals_eager_training(tmp_path):
         assert_close(b, a, 1e-6, "parameters after 3 epochs")
 
 
+def test_g10_power_imbalance_matches_reference_goldens():
+    """pfn_power_imbalance vs outputs of the reference's own PowerImbalance / MixedMSEPoweImbalance (stored-once and
+    already-symmetric edge lists), then against the oracle on a case118 batch."""
+    from poweflownet_amd.utils.custom_loss_functions import MixedMSEPoweImbalance, PowerImbalance
+    fx = load("g10_power_imbalance")
+    st = (fx["xymean"], fx["xystd"], fx["edgemean"], fx["edgestd"])
+    for tag, (ei, ea) in {"dir": (fx["edge_index"], fx["edge_attr"]), "sym": (fx["edge_index_sym"], fx["edge_attr_sym"])}.items():
+        x = fx["x"].to(DEV).requires_grad_(True)
+        loss = PowerImbalance(*st)(x, ei.to(DEV), ea.to(DEV))
+        loss.backward()
+        assert_close(loss, fx[f"pi_{tag}.loss"], RTOL, f"pi {tag} loss")
+        assert_close(x.grad, fx[f"pi_{tag}.grad"], RTOL, f"pi {tag} grad")
+        x = fx["x"].to(DEV).requires_grad_(True)
+        loss = MixedMSEPoweImbalance(*st, alpha=0.9)(x, ei.to(DEV), ea.to(DEV), fx["y"].to(DEV))
+        loss.backward()
+        assert_close(loss, fx[f"mix_{tag}.loss"], RTOL, f"mix {tag} loss")
+        assert_close(x.grad, fx[f"mix_{tag}.grad"], RTOL, f"mix {tag} grad")
+    d = make_batch("118v2", 32, seed=2)
+    stats = (torch.tensor([[1.0, -5.0, 25.0, 9.0]]), torch.tensor([[0.04, 12.0, 35.0, 14.0]]),
+             torch.tensor([[0.05, 0.2]]), torch.tensor([[0.01, 0.05]]))
+    ea = d.edge_attr.clamp(-3, 3)
+    x_ref = d.x.clone().requires_grad_(True)
+    l_ref = ref_cpu.power_imbalance(x_ref, d.edge_index, ea, *stats)
+    l_ref.backward()
+    x = d.x.to(DEV).requires_grad_(True)
+    loss_fn = PowerImbalance(*stats)
+    loss = loss_fn(x, d.edge_index.to(DEV), ea.to(DEV))
+    loss.backward(PowerImbalance.unit_grad(loss))
+    assert_close(loss, l_ref, RTOL, "loss, case118 x 32")
+    assert_close(x.grad, x_ref.grad, 2 * RTOL, "grad, case118 x 32")
+
+
 def test_g7_batch_equals_concat_of_singles():
     fx = load("g7_collate")
     m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)

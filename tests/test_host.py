@@ -35,8 +35,10 @@ def test_masked_l2_loss_matches_definition():
     want = ((out - y)[m] ** 2).mean() + 0.5 * ((out - y)[~m] ** 2).mean()
     assert torch.allclose(Masked_L2_loss(regularize=True, regcoeff=0.5)(out, y, mask), want)
     assert torch.allclose(Masked_L2_loss(regularize=False)(out, y, mask), ((out - y)[m] ** 2).mean())
-    with pytest.raises(NotImplementedError):
-        PowerImbalance()
+    # the physics loss has no CPU path: it fails loudly on host tensors
+    pi = PowerImbalance(torch.zeros(1, 4), torch.ones(1, 4), torch.zeros(1, 2), torch.ones(1, 2))
+    with pytest.raises(RuntimeError):
+        pi(out, torch.zeros(2, 3, dtype=torch.long), torch.randn(3, 2))
 
 
 def test_train_and_eval_epoch_semantics_on_oracle_model():

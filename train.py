@@ -21,7 +21,7 @@ from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
 from poweflownet_amd.optim import FlatAdamW
 from poweflownet_amd.synth import make_dataset
 from poweflownet_amd.utils.argument_parser import argument_parser
-from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss
+from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss, MixedMSEPoweImbalance, PowerImbalance
 from poweflownet_amd.utils.evaluation import evaluate_epoch
 from poweflownet_amd.utils.training import GraphedTrainStep, append_to_json, train_epoch
 
@@ -58,8 +58,14 @@ def main():
     elif args.train_loss_fn == "mse_loss":
         from poweflownet_amd.loss import MSELoss
         loss_fn = MSELoss()                                       # torch.nn.MSELoss semantics (train.py:103), one kernel
+    elif args.train_loss_fn in ("power_imbalance", "mixed_mse_power_imbalance"):
+        if not hasattr(trainset, "get_data_means_stds"):
+            raise SystemExit("the physics losses need the dataset statistics: pass --data-dir with the raw files")
+        cls = PowerImbalance if args.train_loss_fn == "power_imbalance" else MixedMSEPoweImbalance
+        kw = {} if args.train_loss_fn == "power_imbalance" else {"alpha": 0.9}       # train.py:97,101
+        loss_fn = cls(*[t.cpu() for t in trainset.get_data_means_stds()], **kw)
     else:
-        raise SystemExit(f"--train_loss_fn {args.train_loss_fn} is out of this round's scope (SURVEY.md 8f N4)")
+        raise SystemExit(f"unknown --train_loss_fn {args.train_loss_fn}")
     eval_loss_fn = Masked_L2_loss(regularize=False)
     model = MaskEmbdMultiMPN(nfeature_dim=4, efeature_dim=2, output_dim=4, hidden_dim=args.hidden_dim,
                              n_gnn_layers=args.n_gnn_layers, K=args.K, dropout_rate=args.dropout_rate).to(device)
