@@ -15,6 +15,7 @@ Only the vectors are committed; no reference source travels.  Refuses to run wit
   G8 Masked_L2_loss fwd + grad (utils/custom_loss_functions.py:10-46), the reference's default loss
   G9 PowerFlowData: raw .npy -> split -> masks -> normalised samples (datasets/PowerFlowData.py:44-217)
   G10 PowerImbalance / MixedMSEPoweImbalance fwd + grad (utils/custom_loss_functions.py:99-306)
+  G11 MPN_simplenet fwd + all parameter grads (networks/MPN.py:753-792)
 
 usage:  python oracle/make_goldens.py [g8]      (no argument: every fixture; a name: only that one)
 """
@@ -283,6 +284,29 @@ def g10():
     npz("g10_power_imbalance", **out)
 
 
+def g11():
+    """MPN_simplenet of the reference, imported unmodified, dropout_rate 0 (its dropout is active even in eval)."""
+    from networks.MPN import MPN_simplenet
+    torch.manual_seed(11)
+    ei = seven_node_multigraph()
+    n, e = 7, ei.shape[1]
+    out = {}
+    for tag, (L_, K, h) in {"L3K2": (3, 2, 16), "L2K3": (2, 3, 129)}.items():
+        m = MPN_simplenet(4, 2, 4, h, L_, K, 0.0)
+        with torch.no_grad():
+            for conv in m.convs:
+                conv.bias.normal_(std=0.1)
+        x, ea, y = torch.randn(n, 4), torch.randn(e, 2), torch.randn(n, 4)
+        d = Data(x=x, edge_index=ei, edge_attr=ea, y=y)
+        o = m(d)
+        torch.nn.MSELoss()(o, y).backward()
+        out.update({f"{tag}.cfg": np.array([L_, K, h]), f"{tag}.x": x, f"{tag}.edge_attr": ea, f"{tag}.y": y, f"{tag}.out": o})
+        for k, p in m.named_parameters():
+            out[f"{tag}.param.{k}"] = p.detach().clone()
+            out[f"{tag}.grad.{k}"] = p.grad.detach().clone()
+    npz("g11_mpn_simplenet", edge_index=ei, **out)
+
+
 def g9():
     """The reference's PowerFlowData, imported unmodified (torch_geometric.data / .datasets through the stand-in), run on
     a synthetic raw directory in the reference's file format; the raw arrays travel in the fixture."""
@@ -333,7 +357,7 @@ def g9():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
-    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10}
+    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
     for name, fn in todo.items():
         if only is None or only == name:
             fn()

@@ -411,3 +411,32 @@ class MaskEmbdMultiMPN(nn.Module):
             seg_hint = x.shape[0] // nseg if nseg > 0 and x.shape[0] % nseg == 0 else 0
             graph = self._graphs.get(edge_index, x.shape[0], -1, seg_hint)   # is_directed + undirect_graph (:539)
             return _MpnFn.apply(self, graph, x, mask, edge_features, *self._ordered_params())
+
+
+# ============================================================================================ MPN_simplenet
+class MPN_simplenet(nn.Module):
+    """networks/MPN.py:753-792 -- the one sibling of `MaskEmbdMultiMPN` in train.py's `models` table (:30-38) that accepts
+    the 4-wide node features the dataset produces (the others assert a stale 12-wide layout, :194,:267,:349,:430,:625,
+    :728): ONE EdgeAggregation on the edge list AS GIVEN (no undirecting), then `n_gnn_layers` TAGConvs with
+    dropout -> ReLU between them.  A composition of this package's two HIP layers under torch autograd.
+
+    Kept quirk (:788): the reference builds a fresh `nn.Dropout` inside forward, which is always in training mode, so
+    dropout stays active under `model.eval()`."""
+
+    def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
+        super().__init__()
+        self.nfeature_dim, self.efeature_dim, self.output_dim = nfeature_dim, efeature_dim, output_dim
+        self.hidden_dim, self.n_gnn_layers, self.K, self.dropout_rate = hidden_dim, n_gnn_layers, K, dropout_rate
+        self.edge_aggr = EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, hidden_dim)
+        self.convs = nn.ModuleList()
+        self.convs.append(TAGConv(hidden_dim, output_dim if n_gnn_layers == 1 else hidden_dim, K=K))
+        for _ in range(n_gnn_layers - 2):
+            self.convs.append(TAGConv(hidden_dim, hidden_dim, K=K))
+        self.convs.append(TAGConv(hidden_dim, output_dim, K=K))
+
+    def forward(self, data):
+        x = self.edge_aggr(data.x, data.edge_index, data.edge_attr)
+        for conv in list(self.convs)[:-1]:
+            x = conv(x, data.edge_index)
+            x = torch.relu(torch.nn.functional.dropout(x, self.dropout_rate, training=True))
+        return self.convs[-1](x, data.edge_index)

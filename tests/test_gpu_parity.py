@@ -375,6 +375,25 @@ def test_g10_power_imbalance_matches_reference_goldens():
     assert_close(x.grad, x_ref.grad, 2 * RTOL, "grad, case118 x 32")
 
 
+@pytest.mark.parametrize("tag", ["L3K2", "L2K3"])
+def test_g11_mpn_simplenet_matches_reference(tag):
+    """The sibling model that still runs on the dataset's 4-wide features (networks/MPN.py:753-792), composed from the two
+    HIP layers, against the reference class's own output and parameter gradients."""
+    from poweflownet_amd.data import Data
+    from poweflownet_amd.networks.MPN import MPN_simplenet
+    fx = load("g11_mpn_simplenet")
+    L_, K, h = (int(v) for v in fx[f"{tag}.cfg"])
+    m = MPN_simplenet(4, 2, 4, h, L_, K, 0.0)
+    m.load_state_dict({k[len(tag) + 7:]: v for k, v in fx.items() if k.startswith(f"{tag}.param.")})
+    m = m.to(DEV)
+    d = Data(x=fx[f"{tag}.x"].to(DEV), edge_index=fx["edge_index"].to(DEV), edge_attr=fx[f"{tag}.edge_attr"].to(DEV))
+    out = m(d)
+    assert_close(out, fx[f"{tag}.out"], RTOL, "out")
+    torch.nn.MSELoss()(out, fx[f"{tag}.y"].to(DEV)).backward()
+    for k, p in m.named_parameters():
+        assert_close(p.grad, fx[f"{tag}.grad.{k}"], 2 * RTOL, f"grad {k}")
+
+
 def test_g7_batch_equals_concat_of_singles():
     fx = load("g7_collate")
     m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)

@@ -17,7 +17,7 @@ import torch
 from poweflownet_amd import dp
 from poweflownet_amd.data import DataLoader
 from poweflownet_amd.datasets import PowerFlowData, random_bus_type
-from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN, MPN_simplenet
 from poweflownet_amd.optim import FlatAdamW
 from poweflownet_amd.synth import make_dataset
 from poweflownet_amd.utils.argument_parser import argument_parser
@@ -28,8 +28,10 @@ from poweflownet_amd.utils.training import GraphedTrainStep, append_to_json, tra
 
 def main():
     args = argument_parser()
-    if args.model != "MaskEmbdMultiMPN":
-        raise SystemExit("only --model MaskEmbdMultiMPN (the hot path) is built; see DESIGN.md 'out of scope'")
+    models = {"MaskEmbdMultiMPN": MaskEmbdMultiMPN, "MPN_simplenet": MPN_simplenet}     # train.py:30-38
+    if args.model not in models:
+        raise SystemExit(f"--model {args.model}: the reference's other models assert a stale 12-wide node-feature layout "
+                         "(networks/MPN.py:194,267,349,430,625,728) and cannot run on its own dataset; see DESIGN.md")
     rank, local_rank, world = dp.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs a HIP device: poweflownet_amd has no CPU fallback")
@@ -67,7 +69,7 @@ def main():
     else:
         raise SystemExit(f"unknown --train_loss_fn {args.train_loss_fn}")
     eval_loss_fn = Masked_L2_loss(regularize=False)
-    model = MaskEmbdMultiMPN(nfeature_dim=4, efeature_dim=2, output_dim=4, hidden_dim=args.hidden_dim,
+    model = models[args.model](nfeature_dim=4, efeature_dim=2, output_dim=4, hidden_dim=args.hidden_dim,
                              n_gnn_layers=args.n_gnn_layers, K=args.K, dropout_rate=args.dropout_rate).to(device)
     dp.broadcast_parameters(model)
     if rank == 0:
