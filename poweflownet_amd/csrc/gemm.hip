@@ -157,13 +157,8 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_kernel(const TnArgs a) 
             const char* rowR = reinterpret_cast<const char*>(Rs2) + (size_t)mu * rs_stride * 4;
 #pragma unroll
             for (int s = 0; s < TN_U; ++s) {
-#if defined(PFN_TN_CONST)
-                t.a[s] = f32x2{(float)m0, 1.f};
-                t.b[s] = f32x2{1.f, (float)s};
-#else
                 t.a[s] = *reinterpret_cast<const f32x2*>(rowA + (size_t)(2 * s) * pr.lda * 4 + voA);
                 t.b[s] = *reinterpret_cast<const f32x2*>(rowB + (size_t)(2 * s) * pr.ldb * 4 + voB);
-#endif
                 if (EX) {
                     t.xv[s] = *reinterpret_cast<const float*>(rowX + (size_t)(2 * s) * pr.ldb * 4 + voB);
                     t.yv[s] = *reinterpret_cast<const float*>(rowY + (size_t)(2 * s) * pr.lda * 4 + voA);
@@ -193,11 +188,7 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_kernel(const TnArgs a) 
                 for (int sa = 0; sa < 2; ++sa)
 #pragma unroll
                     for (int sb = 0; sb < 2; ++sb)
-#if defined(PFN_TN_NOMFMA)
-                        acc[sa][sb][0] += t.a[s][sa] * t.b[s][sb];
-#else
                         acc[sa][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(t.a[s][sa], t.b[s][sb], acc[sa][sb], 0, 0, 0);
-#endif
                 if (EX) {
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {

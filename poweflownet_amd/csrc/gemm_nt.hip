@@ -236,19 +236,11 @@ __device__ __forceinline__ float vload_x1_addr(const float* p) {
 __device__ __forceinline__ void vstore_x4(float* p, f32x4 v) {
     // the s_nop is the ISA's "VMEM store wider than 64 bits -> VALU overwrites its data registers" hazard (2 wait states),
     // which hipcc fills in for its own stores but cannot see inside inline asm (without it: intermittently wrong elements)
-#if defined(PFN_NT_NOSTORE)
-    asm volatile("; no store %0 %1" : : "v"(p), "v"(v) : "memory");
-#else
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
-#endif
 }
 template <int N>
 __device__ __forceinline__ void wait_a(f32x4& v) {   // the fragment chunk about to be consumed has landed
-#if defined(PFN_NT_SAFE)
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v));
-#else
     asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
-#endif
 }
 
 // Multiply one LDS-resident piece into the accumulators and refill the A fragment for the next piece.
@@ -303,9 +295,6 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
         // Address = wave-uniform 64-bit base (SGPRs) + 32-bit per-lane offset.
         const uint32_t kk = min(kh4 + 8u * m, (uint32_t)nkmax);
         vload_x4(a_cur[m], nbase, nvoff + 4u * kk);
-#if defined(PFN_NT_SAFE) && PFN_NT_SAFE == 2
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         __builtin_amdgcn_sched_barrier(0);
     }
 }
