@@ -196,16 +196,24 @@ def main():
                     opt.step()
                 step = g_fb.replay
             else:
-                g_opt = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g_fb):
-                    fwd_bwd()
-                with torch.cuda.graph(g_opt):
-                    opt.step()
+                # DP: forward+backward graph, ONE eager RCCL all-reduce of the flat gradient buffer, optimizer graph.  A capture
+                # that fails next to a live process group falls back to eager launches instead of taking the run down.
+                try:
+                    g_opt = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_fb):
+                        fwd_bwd()
+                    with torch.cuda.graph(g_opt):
+                        opt.step()
 
-                def step():
-                    g_fb.replay()
-                    dp.allreduce_gradients(model)     # one RCCL all-reduce of the flat gradient buffer
-                    g_opt.replay()
+                    def step():
+                        g_fb.replay()
+                        dp.allreduce_gradients(model)     # one RCCL all-reduce of the flat gradient buffer
+                        g_opt.replay()
+                except Exception as exc:                  # noqa: BLE001
+                    print(f"rank {rank}: hipGraph capture failed ({exc}); running eager", file=sys.stderr)
+                    torch.cuda.synchronize()
+                    use_graph = False
+                    step = step_eager
         else:
             g_inf = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_inf):
@@ -241,13 +249,18 @@ def main():
 
     # ---- per-kernel timing pass (eager, HIP events on the launch stream) -> roofline of the dominant kernel
     roofline, kernels = None, {}
-    if rank == 0 and args.profile_steps > 0:
+    if args.profile_steps > 0:
+        # every rank runs the eager steps (they contain the gradient all-reduce: a rank that skipped them would leave the
+        # others waiting in the collective); only rank 0 records and reports
         torch.cuda.synchronize()
-        L.profile_report(reset=True)
-        L.profile_enable(True)
+        if rank == 0:
+            L.profile_report(reset=True)
+            L.profile_enable(True)
         for _ in range(args.profile_steps):
             step_eager()
         torch.cuda.synchronize()
+        barrier()
+    if rank == 0 and args.profile_steps > 0:
         L.profile_enable(False)
         rep = L.profile_report(reset=True)
         ab = alg_bytes(n_nodes, e_eff, h, 2, K)

@@ -21,6 +21,11 @@ def init_from_env(backend: Optional[str] = None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # test aids for a ONE-GPU box (the multi-process code path of bench.py / train.py cannot be exercised there otherwise):
+    # PFN_SINGLE_DEVICE=1 puts every rank on device 0, PFN_DIST_BACKEND=gloo replaces RCCL (which refuses two ranks per GPU)
+    if os.environ.get("PFN_SINGLE_DEVICE"):
+        local_rank = 0
+    backend = backend or os.environ.get("PFN_DIST_BACKEND")
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
     if world > 1 and not dist.is_initialized():
