@@ -912,7 +912,7 @@ int pfn_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, i
 int pfn_mse_loss(const float* out, const float* y, int64_t count, float* loss, float* grad, void* ws, size_t ws_bytes,
                  void* stream) {
     PFN_CHECK_ARG(out && y && loss && ws, "pfn_mse_loss: null pointer");
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 256));
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 1023) / 1024, 256));
     if (ws_bytes < 257 * sizeof(float)) {
         set_error("pfn_mse_loss: workspace too small (need %zu bytes)", 257 * sizeof(float));
         return PFN_ENOSPACE;
@@ -935,7 +935,7 @@ int pfn_masked_l2_loss(const float* out, const float* y, const void* mask, int m
     }
     hipStream_t s = static_cast<hipStream_t>(stream);
     MaskedL2Ws* w = static_cast<MaskedL2Ws*>(ws);
-    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 256));
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 1023) / 1024, 256));
     masked_l2_reduce_kernel<<<nb, 256, 0, s>>>(out, y, mask, mask_dtype, count, regularize, regcoeff, w, loss);
     PFN_CHECK_LAUNCH();
     if (grad && count > 0) {
