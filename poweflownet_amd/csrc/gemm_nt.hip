@@ -202,6 +202,7 @@ struct NtArgs {
     int tps, cshift, nq, remv;   // quarters per LDS slice; log2(column groups per block); MFMA quarters; VALU columns (padded)
     int nrem, bias_group, ldr, ldg;
     int kuni, bias_lds_off;      // k length shared by every piece of the launch, or 0; float offset of the bias image in LDS
+    int klast, pad1_;            // 1: in every piece only the first MFMA step of the last chunk has real k's (K = 129); else 4
     NtPiece piece[NT_MAX_PIECES];
     float* C[8];
     int gflags[8];               // per group: 1 = add the C already in memory, 2 = store raw sums (no epilogue).  int, not
@@ -245,11 +246,13 @@ __device__ __forceinline__ void wait_a(f32x4& v) {   // the fragment chunk about
 
 // Multiply one LDS-resident piece into the accumulators and refill the A fragment for the next piece.
 //   NFAST: 17 / 16 = the piece has exactly that many chunks -> straight-line code; 0 = generic (per-chunk guard).
+//   LS   : MFMA steps of the LAST chunk that carry real k's (H = 129: k = 128 alone -> 1 step instead of 4; the other
+//          three would multiply all-zero weight rows).
 //   NR   : trailing VALU columns this wave accumulates (0, 1 or 4).
 // Chunk m waits for a_cur[m] with vmcnt(16): after the load that filled it, the wave issued the 16 other refills of that
 // round (plus, around a flush, a few stores / epilogue operands -- then the wait asks for slightly younger prefetches
 // than strictly needed, never for the stores).
-template <int CT, int NR, int NFAST>
+template <int CT, int NR, int NFAST, int LS>
 __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], float (&racc)[4], f32x4 (&a_cur)[NCH],
                                             const float* S, int klen, int tps, int tsel, uint32_t kh4, int r32,
                                             const char* nbase, uint32_t nvoff, int nkmax) {
@@ -283,7 +286,7 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
             wait_a<NCH - 1>(a_cur[m]);
             const f32x4 av = a_cur[m];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < ((FAST && m == NFAST - 1) ? LS : 4); ++i) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b[ct][i], acc[ct], 0, 0, 0);
 #pragma unroll
@@ -406,8 +409,8 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     // The round loop is instantiated ONCE per multiply variant and the variant is chosen outside it (all pieces of a
     // launch normally share one k length): with several variants merging inside the loop, the fragment's loop-carried
     // registers are copied to working registers and back every round (a second 68-register set, spills in the flush).
-    auto rounds = [&](auto nfast_c, auto nr_c) {
-    constexpr int NFAST = decltype(nfast_c)::value, NR = decltype(nr_c)::value;
+    auto rounds = [&](auto nfast_c, auto nr_c, auto ls_c) {
+    constexpr int NFAST = decltype(nfast_c)::value, NR = decltype(nr_c)::value, LS = decltype(ls_c)::value;
     int p = 0;
     while (true) {
         asm volatile("" : "+v"(kh4));   // opaque per round: keeps the 17 refill offsets from being hoisted into 17 VGPRs
@@ -466,7 +469,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         {
             const float* S = lds + a.piece[p].lds_off;
             const int klen = a.piece[p].klen, tsel = cg * CT;
-            nt_multiply<CT, NR, NFAST>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax);
+            nt_multiply<CT, NR, NFAST, LS>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax);
         }
         if (flush_after) {
             // ---- flush straight from registers: acc[q] of lane (r32, kh) is D[row (q&3) + 8 (q>>2) + 4 kh][col r32];
@@ -615,10 +618,23 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     }
     };
     using std::integral_constant;
-    if (a.kuni == KP && nr == 0) rounds(integral_constant<int, NCH>{}, integral_constant<int, 0>{});
-    else if (a.kuni == KP && nr == 1) rounds(integral_constant<int, NCH>{}, integral_constant<int, 1>{});
-    else if (a.kuni == KP - 8 && nr == 0) rounds(integral_constant<int, NCH - 1>{}, integral_constant<int, 0>{});
-    else if constexpr (CT < 2) rounds(integral_constant<int, 0>{}, integral_constant<int, 4>{});
+    using I0 = integral_constant<int, 0>;
+    using I1 = integral_constant<int, 1>;
+    using I4 = integral_constant<int, 4>;
+    // (the one-step tail is instantiated for CT < 2 only: in the CT = 2 kernel the extra variants cost registers -> spills)
+    bool done = false;
+    if constexpr (CT < 2) {
+        if (a.kuni == KP && a.klast == 1 && nr <= 1) {
+            if (nr == 0) rounds(integral_constant<int, NCH>{}, I0{}, I1{});
+            else rounds(integral_constant<int, NCH>{}, I1{}, I1{});
+            done = true;
+        }
+    }
+    if (done) return;
+    if (a.kuni == KP && nr == 0) rounds(integral_constant<int, NCH>{}, I0{}, I4{});
+    else if (a.kuni == KP && nr == 1) rounds(integral_constant<int, NCH>{}, I1{}, I4{});
+    else if (a.kuni == KP - 8 && nr == 0) rounds(integral_constant<int, NCH - 1>{}, I0{}, I4{});
+    else if constexpr (CT < 2) rounds(I0{}, I4{}, I4{});
     // CT == 2 exists only for the straight-line variants (the launcher never pairs it with the generic one: two tiles plus
     // four trailing columns plus per-chunk guards do not fit the register file without spills)
 }
@@ -650,6 +666,7 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     }
     double flops = 0.0, bytes = (double)a.ngroup * a.M * a.ncols * 4.0;
     std::vector<NtPiece> pieces;
+    std::vector<int> last_steps;   // per piece: MFMA steps of its last chunk that carry real k's (only meaningful for 136-k pieces)
     for (int t = 0; t < a.nterm; ++t) {
         const GemmTerm& tm = a.term[t];
         if (tm.lda % 4 != 0 || tm.lda < ((tm.K + 3) & ~3)) {
@@ -679,6 +696,10 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
             pc.group = tm.group;
             pc.lds_off = 0;
             pieces.push_back(pc);
+            {
+                const int real_tail = std::min(tm.K - k0, KP) - (KP - 8);   // real k's in chunk 16 of a full piece
+                last_steps.push_back(real_tail >= 1 && real_tail <= 4 ? real_tail : 4);
+            }
         }
     }
     // ---- how many 32-column quarters of every piece fit in LDS at once (tps), and where the launch has to be cut
@@ -748,8 +769,11 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
         k.npiece = (int)(i1 - i0);
         k.bias_lds_off = (int)(used / sizeof(float));
         k.kuni = pieces[i0].klen;
-        for (size_t i = i0; i < i1; ++i)
+        k.klast = 1;
+        for (size_t i = i0; i < i1; ++i) {
             if (pieces[i].klen != k.kuni) k.kuni = 0;
+            if (last_steps[i] != 1) k.klast = 4;
+        }
         bool here[8] = {false, false, false, false, false, false, false, false};
         for (size_t i = i0; i < i1; ++i) {
             k.piece[i - i0] = pieces[i];
