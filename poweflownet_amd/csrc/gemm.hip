@@ -53,7 +53,10 @@ struct TnArgs {
 
 struct TnBatch {
     f32x2 a[TN_U], b[TN_U];
-    float xv[TN_U], rs[TN_U], yv[TN_U];
+    // side operands of the VALU extras, ONE value per lane for the whole batch: lane l holds row (l & 15) of the batch; step s
+    // fetches row 2s + kh through the LDS crossbar (ds_bpermute).  As three broadcast loads per step they made the kernel
+    // VMEM-issue-bound: 5 vector-memory instructions per 4 MFMAs, 8 waves per CU.
+    float xv16, rs16, yv16;
 };
 
 // Scatter one float4 quad of a quadrant partial into the nn.Linear gradient layout.  Quad Q < 16 = accumulator registers
@@ -147,7 +150,9 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_kernel(const TnArgs a) 
         // address math in the loop (with per-load 64-bit multiply-adds the kernel was VALU-bound at 31 % of the MFMA
         // peak even when every load hit L1).  A batch that would run past the matrix is moved back as a whole (uniform
         // clamp); the only caller that can see moved rows is the prefetch of a batch that is never consumed.
-        const uint32_t voA = (uint32_t)(kh * pr.lda) * 4u, voB = (uint32_t)(kh * pr.ldb) * 4u, voR = (uint32_t)(kh * (int)rs_stride) * 4u;
+        const uint32_t voA = (uint32_t)(kh * pr.lda) * 4u, voB = (uint32_t)(kh * pr.ldb) * 4u;
+        const int l16 = lane & 15;
+        const uint32_t voX16 = (uint32_t)(l16 * pr.ldb) * 4u, voY16 = (uint32_t)(l16 * pr.lda) * 4u, voR16 = (uint32_t)(l16 * (int)rs_stride) * 4u;
         auto load = [&](TnBatch& t, int m0) {   // rows m0 .. m0+15
             const int mu = max(0, min(m0, a.M - 2 * TN_U));
             const char* rowA = reinterpret_cast<const char*>(Ap) + (size_t)mu * pr.lda * 4;
@@ -159,12 +164,12 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_kernel(const TnArgs a) 
             for (int s = 0; s < TN_U; ++s) {
                 t.a[s] = *reinterpret_cast<const f32x2*>(rowA + (size_t)(2 * s) * pr.lda * 4 + voA);
                 t.b[s] = *reinterpret_cast<const f32x2*>(rowB + (size_t)(2 * s) * pr.ldb * 4 + voB);
-                if (EX) {
-                    t.xv[s] = *reinterpret_cast<const float*>(rowX + (size_t)(2 * s) * pr.ldb * 4 + voB);
-                    t.yv[s] = *reinterpret_cast<const float*>(rowY + (size_t)(2 * s) * pr.lda * 4 + voA);
-                    const float r = *reinterpret_cast<const float*>(rowR + (size_t)(2 * s) * rs_stride * 4 + voR);
-                    t.rs[s] = has_rs ? r : 1.f;
-                }
+            }
+            if (EX) {
+                t.xv16 = *reinterpret_cast<const float*>(rowX + voX16);
+                t.yv16 = *reinterpret_cast<const float*>(rowY + voY16);
+                const float r = *reinterpret_cast<const float*>(rowR + voR16);
+                t.rs16 = has_rs ? r : 1.f;
             }
         };
         auto load_tail = [&](TnBatch& t, int m0) {   // per-lane clamped rows (ragged tail only)
@@ -173,12 +178,13 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_kernel(const TnArgs a) 
                 const int row = min(m0 + 2 * s + kh, mlast);
                 t.a[s] = *reinterpret_cast<const f32x2*>(Ap + (size_t)row * pr.lda);
                 t.b[s] = *reinterpret_cast<const f32x2*>(Bp + (size_t)row * pr.ldb);
-                if (EX) {
-                    t.xv[s] = Xc[(size_t)row * pr.ldb];
-                    t.yv[s] = Yr[(size_t)row * pr.lda];
-                    const float r = Rs2[(size_t)row * rs_stride];
-                    t.rs[s] = has_rs ? r : 1.f;
-                }
+            }
+            if (EX) {
+                const int row = min(m0 + l16, mlast);
+                t.xv16 = Xc[(size_t)row * pr.ldb];
+                t.yv16 = Yr[(size_t)row * pr.lda];
+                const float r = Rs2[(size_t)row * rs_stride];
+                t.rs16 = has_rs ? r : 1.f;
             }
         };
         auto compute = [&](const TnBatch& t) {
@@ -190,14 +196,15 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_kernel(const TnArgs a) 
                     for (int sb = 0; sb < 2; ++sb)
                         acc[sa][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(t.a[s][sa], t.b[s][sb], acc[sa][sb], 0, 0, 0);
                 if (EX) {
+                    const float xv = __shfl(t.xv16, 2 * s + kh), rs = __shfl(t.rs16, 2 * s + kh), yv = __shfl(t.yv16, 2 * s + kh);
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
-                        xc[e] = fmaf(t.a[s][e], t.xv[s], xc[e]);
-                        bs[e] = fmaf(t.a[s][e], t.rs[s], bs[e]);
-                        xr[e] = fmaf(t.yv[s], t.b[s][e], xr[e]);
+                        xc[e] = fmaf(t.a[s][e], xv, xc[e]);
+                        bs[e] = fmaf(t.a[s][e], rs, bs[e]);
+                        xr[e] = fmaf(yv, t.b[s][e], xr[e]);
                     }
-                    cn = fmaf(t.yv[s], t.xv[s], cn);
-                    cb = fmaf(t.yv[s], t.rs[s], cb);
+                    cn = fmaf(yv, xv, cn);
+                    cb = fmaf(yv, rs, cb);
                 }
             }
         };
@@ -223,11 +230,12 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_kernel(const TnArgs a) 
                     const bool ok = m + 2 * s + kh < R1;
                     t0.b[s][0] = ok ? t0.b[s][0] : 0.f;
                     t0.b[s][1] = ok ? t0.b[s][1] : 0.f;
-                    if (EX) {
-                        t0.xv[s] = ok ? t0.xv[s] : 0.f;
-                        t0.rs[s] = ok ? t0.rs[s] : 0.f;
-                        t0.yv[s] = ok ? t0.yv[s] : 0.f;
-                    }
+                }
+                if (EX) {
+                    const bool ok16 = m + l16 < R1;
+                    t0.xv16 = ok16 ? t0.xv16 : 0.f;
+                    t0.rs16 = ok16 ? t0.rs16 : 0.f;
+                    t0.yv16 = ok16 ? t0.yv16 : 0.f;
                 }
                 compute(t0);
             }
