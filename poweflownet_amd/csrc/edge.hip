@@ -203,9 +203,10 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
         attr_set = true;
     }
-    ProfScope ps(a.transpose ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
+    const bool adjt = a.adjt < 0 ? a.transpose != 0 : a.adjt != 0;
+    ProfScope ps((a.transpose || adjt) ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
     fused_hops_kernel<<<dim3((g.n + rows_pb - 1) / rows_pb, cs), FH_THREADS, lds_total, s>>>(
-        g.n, rows_pb, cw, nbr_cap, a.transpose ? g.rowptr_out : g.rowptr_in, a.transpose ? g.out_dst : g.in_src, g.dinv, a);
+        g.n, rows_pb, cw, nbr_cap, adjt ? g.rowptr_out : g.rowptr_in, adjt ? g.out_dst : g.in_src, g.dinv, a);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

@@ -281,6 +281,33 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             set_error("TAGConv backward: grad_x stride %d != x stride %d", ldgx, ldx);
             return PFN_EINVAL;
         }
+        if (K > 0 && ldgo <= ldx) {
+            // dx = sum_k (A^T)^k (gout W_k) = sum_k ((A^T)^k gout) W_k: hop the incoming gradient first (K hops over the
+            // transposed adjacency, LDS-resident when the graphs fit), then ONE multi-term GEMM with the gate in its epilogue --
+            // one output instead of K + 1 (measured 607 vs 754 us for the GEMM at 414 k nodes) and no Horner pass.
+            const size_t gstride = (size_t)g.n * ldgo;
+            if (fused_hops_fit(seg, ldgo, g.n)) {
+                FusedHopsArgs fh{gout, sc.G, nullptr, nullptr, nullptr, 1.f, gstride, ldgo, K, 0, seg, 1};
+                PFN_TRY(launch_fused_hops(g, fh, s));
+            } else {
+                const float* prev = gout;
+                for (int k = 1; k <= K; ++k) {
+                    HopArgs hp{prev, nullptr, sc.G + (size_t)(k - 1) * gstride, nullptr, 1.f, ldgo, 1, 1};
+                    PFN_TRY(launch_hop(g, hp, s));
+                    prev = hp.y;
+                }
+            }
+            GemmArgs a = gemm_defaults(g.n, cin, ldx);
+            a.C[0] = gx;
+            a.nterm = K + 1;
+            for (int k = 0; k <= K; ++k)
+                a.term[k] = term(k == 0 ? gout : sc.G + (size_t)(k - 1) * gstride, ldgo, cout, pw.wd[k], 0);
+            a.gate = gate.y;
+            a.ldg = gate.ld;
+            a.gate_scale = gate.scale;
+            if (sq) PFN_TRY(sq->main_wait(layer + 1));   // gx overwrites what the outer layer's side work reads
+            return launch_gemm_nt(a, s);
+        }
         // G_k = gout W_k ; dx = G_0 + A^T (G_1 + A^T (G_2 + ...))   (Horner over the transposed adjacency)
         GemmArgs a = gemm_defaults(g.n, cin, ldx);
         a.ngroup = K + 1;

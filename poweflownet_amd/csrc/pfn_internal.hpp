@@ -177,7 +177,8 @@ struct FusedHopsArgs {
     const float* gate;
     float gate_scale;
     size_t stride;        // floats between consecutive k buffers
-    int ld, K, transpose, seg;
+    int ld, K, transpose, seg;   // transpose = backward (Horner) data flow
+    int adjt = -1;               // which adjacency: 1 = by-source rows (A_hat^T), 0 = by-destination; -1 = same as `transpose`
 };
 bool fused_hops_fit(int seg, int ld, int n);
 int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s);
