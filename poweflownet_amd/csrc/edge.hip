@@ -93,7 +93,9 @@ int launch_hop(const GraphView& g, const HopArgs& a, hipStream_t s) {
 // PyG batches are block diagonal: when every graph's node rows fit in LDS (118 buses x 528 B = 62 KB) the K hops of a
 // TAGConv need no trip through L2/HBM between hops: a workgroup stages the rows of its graph(s) once, then ping-pongs
 // between two LDS tiles, gathering neighbour rows with ds_read_b128.  Forward writes every hop result out (they are
-// GEMM operands and saved for the weight gradients); backward keeps the Horner iterates on chip and writes only the end.
+// GEMM operands and saved for the weight gradients).  The TAGConv backward uses the same data flow over the transposed
+// adjacency (it hops the incoming gradient, model.hip: tag_backward); the Horner mode (iterates kept on chip, only the end
+// written) remains for layers whose output is wider than their input.
 constexpr int FH_THREADS = 512;
 constexpr int FH_LDS_BYTES = 156 * 1024;
 

@@ -39,7 +39,7 @@ static TnPair tn_pair(const float* A, int lda, int na, const float* B, int ldb, 
     return p;
 }
 
-// Collects the weight re-layout jobs of a forward pass (gemm.hip: pack) and hands out the packed addresses.
+// Collects the weight re-layout jobs of a forward pass (gemm_nt.hip: pack) and hands out the packed addresses.
 // With base == nullptr it only measures.
 struct Packer {
     float* base;
