@@ -298,6 +298,27 @@ def main():
                 except Exception:
                     pass
 
+    # ---- SURVEY 8(d) extras (single GPU, training): the optimiser-free step, and a step with a COLD topology cache (a new
+    # edge_index tensor: adjacency rebuilt on device, one host sync for the id-range check), both eager-launched
+    extras = {}
+    if rank == 0 and world == 1 and train:
+        def timed(fn, reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t0) / reps
+        extras["eager_ms_per_step"] = round(timed(step_eager, 10), 4)
+        extras["eager_fwd_bwd_only_ms"] = round(timed(fwd_bwd, 10), 4)
+        ei_saved = data.edge_index
+
+        def cold():
+            data.edge_index = ei_saved.clone()      # a tensor the cache has never seen
+            fwd_bwd()
+        extras["cold_topology_fwd_bwd_ms"] = round(timed(cold, 5), 4)
+        data.edge_index = ei_saved
+
     bytes_step = b_fwd(n_nodes, e_eff, h, Lg, K) * (3.0 if train else 1.0)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -319,7 +340,7 @@ def main():
                        "launch": "eager" if not use_graph else "hipGraph replay", "undirected_on_device": directed},
             "step_algorithmic_bytes": bytes_step,
             "step_hbm_frac": round(bytes_step / (1e-3 * ms_per_step) / HBM_PEAK, 4),
-            "final_loss": final_loss,
+            "final_loss": final_loss, **extras,
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         if cpu:
