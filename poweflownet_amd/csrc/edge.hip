@@ -183,14 +183,15 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
         set_error("fused hops: a %d-row graph does not fit in LDS", a.seg);
         return PFN_EINVAL;
     }
-    int cs = std::max(1, std::min(nchunk, (512 + ngraphs - 1) / std::max(1, ngraphs)));   // slices wanted
+    static const int want = getenv("PFN_FH_BLOCKS") ? atoi(getenv("PFN_FH_BLOCKS")) : 512;   // tuning aid
+    int cs = std::max(1, std::min(nchunk, (want + ngraphs - 1) / std::max(1, ngraphs)));   // slices wanted
     int cw = (nchunk + cs - 1) / cs;
     cw = std::min(cw, max_cw);
     cs = (nchunk + cw - 1) / cw;
     // whole graphs per block: as many as fit the two LDS tiles, but keep >= ~2 blocks per CU worth of parallelism
     int gpb = (int)((size_t)FH_LDS_BYTES / ((size_t)2 * a.seg * cw * 4 * sizeof(float) + (size_t)2 * a.seg * sizeof(int)));
     gpb = std::max(1, gpb);
-    while (gpb > 1 && (long)((ngraphs + gpb - 1) / gpb) * cs < 512) --gpb;
+    while (gpb > 1 && (long)((ngraphs + gpb - 1) / gpb) * cs < want) --gpb;
     const int rows_pb = gpb * a.seg;
     const size_t tile_bytes = (size_t)2 * rows_pb * cw * 4 * sizeof(float);
     const size_t fixed = tile_bytes + (size_t)(2 * rows_pb + 1) * sizeof(int);
