@@ -35,6 +35,34 @@ class Masked_L2_loss(nn.Module):
         return unit_grad(loss)
 
 
+def _per_feature_terms(error, mask):
+    """Shared tail of the two evaluation metrics below (reference :70-79, :88-97): masked column means, their overall and
+    their balanced mean, and the four named features."""
+    cnt = mask.sum(dim=0).clamp(min=1e-6)
+    per_feature = (error * mask.float()).sum(dim=0) / cnt
+    terms = {"total": (per_feature * cnt).sum() / mask.sum().clamp(min=1e-6), "balanced total": per_feature.mean()}
+    terms.update(zip(("vm", "va", "p", "q"), per_feature[:4]))
+    return terms
+
+
+class MaskedL2V2(nn.Module):
+    """Evaluation metric of test.py (:113-118): per-feature masked MSE as a dict of terms (reference :48-79).  A metric on
+    (N, 4) outputs, outside the training path: plain tensor ops on whatever device the tensors live on."""
+
+    def __init__(self, regularize=False, regcoeff=1):   # both unused, as in the reference
+        super().__init__()
+
+    def forward(self, output, target, mask):
+        return _per_feature_terms((output - target) ** 2, mask)
+
+
+class MaskedL1(nn.Module):
+    """Per-feature masked mean absolute error as a dict of terms (reference :82-97)."""
+
+    def forward(self, output, target, mask):
+        return _per_feature_terms((output - target).abs(), mask)
+
+
 class PowerImbalance(nn.Module):
     """Power-imbalance loss (reference :99-286): mean over buses of dP^2 + dQ^2, where dP/dQ are the mismatch between the
     predicted injections and the branch flows implied by the predicted voltages.  Same constructor and forward signature

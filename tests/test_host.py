@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 from oracle import ref_cpu
 from poweflownet_amd import dp
 from poweflownet_amd.data import DataLoader
-from poweflownet_amd.synth import make_dataset
+from poweflownet_amd.synth import make_batch, make_dataset
 from poweflownet_amd.utils.argument_parser import argument_parser
 from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss, PowerImbalance
 from poweflownet_amd.utils.evaluation import evaluate_epoch, num_params
@@ -97,3 +97,30 @@ def test_dp_world2_gloo_equals_single_process_global_batch():
     want = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
     got = ret["grad"]
     assert (got - want).abs().max().item() <= 1e-6 * want.abs().max().item() + 1e-9
+
+
+def test_evaluation_metrics_and_evaluate_epoch_v2():
+    """MaskedL2V2 / MaskedL1 (reference utils/custom_loss_functions.py:48-97) by their definitions, and evaluate_epoch_v2's
+    accumulation rule (utils/evaluation.py:158-165: first batch unweighted, the rest weighted by len(data))."""
+    from poweflownet_amd.utils.custom_loss_functions import MaskedL1, MaskedL2V2
+    from poweflownet_amd.utils.evaluation import evaluate_epoch_v2
+    torch.manual_seed(1)
+    out, y = torch.randn(30, 4), torch.randn(30, 4)
+    mask = torch.randint(0, 2, (30, 4))
+    for cls, err in ((MaskedL2V2, (out - y) ** 2), (MaskedL1, (out - y).abs())):
+        t = cls()(out, y, mask)
+        per = torch.stack([err[:, f][mask[:, f].bool()].mean() for f in range(4)])
+        assert torch.allclose(torch.stack([t["vm"], t["va"], t["p"], t["q"]]), per, atol=1e-6)
+        assert torch.allclose(t["balanced total"], per.mean(), atol=1e-6)
+        assert torch.allclose(t["total"], err[mask.bool()].mean(), atol=1e-6)
+
+    class Echo(torch.nn.Module):             # "model" whose prediction is its input
+        def forward(self, data):
+            return data.x
+
+    batches = [make_batch("14", b, seed=b) for b in (2, 3, 1)]
+    got = evaluate_epoch_v2(Echo(), batches, MaskedL2V2(), "cpu")
+    terms = [MaskedL2V2()(b.x, b.y, b.pred_mask) for b in batches]
+    lens = [len(b) for b in batches]
+    want = (terms[0]["total"].item() + sum(t["total"].item() * n for t, n in zip(terms[1:], lens[1:]))) / sum(lens)
+    assert abs(got["total"] - want) < 1e-6 and set(got) == {"total", "balanced total", "vm", "va", "p", "q"}
