@@ -78,6 +78,10 @@ def main():
     scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=args.lr, steps_per_epoch=len(train_loader),
                                                     epochs=args.num_epochs)
     run_id = time.strftime("%Y%m%d-%H%M%S")
+    if rank == 0 and hasattr(trainset, "xymean") and trainset.xymean is not None:     # normalising params (train.py:81-88)
+        os.makedirs(os.path.join(args.data_dir, "params"), exist_ok=True)
+        torch.save({k: getattr(trainset, k).cpu() for k in ("xymean", "xystd", "edgemean", "edgestd")},
+                   os.path.join(args.data_dir, "params", f"data_params_{run_id}.pt"))
     best_val = float("inf")
     graphed = GraphedTrainStep(model, loss_fn, optimizer) if world == 1 else None   # one hipGraph launch per batch
     for epoch in range(args.num_epochs):
@@ -94,6 +98,7 @@ def main():
                 os.makedirs("models", exist_ok=True)
                 torch.save({"epoch": epoch, "args": vars(args), "val_loss": best_val,
                             "model_state_dict": model.state_dict()}, os.path.join("models", f"model_{run_id}.pt"))
+                print(f"saved models/model_{run_id}.pt")
                 append_to_json(os.path.join("logs", "save_logs.json"), run_id,
                                {"val_loss": f"{best_val:.4f}", "train_loss": f"{train_loss:.4f}", "epoch": epoch})
 
