@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 1
+#define PFN_ABI_VERSION 2
 
 enum {
     PFN_OK = 0,
@@ -49,6 +49,15 @@ typedef struct pfn_mpn_config {
     float dropout_rate;     /* p of nn.Dropout (networks/MPN.py:496) */
     int32_t training;       /* 1: dropout active (model.train()), 0: model.eval() */
 } pfn_mpn_config;
+
+/* The library keeps NO process-global mutable state: no stream, event, cache or "first caller" device binding of its
+ * own.  What a call cannot create on the fly lives in a context the CALLER owns: today the second HIP stream and the
+ * events pfn_mpn_backward uses to overlap weight-gradient work with the input-gradient chain.  A context is bound to the
+ * device that was current when it was created and serves ONE call at a time (one per model or host thread; two models
+ * on two devices, or two threads, each bring their own).  Every entry point that takes a context accepts NULL = no
+ * overlap.  Creation and destruction are the only calls that create / destroy HIP objects.                          */
+int pfn_context_create(void** ctx_out);
+int pfn_context_destroy(void* ctx);
 
 int pfn_abi_version(void);
 const char* pfn_last_error(void);            /* thread-local, valid until the next failing call */
@@ -104,7 +113,8 @@ int pfn_mpn_forward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_n
 int pfn_mpn_backward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
                      const float* const* params, float* const* grads, const float* x,
                      const void* pred_mask, int mask_dtype, const float* edge_attr, const float* grad_out,
-                     float* grad_x, float* grad_edge_attr, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream);
+                     float* grad_x, float* grad_edge_attr, void* ws, size_t ws_bytes, int64_t seg_nodes,
+                     void* ctx /* pfn_context_create, or NULL */, void* stream);
 
 /* ------------------------------------------------------------------------------------- single layers
  * EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, output_dim).forward (networks/MPN.py:30-56):
@@ -170,6 +180,13 @@ int pfn_masked_l2_loss(const float* out, const float* y, const void* mask, int m
  * the first call and is left zero by every call.                                                                       */
 int pfn_power_imbalance(const void* graph_ws, int64_t n_nodes, int64_t e_stored, const float* x, const float* edge_attr,
                         const float* stats, float* loss, float* grad_x, float* dpq, void* ws, size_t ws_bytes, void* stream);
+/* Dropout bookkeeping (nn.Dropout, networks/MPN.py:496,546-547).  The train-mode epilogues draw their mask from
+ * Philox4x32-10 with key {seed[31:0], seed[63:32] ^ offset[63:32]} and counter {row, column / 4, layer index i of
+ * `layers`, offset[31:0]}; an element is KEPT (and scaled by 1/(1-p)) iff its uniform >= p.  This debug/verification entry
+ * writes the keep mask (1.0 / 0.0, [rows, ncols] unpadded) layer `layer` uses for the CURRENT {seed, offset} of
+ * `rng_state` (after a training forward: the mask that forward applied), so a train-mode pass can be replayed elsewhere. */
+int pfn_dropout_mask(const uint64_t* rng_state, int32_t layer, int64_t rows, int64_t ncols, float p, float* keep,
+                     void* stream);
 /* AdamW on one flat buffer (train.py:123; torch defaults betas (0.9,0.999), eps 1e-8, wd 0.01).
  * `step` is a device int64[2] {completed steps, arrival scratch (zero)}; the call increments step[0] itself,
  * so one launch per update and the whole step stays hipGraph-replayable.                           */

@@ -16,6 +16,7 @@ Only the vectors are committed; no reference source travels.  Refuses to run wit
   G9 PowerFlowData: raw .npy -> split -> masks -> normalised samples (datasets/PowerFlowData.py:44-217)
   G10 PowerImbalance / MixedMSEPoweImbalance fwd + grad (utils/custom_loss_functions.py:99-306)
   G11 MPN_simplenet fwd + all parameter grads (networks/MPN.py:753-792)
+  G12 MPN / SkipMPN / MaskEmbdMPN / MultiMPN / MaskEmbdMultiMPN_NoMP fwd + all parameter grads (:143-453, :562-650)
 
 usage:  python oracle/make_goldens.py [g8]      (no argument: every fixture; a name: only that one)
 """
@@ -307,6 +308,39 @@ def g11():
     npz("g11_mpn_simplenet", edge_index=ei, **out)
 
 
+def g12():
+    """The reference's older model classes (networks/MPN.py:143-453, :562-650), imported unmodified, on the 12-wide node
+    layout they assert (4 one-hot node-type columns | nfeature_dim features | their mask), dropout_rate 0 (their dropout is
+    built inside forward and therefore always active).  7-node multigraph stored once -> the undirect path runs."""
+    from networks.MPN import MPN, MaskEmbdMPN, MaskEmbdMultiMPN_NoMP, MultiMPN, SkipMPN
+    torch.manual_seed(12)
+    ei = seven_node_multigraph()
+    n, e = 7, ei.shape[1]
+    out = {}
+    # (class, nfeature_dim, output_dim, hidden_dim, n_gnn_layers, K)
+    cases = {"MPN": (MPN, 4, 4, 16, 3, 2), "SkipMPN": (SkipMPN, 4, 4, 16, 2, 3), "MaskEmbdMPN": (MaskEmbdMPN, 4, 6, 33, 2, 3),
+             "MultiMPN": (MultiMPN, 4, 4, 129, 2, 1), "MaskEmbdMultiMPN_NoMP": (MaskEmbdMultiMPN_NoMP, 8, 4, 8, 3, 2)}
+    for tag, (cls, f, o, h, L_, K) in cases.items():
+        m = cls(f, 2, o, h, L_, K, 0.0)
+        with torch.no_grad():
+            for mod in m.modules():
+                if isinstance(mod, TAGConv):
+                    mod.bias.normal_(std=0.1)
+        onehot = torch.nn.functional.one_hot(torch.randint(0, 4, (n,)), 4).float()
+        mask = torch.randint(0, 2, (n, f)).float()
+        x = torch.cat([onehot, torch.randn(n, f) * (1 - mask), mask], dim=1)
+        ea, y = torch.randn(e, 2), torch.randn(n, o)
+        d = Data(x=x, edge_index=ei, edge_attr=ea, y=y)
+        res = m(d)
+        torch.nn.MSELoss()(res, y).backward()
+        out.update({f"{tag}.cfg": np.array([f, o, h, L_, K]), f"{tag}.x": x, f"{tag}.edge_attr": ea, f"{tag}.y": y,
+                    f"{tag}.out": res})
+        for k, p_ in m.named_parameters():
+            out[f"{tag}.param.{k}"] = p_.detach().clone()
+            out[f"{tag}.grad.{k}"] = p_.grad.detach().clone()
+    npz("g12_sibling_models", edge_index=ei, **out)
+
+
 def g9():
     """The reference's PowerFlowData, imported unmodified (torch_geometric.data / .datasets through the stand-in), run on
     a synthetic raw directory in the reference's file format; the raw arrays travel in the fixture."""
@@ -357,7 +391,7 @@ def g9():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None
-    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11}
+    todo = {"g1": g1, "g2": g2, "g3": g3, "g4": g4_g6, "g7": g7, "g8": g8, "g9": g9, "g10": g10, "g11": g11, "g12": g12}
     for name, fn in todo.items():
         if only is None or only == name:
             fn()

@@ -124,6 +124,9 @@ class MaskEmbdMultiMPN(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.mask_embd = nn.Sequential(nn.Linear(nfeature_dim, hidden_dim), nn.ReLU(), nn.Linear(hidden_dim, nfeature_dim))
         self.dropout = nn.Dropout(dropout_rate)
+        # test hook: per hidden layer a {0,1} keep mask (N, H).  When set, dropout(x) is x * keep / (1 - p) -- nn.Dropout's
+        # definition with the Bernoulli draw supplied from outside (the HIP path exports its masks: pfn_dropout_mask)
+        self.dropout_masks = None
 
     is_directed = staticmethod(is_directed)
     undirect_graph = staticmethod(undirect_graph)
@@ -134,10 +137,13 @@ class MaskEmbdMultiMPN(nn.Module):
         x = self.mask_embd(data.pred_mask.to(data.x.dtype)) + data.x      # :533,:537
         edge_index, edge_attr = undirect_graph(data.edge_index, data.edge_attr)   # :539
         inter = [x]
-        for layer in self.layers[:-1]:                                     # :541-547
+        for li, layer in enumerate(self.layers[:-1]):                      # :541-547
             x = layer(x, edge_index, edge_attr) if isinstance(layer, EdgeAggregation) else layer(x, edge_index)
             inter.append(x)                                                # pre-activation layer output
-            x = F.relu(self.dropout(x))
+            if self.dropout_masks is not None:
+                x = F.relu(x * self.dropout_masks[li].to(x.dtype) / (1.0 - self.dropout_rate))
+            else:
+                x = F.relu(self.dropout(x))
         x = self.layers[-1](x, edge_index, edge_attr)                      # :554-555
         inter.append(x)
         return (x, inter) if return_intermediates else x

@@ -200,12 +200,8 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
     const size_t lds_cap = (size_t)160 * 1024;
     const size_t lds_total = std::min(lds_cap, fixed + want_nb);
     const int nbr_cap = (int)((lds_total - fixed) / sizeof(int));
-    static bool attr_set = false;
-    if (!attr_set) {
-        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fused_hops_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_raised{0};
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(fused_hops_kernel), (int)lds_cap, lds_raised));
     const bool adjt = a.adjt < 0 ? a.transpose != 0 : a.adjt != 0;
     ProfScope ps((a.transpose || adjt) ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
     fused_hops_kernel<<<dim3((g.n + rows_pb - 1) / rows_pb, cs), FH_THREADS, lds_total, s>>>(

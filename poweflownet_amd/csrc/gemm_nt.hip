@@ -143,17 +143,6 @@ __device__ __forceinline__ void dma_1k(const char* g, float* lds_dst) {
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// cheap counter-based uniform in [0,1) for the dropout mask (32-bit mixing; the 64-bit state is folded once per launch)
-__device__ __forceinline__ float uniform32(uint32_t key0, uint32_t key1, uint32_t idx) {
-    uint32_t h = idx * 0x9E3779B1u ^ key0;
-    h ^= h >> 16; h *= 0x85EBCA6Bu;
-    h ^= h >> 13; h *= 0xC2B2AE35u;
-    h ^= h >> 16; h += key1;
-    h ^= h >> 15; h *= 0x2C1B3C6Du;
-    h ^= h >> 12;
-    return (float)(h >> 8) * (1.0f / 16777216.0f);
-}
-
 // 4 x 4 transpose across the four lanes of a quad (DPP quad_perm, no LDS): on entry lane j of the quad holds v[i] =
 // M[i][j], on exit v[i] = M[j][i].  Turns the 32x32 accumulator layout (one column per lane) into four consecutive
 // columns of ONE row per lane, so the epilogue stores 16 bytes per lane (whole 128-byte lines per 8 lanes) instead of
@@ -184,7 +173,7 @@ struct EpiCfg {
     int ncols, act;
     bool has_rowscale, has_resid, has_gate;
     float p_drop, keep_scale, gate_scale;
-    uint32_t key0, key1;
+    DropKey dk;
 };
 struct NtPiece {
     const float* A;      // operand rows, advanced to this piece's first k
@@ -383,16 +372,10 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     ep.has_gate = a.gate != nullptr;
     ep.p_drop = a.p_drop;
     ep.gate_scale = a.gate_scale;
-    ep.key0 = ep.key1 = 0;
+    ep.dk = DropKey{0u, 0u, 0u, 0u};
     ep.keep_scale = 1.f;
     if (a.act == ACT_DROPOUT_RELU) {
-        const uint64_t seed = a.rng[0], offset = a.rng[1];
-        uint64_t z = seed + 0x9E3779B97F4A7C15ull * (offset * 0x100000001B3ull + ((uint64_t)a.rng_stream << 40) + 1);
-        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-        z = z ^ (z >> 31);
-        ep.key0 = (uint32_t)z;
-        ep.key1 = (uint32_t)(z >> 32);
+        ep.dk = drop_key(a.rng[0], a.rng[1], a.rng_stream);
         ep.keep_scale = 1.0f / (1.0f - a.p_drop);
     }
 
@@ -556,12 +539,12 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                                 for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
                         } else if (ep.act == ACT_DROPOUT_RELU) {
 #pragma unroll
-                            for (int g = 0; g < 4; ++g)
+                            for (int g = 0; g < 4; ++g) {
+                                float u[4];
+                                dropout_uniform4(ep.dk, (uint32_t)row[g], (uint32_t)(col0 >> 2), u);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) {
-                                    const float u = uniform32(ep.key0, ep.key1, (uint32_t)row[g] * (uint32_t)ep.ncols + (uint32_t)(col0 + e));
-                                    v[g][e] = (u >= ep.p_drop && v[g][e] > 0.f) ? v[g][e] * ep.keep_scale : 0.f;
-                                }
+                                for (int e = 0; e < 4; ++e) v[g][e] = (u[e] >= ep.p_drop && v[g][e] > 0.f) ? v[g][e] * ep.keep_scale : 0.f;
+                            }
                         }
                         if (ep.has_gate) {
 #pragma unroll
@@ -588,6 +571,8 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                     }
                     if (!raw) {
                         const f32x4 rcb = *reinterpret_cast<const f32x4*>(lds + a.bias_lds_off + rem_col);
+                        float ud[4] = {1.f, 1.f, 1.f, 1.f};
+                        if (ep.act == ACT_DROPOUT_RELU) dropout_uniform4(ep.dk, (uint32_t)row, (uint32_t)(rem_col >> 2), ud);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = v[e] + ((use_bias && !ep.has_rowscale) ? rcb[e] : 0.f);
@@ -596,8 +581,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                             if (ep.act == ACT_RELU) {
                                 x = fmaxf(x, 0.f);
                             } else if (ep.act == ACT_DROPOUT_RELU) {
-                                const float u = uniform32(ep.key0, ep.key1, (uint32_t)row * (uint32_t)ep.ncols + (uint32_t)(rem_col + e));
-                                x = (u >= ep.p_drop && x > 0.f) ? x * ep.keep_scale : 0.f;
+                                x = (ud[e] >= ep.p_drop && x > 0.f) ? x * ep.keep_scale : 0.f;
                             }
                             if (ep.has_gate) x = raux[e] > 0.f ? x * ep.gate_scale : 0.f;
                             v[e] = rem_col + e < ep.ncols ? x : 0.f;
@@ -641,12 +625,8 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 
 template <int CT>
 static int launch_variant(const NtArgs& k, dim3 grid, size_t lds_bytes, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        PFN_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_kernel<CT>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, NT_LDS_BYTES));
-        attr_set = true;
-    }
+    static std::atomic<uint64_t> lds_raised{0};
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<CT>), NT_LDS_BYTES, lds_raised));
     gemm_nt_kernel<CT><<<grid, NT_THREADS, lds_bytes, s>>>(k);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
@@ -716,13 +696,7 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
         }
         if (tps < 1) tps = std::min(start, 2);   // does not fit whole: several accumulating launches
     }
-    static int ncu = 0;
-    if (ncu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        if (ncu <= 0) ncu = 256;
-    }
+    const int ncu = device_cus();
     const int nrt = (a.M + 31) / 32;
     const int nslices = tps > 0 ? (nq + tps - 1) / tps : 1;
     // wave tile: two quarters per wave halve the A re-reads, but only when there is enough work to fill the chip twice over

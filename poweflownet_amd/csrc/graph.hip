@@ -24,6 +24,30 @@ void set_error(const char* fmt, ...) {
 }
 const char* last_error() { return g_err; }
 
+int device_cus() {
+    static std::atomic<int> cus[64];          // zero-initialised; 0 = not asked yet
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    std::atomic<int>& slot = cus[dev & 63];
+    int v = slot.load(std::memory_order_relaxed);
+    if (v == 0) {
+        hipDeviceProp_t prop;
+        v = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        slot.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    PFN_CHECK_HIP(hipGetDevice(&dev));
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return PFN_OK;
+    PFN_CHECK_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.fetch_or(bit, std::memory_order_release);
+    return PFN_OK;
+}
+
 GraphView graph_view(void* ws, int64_t n, int64_t e) {
     Carver c(ws);
     GraphView g;

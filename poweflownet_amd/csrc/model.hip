@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 #include <vector>
 
 #include "pfn_internal.hpp"
@@ -99,21 +100,19 @@ struct SideQ {
         return PFN_OK;
     }
 };
-static SideQ* side_queue(hipStream_t main_s) {
-    static SideQ q;
-    static bool ready = false, failed = false;
-    if (failed) return nullptr;
-    if (!ready) {
-        if (getenv("PFN_NO_SIDE_STREAM")) { failed = true; return nullptr; }
-        bool ok = hipStreamCreateWithFlags(&q.side_s, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&q.fork_ev, hipEventDisableTiming) == hipSuccess;
-        for (int i = 0; ok && i < 64; ++i) ok = hipEventCreateWithFlags(&q.marks[i], hipEventDisableTiming) == hipSuccess;
-        if (!ok) { failed = true; return nullptr; }
-        ready = true;
-    }
-    q.main_s = main_s;
-    for (int i = 0; i < 64; ++i) q.marked[i] = false;
-    return &q;
+// The second stream and its events belong to a CONTEXT the caller creates (pfn_context_create) -- one per model / host
+// thread, bound to the device it was created on; the library itself keeps no stream or event of its own.  A call
+// without a context runs the weight-gradient work on the main stream.
+struct Context {
+    int device = 0;
+    SideQ q;
+};
+static SideQ* side_queue(Context* ctx, hipStream_t main_s) {
+    static const bool disabled = getenv("PFN_NO_SIDE_STREAM") != nullptr;   // experiments
+    if (!ctx || disabled) return nullptr;
+    ctx->q.main_s = main_s;
+    for (int i = 0; i < 64; ++i) ctx->q.marked[i] = false;
+    return &ctx->q;
 }
 
 // ---------------------------------------------------------------------------------- EdgeAggregation
@@ -508,7 +507,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
 
 static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
                           float* const* grads, const float* x, const float* edge_attr, const float* gout, float* gx,
-                          float* gea, int seg, hipStream_t s) {
+                          float* gea, int seg, Context* ctx, hipStream_t s) {
     (void)x;
     const bool drop = c.training && c.dropout_rate > 0.f;
     const float gscale = drop ? 1.f / (1.f - c.dropout_rate) : 1.f;
@@ -523,7 +522,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         pi += is_ea(i) ? 4 : lo.K + 2;
     }
     if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)lo.e * lo.fe * sizeof(float), s));
-    SideQ* sq = lo.nlayers + 2 <= 64 ? side_queue(s) : nullptr;
+    SideQ* sq = lo.nlayers + 2 <= 64 ? side_queue(ctx, s) : nullptr;
     const float* gcur = gout;
     int ldg = lo.ldo;
     for (int i = lo.nlayers - 1; i >= 0; --i) {
@@ -721,12 +720,62 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
 }
 
+// The keep mask (1 = kept, 0 = dropped) the dropout epilogue of layer `stream` applies for the CURRENT {seed, offset} of
+// rng -- the same dropout_uniform4 call, element for element -- so a test can replay a train-mode pass on the CPU oracle.
+__global__ __launch_bounds__(256) void dropout_mask_kernel(const uint64_t* __restrict__ rng, uint32_t stream, int64_t rows,
+                                                           int ncols, float p, float* __restrict__ out) {
+    const int ncg = (ncols + 3) >> 2;
+    const DropKey dk = drop_key(rng[0], rng[1], stream);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows * ncg; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = i / ncg;
+        const int cg = (int)(i - row * ncg);
+        float u[4];
+        dropout_uniform4(dk, (uint32_t)row, (uint32_t)cg, u);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (4 * cg + e < ncols) out[row * ncols + 4 * cg + e] = u[e] >= p ? 1.f : 0.f;
+    }
+}
+
 }  // namespace pfn
 
 using namespace pfn;
 
 // =============================================================================================== C ABI
 extern "C" {
+
+int pfn_context_create(void** out) {
+    PFN_CHECK_ARG(out != nullptr, "pfn_context_create: null out pointer");
+    *out = nullptr;
+    Context* cx = new (std::nothrow) Context();
+    PFN_CHECK_ARG(cx != nullptr, "pfn_context_create: out of host memory");
+    bool ok = hipGetDevice(&cx->device) == hipSuccess &&
+              hipStreamCreateWithFlags(&cx->q.side_s, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&cx->q.fork_ev, hipEventDisableTiming) == hipSuccess;
+    int made = 0;
+    for (; ok && made < 64; ++made) ok = hipEventCreateWithFlags(&cx->q.marks[made], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
+        for (int i = 0; i < made - 1; ++i) (void)hipEventDestroy(cx->q.marks[i]);
+        if (cx->q.fork_ev) (void)hipEventDestroy(cx->q.fork_ev);
+        if (cx->q.side_s) (void)hipStreamDestroy(cx->q.side_s);
+        delete cx;
+        set_error("pfn_context_create: could not create the side stream / events: %s", hipGetErrorString(hipGetLastError()));
+        return PFN_EHIP;
+    }
+    for (int i = 0; i < 64; ++i) cx->q.marked[i] = false;
+    *out = cx;
+    return PFN_OK;
+}
+
+int pfn_context_destroy(void* ctx) {
+    Context* cx = static_cast<Context*>(ctx);
+    if (!cx) return PFN_OK;
+    for (int i = 0; i < 64; ++i) (void)hipEventDestroy(cx->q.marks[i]);
+    (void)hipEventDestroy(cx->q.fork_ev);
+    (void)hipStreamDestroy(cx->q.side_s);
+    delete cx;
+    return PFN_OK;
+}
 
 int pfn_mpn_num_params(const pfn_mpn_config* c) {
     if (!c || c->n_gnn_layers < 2) return -1;
@@ -768,7 +817,8 @@ int pfn_mpn_forward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t
 
 int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
                      float* const* grads, const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr,
-                     const float* gout, float* gx, float* gea, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream) {
+                     const float* gout, float* gx, float* gea, void* ws, size_t ws_bytes, int64_t seg_nodes, void* ctx,
+                     void* stream) {
     (void)pred_mask; (void)mask_dtype;
     PFN_TRY(check_common(c, gws, n, e, ws));
     PFN_CHECK_ARG(params && grads && (n == 0 || (x && gout)), "pfn_mpn_backward: null tensor");
@@ -780,7 +830,13 @@ int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_
     }
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
     PFN_CHECK_ARG(seg_nodes >= 0 && (seg_nodes == 0 || n % seg_nodes == 0), "seg_nodes must be 0 or divide n_nodes");
-    return model_backward(*c, g, lo, params, grads, x, edge_attr, gout, gx, gea, (int)seg_nodes, static_cast<hipStream_t>(stream));
+    Context* cx = static_cast<Context*>(ctx);
+    if (cx) {
+        int dev = -1;
+        PFN_CHECK_HIP(hipGetDevice(&dev));
+        PFN_CHECK_ARG(dev == cx->device, "pfn_mpn_backward: context belongs to device %d, current device is %d", cx->device, dev);
+    }
+    return model_backward(*c, g, lo, params, grads, x, edge_attr, gout, gx, gea, (int)seg_nodes, cx, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------- single layers
@@ -970,6 +1026,18 @@ int pfn_masked_l2_loss(const float* out, const float* y, const void* mask, int m
                                                                                               regularize, regcoeff, w, grad);
         PFN_CHECK_LAUNCH();
     }
+    return PFN_OK;
+}
+
+int pfn_dropout_mask(const uint64_t* rng_state, int32_t layer, int64_t rows, int64_t ncols, float p, float* keep,
+                     void* stream) {
+    PFN_CHECK_ARG(rng_state && (rows == 0 || keep), "pfn_dropout_mask: null pointer");
+    PFN_CHECK_ARG(layer >= 0 && rows >= 0 && rows < (1ll << 32) && ncols > 0 && ncols < (1ll << 30), "pfn_dropout_mask: bad sizes");
+    if (rows == 0) return PFN_OK;
+    const int64_t items = rows * ((ncols + 3) / 4);
+    dropout_mask_kernel<<<(int)std::min<int64_t>((items + 255) / 256, 4096), 256, 0, static_cast<hipStream_t>(stream)>>>(
+        rng_state, (uint32_t)layer, rows, (int)ncols, p, keep);
+    PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
 

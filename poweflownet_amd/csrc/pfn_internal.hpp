@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/pfn_hip.h"
 
 namespace pfn {
@@ -40,6 +42,13 @@ struct ProfScope {
     long idx_;
     hipStream_t s_;
 };
+
+// ---- per-device facts, safe from any host thread and with several devices in one process (no process-global "first
+// caller wins" state): compute-unit count of the CURRENT device, and "raise this kernel's dynamic-LDS limit" done once
+// per device (hipFuncSetAttribute applies to the current device only; repeating it is harmless, so no lock is needed --
+// `done` is a bit mask over device ordinals).
+int device_cus();
+int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done);
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 static inline int ld_of(int f) { return (int)round_up(f, 4); }
@@ -217,13 +226,40 @@ int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, 
 int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t f,
                     hipStream_t s);
 
-// uniform in [0,1) from a counter-based hash (dropout mask; recomputation-free: backward reads y > 0)
-__device__ __forceinline__ float uniform_hash(uint64_t seed, uint64_t offset, uint32_t stream, uint64_t idx) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (offset * 0x100000001B3ull + ((uint64_t)stream << 40) + idx + 1);
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (float)(z >> 40) * (1.0f / 16777216.0f);
+// ---------------------------------------------------------------------------------------- dropout RNG
+// Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based, so the mask of a
+// forward pass is a pure function of (seed, offset, layer, element) -- nothing is stored, any kernel can re-derive it.
+//   key     = { seed[31:0], seed[63:32] ^ offset[63:32] }
+//   counter = { row, column / 4, layer stream id, offset[31:0] }         (no flattened index: rows up to 2^32)
+// The four output words serve the four columns 4*(col/4) .. +3 of that row; word -> uniform in [0,1) with 24 bits.
+struct DropKey { uint32_t k0, k1, stream, off; };
+__host__ __device__ __forceinline__ DropKey drop_key(uint64_t seed, uint64_t offset, uint32_t stream) {
+    DropKey k;
+    k.k0 = (uint32_t)seed;
+    k.k1 = (uint32_t)(seed >> 32) ^ (uint32_t)(offset >> 32);
+    k.stream = stream;
+    k.off = (uint32_t)offset;
+    return k;
+}
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        c[0] = hi1 ^ c[1] ^ k0;
+        c[1] = lo1;
+        c[2] = hi0 ^ c[3] ^ k1;
+        c[3] = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+// four uniforms in [0,1) for columns 4*cg .. 4*cg+3 of `row`
+__device__ __forceinline__ void dropout_uniform4(const DropKey& k, uint32_t row, uint32_t cg, float (&u)[4]) {
+    uint32_t c[4] = {row, cg, k.stream, k.off};
+    philox4x32_10(c, k.k0, k.k1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * (1.0f / 16777216.0f);
 }
 
 }  // namespace pfn

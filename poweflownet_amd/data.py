@@ -100,29 +100,46 @@ class Batch(Data):
 
 class DataLoader:
     """Single-process loader (the reference uses num_workers=0, train.py:90): iterates a sequence of
-    `Data`, collating `batch_size` of them per step.  `shard=(rank, world)` gives rank r the graphs
-    r::world of every global batch (SURVEY 8e partitioning)."""
+    `Data`, collating `batch_size` of them per step.
+
+    `shard=(rank, world)` (SURVEY 8e partitioning; new -- the reference is single-process): `batch_size` is then the
+    GLOBAL batch and rank r takes graphs r::world of it.  Every rank must run the same number of steps with equally sized
+    shards -- each step ends in one collective, and the mean of the rank means equals the global mean only for equal
+    shards -- so a global batch is truncated to a multiple of `world` and a tail batch with fewer than `world` samples
+    is dropped ON EVERY RANK (`len(loader)` counts exactly the batches that are yielded)."""
 
     def __init__(self, dataset: Sequence[Data], batch_size: int = 1, shuffle: bool = False,
                  generator: Optional[torch.Generator] = None, shard: Optional[tuple] = None,
                  drop_last: bool = False):
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
         self.generator, self.shard, self.drop_last = generator, shard, drop_last
+        if shard is not None:
+            r, w = shard
+            if not (0 <= r < w):
+                raise ValueError(f"shard=(rank, world) needs 0 <= rank < world, got {shard}")
+            if self.batch_size < w:
+                raise ValueError(f"global batch_size {self.batch_size} < world size {w}")
+
+    def _num_batches(self) -> int:
+        n = len(self.dataset)
+        full, tail = divmod(n, self.batch_size)
+        if self.drop_last or tail == 0:
+            return full
+        if self.shard is not None and tail < self.shard[1]:
+            return full                                        # a tail no rank could share: dropped everywhere
+        return full + 1
 
     def __len__(self):
-        n = len(self.dataset)
-        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+        return self._num_batches()
 
     def __iter__(self) -> Iterable[Batch]:
         n = len(self.dataset)
         order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
-        for b in range(len(self)):
+        for b in range(self._num_batches()):
             idx = order[b * self.batch_size:(b + 1) * self.batch_size]
             if self.shard is not None:
                 r, w = self.shard
-                idx = idx[r::w]
-                if not idx:
-                    continue
+                idx = idx[:len(idx) // w * w][r::w]            # equal shards: len(idx) // w graphs on every rank
             if hasattr(self.dataset, "collate_indices"):       # device-resident dataset: one gather per field, no host loop
                 yield self.dataset.collate_indices(idx)
             else:

@@ -28,7 +28,9 @@ def init_from_env(backend: Optional[str] = None):
     backend = backend or os.environ.get("PFN_DIST_BACKEND")
     if torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
+    # PFN_FORCE_DIST=1: initialise the process group even at world size 1, so the collective code path (RCCL all-reduce of
+    # the flat gradient buffer between two hipGraph replays) can be exercised on a one-GPU box
+    if (world > 1 or os.environ.get("PFN_FORCE_DIST")) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -44,9 +46,14 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def active() -> bool:
+    """A process group exists (normally world > 1): steps end in the gradient all-reduce."""
+    return dist.is_available() and dist.is_initialized()
+
+
 def broadcast_parameters(model: torch.nn.Module, src: int = 0) -> None:
     """Replicate rank `src`'s parameters (one flat broadcast)."""
-    if world_size() == 1:
+    if not active():
         return
     params = [p.data for p in model.parameters()]
     flat = torch.cat([p.reshape(-1) for p in params])
@@ -70,9 +77,9 @@ def allreduce_gradients(model: torch.nn.Module, ordered_params=None) -> None:
     """Average gradients across ranks with ONE collective.  Fast path: the `.grad`s are views of the flat buffer
     the HIP backward produced (model.flat_grad()) -> all-reduce it in place, nothing is copied.  Generic path
     (any nn.Module, used by the gloo CPU tests): flatten -> all-reduce -> scatter back."""
-    w = world_size()
-    if w == 1:
+    if not active():
         return
+    w = world_size()
     flat = model.flat_grad() if hasattr(model, "flat_grad") else None
     params = ordered_params if ordered_params is not None else (
         model._ordered_params() if hasattr(model, "_ordered_params") else list(model.parameters()))

@@ -12,27 +12,45 @@ import torch.nn as nn
 from . import _lib as L
 
 
-_WS = {}      # per device: (workspace with the zeroed arrival counter, the constant 1 used as the unit loss gradient)
+_ONE = {}     # per device: the constant 1 used as the unit loss gradient (immutable after creation)
 
 
-def _state(device):
+def _one(device):
     key = (device.type, device.index)
-    if key not in _WS:
-        _WS[key] = (torch.zeros(264, dtype=torch.float32, device=device), torch.ones((), dtype=torch.float32, device=device),
-                    torch.zeros(1032, dtype=torch.float32, device=device), torch.zeros(320, dtype=torch.float32, device=device))
-    return _WS[key]
+    if key not in _ONE:
+        _ONE[key] = torch.ones((), dtype=torch.float32, device=device)
+    return _ONE[key]
+
+
+class _Workspace:
+    """Reduction scratch of ONE loss object (partials + an arrival counter that is zero between calls), per device.  Owned
+    by the loss module that uses it -- two models / host threads / streams bring two loss objects and share nothing; one
+    object serves one call at a time (the rule of pfn_context, include/pfn_hip.h).  Allocated on the first call, i.e. in
+    the warm-up steps that precede a hipGraph capture, never inside one."""
+
+    def __init__(self, floats: int):
+        self.floats, self._buf = floats, {}
+
+    def on(self, device) -> torch.Tensor:
+        key = (device.type, device.index)
+        if key not in self._buf:
+            self._buf[key] = torch.zeros(self.floats, dtype=torch.float32, device=device)
+        return self._buf[key]
+
+    def __reduce__(self):
+        return (_Workspace, (self.floats,))
 
 
 class _MseFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, out, y):
+    def forward(ctx, out, y, wsp):
         L.require_device(out, y, what="MSELoss input")
         out, y = L.f32c(out, "out"), L.f32c(y, "y")
         if out.shape != y.shape:
             raise RuntimeError(f"MSELoss: shape mismatch {tuple(out.shape)} vs {tuple(y.shape)}")
         loss = torch.empty((), dtype=torch.float32, device=out.device)
         grad = torch.empty_like(out) if ctx.needs_input_grad[0] else None
-        ws = _state(out.device)[0]
+        ws = wsp.on(out.device)
         with torch.cuda.device(out.device):
             L.check(L.load().pfn_mse_loss(out.data_ptr(), y.data_ptr(), out.numel(), loss.data_ptr(), L.ptr(grad),
                                           ws.data_ptr(), ws.numel() * 4, L.stream_ptr()), "pfn_mse_loss")
@@ -42,28 +60,32 @@ class _MseFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         if ctx.grad is None:
-            return None, None
-        if gloss.data_ptr() == _state(ctx.grad.device)[1].data_ptr():   # MSELoss.unit_grad(): the constant 1, never written
-            return ctx.grad, None
-        return ctx.grad * gloss, None
+            return None, None, None
+        if gloss.data_ptr() == _one(ctx.grad.device).data_ptr():   # MSELoss.unit_grad(): the constant 1, never written
+            return ctx.grad, None, None
+        return ctx.grad * gloss, None, None
 
 
 class MSELoss(nn.Module):
     """Drop-in for `torch.nn.MSELoss()` (reduction='mean') on HIP tensors."""
 
+    def __init__(self):
+        super().__init__()
+        self._ws = _Workspace(264)
+
     def forward(self, input, target):
-        return _MseFn.apply(input, target)
+        return _MseFn.apply(input, target, self._ws)
 
     @staticmethod
     def unit_grad(loss):
         """The constant 1 on `loss`'s device.  `loss.backward(MSELoss.unit_grad(loss))` is `loss.backward()` without the
         two tiny kernels autograd spends on creating that 1 and multiplying the gradient by it."""
-        return _state(loss.device)[1]
+        return _one(loss.device)
 
 
 class _MaskedL2Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, out, y, mask, regularize, regcoeff):
+    def forward(ctx, out, y, mask, regularize, regcoeff, wsp):
         L.require_device(out, y, mask, what="Masked_L2_loss input")
         out, y = L.f32c(out, "output"), L.f32c(y, "target")
         if out.shape != y.shape or mask.shape != out.shape:
@@ -75,7 +97,7 @@ class _MaskedL2Fn(torch.autograd.Function):
         mask = mask.contiguous()
         loss = torch.empty((), dtype=torch.float32, device=out.device)
         grad = torch.empty_like(out) if ctx.needs_input_grad[0] else None
-        ws = _state(out.device)[2]
+        ws = wsp.on(out.device)
         with torch.cuda.device(out.device):
             L.check(L.load().pfn_masked_l2_loss(out.data_ptr(), y.data_ptr(), mask.data_ptr(), code, out.numel(), int(bool(regularize)),
                                                 float(regcoeff), loss.data_ptr(), L.ptr(grad), ws.data_ptr(), ws.numel() * 4,
@@ -86,26 +108,31 @@ class _MaskedL2Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         if ctx.grad is None:
-            return None, None, None, None, None
-        if gloss.data_ptr() == _state(ctx.grad.device)[1].data_ptr():
-            return ctx.grad, None, None, None, None
-        return ctx.grad * gloss, None, None, None, None
+            return None, None, None, None, None, None
+        if gloss.data_ptr() == _one(ctx.grad.device).data_ptr():
+            return ctx.grad, None, None, None, None, None
+        return ctx.grad * gloss, None, None, None, None, None
 
 
-def masked_l2_loss(output, target, mask, regularize=True, regcoeff=1):
+MASKED_L2_WS_FLOATS = 1032
+POWER_IMBALANCE_WS_FLOATS = 320
+
+
+def masked_l2_loss(output, target, mask, regularize=True, regcoeff=1, workspace=None):
     """Masked_L2_loss.forward (utils/custom_loss_functions.py:30-46) on HIP tensors: loss and its gradient in two launches
-    instead of four `masked_select` compactions, two means and their autograd graph."""
-    return _MaskedL2Fn.apply(output, target, mask, regularize, regcoeff)
+    instead of four `masked_select` compactions, two means and their autograd graph.  `workspace`: the calling loss
+    object's `_Workspace(MASKED_L2_WS_FLOATS)` (a throw-away one is made when omitted)."""
+    return _MaskedL2Fn.apply(output, target, mask, regularize, regcoeff, workspace or _Workspace(MASKED_L2_WS_FLOATS))
 
 
 def unit_grad(loss):
     """The constant 1 on `loss`'s device: `loss.backward(unit_grad(loss))` == `loss.backward()` minus two tiny kernels."""
-    return _state(loss.device)[1]
+    return _one(loss.device)
 
 
 class _PowerImbalanceFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, graph, edge_attr, stats):
+    def forward(ctx, x, graph, edge_attr, stats, wsp):
         L.require_device(x, edge_attr, what="PowerImbalance input")
         x, edge_attr = L.f32c(x, "x"), L.f32c(edge_attr, "edge_attr")
         n = x.shape[0]
@@ -114,7 +141,7 @@ class _PowerImbalanceFn(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=x.device)
         grad = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dpq = torch.empty(max(n, 1), 2, dtype=torch.float32, device=x.device)
-        ws = _state(x.device)[3]
+        ws = wsp.on(x.device)
         import ctypes as C
         st = (C.c_float * 12)(*stats)
         with torch.cuda.device(x.device):
@@ -127,13 +154,13 @@ class _PowerImbalanceFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gloss):
         if ctx.grad is None:
-            return None, None, None, None
-        if gloss.data_ptr() == _state(ctx.grad.device)[1].data_ptr():
-            return ctx.grad, None, None, None
-        return ctx.grad * gloss, None, None, None
+            return None, None, None, None, None
+        if gloss.data_ptr() == _one(ctx.grad.device).data_ptr():
+            return ctx.grad, None, None, None, None
+        return ctx.grad * gloss, None, None, None, None
 
 
-def power_imbalance(x, graph, edge_attr, stats):
+def power_imbalance(x, graph, edge_attr, stats, workspace=None):
     """PowerImbalance.forward on HIP tensors; `graph` = the GraphCSR of the stored-once edge_index (mode -1), `stats` = 12
-    floats {xymean[4], xystd[4], edgemean[2], edgestd[2]}."""
-    return _PowerImbalanceFn.apply(x, graph, edge_attr, stats)
+    floats {xymean[4], xystd[4], edgemean[2], edgestd[2]}; `workspace` as in masked_l2_loss."""
+    return _PowerImbalanceFn.apply(x, graph, edge_attr, stats, workspace or _Workspace(POWER_IMBALANCE_WS_FLOATS))

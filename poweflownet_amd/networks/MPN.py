@@ -174,13 +174,20 @@ class EdgeAggregation(nn.Module):
 
     def forward(self, x, edge_index, edge_attr):
         L.require_device(x, edge_index, edge_attr, *self.parameters(), what="EdgeAggregation input")
+        with torch.cuda.device(x.device):
+            graph = self._graphs.get(edge_index, x.shape[0], 0)     # the layer takes the list as given
+            return self.on_graph(graph, x, edge_attr)
+
+    def on_graph(self, graph: GraphCSR, x, edge_attr):
+        """The layer over an adjacency that is already built (model compositions build ONE per batch, with the model's
+        undirect rule; `edge_attr` stays the stored list -- the kernels read reversed copies through eid mod E)."""
+        L.require_device(x, edge_attr, *self.parameters(), what="EdgeAggregation input")
         x, edge_attr = L.f32c(x, "x"), L.f32c(edge_attr, "edge_attr")
         if x.dim() != 2 or x.shape[1] != self.nfeature_dim:
             raise RuntimeError(f"x must be (N, {self.nfeature_dim}), got {tuple(x.shape)}")
-        if edge_attr.shape != (edge_index.shape[1], self.efeature_dim):
-            raise RuntimeError(f"edge_attr must be ({edge_index.shape[1]}, {self.efeature_dim}), got {tuple(edge_attr.shape)}")
+        if edge_attr.shape != (graph.e_stored, self.efeature_dim):
+            raise RuntimeError(f"edge_attr must be ({graph.e_stored}, {self.efeature_dim}), got {tuple(edge_attr.shape)}")
         with torch.cuda.device(x.device):
-            graph = self._graphs.get(edge_index, x.shape[0], 0)     # the layer takes the list as given
             l1, l2 = self.edge_aggr[0], self.edge_aggr[2]
             dims = (self.nfeature_dim, self.efeature_dim, l1.out_features, self.output_dim)
             return _EdgeAggrFn.apply(graph, dims, x, edge_attr, l1.weight, l1.bias, l2.weight, l2.bias)
@@ -237,13 +244,24 @@ class TAGConv(nn.Module):
 
     def forward(self, x, edge_index):
         L.require_device(x, edge_index, *self.parameters(), what="TAGConv input")
+        with torch.cuda.device(x.device):
+            graph = self._graphs.get(edge_index, x.shape[0], 0)
+            return self.on_graph(graph, x)
+
+    def on_graph(self, graph: GraphCSR, x):
+        """The layer over an adjacency that is already built (see EdgeAggregation.on_graph)."""
+        L.require_device(x, *self.parameters(), what="TAGConv input")
         x = L.f32c(x, "x")
         if x.dim() != 2 or x.shape[1] != self.in_channels:
             raise RuntimeError(f"x must be (N, {self.in_channels}), got {tuple(x.shape)}")
         with torch.cuda.device(x.device):
-            graph = self._graphs.get(edge_index, x.shape[0], 0)
             return _TagConvFn.apply(graph, (self.in_channels, self.out_channels, self.K), x, self.bias,
                                     *[l.weight for l in self.lins])
+
+
+def _hip_linear(graph: GraphCSR, x, lin: nn.Linear):
+    """`nn.Linear` on the HIP GEMM: a TAGConv with K = 0 IS x W^T + b (no hop runs; the adjacency is only a handle)."""
+    return _TagConvFn.apply(graph, (lin.in_features, lin.out_features, 0), L.f32c(x, "x"), lin.bias, lin.weight)
 
 
 # ============================================================================================ whole model
@@ -286,12 +304,40 @@ class _MpnFn(torch.autograd.Function):
         L.check(lib.pfn_mpn_backward(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
                                      L.ptr_table(grads), x.data_ptr(), pred_mask.data_ptr(), ctx.mask_dtype,
                                      edge_attr.data_ptr(), gp.data_ptr(), L.ptr(gx), L.ptr(gea), ctx.ws.data_ptr(),
-                                     ctx.ws.numel(), graph.seg_nodes, L.stream_ptr()), "pfn_mpn_backward")
+                                     ctx.ws.numel(), graph.seg_nodes, model._context_on(x.device).ptr, L.stream_ptr()),
+                "pfn_mpn_backward")
         model._last_flat_grad = flat
         return (None, None, gx, None, gea, *grads)
 
 
-class MaskEmbdMultiMPN(nn.Module):
+class _UndirectHelpers:
+    """`is_directed` / `undirect_graph` as every model class of the reference exposes them (networks/MPN.py:172-193,
+    :245-266, ..., :498-523), evaluated by the device kernel the forward pass uses."""
+
+    def is_directed(self, edge_index):
+        """First-edge heuristic (networks/MPN.py:498-504): with (u0, v0) the first stored edge, 'directed' iff no stored edge
+        (v0 -> u0) exists."""
+        if edge_index.shape[1] == 0:
+            return False
+        L.require_device(edge_index, what="edge_index")
+        with torch.cuda.device(edge_index.device):
+            n = int(edge_index.max().item()) + 1
+            return GraphCSR(edge_index, n, mode=-1).info()[0]
+
+    def undirect_graph(self, edge_index, edge_attr):
+        """networks/MPN.py:506-523 (originals first, reversed copies second, attributes duplicated)."""
+        if edge_index.shape[1] == 0:
+            return edge_index, edge_attr
+        L.require_device(edge_index, edge_attr, what="edge_index/edge_attr")
+        with torch.cuda.device(edge_index.device):
+            n = int(edge_index.max().item()) + 1
+            g = GraphCSR(edge_index, n, mode=-1)
+            if not g.info()[0]:
+                return edge_index, edge_attr
+            return g.export_edges(), torch.cat([edge_attr, edge_attr], dim=0)
+
+
+class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
     """networks/MPN.py:456-559: mask embedding + (EdgeAggregation, TAGConv) x (L-1) + EdgeAggregation."""
 
     def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
@@ -323,28 +369,7 @@ class MaskEmbdMultiMPN(nn.Module):
         self._graphs = _GraphCache()
         self._rng_state: Optional[torch.Tensor] = None
         self._last_flat_grad: Optional[torch.Tensor] = None
-
-    # ------------------------------------------------------------------ helpers the reference exposes
-    def is_directed(self, edge_index):
-        """networks/MPN.py:498-504, evaluated by the same device kernel the forward pass uses."""
-        if edge_index.shape[1] == 0:
-            return False
-        L.require_device(edge_index, what="edge_index")
-        with torch.cuda.device(edge_index.device):
-            n = int(edge_index.max().item()) + 1
-            return GraphCSR(edge_index, n, mode=-1).info()[0]
-
-    def undirect_graph(self, edge_index, edge_attr):
-        """networks/MPN.py:506-523 (originals first, reversed copies second, attributes duplicated)."""
-        if edge_index.shape[1] == 0:
-            return edge_index, edge_attr
-        L.require_device(edge_index, edge_attr, what="edge_index/edge_attr")
-        with torch.cuda.device(edge_index.device):
-            n = int(edge_index.max().item()) + 1
-            g = GraphCSR(edge_index, n, mode=-1)
-            if not g.info()[0]:
-                return edge_index, edge_attr
-            return g.export_edges(), torch.cat([edge_attr, edge_attr], dim=0)
+        self._contexts = {}
 
     # ------------------------------------------------------------------------------------- plumbing
     def _config(self) -> L.MpnConfig:
@@ -362,6 +387,13 @@ class MaskEmbdMultiMPN(nn.Module):
                 out += [lin.weight for lin in layer.lins] + [layer.bias]
         a, b = self.mask_embd[0], self.mask_embd[2]
         return out + [a.weight, a.bias, b.weight, b.bias]
+
+    def _context_on(self, device) -> "L.Context":
+        """This model's `pfn_context` on `device` (side stream + events of the backward pass), created on first use."""
+        ctx = self._contexts.get(device)
+        if ctx is None:
+            ctx = self._contexts[device] = L.Context(device)
+        return ctx
 
     def _rng_state_on(self, device):
         if not (self.training and self.dropout_rate > 0):
@@ -440,3 +472,142 @@ class MPN_simplenet(nn.Module):
             x = conv(x, data.edge_index)
             x = torch.relu(torch.nn.functional.dropout(x, self.dropout_rate, training=True))
         return self.convs[-1](x, data.edge_index)
+
+
+# ===================================================================== sibling models
+class _Stale12Wide(_UndirectHelpers, nn.Module):
+    """Shared front end of the reference's older model classes (`MPN`, `SkipMPN`, `MaskEmbdMPN`, `MultiMPN`,
+    `MaskEmbdMultiMPN_NoMP`; train.py:30-38 lists them): they read a node tensor of width 2 * nfeature_dim + 4 -- four
+    one-hot node-type columns, the features, then their mask -- which the reference's CURRENT dataset no longer produces
+    (it emits 4-wide `x` and a separate `pred_mask`), so on that dataset their first line raises, there and here alike
+    (the assert is kept verbatim).  On a tensor of the width they ask for they run: re-compositions of the two HIP layers
+    over ONE adjacency per batch built with the model's undirect rule.
+
+    Kept quirk: like `MPN_simplenet` they build a fresh `nn.Dropout` inside forward (:208, :281, ...), which is always in
+    training mode, so dropout stays active under `model.eval()`."""
+
+    def _split(self, data):
+        assert data.x.shape[-1] == self.nfeature_dim * 2 + 4      # networks/MPN.py:194,:267,:349,:430,:625
+        L.require_device(data.x, data.edge_index, data.edge_attr, *self.parameters(), what=f"{type(self).__name__} input")
+        x = data.x[:, 4:4 + self.nfeature_dim]
+        mask = data.x[:, -self.nfeature_dim:]
+        graph = self._graphs.get(data.edge_index, data.x.shape[0], -1)     # is_directed + undirect_graph
+        return x.contiguous(), mask.contiguous(), graph, L.f32c(data.edge_attr, "data.edge_attr")
+
+    def _act(self, x):
+        return torch.relu(torch.nn.functional.dropout(x, self.dropout_rate, training=True))
+
+    def _store_dims(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
+        self.nfeature_dim, self.efeature_dim, self.output_dim = nfeature_dim, efeature_dim, output_dim
+        self.hidden_dim, self.n_gnn_layers, self.K, self.dropout_rate = hidden_dim, n_gnn_layers, K, dropout_rate
+        self._graphs = _GraphCache()
+
+    def _conv_stack(self):
+        """`convs` of MPN / SkipMPN / MaskEmbdMPN (:158-170): TAGConv(H, out if L == 1 else H), (L-2) x TAGConv(H, H),
+        TAGConv(H, out)."""
+        h, o, L_, K = self.hidden_dim, self.output_dim, self.n_gnn_layers, self.K
+        convs = nn.ModuleList([TAGConv(h, o if L_ == 1 else h, K=K)])
+        for _ in range(L_ - 2):
+            convs.append(TAGConv(h, h, K=K))
+        convs.append(TAGConv(h, o, K=K))
+        return convs
+
+    def _mask_mlp(self):
+        return nn.Sequential(nn.Linear(self.nfeature_dim, self.hidden_dim), nn.ReLU(),
+                             nn.Linear(self.hidden_dim, self.nfeature_dim))
+
+    def _embed(self, graph, mask, x):
+        """x + mask_embd(mask) (:352, :634) on the HIP GEMM."""
+        a, b = self.mask_embd[0], self.mask_embd[2]
+        return _hip_linear(graph, torch.relu(_hip_linear(graph, mask, a)), b) + x
+
+    def _run_convs(self, graph, x):
+        for conv in list(self.convs)[:-1]:
+            x = self._act(conv.on_graph(graph, x))
+        return self.convs[-1].on_graph(graph, x)
+
+    def _run_layers(self, graph, x, edge_attr):
+        """The mixed EdgeAggregation / TAGConv stack of MultiMPN and MaskEmbdMultiMPN_NoMP (:437-451, :636-648)."""
+        layers = list(self.layers)
+        for layer in layers[:-1]:
+            x = layer.on_graph(graph, x, edge_attr) if isinstance(layer, EdgeAggregation) else layer.on_graph(graph, x)
+            x = self._act(x)
+        last = layers[-1]
+        return last.on_graph(graph, x, edge_attr) if isinstance(last, EdgeAggregation) else last.on_graph(graph, x)
+
+
+class MPN(_Stale12Wide):
+    """networks/MPN.py:143-213: one EdgeAggregation, then the TAGConv stack."""
+
+    def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
+        super().__init__()
+        self._store_dims(nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate)
+        self.edge_aggr = EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, hidden_dim)
+        self.convs = self._conv_stack()
+
+    def forward(self, data):
+        x, _, graph, ea = self._split(data)
+        return self._run_convs(graph, self.edge_aggr.on_graph(graph, x, ea))
+
+
+class SkipMPN(MPN):
+    """networks/MPN.py:215-289: `MPN` plus the skip connection input_x + x (:286-287; needs output_dim == nfeature_dim)."""
+
+    def forward(self, data):
+        x, _, graph, ea = self._split(data)
+        return x + self._run_convs(graph, self.edge_aggr.on_graph(graph, x, ea))
+
+
+class MaskEmbdMPN(_Stale12Wide):
+    """networks/MPN.py:291-371: mask embedding, one EdgeAggregation, then the TAGConv stack."""
+
+    def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
+        super().__init__()
+        self._store_dims(nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate)
+        self.edge_aggr = EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, hidden_dim)
+        self.convs = self._conv_stack()
+        self.mask_embd = self._mask_mlp()
+
+    def forward(self, data):
+        x, mask, graph, ea = self._split(data)
+        x = self._embed(graph, mask, x)
+        return self._run_convs(graph, self.edge_aggr.on_graph(graph, x, ea))
+
+
+class MultiMPN(_Stale12Wide):
+    """networks/MPN.py:374-453: `MaskEmbdMultiMPN` without the mask embedding (E T E T ... E)."""
+
+    def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
+        super().__init__()
+        self._store_dims(nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate)
+        h = hidden_dim
+        self.layers = nn.ModuleList([EdgeAggregation(nfeature_dim, efeature_dim, h, h),
+                                     TAGConv(h, output_dim if n_gnn_layers == 1 else h, K=K)])
+        for _ in range(n_gnn_layers - 2):
+            self.layers.append(EdgeAggregation(h, efeature_dim, h, h))
+            self.layers.append(TAGConv(h, h, K=K))
+        self.layers.append(EdgeAggregation(h, efeature_dim, h, output_dim))
+
+    def forward(self, data):
+        x, _, graph, ea = self._split(data)
+        return self._run_layers(graph, x, ea)
+
+
+class MaskEmbdMultiMPN_NoMP(_Stale12Wide):
+    """networks/MPN.py:562-650: mask embedding, TAGConvs only, one closing EdgeAggregation.  Its first TAGConv takes
+    hidden_dim inputs but is fed the nfeature_dim-wide embedding (:579-585, :634-641), so -- as in the reference -- it runs
+    only when nfeature_dim == hidden_dim."""
+
+    def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
+        super().__init__()
+        self._store_dims(nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate)
+        h = hidden_dim
+        self.layers = nn.ModuleList([TAGConv(h, output_dim if n_gnn_layers == 1 else h, K=K)])
+        for _ in range(n_gnn_layers - 2):
+            self.layers.append(TAGConv(h, h, K=K))
+        self.layers.append(EdgeAggregation(h, efeature_dim, h, output_dim))
+        self.mask_embd = self._mask_mlp()
+
+    def forward(self, data):
+        x, mask, graph, ea = self._split(data)
+        return self._run_layers(graph, self._embed(graph, mask, x), ea)

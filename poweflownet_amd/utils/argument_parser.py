@@ -1,13 +1,22 @@
 """Two-stage argument parsing of the reference (utils/argument_parser.py:5-65): defaults < JSON config < command
 line.  Same flag names so `train.py --cfg_json ... --case ... --model ...` invocations carry over.  (`--regularize`
-keeps the reference's `type=bool` quirk: any non-empty string is True.)"""
+keeps the reference's `type=bool` quirk: any non-empty string is True.)
+
+Like the reference (:10), `--cfg_json` defaults to `configs/standard.json` (hidden_dim 129), so a bare
+`train.py --case 118v2` builds the same 129-wide model there and here; the path is tried relative to the working
+directory first (the reference's behaviour) and then relative to this repository.  One deliberate deviation: `--model`
+defaults to `MaskEmbdMultiMPN` (the reference's default `MPN` asserts a stale 12-wide node layout, networks/MPN.py:194,
+and cannot run on its own dataset)."""
 import argparse
 import json
+import os
+
+_REPO = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def argument_parser(argv=None):
     cfg = argparse.ArgumentParser(prog="PowerFlowNet", add_help=False)
-    cfg.add_argument("--cfg_json", "--config", "--configs", default=None, type=str)
+    cfg.add_argument("--cfg_json", "--config", "--configs", default="configs/standard.json", type=str)
     p = argparse.ArgumentParser(prog="PowerFlowNet", description="train the MI355X PowerFlowNet hot path")
     p.add_argument("--nfeature_dim", type=int, default=6)
     p.add_argument("--efeature_dim", type=int, default=2)
@@ -34,7 +43,10 @@ def argument_parser(argv=None):
     p.add_argument("--synthetic-samples", type=int, default=512)
     args, left = cfg.parse_known_args(argv)
     if args.cfg_json is not None:
-        with open(args.cfg_json) as f:
+        path = args.cfg_json
+        if not os.path.exists(path) and not os.path.isabs(path) and os.path.exists(os.path.join(_REPO, path)):
+            path = os.path.join(_REPO, path)
+        with open(path) as f:
             d = json.load(f)
         jargv = []
         for k, v in d.items():

@@ -1,8 +1,9 @@
 """Loss counterparts the train/eval loops dispatch on (reference utils/custom_loss_functions.py).
 
 `Masked_L2_loss` (:10-46) is the reference's default loss (utils/argument_parser.py:36-39): two masked MSE means over
-(N, 4).  On HIP tensors it is `pfn_masked_l2_loss` (loss + gradient in two launches); on host tensors
-(metrics on the CPU) plain torch ops.  The physics losses (`PowerImbalance`, `MixedMSEPoweImbalance`, :99-306; SURVEY.md
+(N, 4), computed by `pfn_masked_l2_loss` (loss + gradient in two launches).  Like everything else in
+this package it has NO CPU path: host tensors raise RuntimeError (the CPU restatement lives in oracle/ref_cpu.py, for tests
+only).  The physics losses (`PowerImbalance`, `MixedMSEPoweImbalance`, :99-306; SURVEY.md
 8f row N4) run as `pfn_power_imbalance` (csrc/physics.hip).
 """
 import torch
@@ -17,17 +18,12 @@ class Masked_L2_loss(nn.Module):
         self.criterion = nn.MSELoss(reduction="mean")
         self.regularize = regularize
         self.regcoeff = regcoeff
+        from ..loss import MASKED_L2_WS_FLOATS, _Workspace
+        self._ws = _Workspace(MASKED_L2_WS_FLOATS)
 
     def forward(self, output, target, mask):
-        if output.is_cuda:
-            from ..loss import masked_l2_loss
-            return masked_l2_loss(output, target, mask, self.regularize, self.regcoeff)
-        sel = mask.type(torch.bool)
-        loss = self.criterion(torch.masked_select(output, sel), torch.masked_select(target, sel))
-        if self.regularize:
-            rest = (1 - mask).type(torch.bool)
-            loss = loss + self.regcoeff * self.criterion(torch.masked_select(output, rest), torch.masked_select(target, rest))
-        return loss
+        from ..loss import masked_l2_loss
+        return masked_l2_loss(output, target, mask, self.regularize, self.regcoeff, self._ws)   # raises on host tensors
 
     @staticmethod
     def unit_grad(loss):
@@ -79,6 +75,8 @@ class PowerImbalance(nn.Module):
         self.edgemean, self.edgestd = edgemean, edgestd
         self._stats = None
         self._graphs = None
+        from ..loss import POWER_IMBALANCE_WS_FLOATS, _Workspace
+        self._ws = _Workspace(POWER_IMBALANCE_WS_FLOATS)
 
     def forward(self, x, edge_index, edge_attr):
         if not x.is_cuda:
@@ -92,7 +90,7 @@ class PowerImbalance(nn.Module):
         if self._graphs is None:
             self._graphs = _GraphCache()
         graph = self._graphs.get(edge_index, x.shape[0], -1)
-        return power_imbalance(x, graph, edge_attr, self._stats)
+        return power_imbalance(x, graph, edge_attr, self._stats, self._ws)
 
     @staticmethod
     def unit_grad(loss):

@@ -11,7 +11,9 @@ def load_model(model: nn.Module, run_id: str, device, models_dir: str = "models"
     """utils/evaluation.py:20-36: load `model_state_dict` of the best-validation checkpoint of a run."""
     import os
     path = os.path.join(models_dir, f"model_{run_id}.pt")
-    saved = torch.load(path, map_location=device)
+    # a reference checkpoint stores `args` as an argparse.Namespace (reference train.py:160-165), which torch's default
+    # weights_only unpickler rejects; these are the user's own local training artefacts, exactly what the reference loads
+    saved = torch.load(path, map_location=device, weights_only=False)
     model.load_state_dict(saved["model_state_dict"])
     return model, saved
 

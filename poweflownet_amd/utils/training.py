@@ -56,7 +56,16 @@ class GraphedTrainStep:
     def __init__(self, model, loss_fn, optimizer):
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
         self.graph = self.static = self.loss = None
-        self.lr = None
+        self.key = None            # optimiser hyper-parameters baked into the captured launches
+        self.disabled = False      # a failed capture, or a dataset that never hands the same edge_index twice: stay eager
+        self.misses = 0
+
+    def _hyper_key(self):
+        """Every optimiser scalar `pfn_adamw_step` receives BY VALUE (captured as a kernel argument): lr, betas (OneCycleLR
+        cycles beta1 together with lr), eps, weight_decay.  Any change re-captures."""
+        g = self.opt.param_groups[0]
+        betas = tuple(float(b) for b in g.get("betas", ()))
+        return (float(g["lr"]), betas, float(g.get("eps", 0.0)), float(g.get("weight_decay", 0.0)))
 
     def _eager(self, data):
         self.opt.zero_grad()
@@ -106,7 +115,7 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._eager(self.static)
-        self.lr = self.opt.param_groups[0]["lr"]
+        self.key = self._hyper_key()
         return self.loss                                           # the capture pass does not execute: caller replays
 
     def _compatible(self, data):
@@ -115,14 +124,33 @@ class GraphedTrainStep:
                 data.edge_attr.shape == s.edge_attr.shape and data.x.device == s.x.device)
 
     def __call__(self, data):
-        if not data.x.is_cuda or dp.world_size() > 1:
+        if self.disabled or not data.x.is_cuda or dp.world_size() > 1:
             return self._eager(data)
-        if self.graph is not None and self.lr != self.opt.param_groups[0]["lr"]:
-            self.graph = self.static = None                        # scheduler moved the learning rate: capture again
+        if self.graph is not None and self.key != self._hyper_key():
+            self.graph = self.static = None                        # a scheduler moved lr / betas / ...: capture again
         if self.graph is None:
-            self._capture(data)
+            snap = self._snapshot()
+            try:
+                self._capture(data)
+            except Exception as exc:                               # noqa: BLE001  (the eager body is always available)
+                import warnings
+                warnings.warn(f"GraphedTrainStep: hipGraph capture failed ({exc}); running eager launches from here on")
+                torch.cuda.synchronize()
+                self._restore(snap)
+                self.graph = self.static = None
+                self.disabled = True
+                return self._eager(data)
         if not self._compatible(data):
-            return self._eager(data)                               # e.g. the short last batch of an epoch
+            # e.g. the short last batch of an epoch.  A list-backed dataset collates a NEW edge_index per batch and would
+            # never replay: after a few misses in a row graphing is switched off instead of re-capturing every epoch.
+            s0 = self.static
+            if data.edge_index is not s0.edge_index and data.x.shape == s0.x.shape:
+                self.misses += 1
+                if self.misses >= 4:
+                    self.graph = self.static = None
+                    self.disabled = True
+            return self._eager(data)
+        self.misses = 0
         for k in ("x", "y", "pred_mask", "edge_attr"):
             getattr(self.static, k).copy_(getattr(data, k))
         self.graph.replay()

@@ -12,6 +12,34 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """`pytest tests` on a box without a HIP device: GPU tests are skipped, not failed (the product has no CPU path)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible (run with -m gpu on an MI355X box)")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Achieved parity errors of this session (tests/util.REPORT) -> gpurun_out/parity_report.json (GPU sessions only)."""
+    try:
+        import json
+        import torch
+        from tests import util
+        if not util.REPORT or not torch.cuda.is_available():
+            return
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        worst = {t: max(r["rel"] for r in rows) for t, rows in util.REPORT.items()}
+        with open(os.path.join(out, "parity_report.json"), "w") as f:
+            json.dump({"worst_rel_per_test": worst, "detail": util.REPORT}, f, indent=1)
+    except Exception:       # a report must never turn a green run red
+        pass

@@ -73,6 +73,25 @@ def test_loader_shards_partition_global_batch():
     assert torch.equal(x, want)
 
 
+@pytest.mark.parametrize("n,bs,world", [(5, 4, 2), (9, 4, 2), (11, 8, 4), (13, 6, 3), (7, 8, 2), (8, 4, 2)])
+def test_loader_shards_are_equal_on_every_rank(n, bs, world):
+    """Every rank yields the same number of batches with the same number of graphs each (a rank that skipped a step would
+    leave the others waiting in the gradient all-reduce; unequal shards break mean-of-rank-means == global mean).
+    Covers n % (bs * world)-style tails with fewer samples than ranks."""
+    ds = make_dataset("14", n)
+    per_rank = [list(DataLoader(ds, batch_size=bs, shard=(r, world))) for r in range(world)]
+    lens = [len(DataLoader(ds, batch_size=bs, shard=(r, world))) for r in range(world)]
+    assert len(set(lens)) == 1 and all(len(b) == lens[0] for b in per_rank)
+    for step in range(lens[0]):
+        sizes = {b[step].num_graphs for b in per_rank}
+        assert len(sizes) == 1 and sizes.pop() >= 1
+    tail = n % bs
+    expect = n // bs + (1 if tail >= world else 0)
+    assert lens[0] == expect
+    with pytest.raises(ValueError):
+        DataLoader(ds, batch_size=1, shard=(0, 2))
+
+
 def test_make_batch_offsets():
     b = make_batch("14", 3)
     assert b.edge_index.shape == (2, 60) and int(b.edge_index[:, 20:40].min()) >= 14

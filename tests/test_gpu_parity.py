@@ -8,10 +8,15 @@ import torch
 from oracle import ref_cpu
 from poweflownet_amd.networks.MPN import EdgeAggregation, GraphCSR, MaskEmbdMultiMPN, TAGConv
 from poweflownet_amd.synth import make_batch
-from tests.util import RTOL, assert_close, data_from, load, params_from
+from tests.util import RTOL, assert_close, data_from, load, params_from, record, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+# Full-size parameter gradients (15k..414k nodes) are bounded against the float64 oracle by this fraction of the tensor's
+# largest entry OR 3x the fp32 oracle's own error, whichever is larger: a ReLU mask that flips within the fp32 forward
+# error moves a weight gradient by 1e-5..2e-4 of its largest entry.  50x north_star's forward figure;
+# the achieved per-tensor errors are in gpurun_out/parity_report.json.
+GRAD_FULL_RTOL = 5e-4
 
 
 # ------------------------------------------------------------------------------------------------ graph
@@ -394,6 +399,29 @@ def test_g11_mpn_simplenet_matches_reference(tag):
         assert_close(p.grad, fx[f"{tag}.grad.{k}"], 2 * RTOL, f"grad {k}")
 
 
+@pytest.mark.parametrize("tag", ["MPN", "SkipMPN", "MaskEmbdMPN", "MultiMPN", "MaskEmbdMultiMPN_NoMP"])
+def test_g12_sibling_models_match_reference(tag):
+    """the reference's older model classes (networks/MPN.py:143-453, :562-650) as compositions of the two
+    HIP layers (and the HIP GEMM for their mask embedding), against the reference classes' own outputs and parameter
+    gradients on the 12-wide node layout they assert; on the dataset's 4-wide layout their first line raises, as there."""
+    import poweflownet_amd.networks.MPN as M
+    from poweflownet_amd.data import Data
+    fx = load("g12_sibling_models")
+    f, o, h, L_, K = (int(v) for v in fx[f"{tag}.cfg"])
+    m = getattr(M, tag)(f, 2, o, h, L_, K, 0.0)
+    m.load_state_dict({k[len(tag) + 7:]: v for k, v in fx.items() if k.startswith(f"{tag}.param.")})
+    m = m.to(DEV)
+    d = Data(x=fx[f"{tag}.x"].to(DEV), edge_index=fx["edge_index"].to(DEV), edge_attr=fx[f"{tag}.edge_attr"].to(DEV))
+    out = m(d)
+    assert_close(out, fx[f"{tag}.out"], RTOL, "out")
+    torch.nn.MSELoss()(out, fx[f"{tag}.y"].to(DEV)).backward()
+    for k, p in m.named_parameters():
+        assert_close(p.grad, fx[f"{tag}.grad.{k}"], RTOL, f"grad {k}")
+    assert m.is_directed(d.edge_index) is True
+    with pytest.raises(AssertionError):                  # the stale-width assert, verbatim (:194 etc.)
+        m(make_batch("14", 2).to(DEV))
+
+
 def test_g7_batch_equals_concat_of_singles():
     fx = load("g7_collate")
     m = MaskEmbdMultiMPN(4, 2, 4, 8, 2, 3, 0.0)
@@ -512,30 +540,159 @@ def test_forward_does_not_mutate_data_and_is_deterministic():
         assert torch.equal(getattr(d, k), v), k
 
 
-def test_dropout_statistics_and_gradient_mask():
-    """Train-mode check is statistical (torch's CPU bernoulli stream cannot be reproduced)."""
-    torch.manual_seed(0)
+def _exported_masks(m, n_rows):
+    """Keep masks (N, H) of the hidden layers for the model's CURRENT dropout state (= the last training forward)."""
+    from poweflownet_amd import _lib as L
+    masks = []
+    for li in range(len(m.layers) - 1):
+        k = torch.empty(n_rows, m.hidden_dim, device=DEV)
+        L.check(L.load().pfn_dropout_mask(m._rng_state.data_ptr(), li, n_rows, m.hidden_dim, float(m.dropout_rate),
+                                          k.data_ptr(), L.stream_ptr()), "pfn_dropout_mask")
+        masks.append(k)
+    return masks
+
+
+def test_dropout_mask_statistics_config2():
+    """Row a10 (networks/MPN.py:496,546-547), the Bernoulli draw itself: at configs[1]'s size every hidden layer's keep-rate
+    lies in a 4-sigma binomial band around 1 - p, so do the per-column and per-row marginals (5 sigma over 129 / 15,104
+    cells), masks of different layers and of consecutive forwards are uncorrelated, the stream is reproducible from
+    (seed, offset), and it never depends on the data."""
     p = 0.2
-    m = MaskEmbdMultiMPN(4, 2, 4, 129, 2, 3, p).to(DEV)
-    m.seed_dropout(123)
-    d = make_batch("118", 16).to(DEV)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, p).to(DEV).train()
+    d = make_batch("118v2", 128, seed=0).to(DEV)
+    n = d.x.shape[0]
+    m.seed_dropout(2024)
+    with torch.no_grad():
+        m(d)
+    first = _exported_masks(m, n)
+    cnt = n * 129
+    sigma = (p * (1 - p) / cnt) ** 0.5
+    for li, k in enumerate(first):
+        assert ((k == 0) | (k == 1)).all()
+        rate = k.mean().item()
+        assert abs(rate - (1 - p)) <= 4 * sigma, (li, rate, sigma)
+        col = k.mean(0)
+        assert (col - (1 - p)).abs().max().item() <= 5 * (p * (1 - p) / n) ** 0.5, (li, "column marginal")
+        row = k.mean(1)
+        assert (row - (1 - p)).abs().max().item() <= 5.5 * (p * (1 - p) / 129) ** 0.5, (li, "row marginal")
+        # neighbouring elements (the four words of one Philox call, and consecutive calls) are independent
+        c = k - k.mean()
+        for shift in (1, 4, 129):
+            flat = c.flatten()
+            corr = (flat[:-shift] * flat[shift:]).mean().item() / (p * (1 - p))
+            assert abs(corr) <= 5 / cnt ** 0.5, (li, shift, corr)
+    for a in range(len(first)):
+        for b in range(a + 1, len(first)):
+            corr = ((first[a] - (1 - p)) * (first[b] - (1 - p))).mean().item() / (p * (1 - p))
+            assert abs(corr) <= 5 / cnt ** 0.5, (a, b, corr)
+    with torch.no_grad():
+        m(d)                                                     # offset advanced: a fresh, independent mask
+    second = _exported_masks(m, n)
+    for a, b in zip(first, second):
+        assert not torch.equal(a, b)
+        corr = ((a - (1 - p)) * (b - (1 - p))).mean().item() / (p * (1 - p))
+        assert abs(corr) <= 5 / cnt ** 0.5
+    m.seed_dropout(2024)                                         # same seed -> the same stream, whatever the input
+    d2 = make_batch("118v2", 128, seed=7).to(DEV)
+    with torch.no_grad():
+        m(d2)
+    for a, b in zip(first, _exported_masks(m, n)):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case,B,cfg", [("14", 4, (129, 4, 3)), ("118v2", 8, (129, 4, 3)), ("118v2", 128, (129, 4, 3)),
+                                        ("118v2", 4, (129, 6, 6))])
+def test_train_mode_matches_oracle_fed_the_exported_masks(case, B, cfg):
+    """Row a10 end to end: a TRAIN-mode pass (dropout 0.2) against the CPU oracle whose nn.Dropout is replaced by
+    multiplication with the masks the HIP path exports (pfn_dropout_mask) and 1/(1-p).  Checks the three things SURVEY H4
+    lists at once -- the kept set, the 1/(1-p) scale, and that backward uses the forward's mask: forward and ALL parameter
+    gradients (plus d/dx) must agree with the oracle; the float64 oracle is the yardstick for the gradients (see
+    test_config2_full_size_vs_oracle for why full-size gradients are not smooth in the rounding error)."""
+    h, L_, K = cfg
+    p = 0.2
+    torch.manual_seed(99)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, h, L_, K, p).train()
+    m = MaskEmbdMultiMPN(4, 2, 4, h, L_, K, p)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).train()
+    m.seed_dropout(31337)
+    data = make_batch(case, B, seed=3)
+    dd = data.to(DEV)
+    out = m(dd)
+    torch.nn.MSELoss()(out, dd.y).backward()
+    ref.dropout_masks = [k.cpu() for k in _exported_masks(m, dd.x.shape[0])]
+    torch.set_num_threads(8)
+    out_ref = ref(data)
+    torch.nn.MSELoss()(out_ref, data.y).backward()
+    out64, g64 = _fp64_truth(ref, data)                          # deepcopy carries the masks along
+    assert_close(out, out_ref, RTOL, "train-mode out")
+    assert_close(out, out64.float(), RTOL, "train-mode out vs fp64")
+    small = dd.x.shape[0] <= 2000
+    for (k, q_), q, t in zip(m.named_parameters(), ref.parameters(), g64):
+        e_ours, scale = rel_err(q_.grad, t)
+        e_ref, _ = rel_err(q.grad, t)
+        record(f"train-mode grad.{k} (fp32 oracle: {e_ref / max(scale, 1e-300):.2e})", e_ours, scale, None)
+        bound = RTOL * scale if small else max(GRAD_FULL_RTOL * scale, 3 * e_ref)
+        assert e_ours <= bound, (k, e_ours, e_ref, scale)
+    # and the eval-mode pass of the same model ignores the stream entirely
     m.eval()
-    ref_out = m(d)
-    m.train()
-    o1 = m(d)
-    o2 = m(d)
-    assert not torch.equal(o1, o2)                          # offset advanced
-    m.seed_dropout(123)
-    assert torch.equal(m(d), o1)                            # same seed/offset -> same mask
-    assert not torch.equal(o1, ref_out)
-    # E[train output] ~ eval output within a loose bound (linear last layer after the dropped activations)
-    outs = torch.stack([m(d) for _ in range(64)]).mean(0)
-    rel = (outs - ref_out).abs().mean() / ref_out.abs().mean()
-    assert rel < 0.25, rel
-    # gradients flow and are finite
-    loss = torch.nn.MSELoss()(m(d), d.y)
-    loss.backward()
-    assert all(torch.isfinite(q.grad).all() for q in m.parameters())
+    ref.eval()
+    ref.dropout_masks = None
+    with torch.no_grad():
+        assert_close(m(dd), ref(data), RTOL, "eval out")
+
+
+def test_two_models_two_streams_two_threads_do_not_share_state():
+    """The library holds no stream / event / device binding of its own (include/pfn_hip.h: pfn_context): two models, each
+    on its own torch stream, driven (a) interleaved from one thread and (b) concurrently from two host threads, produce
+    bit-for-bit the gradients each produces alone."""
+    import threading
+    torch.manual_seed(5)
+    models = [MaskEmbdMultiMPN(4, 2, 4, 129, 3, 3, 0.0).to(DEV).train() for _ in range(2)]
+    datas = [make_batch("118", 16, seed=s_).to(DEV) for s_ in (1, 2)]
+
+    def run(i, reps=1):
+        for _ in range(reps):
+            models[i].zero_grad(set_to_none=True)
+            torch.nn.MSELoss()(models[i](datas[i]), datas[i].y).backward()
+        return models[i].flat_grad().clone()
+
+    alone = [run(0), run(1)]
+    torch.cuda.synchronize()
+    assert models[0]._context_on(torch.device(DEV)).ptr != models[1]._context_on(torch.device(DEV)).ptr
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    # (a) interleaved on two streams from one thread: forward 0, forward 1, backward 0, backward 1
+    outs = []
+    for i in range(2):
+        streams[i].wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(streams[i]):
+            models[i].zero_grad(set_to_none=True)
+            outs.append(torch.nn.MSELoss()(models[i](datas[i]), datas[i].y))
+    for i in range(2):
+        with torch.cuda.stream(streams[i]):
+            outs[i].backward()
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(models[i].flat_grad(), alone[i]), f"interleaved, model {i}"
+    # (b) two host threads, each with its own stream, 20 steps each
+    got, errs = [None, None], []
+
+    def worker(i):
+        try:
+            with torch.cuda.stream(streams[i]):
+                got[i] = run(i, reps=20)
+            streams[i].synchronize()
+        except Exception as exc:      # noqa: BLE001
+            errs.append(exc)
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
+    for i in range(2):
+        assert torch.equal(got[i], alone[i]), f"threaded, model {i}"
 
 
 # ------------------------------------------------------------------------------------ BASELINE.json full sizes
@@ -579,7 +736,8 @@ def test_config2_full_size_vs_oracle():
         scale = t.abs().max().item()
         e_ours = (p.grad.cpu().double() - t).abs().max().item()
         e_ref = (q.grad.double() - t).abs().max().item()
-        assert e_ours <= max(5e-4 * scale, 3 * e_ref), (k, e_ours, e_ref, scale)
+        record(f"grad.{k} vs fp64 (fp32 oracle: {e_ref / max(scale, 1e-300):.2e})", e_ours, scale, GRAD_FULL_RTOL)
+        assert e_ours <= max(GRAD_FULL_RTOL * scale, 3 * e_ref), (k, e_ours, e_ref, scale)
 
 
 def test_config3_inference_batch2048_properties():
@@ -642,4 +800,5 @@ def test_config4_case6470_batch64_properties(hub):
         scale = t.abs().max().item()
         e_ours = (p.grad.cpu().double() - t).abs().max().item()
         e_ref = (q.grad.double() - t).abs().max().item()
-        assert e_ours <= max(5e-4 * scale, 3 * e_ref), (k, e_ours, e_ref, scale)
+        record(f"grad.{k} vs fp64 (fp32 oracle: {e_ref / max(scale, 1e-300):.2e})", e_ours, scale, GRAD_FULL_RTOL)
+        assert e_ours <= max(GRAD_FULL_RTOL * scale, 3 * e_ref), (k, e_ours, e_ref, scale)

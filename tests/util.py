@@ -8,9 +8,11 @@ from poweflownet_amd.data import Data
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
-# north_star tolerance: 1e-5 relative, fp32.  "Relative" is taken against the tensor's scale
-# (max |ref|), plus the same factor elementwise, i.e. |a-b| <= RTOL * (|b| + max|b|).
+# north_star tolerance: 1e-5 relative, fp32.  "Relative" is normwise and FLAT: |a - b| <= RTOL * max|b| for every element
+# (no extra elementwise slack).  Every comparison also records the error it achieved (`REPORT`), which conftest.py dumps
+# to gpurun_out/parity_report.json at the end of a GPU session -- the bounds in the tests are set from those numbers.
 RTOL = 1e-5
+REPORT = {}
 
 
 def load(name):
@@ -32,14 +34,27 @@ def params_from(fx, prefix="param."):
     return {k[len(prefix):]: v for k, v in fx.items() if k.startswith(prefix)}
 
 
-def assert_close(a, b, rtol=RTOL, what=""):
+def rel_err(a, b):
+    """(max |a - b|, max |b|) in float64."""
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
+    if b.numel() == 0:
+        return 0.0, 0.0
+    return (a - b).abs().max().item(), b.abs().max().item()
+
+
+def record(what, err, scale, bound=None):
+    import os
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    REPORT.setdefault(test, []).append({"what": what, "max_abs_err": err, "scale": scale,
+                                        "rel": (err / scale if scale > 0 else 0.0), "bound_rel": bound})
+
+
+def assert_close(a, b, rtol=RTOL, what=""):
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     if b.numel() == 0:
         return
-    scale = b.abs().max().item()
-    err = (a - b).abs()
-    bound = rtol * (b.abs() + scale) + 1e-30
-    worst = (err / bound).max().item()
-    assert worst <= 1.0, f"{what}: max err {err.max().item():.3e} (scale {scale:.3e}) exceeds rtol {rtol:g} by x{worst:.2f}"
+    err, scale = rel_err(a, b)
+    record(what, err, scale, rtol)
+    assert err <= rtol * scale + 1e-30, \
+        f"{what}: max err {err:.3e} = {err / max(scale, 1e-300):.2e} of the largest entry {scale:.3e}, bound {rtol:g}"

@@ -17,7 +17,8 @@ import torch
 from poweflownet_amd import dp
 from poweflownet_amd.data import DataLoader
 from poweflownet_amd.datasets import PowerFlowData, random_bus_type
-from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN, MPN_simplenet
+from poweflownet_amd.networks.MPN import (MPN, MaskEmbdMPN, MaskEmbdMultiMPN, MaskEmbdMultiMPN_NoMP, MPN_simplenet, MultiMPN,
+                                          SkipMPN)
 from poweflownet_amd.optim import FlatAdamW
 from poweflownet_amd.synth import make_dataset
 from poweflownet_amd.utils.argument_parser import argument_parser
@@ -28,10 +29,14 @@ from poweflownet_amd.utils.training import GraphedTrainStep, append_to_json, tra
 
 def main():
     args = argument_parser()
-    models = {"MaskEmbdMultiMPN": MaskEmbdMultiMPN, "MPN_simplenet": MPN_simplenet}     # train.py:30-38
+    # train.py:30-38.  As in the reference, every entry but MaskEmbdMultiMPN / MPN_simplenet asserts a 12-wide node layout
+    # the dataset does not produce (networks/MPN.py:194,...) and stops at its first forward.  `MultiConvNet` (ChebConv over
+    # 5 edge features, :671-750) is not on the EdgeAggregation/TAGConv path and is not built; `MaskEmbdMultiMPN_NoMP` is
+    # defined by the reference but absent from its table -- accepted here for completeness.
+    models = {"MPN": MPN, "MPN_simplenet": MPN_simplenet, "SkipMPN": SkipMPN, "MaskEmbdMPN": MaskEmbdMPN,
+              "MultiMPN": MultiMPN, "MaskEmbdMultiMPN": MaskEmbdMultiMPN, "MaskEmbdMultiMPN_NoMP": MaskEmbdMultiMPN_NoMP}
     if args.model not in models:
-        raise SystemExit(f"--model {args.model}: the reference's other models assert a stale 12-wide node-feature layout "
-                         "(networks/MPN.py:194,267,349,430,625,728) and cannot run on its own dataset; see DESIGN.md")
+        raise SystemExit(f"--model {args.model}: not one of {sorted(models)}")
     rank, local_rank, world = dp.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("train.py needs a HIP device: poweflownet_amd has no CPU fallback")
@@ -78,9 +83,10 @@ def main():
     scheduler = torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=args.lr, steps_per_epoch=len(train_loader),
                                                     epochs=args.num_epochs)
     run_id = time.strftime("%Y%m%d-%H%M%S")
-    if rank == 0 and hasattr(trainset, "xymean") and trainset.xymean is not None:     # normalising params (train.py:81-88)
+    if rank == 0 and hasattr(trainset, "xymean"):     # normalising params (train.py:81-88); None entries under --disable_normalize
         os.makedirs(os.path.join(args.data_dir, "params"), exist_ok=True)
-        torch.save({k: getattr(trainset, k).cpu() for k in ("xymean", "xystd", "edgemean", "edgestd")},
+        torch.save({k: (None if getattr(trainset, k) is None else getattr(trainset, k).cpu())
+                    for k in ("xymean", "xystd", "edgemean", "edgestd")},
                    os.path.join(args.data_dir, "params", f"data_params_{run_id}.pt"))
     best_val = float("inf")
     graphed = GraphedTrainStep(model, loss_fn, optimizer) if world == 1 else None   # one hipGraph launch per batch
