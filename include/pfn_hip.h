@@ -50,15 +50,10 @@ typedef struct pfn_mpn_config {
     int32_t training;       /* 1: dropout active (model.train()), 0: model.eval() */
 } pfn_mpn_config;
 
-/* The library keeps NO process-global mutable state: no stream, event, cache or "first caller" device binding of its
- * own.  What a call cannot create on the fly lives in a context the CALLER owns: today the second HIP stream and the
- * events pfn_mpn_backward uses to overlap weight-gradient work with the input-gradient chain.  A context is bound to the
- * device that was current when it was created and serves ONE call at a time (one per model or host thread; two models
- * on two devices, or two threads, each bring their own).  Every entry point that takes a context accepts NULL = no
- * overlap.  Creation and destruction are the only calls that create / destroy HIP objects.                          */
-int pfn_context_create(void** ctx_out);
-int pfn_context_destroy(void* ctx);
-
+/* The library keeps NO process-global mutable state: no stream, event, cache or "first caller" device binding of its own
+ * (per-device facts such as the CU count are looked up per call; kernel attributes are raised once per device, lock-free).
+ * Every call works on the caller's stream and the caller's workspaces only, so two models on two devices or two host
+ * threads may run concurrently as long as they do not share a workspace.                                              */
 int pfn_abi_version(void);
 const char* pfn_last_error(void);            /* thread-local, valid until the next failing call */
 int64_t pfn_padded_ld(int64_t features);     /* roundup(features, 4) */
@@ -113,8 +108,7 @@ int pfn_mpn_forward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_n
 int pfn_mpn_backward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
                      const float* const* params, float* const* grads, const float* x,
                      const void* pred_mask, int mask_dtype, const float* edge_attr, const float* grad_out,
-                     float* grad_x, float* grad_edge_attr, void* ws, size_t ws_bytes, int64_t seg_nodes,
-                     void* ctx /* pfn_context_create, or NULL */, void* stream);
+                     float* grad_x, float* grad_edge_attr, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream);
 
 /* ------------------------------------------------------------------------------------- single layers
  * EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, output_dim).forward (networks/MPN.py:30-56):

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpfn_hip.so")
 
 # every symbol include/pfn_hip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = (
-    "pfn_abi_version", "pfn_last_error", "pfn_padded_ld", "pfn_context_create", "pfn_context_destroy",
+    "pfn_abi_version", "pfn_last_error", "pfn_padded_ld",
     "pfn_graph_workspace_bytes", "pfn_graph_build", "pfn_graph_info", "pfn_graph_segments", "pfn_graph_export_edges",
     "pfn_mpn_num_params", "pfn_mpn_workspace_bytes", "pfn_mpn_forward", "pfn_mpn_backward",
     "pfn_edge_aggr_workspace_bytes", "pfn_edge_aggr_forward", "pfn_edge_aggr_backward",
@@ -53,8 +53,6 @@ def load() -> C.CDLL:
         "pfn_abi_version": (C.c_int, []),
         "pfn_last_error": (C.c_char_p, []),
         "pfn_padded_ld": (i64, [i64]),
-        "pfn_context_create": (C.c_int, [C.POINTER(C.c_void_p)]),
-        "pfn_context_destroy": (C.c_int, [p]),
         "pfn_graph_workspace_bytes": (sz, [i64, i64]),
         "pfn_graph_build": (C.c_int, [p, i64, i64, i32, p, sz, p]),
         "pfn_graph_info": (C.c_int, [p, i64, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int64), p]),
@@ -63,7 +61,7 @@ def load() -> C.CDLL:
         "pfn_mpn_num_params": (C.c_int, [cfgp]),
         "pfn_mpn_workspace_bytes": (sz, [cfgp, i64, i64]),
         "pfn_mpn_forward": (C.c_int, [cfgp, p, i64, i64, p, p, p, i32, p, p, p, sz, p, i64, p]),
-        "pfn_mpn_backward": (C.c_int, [cfgp, p, i64, i64, p, p, p, p, i32, p, p, p, p, p, sz, i64, p, p]),
+        "pfn_mpn_backward": (C.c_int, [cfgp, p, i64, i64, p, p, p, p, i32, p, p, p, p, p, sz, i64, p]),
         "pfn_edge_aggr_workspace_bytes": (sz, [i64, i64, i32, i32, i32, i32]),
         "pfn_edge_aggr_forward": (C.c_int, [p, i64, i64, i32, i32, i32, i32, p, i64, p, p, p, p, p, p, i64, p, sz, p]),
         "pfn_edge_aggr_backward": (C.c_int, [p, i64, i64, i32, i32, i32, i32, p, i64, p, p, p, p, p, p, i64, p, i64, p,
@@ -88,30 +86,6 @@ def load() -> C.CDLL:
         raise RuntimeError("libpfn_hip.so ABI version mismatch")
     _lib = lib
     return lib
-
-
-class Context:
-    """Owner of a `pfn_context` (include/pfn_hip.h): the side stream + events of one model on one device."""
-
-    def __init__(self, device: torch.device):
-        self.device, self._h = device, C.c_void_p()
-        with torch.cuda.device(device):
-            check(load().pfn_context_create(C.byref(self._h)), "pfn_context_create")
-
-    @property
-    def ptr(self):
-        return self._h.value
-
-    def __reduce__(self):                    # copy.deepcopy / pickle of a model: the copy gets its own fresh context
-        return (Context, (self.device,))
-
-    def __del__(self):
-        try:
-            if self._h and _lib is not None:
-                _lib.pfn_context_destroy(self._h)
-                self._h = C.c_void_p()
-        except Exception:
-            pass
 
 
 def check(rc: int, what: str) -> None:

@@ -5,247 +5,277 @@
 //   dW[i][j] = sum_m A[m][i] * B[m][j]     A = gradient of the layer output (M x na), B = layer input (M x nb),
 // M = nodes (1e4..1e6) is the REDUCTION dimension, na, nb <= a few hundred.  Exact fp32 on v_mfma_f32_32x32x2_f32.
 //
-// Both operands are row-major with the reduction index as the row, which is exactly the MFMA operand order: at step s
-// lane (c = lane & 31, kh = lane >> 5) supplies row m + 2s + kh.  A lane loads TWO adjacent columns (8 bytes: columns
-// 2c, 2c+1 of a 64-column quadrant), so a wave load covers 2 rows x 256 contiguous bytes and the wave owns a 64 x 64
-// output quadrant as 2 x 2 interleaved 32 x 32 accumulator tiles (tile (sa, sb) = rows 2i + sa, columns 2j + sb).
-// No LDS staging, no barriers in the loop: every wave streams its own row range straight from global memory
-// (hand double-buffered batches of 16 rows), 4 MFMAs per 2 loads.  H = 129 = 2*64 + 1: the odd row / column and the
-// bias gradient (a virtual ones- or rowscale-column of B) never get a tile -- they are VALU dot products off the
-// fragments the wave already holds.
+// ONE launch serves every weight of the network (model.hip defers all weight gradients to the end of the backward
+// pass): a task = one 128 x 128 tile of one weight x one contiguous row range, a workgroup = one task, its 8 waves = 4
+// row groups x 2 column halves (two waves per SIMD).  A wave holds a 128 x 64 piece of the tile as 4 x 2 interleaved
+// 32 x 32 accumulators (128 registers) and streams its own rows straight from global memory:
+//   * both operands are row-major with the reduction index as the row -- exactly the MFMA operand order: at step s lane
+//     (c = lane & 31, kh = lane >> 5) supplies row m + 2s + kh;
+//   * a lane loads FOUR adjacent columns (16 bytes) of A and TWO (8 bytes) of B, so a wave load covers 2 rows x 512 / 256
+//     contiguous bytes and the pair feeds 8 MFMAs (tile (ta, tb) = rows 4i + ta, columns 64 half + 2j + tb of the weight):
+//     2 vector-memory instructions per 512 MFMA cycles, no LDS staging, no barrier in the loop, hand double-buffered
+//     batches of 8 rows; the two column halves of a row group read the same A rows (the second one hits L1);
+//   * operands at most 32 columns wide (the 4-wide node features / outputs) take ONE tile with lane c = column c (a
+//     narrow B has no column halves: the 8 waves are 8 row groups);
+//   * H = 129 = 128 + 1: the odd row / column and the bias gradient (a virtual ones- or rowscale-column of B) never get a
+//     tile -- they are VALU dot products off the fragments the wave already holds.
+// The row groups take the 8-row batches of the block's range round-robin (one DRAM stream per operand), are summed by a
+// fixed LDS tree, and a task split over several blocks publishes partials that tn_combine_kernel sums in block order
+// (deterministic, no float atomics) into the nn.Linear gradient layout.
 //
-// Work split: a block's 8 waves = the (up to 4) quadrants of ONE pair x 2..8 consecutive row ranges, so the quadrants
-// share every operand row through the CU's L1 (one quadrant per block re-read each row 2x from L2/HBM: measured 2.6x
-// slower); the ranges are summed by a fixed LDS tree; when a group is split over several blocks they publish partials
-// and tn_combine_kernel sums them in block order (deterministic, no float atomics) into the nn.Linear gradient layout.
-// (A last-arriver combine inside the kernel was tried: one CU pulling ~100 partials of 73 KB serialises -- 270 us.)
+// History: v2 gave every wave a 64 x 64 quadrant (2 x 2 tiles, 8-byte loads, quadrants sharing rows through L1) and ran
+// one launch + one combine per layer on a side stream: 33-50 TF.  A 128 x 128 tile per wave (256 accumulators in the
+// unified VGPR/AGPR file, one wave per SIMD) compiled to 611 spills: VALU cannot read AGPRs, and the cross-wave sum needs
+// every accumulator in a VGPR.
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <type_traits>
+#include <vector>
 
 #include "pfn_internal.hpp"
 
 namespace pfn {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int TN_THREADS = 512;
-constexpr int TN_WAVES = TN_THREADS / 64;
-constexpr int TN_U = 8;                    // MFMA steps (row pairs) per batch: 16 rows
-constexpr int TN_QUADS = 18;               // float4 per lane of a partial: 16 (four 32x32 tiles) + 2 (VALU extras)
-constexpr int TN_PART = TN_QUADS * 64 * 4; // floats per partial
-constexpr int TN_MAX_PAIRS = 8;
-constexpr int TN_MAX_TASKS = 64;
-constexpr int TN_MAX_PARTIALS = 2048;
+constexpr int T3_THREADS = 512;            // 8 waves = two per SIMD
+constexpr int T3_WAVES = 8;
+constexpr int T3_U = 4;                    // MFMA steps (row pairs) per batch: 8 rows
+constexpr int T3_ROWS = 2 * T3_U;
+constexpr int T3_MAX_PAIRS = 24;
+constexpr int T3_MAX_TASKS = 48;
+constexpr int T3_LDS_BYTES = 4 * (4 * 2 * 4 + 4) * 64 * 16;   // the first tree round of the largest shape: 2 row groups x 2 halves x 36 quads
 enum { TNF_XCOL = 1, TNF_BIAS = 2, TNF_XROW = 4 };
 
-struct TnTask { short pair, qi, qj, flags; };
-struct TnGroup { TnTask task[4]; int ng, gshift; };   // ng = 1, 2 or 4 quadrants of one pair; gshift = log2(ng)
-struct TnArgs {
-    TnPair pair[TN_MAX_PAIRS];
-    TnGroup group[TN_MAX_TASKS / 2];
-    int M, rows_per_wave, nblk_x, ntasks;   // ntasks = number of GROUPS
-    float* partial;   // [ngroups][nblk_x][4][TN_QUADS][64] float4
+// quads (float4 per lane) of ONE WAVE's partial: TA*TB tiles x 4 register groups, then 4 quads of VALU extras.  TA = 4 / 1
+// (wide / narrow A), TB = 2 / 1 (wide B: the wave's half of the 128 columns / narrow B)
+__host__ __device__ constexpr int t3_quads(int TA, int TB) { return TA * TB * 4 + 4; }
+
+struct T3Task {
+    short pair, ti, tj, flags;
+    short wa, wb;          // 1: the operand is wide (a lane holds 4 adjacent columns); 0: narrow (lane c = column c)
+    int nsplit, block0;    // row splits of this task; first workgroup id
+    int part0;             // float4 offset of this task's first partial in the partial buffer
+};
+struct T3Args {
+    TnPair pair[T3_MAX_PAIRS];
+    T3Task task[T3_MAX_TASKS];
+    int ntasks, M, nblocks, pad_;
+    float4* partial;
 };
 
-struct TnBatch {
-    f32x2 a[TN_U], b[TN_U];
-    // side operands of the VALU extras, ONE value per lane for the whole batch: lane l holds row (l & 15) of the batch; step s
-    // fetches row 2s + kh through the LDS crossbar (ds_bpermute).  As three broadcast loads per step they made the kernel
-    // VMEM-issue-bound: 5 vector-memory instructions per 4 MFMAs, 8 waves per CU.
-    float xv16, rs16, yv16;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int W>
+struct T3Frag {   // one operand of one MFMA step: 4 (A) / 2 (B) adjacent columns of a wide operand, 1 column of a narrow one
+    typedef typename std::conditional<W == 4, f32x4, typename std::conditional<W == 2, f32x2, float>::type>::type type;
 };
+template <int TA, int TB>
+struct T3Batch {
+    typename T3Frag<TA>::type a[T3_U];
+    typename T3Frag<TB>::type b[T3_U];
+    float xv, yv, rs;      // side operands of the VALU extras: lane l holds row (l & 7) of the batch
+    float ones;            // 1 for a row inside the range, 0 past it: the bias column when there is no rowscale
+};
+__device__ __forceinline__ float frag_at(const f32x4& v, int i) { return v[i]; }
+__device__ __forceinline__ float frag_at(const f32x2& v, int i) { return v[i]; }
+__device__ __forceinline__ float frag_at(const float& v, int) { return v; }
+__device__ __forceinline__ void frag_zero(f32x4& v) { v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void frag_zero(f32x2& v) { v = f32x2{0.f, 0.f}; }
+__device__ __forceinline__ void frag_zero(float& v) { v = 0.f; }
 
-// Scatter one float4 quad of a quadrant partial into the nn.Linear gradient layout.  Quad Q < 16 = accumulator registers
-// 4(Q&3)..+3 of tile (sa = Q >> 3, sb = (Q >> 2) & 1): element e is row 64 qi + 2 (e + 8 (Q&3) + 4 kh) + sa, column
-// 64 qj + 2 c + sb.  Q = 16: {odd column[2c], [2c+1], bias[2c], [2c+1]};  Q = 17: {odd row[2c], [2c+1], corner, corner bias}.
-__device__ __forceinline__ void tn_emit(const TnPair& pr, const TnTask tk, int Q, float4 s, int c, int kh, int lane) {
+// Scatter one float4 quad of a wave partial into the nn.Linear gradient layout.  Quad Q < 4 TA TB = register group g = Q & 3 of
+// tile (ta, tb) = ((Q >> 2) / TB, (Q >> 2) % TB): element e is accumulator row i = e + 8 g + 4 kh, column j = c, i.e.
+// dW row 128 ti + 4 i + ta (wide A; i for a narrow A), column 128 tj + 64 half + 2 j + tb (wide B; j for a narrow B).
+// Extras: quad X+0 = odd column (dW[.][nb-1]) for the lane's TA rows, X+1 = bias for the same rows (both: half 0 only),
+// X+2 = odd row (dW[na-1][.]) for the lane's TB columns, X+3 = {corner, corner bias, -, -} (half 0 only).
+template <int TA, int TB>
+__device__ __forceinline__ void t3_emit(const TnPair& pr, const T3Task& tk, int half, int Q, float4 s, int c, int kh, int lane) {
     const bool f_xcol = tk.flags & TNF_XCOL, f_bias = tk.flags & TNF_BIAS, f_xrow = tk.flags & TNF_XROW;
-    const int na_main = pr.na - ((pr.na % 64 == 1 && pr.na > 1) ? 1 : 0), nb_main = pr.nb - ((pr.nb % 64 == 1 && pr.nb > 1) ? 1 : 0);
+    const int na_main = pr.na - (f_xrow ? 1 : 0), nb_main = pr.nb - (f_xcol ? 1 : 0);
     const float e4[4] = {s.x, s.y, s.z, s.w};
-    if (Q < 16) {
-        const int sa = Q >> 3, sb = (Q >> 2) & 1;
-        const int j = 64 * tk.qj + 2 * c + sb;
+    constexpr int NT = TA * TB * 4;
+    if (Q < NT) {
+        const int t = Q >> 2, g = Q & 3, ta = t / TB, tb = t % TB;
+        const int j = TB == 2 ? 128 * tk.tj + 64 * half + 2 * c + tb : c;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int i = 64 * tk.qi + 2 * (e + 8 * (Q & 3) + 4 * kh) + sa;
+            const int ii = e + 8 * g + 4 * kh;
+            const int i = TA == 4 ? 128 * tk.ti + 4 * ii + ta : ii;
             if (i < na_main && j < nb_main) pr.G[(size_t)(pr.gn0 + i) * pr.ldg + pr.gk0 + j] = e4[e];
         }
-    } else if (Q == 16) {
-        if (kh == 0) {
+        return;
+    }
+    if (kh != 0) return;          // the two k halves were summed into both; the lower half emits
+    const int x = Q - NT;
+    if (x == 0 || x == 1) {
+        if (half != 0) return;
 #pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int i = 64 * tk.qi + 2 * c + e;
-                if (i < na_main) {
-                    if (f_xcol) pr.G[(size_t)(pr.gn0 + i) * pr.ldg + pr.gk0 + pr.nb - 1] = e4[e];
-                    if (f_bias) pr.bias_out[i] = e4[2 + e];
-                }
+        for (int t = 0; t < TA; ++t) {
+            const int i = TA == 4 ? 128 * tk.ti + 4 * c + t : c;
+            if (i < na_main) {
+                if (x == 0 && f_xcol) pr.G[(size_t)(pr.gn0 + i) * pr.ldg + pr.gk0 + pr.nb - 1] = e4[t];
+                if (x == 1 && f_bias) pr.bias_out[i] = e4[t];
             }
         }
-    } else if (kh == 0 && f_xrow) {
+    } else if (x == 2) {
+        if (f_xrow) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int j = 64 * tk.qj + 2 * c + e;
-            if (j < nb_main) pr.G[(size_t)(pr.gn0 + pr.na - 1) * pr.ldg + pr.gk0 + j] = e4[e];
+            for (int t = 0; t < TB; ++t) {
+                const int j = TB == 2 ? 128 * tk.tj + 64 * half + 2 * c + t : c;
+                if (j < nb_main) pr.G[(size_t)(pr.gn0 + pr.na - 1) * pr.ldg + pr.gk0 + j] = e4[t];
+            }
         }
-        if (lane == 0) {
-            if (f_xcol) pr.G[(size_t)(pr.gn0 + pr.na - 1) * pr.ldg + pr.gk0 + pr.nb - 1] = e4[2];
-            if (f_bias) pr.bias_out[pr.na - 1] = e4[3];
-        }
+    } else if (lane == 0 && half == 0 && f_xrow) {
+        if (f_xcol) pr.G[(size_t)(pr.gn0 + pr.na - 1) * pr.ldg + pr.gk0 + pr.nb - 1] = e4[0];
+        if (f_bias) pr.bias_out[pr.na - 1] = e4[1];
     }
 }
 
-__global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_kernel(const TnArgs a) {
-    __shared__ __attribute__((aligned(16))) float4 red[4][TN_QUADS][64];
+template <int TA, int TB>
+__device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int bx, float4* lds) {
+    constexpr int NQ = t3_quads(TA, TB);
+    constexpr int NH = TB == 2 ? 2 : 1;                 // column halves of the block
+    constexpr int NR = T3_WAVES / NH;                   // row groups
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = NH == 2 ? (wave & 1) : 0, wr = NH == 2 ? (wave >> 1) : wave;
     const int c = lane & 31, kh = lane >> 5;
-    // 1-D grid, XCD-aware: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), and all tasks of one row
-    // range read the same rows (a pair's quadrants; the pairs of a TAGConv share A, dP/dQ share B) -> they get linear ids
-    // that agree mod 8:  id = (bx / 8) * 8 * ntasks + task * 8 + bx % 8
-    const int sup = blockIdx.x / (8 * a.ntasks), rem = blockIdx.x - sup * 8 * a.ntasks;
-    const int by = rem >> 3, bx = sup * 8 + (rem & 7);
-    if (bx >= a.nblk_x) return;
-    const int ng = a.group[by].ng, gshift = a.group[by].gshift;
-    const int wq = wave & (ng - 1), wr = wave >> gshift, nr = TN_WAVES >> gshift;   // quadrant / row range of this wave
-    const TnTask tk = a.group[by].task[wq];
-    const TnPair pr = a.pair[tk.pair];
-    const bool f_xcol = tk.flags & TNF_XCOL, f_bias = tk.flags & TNF_BIAS, f_xrow = tk.flags & TNF_XROW;
-    const bool f_any = tk.flags != 0;
-    // columns of this lane: clamped into the row so the 8-byte read is always legal; columns past na / nb produce
-    // outputs that are never stored
-    const int acol = min(64 * tk.qi + 2 * c, pr.lda - 2), bcol = min(64 * tk.qj + 2 * c, pr.ldb - 2);
+    const TnPair& pr = a.pair[tk.pair];
+    const int M = a.M;
+    // the block's row range: nsplit contiguous ranges whose length is a multiple of 8 x 8 rows (the last one is ragged)
+    constexpr int GR = T3_ROWS * T3_WAVES;
+    const int64_t per = ((int64_t)(M + tk.nsplit - 1) / tk.nsplit + GR - 1) / GR * GR;
+    const int R0 = (int)min((int64_t)M, per * bx), R1 = (int)min((int64_t)M, per * (bx + 1));
+    // columns of this lane, clamped into the row so every read is legal; columns past na / nb produce outputs that are
+    // never stored
+    const int acol = TA == 4 ? min(128 * tk.ti + 4 * c, pr.lda - 4) : min(c, pr.lda - 1);
+    const int bcol = TB == 2 ? min(128 * tk.tj + 64 * half + 2 * c, pr.ldb - 2) : min(c, pr.ldb - 1);
     const float* Ap = pr.A + acol;
     const float* Bp = pr.B + bcol;
-    const float* Xc = pr.B + (pr.nb - 1);     // the odd column of B (f_xcol)
-    const float* Yr = pr.A + (pr.na - 1);     // the odd column of A = odd row of dW (f_xrow)
+    const float* Xc = pr.B + (pr.nb - 1);     // the odd column of B (TNF_XCOL)
+    const float* Yr = pr.A + (pr.na - 1);     // the odd column of A = odd row of dW (TNF_XROW)
     const float* Rs = pr.bias_rowscale;
-    // The block owns ONE contiguous row range; its nr row-waves take the 32-row chunks of it round-robin, so the block
-    // reads a single stream per operand (all 8 waves touch the same DRAM pages / L1 lines at about the same time).
-    const int R0 = min(a.M, bx * nr * a.rows_per_wave), R1 = min(a.M, R0 + nr * a.rows_per_wave);
-    const int nchunks = (R1 - R0) >> 5;
-    const int mlast = a.M - 1;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TA][TB];
 #pragma unroll
-    for (int sa = 0; sa < 2; ++sa)
+    for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
-        for (int sb = 0; sb < 2; ++sb)
+        for (int tb = 0; tb < TB; ++tb)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) acc[sa][sb][q] = 0.f;
-    float xc[2] = {0.f, 0.f}, bs[2] = {0.f, 0.f}, xr[2] = {0.f, 0.f}, cn = 0.f, cb = 0.f;
+            for (int q = 0; q < 16; ++q) acc[ta][tb][q] = 0.f;
+    float xc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f}, xr[4] = {0.f, 0.f, 0.f, 0.f}, cn = 0.f, cb = 0.f;
 
-    // The streaming loop exists in two instantiations chosen ONCE per wave -- with and without the VALU extras: as
-    // runtime flags inside load()/compute() they put a scalar branch in front of every load.  With extras all three side
-    // operands are loaded unconditionally from always-valid addresses (results a task does not own are never emitted).
+    // The streaming loop exists in two instantiations chosen ONCE per wave -- with and without the VALU extras: as runtime
+    // flags inside load()/compute() they put a scalar branch in front of every load.  With extras all three side operands
+    // are loaded unconditionally from always-valid addresses (results a task does not own are never emitted).
     const float* Rs2 = Rs ? Rs : pr.A;                 // no rowscale: any valid address, the value is replaced by 1
     const size_t rs_stride = Rs ? 1 : (size_t)pr.lda;
     const bool has_rs = Rs != nullptr;
     auto stream = [&](auto ex_c) {
         constexpr bool EX = decltype(ex_c)::value;
+        typedef T3Batch<TA, TB> Batch;
+        typedef typename T3Frag<TA>::type FA;
+        typedef typename T3Frag<TB>::type FB;
         // Addresses = wave-uniform 64-bit row base (scalar ALU) + a per-lane 32-bit offset that never changes: no vector
-        // address math in the loop (with per-load 64-bit multiply-adds the kernel was VALU-bound at 31 % of the MFMA
-        // peak even when every load hit L1).  A batch that would run past the matrix is moved back as a whole (uniform
-        // clamp); the only caller that can see moved rows is the prefetch of a batch that is never consumed.
+        // address math in the loop and no per-load address registers (with per-lane clamped rows the loop needed > 256
+        // VGPRs).  Only FULL batches take this path; the ragged tail of the range has its own per-lane clamped loads.
         const uint32_t voA = (uint32_t)(kh * pr.lda) * 4u, voB = (uint32_t)(kh * pr.ldb) * 4u;
-        const int l16 = lane & 15;
-        const uint32_t voX16 = (uint32_t)(l16 * pr.ldb) * 4u, voY16 = (uint32_t)(l16 * pr.lda) * 4u, voR16 = (uint32_t)(l16 * (int)rs_stride) * 4u;
-        auto load = [&](TnBatch& t, int m0) {   // rows m0 .. m0+15
-            const int mu = max(0, min(m0, a.M - 2 * TN_U));
-            const char* rowA = reinterpret_cast<const char*>(Ap) + (size_t)mu * pr.lda * 4;
-            const char* rowB = reinterpret_cast<const char*>(Bp) + (size_t)mu * pr.ldb * 4;
-            const char* rowX = reinterpret_cast<const char*>(Xc) + (size_t)mu * pr.ldb * 4;
-            const char* rowY = reinterpret_cast<const char*>(Yr) + (size_t)mu * pr.lda * 4;
-            const char* rowR = reinterpret_cast<const char*>(Rs2) + (size_t)mu * rs_stride * 4;
+        const int l8 = lane & 7;
+        const uint32_t voX = (uint32_t)(l8 * pr.ldb) * 4u, voY = (uint32_t)(l8 * pr.lda) * 4u, voR = (uint32_t)(l8 * (int)rs_stride) * 4u;
+        auto load = [&](Batch& t, int m0) {   // rows m0 .. m0 + 7, all inside the matrix
+            const char* rowA = reinterpret_cast<const char*>(Ap) + (size_t)m0 * pr.lda * 4;
+            const char* rowB = reinterpret_cast<const char*>(Bp) + (size_t)m0 * pr.ldb * 4;
 #pragma unroll
-            for (int s = 0; s < TN_U; ++s) {
-                t.a[s] = *reinterpret_cast<const f32x2*>(rowA + (size_t)(2 * s) * pr.lda * 4 + voA);
-                t.b[s] = *reinterpret_cast<const f32x2*>(rowB + (size_t)(2 * s) * pr.ldb * 4 + voB);
+            for (int s = 0; s < T3_U; ++s) {
+                t.a[s] = *reinterpret_cast<const FA*>(rowA + (size_t)(2 * s) * pr.lda * 4 + voA);
+                t.b[s] = *reinterpret_cast<const FB*>(rowB + (size_t)(2 * s) * pr.ldb * 4 + voB);
             }
             if (EX) {
-                t.xv16 = *reinterpret_cast<const float*>(rowX + voX16);
-                t.yv16 = *reinterpret_cast<const float*>(rowY + voY16);
-                const float r = *reinterpret_cast<const float*>(rowR + voR16);
-                t.rs16 = has_rs ? r : 1.f;
+                t.ones = 1.f;
+                t.xv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Xc) + (size_t)m0 * pr.ldb * 4 + voX);
+                t.yv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Yr) + (size_t)m0 * pr.lda * 4 + voY);
+                // (raw value: selecting `has_rs ? r : 1` HERE makes the load's first use immediate -> a vmcnt(0) drain per batch)
+                t.rs = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Rs2) + (size_t)m0 * rs_stride * 4 + voR);
             }
         };
-        auto load_tail = [&](TnBatch& t, int m0) {   // per-lane clamped rows (ragged tail only)
+        auto load_tail = [&](Batch& t, int m0) {   // per-lane clamped rows; rows past the range contribute zeros
 #pragma unroll
-            for (int s = 0; s < TN_U; ++s) {
-                const int row = min(m0 + 2 * s + kh, mlast);
-                t.a[s] = *reinterpret_cast<const f32x2*>(Ap + (size_t)row * pr.lda);
-                t.b[s] = *reinterpret_cast<const f32x2*>(Bp + (size_t)row * pr.ldb);
+            for (int s = 0; s < T3_U; ++s) {
+                const int row = m0 + 2 * s + kh, rc = min(row, M - 1);
+                t.a[s] = *reinterpret_cast<const FA*>(Ap + (size_t)rc * pr.lda);
+                t.b[s] = *reinterpret_cast<const FB*>(Bp + (size_t)rc * pr.ldb);
+                if (row >= R1) frag_zero(t.b[s]);
             }
             if (EX) {
-                const int row = min(m0 + l16, mlast);
-                t.xv16 = Xc[(size_t)row * pr.ldb];
-                t.yv16 = Yr[(size_t)row * pr.lda];
-                const float r = Rs2[(size_t)row * rs_stride];
-                t.rs16 = has_rs ? r : 1.f;
+                const int row = m0 + l8, rc = min(row, M - 1);
+                const bool ok = row < R1;
+                const float x = Xc[(size_t)rc * pr.ldb], y = Yr[(size_t)rc * pr.lda], r = Rs2[(size_t)rc * rs_stride];
+                t.xv = ok ? x : 0.f;
+                t.yv = ok ? y : 0.f;
+                t.rs = ok ? r : 0.f;
+                t.ones = ok ? 1.f : 0.f;
             }
         };
-        auto compute = [&](const TnBatch& t) {
+        auto compute = [&](const Batch& t) {
 #pragma unroll
-            for (int s = 0; s < TN_U; ++s) {
+            for (int s = 0; s < T3_U; ++s) {
 #pragma unroll
-                for (int sa = 0; sa < 2; ++sa)
+                for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
-                    for (int sb = 0; sb < 2; ++sb)
-                        acc[sa][sb] = __builtin_amdgcn_mfma_f32_32x32x2f32(t.a[s][sa], t.b[s][sb], acc[sa][sb], 0, 0, 0);
+                    for (int tb = 0; tb < TB; ++tb)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag_at(t.a[s], ta), frag_at(t.b[s], tb), acc[ta][tb], 0, 0, 0);
                 if (EX) {
-                    const float xv = __shfl(t.xv16, 2 * s + kh), rs = __shfl(t.rs16, 2 * s + kh), yv = __shfl(t.yv16, 2 * s + kh);
+                    const float xv = __shfl(t.xv, 2 * s + kh), yv = __shfl(t.yv, 2 * s + kh);
+                    const float rs = __shfl(has_rs ? t.rs : t.ones, 2 * s + kh);
 #pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        xc[e] = fmaf(t.a[s][e], xv, xc[e]);
-                        bs[e] = fmaf(t.a[s][e], rs, bs[e]);
-                        xr[e] = fmaf(yv, t.b[s][e], xr[e]);
+                    for (int e = 0; e < TA; ++e) {
+                        xc[e] = fmaf(frag_at(t.a[s], e), xv, xc[e]);
+                        bs[e] = fmaf(frag_at(t.a[s], e), rs, bs[e]);
                     }
+#pragma unroll
+                    for (int e = 0; e < TB; ++e) xr[e] = fmaf(yv, frag_at(t.b[s], e), xr[e]);
                     cn = fmaf(yv, xv, cn);
                     cb = fmaf(yv, rs, cb);
                 }
             }
         };
-        // ---- full 32-row double batches: the next batch's loads fly under the current batch's MFMAs (two register
-        // sets, swapped by unrolling -- no copies)
-        TnBatch t0, t1;
+        // this row group's FULL batches: wr, wr + NR, ... < nfull; the next batch's loads fly under the current batch's
+        // MFMAs (two register sets, swapped by unrolling -- no copies).  A prefetch past the last full batch is moved back
+        // inside the matrix as a whole (uniform clamp) and never consumed.
+        const int nfull = (R1 - R0) / T3_ROWS;
+        const int mlast = max(0, M - T3_ROWS);
+        Batch t0, t1;
         int j = wr;
-        if (j < nchunks) load(t0, R0 + 32 * j);
-        for (; j < nchunks; j += nr) {
-            const int m = R0 + 32 * j;
-            load(t1, m + 16);
+        if (j < nfull) load(t0, R0 + T3_ROWS * j);
+        // (scheduling barriers: left alone, the scheduler sinks the side-operand loads of a batch down to their first use
+        //  in the NEXT compute, whose wait then is vmcnt(0) -- a full drain of the prefetch -- instead of a counted wait)
+        for (; j < nfull; j += 2 * NR) {
+            load(t1, min(R0 + T3_ROWS * (j + NR), mlast));
+            __builtin_amdgcn_sched_barrier(0);
             compute(t0);
-            load(t0, m + 32 * nr);   // this wave's next chunk (past the range on the last round: clamped rows, never used)
+            __builtin_amdgcn_sched_barrier(0);
+            if (j + NR >= nfull) break;
+            load(t0, min(R0 + T3_ROWS * (j + 2 * NR), mlast));
+            __builtin_amdgcn_sched_barrier(0);
             compute(t1);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // ---- ragged tail of the block's range (< 32 rows), taken by the wave whose turn it is: rows past the end
-        // contribute zeros through B and the side operands
-        if (wr == nchunks % nr) {
-            for (int m = R0 + 32 * nchunks; m < R1; m += 16) {
-                load_tail(t0, m);
-#pragma unroll
-                for (int s = 0; s < TN_U; ++s) {
-                    const bool ok = m + 2 * s + kh < R1;
-                    t0.b[s][0] = ok ? t0.b[s][0] : 0.f;
-                    t0.b[s][1] = ok ? t0.b[s][1] : 0.f;
-                }
-                if (EX) {
-                    const bool ok16 = m + l16 < R1;
-                    t0.xv16 = ok16 ? t0.xv16 : 0.f;
-                    t0.rs16 = ok16 ? t0.rs16 : 0.f;
-                    t0.yv16 = ok16 ? t0.yv16 : 0.f;
-                }
-                compute(t0);
-            }
+        // ragged tail (< 8 rows), taken by the row group whose turn it is
+        if (nfull * T3_ROWS < R1 - R0 && wr == nfull % NR) {
+            load_tail(t0, R0 + T3_ROWS * nfull);
+            compute(t0);
         }
     };
-    if (f_any) stream(std::true_type{});
-    else stream(std::false_type{});
+    // (Two instantiations chosen per wave -- with and without the extras -- made the register allocator keep both branches'
+    //  accumulators apart: 370 spills.  The extras cost 3 ds_bpermute + ~14 FMAs per 8 MFMAs and run under the other wave's
+    //  MFMAs, so every wave takes them; results a task does not own are never emitted.)
+    stream(std::true_type{});
     // the two k halves of the VALU extras
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
+    for (int e = 0; e < 4; ++e) {
         xc[e] += __shfl_xor(xc[e], 32);
         bs[e] += __shfl_xor(bs[e], 32);
         xr[e] += __shfl_xor(xr[e], 32);
@@ -253,157 +283,189 @@ __global__ __launch_bounds__(TN_THREADS, 1) void gemm_tn_kernel(const TnArgs a) 
     cn += __shfl_xor(cn, 32);
     cb += __shfl_xor(cb, 32);
 
-    // ---- everything a lane holds, as 18 float4: quad Q < 16 = registers 4(Q&3) .. +3 of tile (sa = Q >> 3, sb = (Q >> 2) & 1)
-    float4 v[TN_QUADS];
+    // ---- everything a lane holds, as NQ float4 (see t3_emit for the order)
+    float4 v[NQ];
 #pragma unroll
-    for (int Q = 0; Q < 16; ++Q) {
-        const f32x16& t = acc[Q >> 3][(Q >> 2) & 1];
+    for (int Q = 0; Q < NQ - 4; ++Q) {
+        const f32x16& t = acc[(Q >> 2) / TB][(Q >> 2) % TB];
         v[Q] = make_float4(t[4 * (Q & 3)], t[4 * (Q & 3) + 1], t[4 * (Q & 3) + 2], t[4 * (Q & 3) + 3]);
     }
-    v[16] = make_float4(xc[0], xc[1], bs[0], bs[1]);
-    v[17] = make_float4(xr[0], xr[1], cn, cb);
-    // ---- fixed tree over the block's row ranges (per quadrant), e.g. nr = 8: ((0+4)+(2+6)) + ((1+5)+(3+7))
-    for (int stride = nr >> 1; stride >= 1; stride >>= 1) {
+    v[NQ - 4] = make_float4(xc[0], xc[1], xc[2], xc[3]);
+    v[NQ - 3] = make_float4(bs[0], bs[1], bs[2], bs[3]);
+    v[NQ - 2] = make_float4(xr[0], xr[1], xr[2], xr[3]);
+    v[NQ - 1] = make_float4(cn, cb, 0.f, 0.f);
+    // ---- fixed tree over the row groups (per column half), e.g. NR = 4: (0 + 2) + (1 + 3)
+#pragma unroll
+    for (int stride = NR / 2; stride >= 1; stride >>= 1) {
         if (wr >= stride && wr < 2 * stride) {
 #pragma unroll
-            for (int Q = 0; Q < TN_QUADS; ++Q) red[((wr - stride) << gshift) + wq][Q][lane] = v[Q];
+            for (int Q = 0; Q < NQ; ++Q) lds[(((wr - stride) * NH + half) * NQ + Q) * 64 + lane] = v[Q];
         }
         __syncthreads();
         if (wr < stride) {
 #pragma unroll
-            for (int Q = 0; Q < TN_QUADS; ++Q) {
-                const float4 o = red[(wr << gshift) + wq][Q][lane];
+            for (int Q = 0; Q < NQ; ++Q) {
+                const float4 o = lds[((wr * NH + half) * NQ + Q) * 64 + lane];
                 v[Q].x += o.x; v[Q].y += o.y; v[Q].z += o.z; v[Q].w += o.w;
+                // left alone the scheduler hoists all NQ LDS reads above the adds: NQ x 4 more live registers -> spills
+                if ((Q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
         __syncthreads();
     }
-    // ---- one block: write the gradient; several: publish the partial for tn_combine_kernel
     if (wr != 0) return;
-    if (a.nblk_x == 1) {
+    // ---- one block: write the gradient; several: publish the partial for tn_combine_kernel
+    if (tk.nsplit == 1) {
 #pragma unroll
-        for (int Q = 0; Q < TN_QUADS; ++Q) tn_emit(pr, tk, Q, v[Q], c, kh, lane);
+        for (int Q = 0; Q < NQ; ++Q) t3_emit<TA, TB>(pr, tk, half, Q, v[Q], c, kh, lane);
         return;
     }
-    float4* mine = reinterpret_cast<float4*>(a.partial) + (((size_t)by * a.nblk_x + bx) * 4 + wq) * (TN_QUADS * 64);
+    float4* mine = a.partial + tk.part0 + ((size_t)bx * NH + half) * NQ * 64;
 #pragma unroll
-    for (int Q = 0; Q < TN_QUADS; ++Q) mine[Q * 64 + lane] = v[Q];
+    for (int Q = 0; Q < NQ; ++Q) mine[Q * 64 + lane] = v[Q];
 }
 
-// Second stage (only when a group was split over several blocks): block = one float4 quad Q of one quadrant, 64 lanes x 8
-// slices of the block list; every slice sums its blocks in block order, then a fixed tree over the slices -> deterministic.
-__global__ __launch_bounds__(512) void tn_combine_kernel(const TnArgs a) {
-    __shared__ float4 red[8][64];
-    const int lane = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int Q = blockIdx.x, by = blockIdx.y >> 2, wq = blockIdx.y & 3;
-    if (wq >= a.group[by].ng) return;
-    const TnTask tk = a.group[by].task[wq];
-    const TnPair pr = a.pair[tk.pair];
-    const size_t qstride = (size_t)TN_QUADS * 64;
-    const float4* src = reinterpret_cast<const float4*>(a.partial) + ((size_t)by * a.nblk_x * 4 + wq) * qstride + Q * 64 + lane;
+__global__ __launch_bounds__(T3_THREADS, 1) void gemm_tn_kernel(const T3Args a) {
+    extern __shared__ __attribute__((aligned(16))) float4 t3_lds[];
+    // task of this workgroup: tasks own consecutive id ranges (block0 ascending)
+    int t = 0;
+    while (t + 1 < a.ntasks && (int)blockIdx.x >= a.task[t + 1].block0) ++t;
+    const T3Task tk = a.task[t];
+    const int bx = blockIdx.x - tk.block0;
+    if (tk.wa && tk.wb) t3_body<4, 2>(a, tk, bx, t3_lds);
+    else if (tk.wa) t3_body<4, 1>(a, tk, bx, t3_lds);
+    else if (tk.wb) t3_body<1, 2>(a, tk, bx, t3_lds);
+    else t3_body<1, 1>(a, tk, bx, t3_lds);
+}
+
+// Second stage (tasks split over several blocks): thread = one (half, quad, lane) of one task; sums the task's partials in
+// block order -> deterministic -- and emits into the nn.Linear layout.
+__global__ __launch_bounds__(256) void tn_combine_kernel(const T3Args a) {
+    const T3Task tk = a.task[blockIdx.y];
+    if (tk.nsplit == 1) return;
+    const int ta = tk.wa ? 4 : 1, tb = tk.wb ? 2 : 1, nh = tk.wb ? 2 : 1, NQ = t3_quads(ta, tb);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nh * NQ * 64) return;
+    const int half = idx / (NQ * 64), Q = (idx >> 6) % NQ, lane = idx & 63;
+    const float4* src = a.partial + tk.part0 + idx;
+    const size_t stride = (size_t)nh * NQ * 64;
     float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    int b = slice;
-    for (; b + 8 < a.nblk_x; b += 16) {
-        const float4 p0 = src[(size_t)b * 4 * qstride], p1 = src[(size_t)(b + 8) * 4 * qstride];
+    int b = 0;
+    for (; b + 1 < tk.nsplit; b += 2) {          // two independent chains, combined in a fixed order
+        const float4 p0 = src[(size_t)b * stride], p1 = src[(size_t)(b + 1) * stride];
         s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
         s1.x += p1.x; s1.y += p1.y; s1.z += p1.z; s1.w += p1.w;
     }
-    if (b < a.nblk_x) {
-        const float4 p0 = src[(size_t)b * 4 * qstride];
+    if (b < tk.nsplit) {
+        const float4 p0 = src[(size_t)b * stride];
         s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
     }
-    red[slice][lane] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
-    __syncthreads();
-    for (int off = 4; off >= 1; off >>= 1) {
-        if (slice < off) {
-            const float4 o = red[slice + off][lane];
-            float4& m = red[slice][lane];
-            m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w;
-        }
-        __syncthreads();
-    }
-    if (slice == 0) tn_emit(pr, tk, Q, red[0][lane], lane & 31, lane >> 5, lane);
+    const float4 s = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    const TnPair& pr = a.pair[tk.pair];
+    const int c = lane & 31, kh = lane >> 5;
+    if (tk.wa && tk.wb) t3_emit<4, 2>(pr, tk, half, Q, s, c, kh, lane);
+    else if (tk.wa) t3_emit<4, 1>(pr, tk, half, Q, s, c, kh, lane);
+    else if (tk.wb) t3_emit<1, 2>(pr, tk, half, Q, s, c, kh, lane);
+    else t3_emit<1, 1>(pr, tk, half, Q, s, c, kh, lane);
 }
+
+constexpr size_t T3_MAX_PARTIAL_F4 = (size_t)400 * 2 * t3_quads(4, 2) * 64;   // ~one workgroup per CU, with slack   // float4 capacity of the partial buffer
 
 size_t reduce_ws_floats(int64_t M, int max_na, int max_nb, int max_pairs) {
     (void)M; (void)max_na; (void)max_nb; (void)max_pairs;
-    return (size_t)TN_MAX_PARTIALS * TN_PART + 256;   // partials + tickets
+    return T3_MAX_PARTIAL_F4 * 4 + 256;
 }
 
 int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s) {
-    if (ws.floats < (size_t)TN_PART + 256) {
-        set_error("launch_weight_grads: reduction workspace too small");
-        return PFN_ENOSPACE;
+    if (npairs == 0 || M == 0) {
+        // no rows: every gradient is an empty sum
+        for (int p = 0; p < npairs; ++p) {
+            const TnPair& pr = pairs[p];
+            for (int i = 0; i < pr.na; ++i)
+                PFN_CHECK_HIP(hipMemsetAsync(pr.G + (size_t)(pr.gn0 + i) * pr.ldg + pr.gk0, 0, (size_t)pr.nb * sizeof(float), s));
+            if (pr.bias_out) PFN_CHECK_HIP(hipMemsetAsync(pr.bias_out, 0, (size_t)pr.na * sizeof(float), s));
+        }
+        return PFN_OK;
     }
-    const size_t max_partials = (ws.floats - 256) / TN_PART;
+    const size_t cap_f4 = ws.floats >= 256 ? (ws.floats - 256) / 4 : 0;
+    static std::atomic<uint64_t> lds_raised{0};
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_tn_kernel), T3_LDS_BYTES, lds_raised));
+    static const int want_env = getenv("PFN_TN_BLOCKS") ? atoi(getenv("PFN_TN_BLOCKS")) : 0;   // tuning aid
+    const int ncu = device_cus();
     int p = 0;
     while (p < npairs) {
-        TnArgs ta;
+        T3Args ta;
         memset(&ta, 0, sizeof(ta));
         ta.M = (int)M;
-        ta.partial = ws.partial;
+        ta.partial = reinterpret_cast<float4*>(ws.partial);
         int np_here = 0;
-        while (p < npairs && np_here < TN_MAX_PAIRS) {
+        double cost_total = 0.0, flops = 0.0, bytes = 0.0;
+        double cost[T3_MAX_TASKS];
+        while (p < npairs && np_here < T3_MAX_PAIRS) {
             const TnPair& pr = pairs[p];
-            if (pr.lda % 4 || pr.ldb % 4 || pr.lda < 2 || pr.ldb < 2) {
-                set_error("launch_weight_grads: row strides must be multiples of 4");
+            if (pr.lda % 4 || pr.ldb % 4 || pr.lda < 4 || pr.ldb < 4 || pr.na < 1 || pr.nb < 1 || pr.na > pr.lda || pr.nb > pr.ldb) {
+                set_error("launch_weight_grads: operand rows must be padded to a multiple of 4 floats (lda %d, ldb %d, na %d, nb %d)",
+                          pr.lda, pr.ldb, pr.na, pr.nb);
                 return PFN_EINVAL;
             }
-            const bool xrow = pr.na % 64 == 1 && pr.na > 1, xcol = pr.nb % 64 == 1 && pr.nb > 1;
-            const int QA = std::max(1, (pr.na - (xrow ? 1 : 0) + 63) / 64), QB = std::max(1, (pr.nb - (xcol ? 1 : 0) + 63) / 64);
-            if (QA * QB > TN_MAX_TASKS) {
-                set_error("launch_weight_grads: a %d x %d weight needs %d quadrant tasks (> %d)", pr.na, pr.nb, QA * QB, TN_MAX_TASKS);
+            const bool wa = pr.na > 32, wb = pr.nb > 32;
+            const bool xrow = wa && pr.na % 128 == 1, xcol = wb && pr.nb % 128 == 1;
+            const int QA = wa ? (pr.na - (xrow ? 1 : 0) + 127) / 128 : 1, QB = wb ? (pr.nb - (xcol ? 1 : 0) + 127) / 128 : 1;
+            if (QA * QB > T3_MAX_TASKS) {
+                set_error("launch_weight_grads: a %d x %d weight needs %d tile tasks (> %d)", pr.na, pr.nb, QA * QB, T3_MAX_TASKS);
                 return PFN_EINVAL;
             }
-            const int nq = QA * QB, ngr = (nq + 3) / 4 + ((nq % 4) == 3 ? 1 : 0);   // groups of 4, then 2, then 1
-            if (ta.ntasks + ngr > TN_MAX_TASKS / 2) break;
-            TnTask all[TN_MAX_TASKS];
-            int n_all = 0;
+            if (ta.ntasks + QA * QB > T3_MAX_TASKS) break;
             for (int qi = 0; qi < QA; ++qi)
                 for (int qj = 0; qj < QB; ++qj) {
-                    TnTask& t = all[n_all++];
+                    T3Task& t = ta.task[ta.ntasks];
                     t.pair = (short)np_here;
-                    t.qi = (short)qi;
-                    t.qj = (short)qj;
+                    t.ti = (short)qi;
+                    t.tj = (short)qj;
+                    t.wa = wa;
+                    t.wb = wb;
                     t.flags = (short)(((xcol && qj == QB - 1) ? TNF_XCOL : 0) | ((pr.bias_out && qj == 0) ? TNF_BIAS : 0) |
                                       ((xrow && qi == QA - 1) ? TNF_XROW : 0));
+                    cost[ta.ntasks] = (wa ? 4.0 : 1.0) * (wb ? 4.0 : 1.0) + 0.5;   // MFMAs per row pair (+ loads / extras)
+                    cost_total += cost[ta.ntasks];
+                    ++ta.ntasks;
                 }
-            for (int t0 = 0; t0 < n_all;) {
-                const int left = n_all - t0, ng = left >= 4 ? 4 : (left >= 2 ? 2 : 1);
-                TnGroup& gr = ta.group[ta.ntasks++];
-                gr.ng = ng;
-                gr.gshift = ng == 4 ? 2 : (ng == 2 ? 1 : 0);
-                for (int q = 0; q < ng; ++q) gr.task[q] = all[t0 + q];
-                t0 += ng;
-            }
+            flops += 2.0 * (double)M * pr.na * pr.nb;
+            bytes += 4.0 * (double)M * (pr.na + pr.nb);
             ta.pair[np_here++] = pr;
             ++p;
         }
-        if (ta.ntasks == 0) continue;
-        // ~512 blocks per launch, at least 32 rows per wave; every wave range is a multiple of 32 rows.  A block covers
-        // at least 2 ranges (4 quadrants) -- the row split below assumes the smallest; blocks with more ranges just get
-        // further into M and the ones past the end idle.
-        static const int want_blocks = getenv("PFN_TN_BLOCKS") ? atoi(getenv("PFN_TN_BLOCKS")) : 256;   // tuning aid
-        int nbx = std::max(1, std::min(128, (want_blocks + ta.ntasks - 1) / ta.ntasks));
-        nbx = (int)std::min<size_t>(nbx, std::max<size_t>(1, std::min<size_t>(max_partials, TN_MAX_PARTIALS) / (4 * ta.ntasks)));
-        int min_nr = TN_WAVES;
-        for (int g2 = 0; g2 < ta.ntasks; ++g2) min_nr = std::min(min_nr, TN_WAVES / ta.group[g2].ng);
-        const int64_t rpw = std::max<int64_t>(32, round_up((M + (int64_t)nbx * min_nr - 1) / ((int64_t)nbx * min_nr), 32));
-        ta.rows_per_wave = (int)rpw;
-        ta.nblk_x = (int)std::max<int64_t>(1, (M + rpw * min_nr - 1) / (rpw * min_nr));
-        double flops = 0.0, bytes = 0.0;
-        for (int q = 0; q < np_here; ++q) {
-            flops += 2.0 * (double)M * ta.pair[q].na * ta.pair[q].nb;
-            bytes += 4.0 * (double)M * (ta.pair[q].na + ta.pair[q].nb);
+        // row splits: about one workgroup per CU in total (two waves per SIMD), shared out in proportion to the tasks'
+        // cost per row; at least 64 rows per row group, and never more partials than the buffer holds
+        const int want = want_env > 0 ? want_env : ncu;
+        const int max_split = (int)std::max<int64_t>(1, M / (64 * T3_WAVES));
+        int nblocks = 0;
+        size_t part = 0;
+        for (int t = 0; t < ta.ntasks; ++t) {
+            T3Task& tk = ta.task[t];
+            int ns = (int)(want * cost[t] / cost_total + 0.5);
+            ns = std::max(1, std::min(ns, max_split));
+            const size_t nq64 = (size_t)(tk.wb ? 2 : 1) * t3_quads(tk.wa ? 4 : 1, tk.wb ? 2 : 1) * 64;
+            while (ns > 1 && part + (size_t)ns * nq64 > cap_f4) --ns;
+            // an empty trailing range would leave its partial unwritten: shrink until every range holds rows
+            while (ns > 1 && round_up((M + ns - 1) / ns, T3_ROWS * T3_WAVES) * (ns - 1) >= M) --ns;
+            tk.nsplit = ns;
+            tk.block0 = nblocks;
+            tk.part0 = (int)part;
+            nblocks += ns;
+            if (ns > 1) part += (size_t)ns * nq64;
         }
+        ta.nblocks = nblocks;
         {
             ProfScope ps("gemm_tn", bytes, flops, s);
-            gemm_tn_kernel<<<(ta.nblk_x + 7) / 8 * 8 * ta.ntasks, TN_THREADS, 0, s>>>(ta);
+            gemm_tn_kernel<<<nblocks, T3_THREADS, T3_LDS_BYTES, s>>>(ta);
             PFN_CHECK_LAUNCH();
         }
-        if (ta.nblk_x > 1) {
+        bool any_split = false;
+        for (int t = 0; t < ta.ntasks; ++t) any_split |= ta.task[t].nsplit > 1;
+        if (any_split) {
             ProfScope ps("tn_reduce", 0.0, 0.0, s);
-            tn_combine_kernel<<<dim3(TN_QUADS, 4 * ta.ntasks), 512, 0, s>>>(ta);
+            tn_combine_kernel<<<dim3((2 * t3_quads(4, 2) * 64 + 255) / 256, ta.ntasks), 256, 0, s>>>(ta);
             PFN_CHECK_LAUNCH();
         }
     }

@@ -9,7 +9,6 @@
 #include <string.h>
 
 #include <algorithm>
-#include <new>
 #include <vector>
 
 #include "pfn_internal.hpp"
@@ -75,45 +74,13 @@ struct Gate {
     float scale = 1.f;
 };
 
-// ------------------------------------------------------------------------------------------ side stream
-// Weight-gradient work (dW GEMMs, their reductions) only feeds the optimizer: it is forked onto a second HIP stream and
-// overlaps the latency-bound chain that propagates the input gradient to the previous layer.  Under hipGraph capture
-// the fork/join events become graph edges, so the replayed step keeps the overlap.  mark(i) = "layer i's side work is
-// enqueued"; the main stream waits for a mark before it overwrites a buffer that side work still reads.
-struct SideQ {
-    hipStream_t main_s = nullptr, side_s = nullptr;
-    hipEvent_t fork_ev = nullptr;
-    hipEvent_t marks[64];
-    bool marked[64];
-    int fork() {            // side stream starts after everything enqueued on main so far
-        PFN_CHECK_HIP(hipEventRecord(fork_ev, main_s));
-        PFN_CHECK_HIP(hipStreamWaitEvent(side_s, fork_ev, 0));
-        return PFN_OK;
-    }
-    int mark(int i) {
-        PFN_CHECK_HIP(hipEventRecord(marks[i], side_s));
-        marked[i] = true;
-        return PFN_OK;
-    }
-    int main_wait(int i) {
-        if (i >= 0 && i < 64 && marked[i]) PFN_CHECK_HIP(hipStreamWaitEvent(main_s, marks[i], 0));
-        return PFN_OK;
-    }
-};
-// The second stream and its events belong to a CONTEXT the caller creates (pfn_context_create) -- one per model / host
-// thread, bound to the device it was created on; the library itself keeps no stream or event of its own.  A call
-// without a context runs the weight-gradient work on the main stream.
-struct Context {
-    int device = 0;
-    SideQ q;
-};
-static SideQ* side_queue(Context* ctx, hipStream_t main_s) {
-    static const bool disabled = getenv("PFN_NO_SIDE_STREAM") != nullptr;   // experiments
-    if (!ctx || disabled) return nullptr;
-    ctx->q.main_s = main_s;
-    for (int i = 0; i < 64; ++i) ctx->q.marked[i] = false;
-    return &ctx->q;
-}
+// ------------------------------------------------------------------------------------ deferred weight gradients
+// Weight gradients only feed the optimizer, so no layer's backward waits for them: every layer appends its (dY, X) pairs to
+// a list and ONE launch at the end of the backward pass computes all of them (gemm.hip) -- the chip is filled by the whole
+// network's dW work at once instead of by 8 small launches competing with the input-gradient chain.  (Round 1 ran them
+// per layer on a second stream: measured 1-2 % over no overlap at all, and the sharing slowed the HBM-bound hops 2x.)
+// The price is memory: every layer's incoming gradient and dP / dQ stay alive until the end (sized for 288 GB).
+typedef std::vector<TnPair> PairList;
 
 // ---------------------------------------------------------------------------------- EdgeAggregation
 struct EaSaved { float *P, *Q, *S; };
@@ -171,9 +138,8 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
 static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
                        const float* w1, const EaPack& pw, const float* gout, int ldgo, const Gate& gate, float* gx,
                        int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
-                       const EaScratch& sc, hipStream_t s, SideQ* sq = nullptr, int layer = 0) {
+                       const EaScratch& sc, hipStream_t s, PairList* defer) {
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
-    if (sq) PFN_TRY(sq->main_wait(layer + 2));   // the previous EA layer's side work still reads dP / dQ / dWe
     {   // dS = gout W2
         GemmArgs a = gemm_defaults(g.n, h, ld);
         a.C[0] = sc.dS;
@@ -183,25 +149,6 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
     }
     EdgeBwdArgs e{sv.P, sv.Q, sc.dS, ea, w1, sc.dP, sc.dQ, sc.dWe, gea, ld, h, fi, fe};
     PFN_TRY(launch_edge_bwd(g, e, nullptr, s));
-    // everything the weight gradients need (gout, S, dP, dQ, dWe partials) exists now: fork them off
-    hipStream_t ws = s;
-    if (sq) {
-        PFN_TRY(sq->fork());
-        ws = sq->side_s;
-    }
-    PFN_TRY(launch_dwe_reduce(sc.dWe, g.n > 0 ? edge_bwd_dst_blocks(g, ld) : 0, fe, ld, h, gw1, ldw1, 2 * fi, ws));
-    {
-        TnPair pairs[3] = {
-            tn_pair(gout, ldgo, fo, sv.S, ld, h, gw2, h, 0, gb2, g.deg),      // dW2 ; db2 = sum_i deg_i gout_i
-            tn_pair(sc.dP, ld, h, x, ldx, fi, gw1, ldw1, 0, gb1, nullptr),    // dW1[:, :Fi] ; db1 = sum_i dP_i
-            tn_pair(sc.dQ, ld, h, x, ldx, fi, gw1, ldw1, fi, nullptr, nullptr),
-        };
-        PFN_TRY(launch_weight_grads(pairs, 3, g.n, sc.red, ws));
-    }
-    if (sq) {
-        PFN_TRY(sq->mark(layer));
-        PFN_TRY(sq->main_wait(layer + 1));   // gx below overwrites the buffer the next-outer layer's side work reads as gout
-    }
     if (gea) PFN_TRY(launch_edge_attr_grad(g, e, s));
     if (gx) {   // dx = dP W1[:, :Fi] + dQ W1[:, Fi:2Fi], gated by the producing layer's activation
         GemmArgs a = gemm_defaults(g.n, fi, ldgx);
@@ -214,7 +161,18 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         a.gate_scale = gate.scale;
         PFN_TRY(launch_gemm_nt(a, s));
     }
-    return PFN_OK;
+    // weight gradients: dWe partials -> W1[:, 2Fi:], and three (dY, X) pairs
+    PFN_TRY(launch_dwe_reduce(sc.dWe, g.n > 0 ? edge_bwd_dst_blocks(g, ld) : 0, fe, ld, h, gw1, ldw1, 2 * fi, s));
+    const TnPair pairs[3] = {
+        tn_pair(gout, ldgo, fo, sv.S, ld, h, gw2, h, 0, gb2, g.deg),      // dW2 ; db2 = sum_i deg_i gout_i
+        tn_pair(sc.dP, ld, h, x, ldx, fi, gw1, ldw1, 0, gb1, nullptr),    // dW1[:, :Fi] ; db1 = sum_i dP_i
+        tn_pair(sc.dQ, ld, h, x, ldx, fi, gw1, ldw1, fi, nullptr, nullptr),
+    };
+    if (defer) {
+        defer->insert(defer->end(), pairs, pairs + 3);
+        return PFN_OK;
+    }
+    return launch_weight_grads(pairs, 3, g.n, sc.red, s);
 }
 
 // ------------------------------------------------------------------------------------------ TAGConv
@@ -259,22 +217,8 @@ struct TagScratch { float* G; float *z0, *z1; ReduceWs red; };
 
 static int tag_backward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
                         const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx, float* const* gw,
-                        float* gbias, const float* xk, const TagScratch& sc, hipStream_t s, SideQ* sq = nullptr,
-                        int layer = 0, int seg = 0) {
+                        float* gbias, const float* xk, const TagScratch& sc, hipStream_t s, PairList* defer, int seg = 0) {
     const size_t stride = (size_t)g.n * ldx;
-    {   // weight gradients need only gout and the saved hops: fork them off first
-        hipStream_t ws = s;
-        if (sq) {
-            PFN_TRY(sq->fork());
-            ws = sq->side_s;
-        }
-        std::vector<TnPair> pairs;
-        for (int k = 0; k <= K; ++k)
-            pairs.push_back(tn_pair(gout, ldgo, cout, k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, gw[k], cin, 0,
-                                    k == 0 ? gbias : nullptr, nullptr));
-        PFN_TRY(launch_weight_grads(pairs.data(), (int)pairs.size(), g.n, sc.red, ws));
-        if (sq) PFN_TRY(sq->mark(layer));
-    }
     if (gx) {
         if (ldgx != ldx) {
             set_error("TAGConv backward: grad_x stride %d != x stride %d", ldgx, ldx);
@@ -304,40 +248,44 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             a.gate = gate.y;
             a.ldg = gate.ld;
             a.gate_scale = gate.scale;
-            if (sq) PFN_TRY(sq->main_wait(layer + 1));   // gx overwrites what the outer layer's side work reads
-            return launch_gemm_nt(a, s);
-        }
-        // G_k = gout W_k ; dx = G_0 + A^T (G_1 + A^T (G_2 + ...))   (Horner over the transposed adjacency)
-        GemmArgs a = gemm_defaults(g.n, cin, ldx);
-        a.ngroup = K + 1;
-        a.nterm = K + 1;
-        for (int k = 0; k <= K; ++k) {
-            a.C[k] = (K == 0) ? gx : sc.G + (size_t)k * stride;
-            a.term[k] = term(gout, ldgo, cout, pw.wd[k], k);
-        }
-        if (K == 0) {
-            a.gate = gate.y;
-            a.ldg = gate.ld;
-            a.gate_scale = gate.scale;
-            if (sq) PFN_TRY(sq->main_wait(layer + 1));
-        }
-        PFN_TRY(launch_gemm_nt(a, s));
-        if (K > 0 && fused_hops_fit(seg, ldx, g.n)) {
-            if (sq) PFN_TRY(sq->main_wait(layer + 1));   // gx overwrites what the outer layer's side work reads
-            FusedHopsArgs fh{nullptr, nullptr, sc.G, gx, gate.y, gate.scale, stride, ldx, K, 1, seg};
-            PFN_TRY(launch_fused_hops(g, fh, s));
+            PFN_TRY(launch_gemm_nt(a, s));
         } else {
-            const float* z = sc.G + (size_t)K * stride;
-            for (int k = K - 1; k >= 0; --k) {
-                float* dst = (k == 0) ? gx : ((k & 1) ? sc.z1 : sc.z0);
-                if (k == 0 && sq) PFN_TRY(sq->main_wait(layer + 1));   // gx overwrites what the outer layer's side work reads
-                HopArgs hp{z, sc.G + (size_t)k * stride, dst, k == 0 ? gate.y : nullptr, k == 0 ? gate.scale : 1.f, ldx, 1, 1};
-                PFN_TRY(launch_hop(g, hp, s));
-                z = dst;
+            // G_k = gout W_k ; dx = G_0 + A^T (G_1 + A^T (G_2 + ...))   (Horner over the transposed adjacency)
+            GemmArgs a = gemm_defaults(g.n, cin, ldx);
+            a.ngroup = K + 1;
+            a.nterm = K + 1;
+            for (int k = 0; k <= K; ++k) {
+                a.C[k] = (K == 0) ? gx : sc.G + (size_t)k * stride;
+                a.term[k] = term(gout, ldgo, cout, pw.wd[k], k);
+            }
+            if (K == 0) {
+                a.gate = gate.y;
+                a.ldg = gate.ld;
+                a.gate_scale = gate.scale;
+            }
+            PFN_TRY(launch_gemm_nt(a, s));
+            if (K > 0 && fused_hops_fit(seg, ldx, g.n)) {
+                FusedHopsArgs fh{nullptr, nullptr, sc.G, gx, gate.y, gate.scale, stride, ldx, K, 1, seg};
+                PFN_TRY(launch_fused_hops(g, fh, s));
+            } else {
+                const float* z = sc.G + (size_t)K * stride;
+                for (int k = K - 1; k >= 0; --k) {
+                    float* dst = (k == 0) ? gx : ((k & 1) ? sc.z1 : sc.z0);
+                    HopArgs hp{z, sc.G + (size_t)k * stride, dst, k == 0 ? gate.y : nullptr, k == 0 ? gate.scale : 1.f, ldx, 1, 1};
+                    PFN_TRY(launch_hop(g, hp, s));
+                    z = dst;
+                }
             }
         }
     }
-    return PFN_OK;
+    // weight gradients need only gout and the saved hops
+    PairList local;
+    PairList& pairs = defer ? *defer : local;
+    for (int k = 0; k <= K; ++k)
+        pairs.push_back(tn_pair(gout, ldgo, cout, k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, gw[k], cin, 0,
+                                k == 0 ? gbias : nullptr, nullptr));
+    if (defer) return PFN_OK;
+    return launch_weight_grads(local.data(), (int)local.size(), g.n, sc.red, s);
 }
 
 // -------------------------------------------------------------------------------------- whole model
@@ -350,9 +298,12 @@ struct Layout {
     std::vector<float*> y;       // per layer output (post-activation); last = nullptr (caller's out)
     std::vector<EaSaved> ea;     // per EA layer
     std::vector<float*> xk;      // per TAG layer: K * n * ld
-    // backward scratch
-    float *gA, *gB, *dh;
-    EaScratch eas;
+    // backward: per-layer buffers that stay alive until the deferred weight-gradient launch ...
+    std::vector<float*> gin;     // gradient w.r.t. the INPUT of layer i (= the incoming gradient of layer i - 1)
+    std::vector<float*> dP, dQ, dWe;   // per EA layer
+    // ... and scratch shared by all layers
+    float* dh;
+    EaScratch eas;               // dS, reduction workspace (dP / dQ / dWe are taken from the per-layer buffers)
     TagScratch tags;
     size_t bytes;
 };
@@ -424,13 +375,21 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
             lo.xk[i] = cv.take<float>(nld * std::max(1, lo.K));
         }
     }
-    lo.gA = cv.take<float>(nld);
-    lo.gB = cv.take<float>(nld);
+    lo.gin.assign(lo.nlayers, nullptr);
+    lo.dP.assign(lo.nlayers, nullptr);
+    lo.dQ.assign(lo.nlayers, nullptr);
+    lo.dWe.assign(lo.nlayers, nullptr);
+    for (int i = 0; i < lo.nlayers; ++i) {
+        lo.gin[i] = cv.take<float>(i == 0 ? (size_t)n * lo.ld0 : nld);
+        if (is_ea(i)) {
+            lo.dP[i] = cv.take<float>(nld);
+            lo.dQ[i] = cv.take<float>(nld);
+            lo.dWe[i] = cv.take<float>((size_t)1025 * lo.fe * lo.ld);
+        }
+    }
     lo.dh = cv.take<float>(nld);
     lo.eas.dS = cv.take<float>(nld);
-    lo.eas.dP = cv.take<float>(nld);
-    lo.eas.dQ = cv.take<float>(nld);
-    lo.eas.dWe = cv.take<float>((size_t)1025 * lo.fe * lo.ld);
+    lo.eas.dP = lo.eas.dQ = lo.eas.dWe = nullptr;
     lo.tags.G = cv.take<float>(nld * (lo.K + 1));
     lo.tags.z0 = cv.take<float>(nld);
     lo.tags.z1 = cv.take<float>(nld);
@@ -507,7 +466,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
 
 static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
                           float* const* grads, const float* x, const float* edge_attr, const float* gout, float* gx,
-                          float* gea, int seg, Context* ctx, hipStream_t s) {
+                          float* gea, int seg, hipStream_t s) {
     (void)x;
     const bool drop = c.training && c.dropout_rate > 0.f;
     const float gscale = drop ? 1.f / (1.f - c.dropout_rate) : 1.f;
@@ -522,7 +481,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         pi += is_ea(i) ? 4 : lo.K + 2;
     }
     if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)lo.e * lo.fe * sizeof(float), s));
-    SideQ* sq = lo.nlayers + 2 <= 64 ? side_queue(ctx, s) : nullptr;
+    PairList pairs;                            // every weight-gradient pair of the network, launched once at the end
     const float* gcur = gout;
     int ldg = lo.ldo;
     for (int i = lo.nlayers - 1; i >= 0; --i) {
@@ -535,15 +494,19 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
             gate.ld = ldi;
             gate.scale = gscale;
         }
-        float* gnext = (gcur == lo.gA) ? lo.gB : lo.gA;
+        float* gnext = lo.gin[i];
         const int p0 = poff[i];
         if (is_ea(i)) {
             const int fi = i == 0 ? lo.f0 : lo.h, fo = last ? lo.fo : lo.h;
+            EaScratch sc = lo.eas;
+            sc.dP = lo.dP[i];
+            sc.dQ = lo.dQ[i];
+            sc.dWe = lo.dWe[i];
             PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], mp.ea[i], gcur, ldg, gate, gnext, ldi,
-                                grads[p0], grads[p0 + 1], grads[p0 + 2], grads[p0 + 3], gea, lo.ea[i], lo.eas, s, sq, i + 1));
+                                grads[p0], grads[p0 + 1], grads[p0 + 2], grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
-                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, sq, i + 1, seg));
+                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg));
         }
         gcur = gnext;
         ldg = ldi;
@@ -559,18 +522,9 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         a.ldg = lo.ld;
         PFN_TRY(launch_gemm_nt(a, s));
     }
-    TnPair pairs[2] = {
-        tn_pair(gcur, lo.ld0, lo.f0, lo.me_h, lo.ld, lo.h, gme[2], lo.h, 0, gme[3], nullptr),     // dWb, dbb
-        tn_pair(lo.dh, lo.ld, lo.h, lo.maskf, lo.ld0, lo.f0, gme[0], lo.f0, 0, gme[1], nullptr),  // dWa, dba
-    };
-    if (sq) {
-        PFN_TRY(sq->fork());
-        PFN_TRY(launch_weight_grads(pairs, 2, lo.n, lo.eas.red, sq->side_s));
-        PFN_TRY(sq->mark(0));
-        PFN_TRY(sq->main_wait(0));   // join: the side stream is in order, its last mark covers all earlier side work
-    } else {
-        PFN_TRY(launch_weight_grads(pairs, 2, lo.n, lo.eas.red, s));
-    }
+    pairs.push_back(tn_pair(gcur, lo.ld0, lo.f0, lo.me_h, lo.ld, lo.h, gme[2], lo.h, 0, gme[3], nullptr));     // dWb, dbb
+    pairs.push_back(tn_pair(lo.dh, lo.ld, lo.h, lo.maskf, lo.ld0, lo.f0, gme[0], lo.f0, 0, gme[1], nullptr));  // dWa, dba
+    PFN_TRY(launch_weight_grads(pairs.data(), (int)pairs.size(), lo.n, lo.eas.red, s));
     if (gx) PFN_CHECK_HIP(hipMemcpyAsync(gx, gcur, (size_t)lo.n * lo.ld0 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return PFN_OK;
 }
@@ -744,39 +698,6 @@ using namespace pfn;
 // =============================================================================================== C ABI
 extern "C" {
 
-int pfn_context_create(void** out) {
-    PFN_CHECK_ARG(out != nullptr, "pfn_context_create: null out pointer");
-    *out = nullptr;
-    Context* cx = new (std::nothrow) Context();
-    PFN_CHECK_ARG(cx != nullptr, "pfn_context_create: out of host memory");
-    bool ok = hipGetDevice(&cx->device) == hipSuccess &&
-              hipStreamCreateWithFlags(&cx->q.side_s, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&cx->q.fork_ev, hipEventDisableTiming) == hipSuccess;
-    int made = 0;
-    for (; ok && made < 64; ++made) ok = hipEventCreateWithFlags(&cx->q.marks[made], hipEventDisableTiming) == hipSuccess;
-    if (!ok) {
-        for (int i = 0; i < made - 1; ++i) (void)hipEventDestroy(cx->q.marks[i]);
-        if (cx->q.fork_ev) (void)hipEventDestroy(cx->q.fork_ev);
-        if (cx->q.side_s) (void)hipStreamDestroy(cx->q.side_s);
-        delete cx;
-        set_error("pfn_context_create: could not create the side stream / events: %s", hipGetErrorString(hipGetLastError()));
-        return PFN_EHIP;
-    }
-    for (int i = 0; i < 64; ++i) cx->q.marked[i] = false;
-    *out = cx;
-    return PFN_OK;
-}
-
-int pfn_context_destroy(void* ctx) {
-    Context* cx = static_cast<Context*>(ctx);
-    if (!cx) return PFN_OK;
-    for (int i = 0; i < 64; ++i) (void)hipEventDestroy(cx->q.marks[i]);
-    (void)hipEventDestroy(cx->q.fork_ev);
-    (void)hipStreamDestroy(cx->q.side_s);
-    delete cx;
-    return PFN_OK;
-}
-
 int pfn_mpn_num_params(const pfn_mpn_config* c) {
     if (!c || c->n_gnn_layers < 2) return -1;
     return c->n_gnn_layers * 4 + (c->n_gnn_layers - 1) * (c->K + 2) + 4;
@@ -817,8 +738,7 @@ int pfn_mpn_forward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t
 
 int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
                      float* const* grads, const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr,
-                     const float* gout, float* gx, float* gea, void* ws, size_t ws_bytes, int64_t seg_nodes, void* ctx,
-                     void* stream) {
+                     const float* gout, float* gx, float* gea, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream) {
     (void)pred_mask; (void)mask_dtype;
     PFN_TRY(check_common(c, gws, n, e, ws));
     PFN_CHECK_ARG(params && grads && (n == 0 || (x && gout)), "pfn_mpn_backward: null tensor");
@@ -830,13 +750,7 @@ int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_
     }
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
     PFN_CHECK_ARG(seg_nodes >= 0 && (seg_nodes == 0 || n % seg_nodes == 0), "seg_nodes must be 0 or divide n_nodes");
-    Context* cx = static_cast<Context*>(ctx);
-    if (cx) {
-        int dev = -1;
-        PFN_CHECK_HIP(hipGetDevice(&dev));
-        PFN_CHECK_ARG(dev == cx->device, "pfn_mpn_backward: context belongs to device %d, current device is %d", cx->device, dev);
-    }
-    return model_backward(*c, g, lo, params, grads, x, edge_attr, gout, gx, gea, (int)seg_nodes, cx, static_cast<hipStream_t>(stream));
+    return model_backward(*c, g, lo, params, grads, x, edge_attr, gout, gx, gea, (int)seg_nodes, static_cast<hipStream_t>(stream));
 }
 
 // ------------------------------------------------------------------------------------- single layers
@@ -909,7 +823,7 @@ int pfn_edge_aggr_backward(const void* gws, int64_t n, int64_t e, int fi, int fe
     Packer pk(w.packed);                       // images were filled by the forward call on the same workspace
     const EaPack pw = ea_pack(pk, fi, fe, h, fo, w1, w2);
     return ea_backward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, pw, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gw1, gb1, gw2,
-                       gb2, gea, w.sv, w.sc, s);
+                       gb2, gea, w.sv, w.sc, s, nullptr);
 }
 
 struct TagLayerWs { float* xk; TagScratch sc; float* packed; size_t bytes; };
@@ -975,7 +889,7 @@ int pfn_tag_conv_backward(const void* gws, int64_t n, int64_t e, int cin, int co
     const TagPack pw = tag_pack(pk, cin, cout, K, weights);
     PFN_CHECK_ARG(seg_nodes >= 0 && (seg_nodes == 0 || n % seg_nodes == 0), "seg_nodes must be 0 or divide n_nodes");
     return tag_backward(g, cin, cout, K, x, (int)ldx, pw, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gweights, gbias, w.xk,
-                        w.sc, static_cast<hipStream_t>(stream), nullptr, 0, (int)seg_nodes);
+                        w.sc, static_cast<hipStream_t>(stream), nullptr, (int)seg_nodes);
 }
 
 // ----------------------------------------------------------------------------------------- utilities

@@ -304,8 +304,7 @@ class _MpnFn(torch.autograd.Function):
         L.check(lib.pfn_mpn_backward(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
                                      L.ptr_table(grads), x.data_ptr(), pred_mask.data_ptr(), ctx.mask_dtype,
                                      edge_attr.data_ptr(), gp.data_ptr(), L.ptr(gx), L.ptr(gea), ctx.ws.data_ptr(),
-                                     ctx.ws.numel(), graph.seg_nodes, model._context_on(x.device).ptr, L.stream_ptr()),
-                "pfn_mpn_backward")
+                                     ctx.ws.numel(), graph.seg_nodes, L.stream_ptr()), "pfn_mpn_backward")
         model._last_flat_grad = flat
         return (None, None, gx, None, gea, *grads)
 
@@ -369,7 +368,6 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
         self._graphs = _GraphCache()
         self._rng_state: Optional[torch.Tensor] = None
         self._last_flat_grad: Optional[torch.Tensor] = None
-        self._contexts = {}
 
     # ------------------------------------------------------------------------------------- plumbing
     def _config(self) -> L.MpnConfig:
@@ -387,13 +385,6 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
                 out += [lin.weight for lin in layer.lins] + [layer.bias]
         a, b = self.mask_embd[0], self.mask_embd[2]
         return out + [a.weight, a.bias, b.weight, b.bias]
-
-    def _context_on(self, device) -> "L.Context":
-        """This model's `pfn_context` on `device` (side stream + events of the backward pass), created on first use."""
-        ctx = self._contexts.get(device)
-        if ctx is None:
-            ctx = self._contexts[device] = L.Context(device)
-        return ctx
 
     def _rng_state_on(self, device):
         if not (self.training and self.dropout_rate > 0):

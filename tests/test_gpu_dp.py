@@ -84,7 +84,9 @@ def test_two_ranks_hip_inplace_allreduce_equals_single_process(tmp_path, case, g
             assert_close(got["grad"], model.flat_grad(), 1e-5, "averaged DP gradient vs single-process global batch")
         opt.step()
         steps += 1
-    assert_close(got["params"], opt.flat_param, 1e-5, f"parameters after {steps} DP steps")
+    # (AdamW's first steps move every weight by ~lr * g / |g|: an update is far less smooth in the gradient than the
+    #  gradient itself, so the parameters are held to 1e-4 of their largest entry -- 0.05 lr -- not to 1e-5)
+    assert_close(got["params"], opt.flat_param, 1e-4, f"parameters after {steps} DP steps")
 
 
 def test_bench_two_ranks_on_one_gpu_gloo():

@@ -643,8 +643,8 @@ def test_train_mode_matches_oracle_fed_the_exported_masks(case, B, cfg):
 
 
 def test_two_models_two_streams_two_threads_do_not_share_state():
-    """The library holds no stream / event / device binding of its own (include/pfn_hip.h: pfn_context): two models, each
-    on its own torch stream, driven (a) interleaved from one thread and (b) concurrently from two host threads, produce
+    """The library holds no stream / event / device binding of its own (include/pfn_hip.h): two models, each on its own
+    torch stream, driven (a) interleaved from one thread and (b) concurrently from two host threads, produce
     bit-for-bit the gradients each produces alone."""
     import threading
     torch.manual_seed(5)
@@ -659,7 +659,6 @@ def test_two_models_two_streams_two_threads_do_not_share_state():
 
     alone = [run(0), run(1)]
     torch.cuda.synchronize()
-    assert models[0]._context_on(torch.device(DEV)).ptr != models[1]._context_on(torch.device(DEV)).ptr
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     # (a) interleaved on two streams from one thread: forward 0, forward 1, backward 0, backward 1
     outs = []
