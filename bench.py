@@ -307,9 +307,17 @@ def main():
             tfile = os.path.join(ROOT, "profiles", "pmc_traffic.json")
             if os.path.exists(tfile):
                 try:
-                    t = json.load(open(tfile)).get(f"{dom}:{args.case}:{args.batch}:{args.mode}")
+                    key = f"{dom}:{args.case}:{args.batch}:{args.mode}"
+                    if args.config != "standard":
+                        key += ":" + args.config
+                    if args.hub_frac > 0:
+                        key += f":hub{args.hub_frac}"
+                    t = json.load(open(tfile)).get(key)
                     if t is not None:
-                        roofline["traffic"] = t      # HBM bytes per launch from rocprofv3 --pmc (profiles/)
+                        # HBM-side bytes per launch: (2 x FETCH_SIZE + WRITE_SIZE) from separate rocprofv3 --pmc passes of this
+                        # very workload (tools/profile_round.sh); counters cannot be read from inside an unprofiled run
+                        roofline["traffic"] = t
+                        roofline["traffic_source"] = "profiles/pmc_traffic.json"
                 except Exception:
                     pass
 

@@ -43,10 +43,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int T3_THREADS = 512;            // 8 waves = two per SIMD
 constexpr int T3_WAVES = 8;
-constexpr int T3_U = 4;                    // MFMA steps (row pairs) per batch: 8 rows
-constexpr int T3_ROWS = 2 * T3_U;
-constexpr int T3_MAX_PAIRS = 24;
-constexpr int T3_MAX_TASKS = 48;
+constexpr int T3_R = 8;                    // ring depth: steps (row pairs) in flight per wave
+constexpr int T3_ROWS = 8;                 // row ranges of blocks are multiples of T3_ROWS x T3_WAVES rows
+constexpr int T3_MAX_PAIRS = 28;            // standard.json needs 26 (kernel arguments: 28 x 72 + 56 x 24 bytes < 4 KB)
+constexpr int T3_MAX_TASKS = 56;
 constexpr int T3_LDS_BYTES = 4 * (4 * 2 * 4 + 4) * 64 * 16;   // the first tree round of the largest shape: 2 row groups x 2 halves x 36 quads
 enum { TNF_XCOL = 1, TNF_BIAS = 2, TNF_XROW = 4 };
 
@@ -71,13 +71,6 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int W>
 struct T3Frag {   // one operand of one MFMA step: 4 (A) / 2 (B) adjacent columns of a wide operand, 1 column of a narrow one
     typedef typename std::conditional<W == 4, f32x4, typename std::conditional<W == 2, f32x2, float>::type>::type type;
-};
-template <int TA, int TB>
-struct T3Batch {
-    typename T3Frag<TA>::type a[T3_U];
-    typename T3Frag<TB>::type b[T3_U];
-    float xv, yv, rs;      // side operands of the VALU extras: lane l holds row (l & 7) of the batch
-    float ones;            // 1 for a row inside the range, 0 past it: the bias column when there is no rowscale
 };
 __device__ __forceinline__ float frag_at(const f32x4& v, int i) { return v[i]; }
 __device__ __forceinline__ float frag_at(const f32x2& v, int i) { return v[i]; }
@@ -168,111 +161,103 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
             for (int q = 0; q < 16; ++q) acc[ta][tb][q] = 0.f;
     float xc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f}, xr[4] = {0.f, 0.f, 0.f, 0.f}, cn = 0.f, cb = 0.f;
 
-    // The streaming loop exists in two instantiations chosen ONCE per wave -- with and without the VALU extras: as runtime
-    // flags inside load()/compute() they put a scalar branch in front of every load.  With extras all three side operands
-    // are loaded unconditionally from always-valid addresses (results a task does not own are never emitted).
+    // ---- the streaming loop: a RING of T3_R steps (2 rows each) per wave, hand-managed like gemm_nt's A fragment.
+    // Every vector-memory instruction is inline asm and every wait a hand-counted `s_waitcnt vmcnt(N)` tied to the
+    // registers it protects: left to hipcc, a slot's first use gets vmcnt(0) (a full drain of the prefetch) and the
+    // prefetch distance is ONE batch -- measured 45-52 TF, latency-bound.  Here step t's operands are requested T3_R steps
+    // (8 x 8 MFMAs x 64 cycles x 2 waves per SIMD ~ 8 k cycles) ahead of their use and refilled IN PLACE right after it;
+    // VMEM returns in issue order, so "at most 5 (T3_R - 1) younger loads outstanding" is exact for the slot about to be
+    // consumed.  A step's five loads: the A and B fragments and three per-row scalars of the VALU extras (the odd column of
+    // B, the odd column of A, the bias rowscale), each a wave-uniform base + a constant per-lane offset (lane half kh reads
+    // row 2t + kh).  All five are always issued, from always-valid addresses (results a task does not own are never
+    // emitted), so the wait counts never depend on the task.
     const float* Rs2 = Rs ? Rs : pr.A;                 // no rowscale: any valid address, the value is replaced by 1
-    const size_t rs_stride = Rs ? 1 : (size_t)pr.lda;
+    const int rs_stride = Rs ? 1 : pr.lda;
     const bool has_rs = Rs != nullptr;
-    auto stream = [&](auto ex_c) {
-        constexpr bool EX = decltype(ex_c)::value;
-        typedef T3Batch<TA, TB> Batch;
-        typedef typename T3Frag<TA>::type FA;
-        typedef typename T3Frag<TB>::type FB;
-        // Addresses = wave-uniform 64-bit row base (scalar ALU) + a per-lane 32-bit offset that never changes: no vector
-        // address math in the loop and no per-load address registers (with per-lane clamped rows the loop needed > 256
-        // VGPRs).  Only FULL batches take this path; the ragged tail of the range has its own per-lane clamped loads.
-        const uint32_t voA = (uint32_t)(kh * pr.lda) * 4u, voB = (uint32_t)(kh * pr.ldb) * 4u;
-        const int l8 = lane & 7;
-        const uint32_t voX = (uint32_t)(l8 * pr.ldb) * 4u, voY = (uint32_t)(l8 * pr.lda) * 4u, voR = (uint32_t)(l8 * (int)rs_stride) * 4u;
-        auto load = [&](Batch& t, int m0) {   // rows m0 .. m0 + 7, all inside the matrix
-            const char* rowA = reinterpret_cast<const char*>(Ap) + (size_t)m0 * pr.lda * 4;
-            const char* rowB = reinterpret_cast<const char*>(Bp) + (size_t)m0 * pr.ldb * 4;
+    typedef typename T3Frag<TA>::type FA;
+    typedef typename T3Frag<TB>::type FB;
+    struct Slot { FA a; FB b; float xv, yv, rs; };
+    auto compute = [&](const Slot& t) {
 #pragma unroll
-            for (int s = 0; s < T3_U; ++s) {
-                t.a[s] = *reinterpret_cast<const FA*>(rowA + (size_t)(2 * s) * pr.lda * 4 + voA);
-                t.b[s] = *reinterpret_cast<const FB*>(rowB + (size_t)(2 * s) * pr.ldb * 4 + voB);
-            }
-            if (EX) {
-                t.ones = 1.f;
-                t.xv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Xc) + (size_t)m0 * pr.ldb * 4 + voX);
-                t.yv = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Yr) + (size_t)m0 * pr.lda * 4 + voY);
-                // (raw value: selecting `has_rs ? r : 1` HERE makes the load's first use immediate -> a vmcnt(0) drain per batch)
-                t.rs = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(Rs2) + (size_t)m0 * rs_stride * 4 + voR);
-            }
-        };
-        auto load_tail = [&](Batch& t, int m0) {   // per-lane clamped rows; rows past the range contribute zeros
+        for (int ta = 0; ta < TA; ++ta)
 #pragma unroll
-            for (int s = 0; s < T3_U; ++s) {
-                const int row = m0 + 2 * s + kh, rc = min(row, M - 1);
-                t.a[s] = *reinterpret_cast<const FA*>(Ap + (size_t)rc * pr.lda);
-                t.b[s] = *reinterpret_cast<const FB*>(Bp + (size_t)rc * pr.ldb);
-                if (row >= R1) frag_zero(t.b[s]);
-            }
-            if (EX) {
-                const int row = m0 + l8, rc = min(row, M - 1);
-                const bool ok = row < R1;
-                const float x = Xc[(size_t)rc * pr.ldb], y = Yr[(size_t)rc * pr.lda], r = Rs2[(size_t)rc * rs_stride];
-                t.xv = ok ? x : 0.f;
-                t.yv = ok ? y : 0.f;
-                t.rs = ok ? r : 0.f;
-                t.ones = ok ? 1.f : 0.f;
-            }
-        };
-        auto compute = [&](const Batch& t) {
+            for (int tb = 0; tb < TB; ++tb)
+                acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag_at(t.a, ta), frag_at(t.b, tb), acc[ta][tb], 0, 0, 0);
+        const float rsv = has_rs ? t.rs : 1.f;
 #pragma unroll
-            for (int s = 0; s < T3_U; ++s) {
-#pragma unroll
-                for (int ta = 0; ta < TA; ++ta)
-#pragma unroll
-                    for (int tb = 0; tb < TB; ++tb)
-                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x2f32(frag_at(t.a[s], ta), frag_at(t.b[s], tb), acc[ta][tb], 0, 0, 0);
-                if (EX) {
-                    const float xv = __shfl(t.xv, 2 * s + kh), yv = __shfl(t.yv, 2 * s + kh);
-                    const float rs = __shfl(has_rs ? t.rs : t.ones, 2 * s + kh);
-#pragma unroll
-                    for (int e = 0; e < TA; ++e) {
-                        xc[e] = fmaf(frag_at(t.a[s], e), xv, xc[e]);
-                        bs[e] = fmaf(frag_at(t.a[s], e), rs, bs[e]);
-                    }
-#pragma unroll
-                    for (int e = 0; e < TB; ++e) xr[e] = fmaf(yv, frag_at(t.b[s], e), xr[e]);
-                    cn = fmaf(yv, xv, cn);
-                    cb = fmaf(yv, rs, cb);
-                }
-            }
-        };
-        // this row group's FULL batches: wr, wr + NR, ... < nfull; the next batch's loads fly under the current batch's
-        // MFMAs (two register sets, swapped by unrolling -- no copies).  A prefetch past the last full batch is moved back
-        // inside the matrix as a whole (uniform clamp) and never consumed.
-        const int nfull = (R1 - R0) / T3_ROWS;
-        const int mlast = max(0, M - T3_ROWS);
-        Batch t0, t1;
-        int j = wr;
-        if (j < nfull) load(t0, R0 + T3_ROWS * j);
-        // (scheduling barriers: left alone, the scheduler sinks the side-operand loads of a batch down to their first use
-        //  in the NEXT compute, whose wait then is vmcnt(0) -- a full drain of the prefetch -- instead of a counted wait)
-        for (; j < nfull; j += 2 * NR) {
-            load(t1, min(R0 + T3_ROWS * (j + NR), mlast));
-            __builtin_amdgcn_sched_barrier(0);
-            compute(t0);
-            __builtin_amdgcn_sched_barrier(0);
-            if (j + NR >= nfull) break;
-            load(t0, min(R0 + T3_ROWS * (j + 2 * NR), mlast));
-            __builtin_amdgcn_sched_barrier(0);
-            compute(t1);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int e = 0; e < TA; ++e) {
+            xc[e] = fmaf(frag_at(t.a, e), t.xv, xc[e]);
+            bs[e] = fmaf(frag_at(t.a, e), rsv, bs[e]);
         }
-        // ragged tail (< 8 rows), taken by the row group whose turn it is
-        if (nfull * T3_ROWS < R1 - R0 && wr == nfull % NR) {
-            load_tail(t0, R0 + T3_ROWS * nfull);
-            compute(t0);
-        }
+#pragma unroll
+        for (int e = 0; e < TB; ++e) xr[e] = fmaf(t.yv, frag_at(t.b, e), xr[e]);
+        cn = fmaf(t.yv, t.xv, cn);
+        cb = fmaf(t.yv, rsv, cb);
     };
-    // (Two instantiations chosen per wave -- with and without the extras -- made the register allocator keep both branches'
-    //  accumulators apart: 370 spills.  The extras cost 3 ds_bpermute + ~14 FMAs per 8 MFMAs and run under the other wave's
-    //  MFMAs, so every wave takes them; results a task does not own are never emitted.)
-    stream(std::true_type{});
+    // rows of the block's range in steps of 2: row group wr takes steps wr, wr + NR, ... (8 consecutive rows = one step of
+    // each of 4 row groups: one DRAM stream per operand).  `count` = this wave's full steps (both rows inside the range).
+    const int nstep = (R1 - R0) >> 1;
+    const int count = nstep > wr ? (nstep - wr + NR - 1) / NR : 0;
+    if (count > 0) {
+        const uint32_t voA = (uint32_t)(kh * pr.lda + acol) * 4u, voB = (uint32_t)(kh * pr.ldb + bcol) * 4u;
+        const uint32_t voX = (uint32_t)(kh * pr.ldb + pr.nb - 1) * 4u, voY = (uint32_t)(kh * pr.lda + pr.na - 1) * 4u;
+        const uint32_t voR = (uint32_t)(kh * rs_stride) * 4u;
+        const char* baseA = reinterpret_cast<const char*>(pr.A);
+        const char* baseB = reinterpret_cast<const char*>(pr.B);
+        const char* baseR = reinterpret_cast<const char*>(Rs2);
+        auto issue = [&](Slot& t, int step) {   // refill IN PLACE; a step past the wave's last one re-reads the last one
+            const int64_t row = R0 + 2 * (int64_t)(wr + NR * min(step, count - 1));
+            const char* pa = baseA + row * pr.lda * 4;
+            const char* pb = baseB + row * pr.ldb * 4;
+            const char* prs = baseR + row * rs_stride * 4;
+            if (TA == 4) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(t.a) : "v"(voA), "s"(pa) : "memory");
+            else asm volatile("global_load_dword %0, %1, %2" : "+v"(t.a) : "v"(voA), "s"(pa) : "memory");
+            if (TB == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "+v"(t.b) : "v"(voB), "s"(pb) : "memory");
+            else asm volatile("global_load_dword %0, %1, %2" : "+v"(t.b) : "v"(voB), "s"(pb) : "memory");
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(t.xv) : "v"(voX), "s"(pb) : "memory");
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(t.yv) : "v"(voY), "s"(pa) : "memory");
+            asm volatile("global_load_dword %0, %1, %2" : "+v"(t.rs) : "v"(voR), "s"(prs) : "memory");
+        };
+        Slot ring[T3_R];
+#pragma unroll
+        for (int r = 0; r < T3_R; ++r) {
+            frag_zero(ring[r].a);
+            frag_zero(ring[r].b);
+            ring[r].xv = ring[r].yv = ring[r].rs = 0.f;
+            issue(ring[r], r);
+        }
+        for (int t0 = 0; t0 < count; t0 += T3_R) {
+#pragma unroll
+            for (int r = 0; r < T3_R; ++r) {
+                // the slot about to be consumed has landed: exactly the 5 loads of each of the T3_R - 1 younger slots may still fly
+                asm volatile("s_waitcnt vmcnt(%5)"
+                             : "+v"(ring[r].a), "+v"(ring[r].b), "+v"(ring[r].xv), "+v"(ring[r].yv), "+v"(ring[r].rs)
+                             : "n"(5 * (T3_R - 1)));
+                if (t0 + r < count) compute(ring[r]);
+                issue(ring[r], t0 + r + T3_R);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-fetched slots: nothing of the ring is in flight past here
+    }
+    // ragged tail: an odd row count leaves ONE row (kh = 0 only) for the row group whose turn it is -- compiler-visible
+    // loads, the upper lane half contributes zeros
+    if (((R1 - R0) & 1) && wr == nstep % NR) {
+        const int row = R1 - 1;
+        Slot t;
+        t.a = *reinterpret_cast<const FA*>(Ap + (size_t)row * pr.lda);
+        t.b = *reinterpret_cast<const FB*>(Bp + (size_t)row * pr.ldb);
+        t.xv = Xc[(size_t)row * pr.ldb];
+        t.yv = Yr[(size_t)row * pr.lda];
+        t.rs = Rs2[(size_t)row * rs_stride];
+        if (kh != 0) {
+            frag_zero(t.b);
+            t.xv = t.yv = t.rs = 0.f;
+            frag_zero(t.a);
+        }
+        // (with has_rs false the bias column is the constant 1: the upper half must not add its 1 * a -- a is zeroed above)
+        compute(t);
+    }
     // the two k halves of the VALU extras
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -426,7 +411,8 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
                     t.wb = wb;
                     t.flags = (short)(((xcol && qj == QB - 1) ? TNF_XCOL : 0) | ((pr.bias_out && qj == 0) ? TNF_BIAS : 0) |
                                       ((xrow && qi == QA - 1) ? TNF_XROW : 0));
-                    cost[ta.ntasks] = (wa ? 4.0 : 1.0) * (wb ? 4.0 : 1.0) + 0.5;   // MFMAs per row pair (+ loads / extras)
+                    // per row pair and block: MFMAs (16 / 4 / 1) plus a fixed per-step part (5 loads + the VALU extras per wave)
+                    cost[ta.ntasks] = (wa ? 4.0 : 1.0) * (wb ? 4.0 : 1.0) + 2.0;
                     cost_total += cost[ta.ntasks];
                     ++ta.ntasks;
                 }
@@ -436,24 +422,31 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
             ++p;
         }
         // row splits: about one workgroup per CU in total (two waves per SIMD), shared out in proportion to the tasks'
-        // cost per row; at least 64 rows per row group, and never more partials than the buffer holds
-        const int want = want_env > 0 ? want_env : ncu;
+        // cost per row; at least 64 rows per row group; when the partials would not fit the buffer the whole plan is scaled
+        // down (never a single task: one task left unsplit would take M rows on one CU)
         const int max_split = (int)std::max<int64_t>(1, M / (64 * T3_WAVES));
         int nblocks = 0;
         size_t part = 0;
-        for (int t = 0; t < ta.ntasks; ++t) {
-            T3Task& tk = ta.task[t];
-            int ns = (int)(want * cost[t] / cost_total + 0.5);
-            ns = std::max(1, std::min(ns, max_split));
-            const size_t nq64 = (size_t)(tk.wb ? 2 : 1) * t3_quads(tk.wa ? 4 : 1, tk.wb ? 2 : 1) * 64;
-            while (ns > 1 && part + (size_t)ns * nq64 > cap_f4) --ns;
-            // an empty trailing range would leave its partial unwritten: shrink until every range holds rows
-            while (ns > 1 && round_up((M + ns - 1) / ns, T3_ROWS * T3_WAVES) * (ns - 1) >= M) --ns;
-            tk.nsplit = ns;
-            tk.block0 = nblocks;
-            tk.part0 = (int)part;
-            nblocks += ns;
-            if (ns > 1) part += (size_t)ns * nq64;
+        for (double want = want_env > 0 ? want_env : ncu; ; want *= 0.8) {
+            nblocks = 0;
+            part = 0;
+            for (int t = 0; t < ta.ntasks; ++t) {
+                T3Task& tk = ta.task[t];
+                int ns = (int)(want * cost[t] / cost_total + 0.5);
+                ns = std::max(1, std::min(ns, max_split));
+                // an empty trailing range would leave its partial unwritten: shrink until every range holds rows
+                while (ns > 1 && round_up((M + ns - 1) / ns, T3_ROWS * T3_WAVES) * (ns - 1) >= M) --ns;
+                tk.nsplit = ns;
+                tk.block0 = nblocks;
+                tk.part0 = (int)part;
+                nblocks += ns;
+                if (ns > 1) part += (size_t)ns * (tk.wb ? 2 : 1) * t3_quads(tk.wa ? 4 : 1, tk.wb ? 2 : 1) * 64;
+            }
+            if (part <= cap_f4 || want < 2.0) break;
+        }
+        if (part > cap_f4) {
+            set_error("launch_weight_grads: reduction workspace too small");
+            return PFN_ENOSPACE;
         }
         ta.nblocks = nblocks;
         {
