@@ -24,6 +24,8 @@ __device__ __forceinline__ float4 fma4(float a, float4 x, float4 acc) {
     return acc;
 }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sel4(bool k, float4 a, float4 b) { return make_float4(k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z, k ? a.w : b.w); }
+__device__ __forceinline__ float4 relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
 
 // ------------------------------------------------------------------------------------------- hop
 template <bool NORM>
@@ -39,25 +41,27 @@ __global__ __launch_bounds__(256) void hop_kernel(int n, int nchunk, const int* 
     const int beg = rowptr[row], end = rowptr[row + 1];
     const float di = NORM ? dinv[row] : 1.0f;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int p = beg;
-    for (; p + 4 <= end; p += 4) {   // 4 independent gathers in flight per lane
-        const int s0 = nbr[p], s1 = nbr[p + 1], s2 = nbr[p + 2], s3 = nbr[p + 3];
+    // Four edge slots per trip, ALWAYS four gathers in flight: slots past the row's end re-read its last edge (the same
+    // cache line again, no extra HBM traffic) and are dropped by a select, so rows of degree 1..3 -- most of a power grid --
+    // no longer walk a chain of dependent index -> row loads one edge at a time.  Sums still run in edge-id order.
+    for (int p = beg; p < end; p += 4) {
+        const int last = end - 1;
+        const int s0 = nbr[p], s1 = nbr[min(p + 1, last)], s2 = nbr[min(p + 2, last)], s3 = nbr[min(p + 3, last)];
         const float4 v0 = ld4(x + (size_t)s0 * ld + col), v1 = ld4(x + (size_t)s1 * ld + col);
         const float4 v2 = ld4(x + (size_t)s2 * ld + col), v3 = ld4(x + (size_t)s3 * ld + col);
+        const bool k1 = p + 1 < end, k2 = p + 2 < end, k3 = p + 3 < end;
         if (NORM) {
-            acc = fma4(dinv[s0] * di, v0, acc);
-            acc = fma4(dinv[s1] * di, v1, acc);
-            acc = fma4(dinv[s2] * di, v2, acc);
-            acc = fma4(dinv[s3] * di, v3, acc);
+            const float w0 = dinv[s0] * di, w1 = dinv[s1] * di, w2 = dinv[s2] * di, w3 = dinv[s3] * di;
+            acc = fma4(w0, v0, acc);
+            acc = sel4(k1, fma4(w1, v1, acc), acc);
+            acc = sel4(k2, fma4(w2, v2, acc), acc);
+            acc = sel4(k3, fma4(w3, v3, acc), acc);
         } else {
-            acc = add4(add4(add4(add4(acc, v0), v1), v2), v3);
+            acc = add4(acc, v0);
+            acc = sel4(k1, add4(acc, v1), acc);
+            acc = sel4(k2, add4(acc, v2), acc);
+            acc = sel4(k3, add4(acc, v3), acc);
         }
-    }
-    for (; p < end; ++p) {
-        const int s0 = nbr[p];
-        const float4 v0 = ld4(x + (size_t)s0 * ld + col);
-        if (NORM) acc = fma4(dinv[s0] * di, v0, acc);
-        else acc = add4(acc, v0);
     }
     const size_t o = (size_t)row * ld + col;
     if (add) acc = add4(acc, ld4(add + o));
@@ -236,22 +240,43 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
     const float4 p4 = ld4(P + (size_t)row * ld + col);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rowptr[row], end = rowptr[row + 1];
-    for (int p = beg; p < end; ++p) {
-        const int s = nbr[p];
-        int id = eid[p];
-        id = id >= e_stored ? id - e_stored : id;
-        float4 v = add4(p4, ld4(Q + (size_t)s * ld + col));
-        if (FE == 2) {
-            const float2 a = *reinterpret_cast<const float2*>(ea + (size_t)id * 2);
-            v = fma4(a.x, ld4(we + col), v);
-            v = fma4(a.y, ld4(we + ld + col), v);
-        } else {
-            for (int f = 0; f < fe; ++f) v = fma4(ea[(size_t)id * fe + f], ld4(we + f * ld + col), v);
+    if (FE == 2) {
+        // four edge slots per trip (see hop_kernel): indices first, then all gathers, then the sums in edge-id order
+        const float4 w0 = ld4(we + col), w1 = ld4(we + ld + col);
+        for (int p = beg; p < end; p += 4) {
+            const int last = end - 1;
+            int s_[4], id_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = min(p + u, last);
+                s_[u] = nbr[q];
+                const int id = eid[q];
+                id_[u] = id >= e_stored ? id - e_stored : id;
+            }
+            float4 q_[4];
+            float2 a_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                q_[u] = ld4(Q + (size_t)s_[u] * ld + col);
+                a_[u] = *reinterpret_cast<const float2*>(ea + (size_t)id_[u] * 2);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float4 v = add4(p4, q_[u]);
+                v = fma4(a_[u].x, w0, v);
+                v = fma4(a_[u].y, w1, v);
+                acc = sel4(p + u < end, add4(acc, relu4(v)), acc);
+            }
         }
-        acc.x += fmaxf(v.x, 0.f);
-        acc.y += fmaxf(v.y, 0.f);
-        acc.z += fmaxf(v.z, 0.f);
-        acc.w += fmaxf(v.w, 0.f);
+    } else {
+        for (int p = beg; p < end; ++p) {
+            const int s = nbr[p];
+            int id = eid[p];
+            id = id >= e_stored ? id - e_stored : id;
+            float4 v = add4(p4, ld4(Q + (size_t)s * ld + col));
+            for (int f = 0; f < fe; ++f) v = fma4(ea[(size_t)id * fe + f], ld4(we + f * ld + col), v);
+            acc = add4(acc, relu4(v));
+        }
     }
     st4(S + (size_t)row * ld + col, acc);
 }
@@ -279,6 +304,9 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
 //   src walk (by-source CSR):       dQ[j] = sum_{e: src(e) = j} dh_e
 // dWe is reduced deterministically: per-block ordered partial -> launch_dwe_reduce.
 #define PFN_MAX_FE 8
+// edge slots per trip of the backward walks: four (as in the forward kernels) cost 86 VGPRs -> 5 waves per SIMD and made the
+// kernel SLOWER (492 -> 566 us at 6470rte x 64); two keep 8 waves per SIMD
+constexpr int BW_SLOTS = 2;
 
 template <int FE>
 __device__ __forceinline__ void edge_bwd_dst_body(int bid, int nblk, int n, int nchunk, int bdx, int bdy, int e_stored,
@@ -316,25 +344,41 @@ __device__ __forceinline__ void edge_bwd_dst_body(int bid, int nblk, int n, int 
                 const float4 g4 = ld4(dS + (size_t)row * ld + col);
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 const int beg = rowptr[row], end = rowptr[row + 1];
-                for (int p = beg; p < end; ++p) {
-                    const int s = nbr[p];
-                    int id = eid[p];
-                    id = id >= e_stored ? id - e_stored : id;
-                    float4 v = add4(p4, ld4(Q + (size_t)s * ld + col));
-                    float a[FE];
+                // BW_SLOTS edge slots per trip (see hop_kernel): a slot past the row's end re-reads the last edge and
+                // contributes dh = 0 (an exact no-op on acc and dWe), sums stay in edge-id order
+                for (int p = beg; p < end; p += BW_SLOTS) {
+                    const int last = end - 1;
+                    int s_[BW_SLOTS], id_[BW_SLOTS];
 #pragma unroll
-                    for (int f = 0; f < FE; ++f) {
-                        a[f] = ea[(size_t)id * FE + f];
-                        v = fma4(a[f], w4[f], v);
+                    for (int u = 0; u < BW_SLOTS; ++u) {
+                        const int q = min(p + u, last);
+                        s_[u] = nbr[q];
+                        const int id = eid[q];
+                        id_[u] = id >= e_stored ? id - e_stored : id;
                     }
-                    float4 dh;
-                    dh.x = v.x > 0.f ? g4.x : 0.f;
-                    dh.y = v.y > 0.f ? g4.y : 0.f;
-                    dh.z = v.z > 0.f ? g4.z : 0.f;
-                    dh.w = v.w > 0.f ? g4.w : 0.f;
-                    acc = add4(acc, dh);
+                    float4 q_[BW_SLOTS];
+                    float a_[BW_SLOTS][FE];
 #pragma unroll
-                    for (int f = 0; f < FE; ++f) dwe[f] = fma4(a[f], dh, dwe[f]);
+                    for (int u = 0; u < BW_SLOTS; ++u) {
+                        q_[u] = ld4(Q + (size_t)s_[u] * ld + col);
+#pragma unroll
+                        for (int f = 0; f < FE; ++f) a_[u][f] = ea[(size_t)id_[u] * FE + f];
+                    }
+#pragma unroll
+                    for (int u = 0; u < BW_SLOTS; ++u) {
+                        float4 v = add4(p4, q_[u]);
+#pragma unroll
+                        for (int f = 0; f < FE; ++f) v = fma4(a_[u][f], w4[f], v);
+                        const bool k = p + u < end;
+                        float4 dh;
+                        dh.x = (k && v.x > 0.f) ? g4.x : 0.f;
+                        dh.y = (k && v.y > 0.f) ? g4.y : 0.f;
+                        dh.z = (k && v.z > 0.f) ? g4.z : 0.f;
+                        dh.w = (k && v.w > 0.f) ? g4.w : 0.f;
+                        acc = add4(acc, dh);
+#pragma unroll
+                        for (int f = 0; f < FE; ++f) dwe[f] = fma4(a_[u][f], dh, dwe[f]);
+                    }
                 }
                 st4(dP + (size_t)row * ld + col, acc);
             }
@@ -381,18 +425,39 @@ __device__ __forceinline__ void edge_bwd_src_body(int bid, int n, int nchunk, in
     const float4 q4 = ld4(Q + (size_t)row * ld + col);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rowptr[row], end = rowptr[row + 1];
-    for (int p = beg; p < end; ++p) {
-        const int d = nbr[p];
-        int id = eid[p];
-        id = id >= e_stored ? id - e_stored : id;
-        float4 v = add4(ld4(P + (size_t)d * ld + col), q4);
-        const float4 g4 = ld4(dS + (size_t)d * ld + col);
+    float4 w4[FE];
 #pragma unroll
-        for (int f = 0; f < FE; ++f) v = fma4(ea[(size_t)id * FE + f], ld4(we + f * ld + col), v);
-        acc.x += v.x > 0.f ? g4.x : 0.f;
-        acc.y += v.y > 0.f ? g4.y : 0.f;
-        acc.z += v.z > 0.f ? g4.z : 0.f;
-        acc.w += v.w > 0.f ? g4.w : 0.f;
+    for (int f = 0; f < FE; ++f) w4[f] = ld4(we + f * ld + col);
+    for (int p = beg; p < end; p += BW_SLOTS) {      // BW_SLOTS edge slots per trip (see hop_kernel)
+        const int last = end - 1;
+        int d_[BW_SLOTS], id_[BW_SLOTS];
+#pragma unroll
+        for (int u = 0; u < BW_SLOTS; ++u) {
+            const int q = min(p + u, last);
+            d_[u] = nbr[q];
+            const int id = eid[q];
+            id_[u] = id >= e_stored ? id - e_stored : id;
+        }
+        float4 p_[BW_SLOTS], g_[BW_SLOTS];
+        float a_[BW_SLOTS][FE];
+#pragma unroll
+        for (int u = 0; u < BW_SLOTS; ++u) {
+            p_[u] = ld4(P + (size_t)d_[u] * ld + col);
+            g_[u] = ld4(dS + (size_t)d_[u] * ld + col);
+#pragma unroll
+            for (int f = 0; f < FE; ++f) a_[u][f] = ea[(size_t)id_[u] * FE + f];
+        }
+#pragma unroll
+        for (int u = 0; u < BW_SLOTS; ++u) {
+            float4 v = add4(p_[u], q4);
+#pragma unroll
+            for (int f = 0; f < FE; ++f) v = fma4(a_[u][f], w4[f], v);
+            const bool k = p + u < end;
+            acc.x += (k && v.x > 0.f) ? g_[u].x : 0.f;
+            acc.y += (k && v.y > 0.f) ? g_[u].y : 0.f;
+            acc.z += (k && v.z > 0.f) ? g_[u].z : 0.f;
+            acc.w += (k && v.w > 0.f) ? g_[u].w : 0.f;
+        }
     }
     st4(dQ + (size_t)row * ld + col, acc);
 }
@@ -459,17 +524,19 @@ int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t*, hi
     }
 }
 
-// dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered: 4 interleaved lanes, then a fixed tree)
-__global__ __launch_bounds__(1024) void dwe_reduce_kernel(const float* __restrict__ partial, int nblocks, int fe, int ld,
-                                                          int h, float* __restrict__ gw1, int ldw, int col0) {
+// dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered: 4 interleaved lanes, then a fixed tree), for up to
+// DWE_MAX_JOBS EdgeAggregation layers in one launch (blockIdx.y = layer)
+__global__ __launch_bounds__(1024) void dwe_reduce_kernel(const DweJobs jobs, int fe, int ld, int h) {
     // block = 16 output elements x 64 partial lanes; every lane sums its stride-64 subset with four independent
     // chains, then a fixed-order tree over the lanes -> deterministic
     __shared__ float red[64][17];
+    const DweJob jb = jobs.job[blockIdx.y];
+    const int nblocks = jb.nblocks;
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int i = blockIdx.x * 16 + tx;
     const bool ok = i < fe * h;
     const int f = ok ? i / h : 0, k = ok ? i - f * h : 0;
-    const float* p = partial + (size_t)f * ld + k;
+    const float* p = jb.partial + (size_t)f * ld + k;
     const size_t stride = (size_t)fe * ld;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (ok) {
@@ -488,15 +555,25 @@ __global__ __launch_bounds__(1024) void dwe_reduce_kernel(const float* __restric
         if (ty < off) red[ty][tx] += red[ty + off][tx];
         __syncthreads();
     }
-    if (ty == 0 && ok) gw1[(size_t)k * ldw + col0 + f] = red[0][tx];
+    if (ty == 0 && ok) jb.gw1[(size_t)k * jb.ldw + jb.col0 + f] = red[0][tx];
+}
+
+int launch_dwe_reduce_multi(const DweJob* jobs, int njobs, int fe, int ld, int h, hipStream_t s) {
+    for (int j0 = 0; j0 < njobs; j0 += DWE_MAX_JOBS) {
+        DweJobs a;
+        const int nj = njobs - j0 < DWE_MAX_JOBS ? njobs - j0 : DWE_MAX_JOBS;
+        for (int j = 0; j < nj; ++j) a.job[j] = jobs[j0 + j];
+        ProfScope ps("dwe_reduce", 0.0, 0.0, s);
+        dwe_reduce_kernel<<<dim3((fe * h + 15) / 16, nj), 1024, 0, s>>>(a, fe, ld, h);
+        PFN_CHECK_LAUNCH();
+    }
+    return PFN_OK;
 }
 
 int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, float* gw1, int ldw, int col0,
                       hipStream_t s) {
-    ProfScope ps("dwe_reduce", 0.0, 0.0, s);
-    dwe_reduce_kernel<<<(fe * h + 15) / 16, 1024, 0, s>>>(partial, nblocks, fe, ld, h, gw1, ldw, col0);
-    PFN_CHECK_LAUNCH();
-    return PFN_OK;
+    const DweJob jb{partial, gw1, nblocks, ldw, col0, 0};
+    return launch_dwe_reduce_multi(&jb, 1, fe, ld, h, s);
 }
 
 // d edge_attr[e][f] = sum over the (one or two) effective copies of stored edge e of  We_f . dh_copy.

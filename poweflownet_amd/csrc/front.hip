@@ -1,0 +1,244 @@
+// The 4-wide front of the network in ONE launch per direction (gfx950).
+//
+// MaskEmbdMultiMPN.forward starts with three per-node products whose short side is the 4 node features
+// (networks/MPN.py:537 and the first EdgeAggregation's Linear1, :17-21,:28 restructured per node):
+//     me_h = relu(mask Wa^T + ba)             (N x H)      mask_embd[0], [1]
+//     x0   = x + me_h Wb^T + bb               (N x 4)      mask_embd[2] + the residual add
+//     P0   = x0 W1[:, 0:4]^T + b1             (N x H)      layer 0, target half of Linear1
+//     Q0   = x0 W1[:, 4:8]^T                  (N x H)      layer 0, source half
+// and the backward pass ends with their mirror image
+//     g0   = dP0 W1[:, 0:4] + dQ0 W1[:, 4:8]  (N x 4)      gradient w.r.t. x0 (= w.r.t. data.x)
+//     dh   = (g0 Wb) * [me_h > 0]             (N x H)      gradient w.r.t. mask_embd's hidden layer.
+// As tall-skinny MFMA GEMMs (gemm_nt.hip) these are five launches of ~8-11 us each at case118v2 x 128 -- K = 4 or N = 4
+// leaves the matrix cores idle and every launch pays its fixed cost.  Here a thread owns (node row, 4 hidden units): the
+// H-wide outputs are 4 + 8 FMAs per element straight from registers, the 4-wide ones a dot product over H reduced through
+// LDS in a fixed order (deterministic).  ~30 MFLOP in total: one launch of a few microseconds per direction.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "pfn_internal.hpp"
+
+namespace pfn {
+
+__device__ __forceinline__ float4 ld4f(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4f(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// Sum of a row's nchunk float4 partials in a FIXED order, in two levels (a single thread walking all 33 was a chain of 33
+// dependent LDS reads, ~1 us per row group): lanes c < 8 each add the partials c, c + 8, c + 16, ... in that order, then lane 0
+// adds the eight sub-sums in lane order.  Called by every thread of the block (two barriers inside); result in part[r * nchunk].
+__device__ __forceinline__ void row_sum(float4* part, int r, int c, int nchunk, bool on) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on && c < 8) {
+        for (int k = c; k < nchunk; k += 8) {
+            const float4 p = part[r * nchunk + k];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+    }
+    __syncthreads();
+    if (on && c < 8) part[r * nchunk + c] = s;
+    __syncthreads();
+    if (on && c == 0) {
+        float4 t = part[r * nchunk];
+        const int m = nchunk < 8 ? nchunk : 8;
+        for (int k = 1; k < m; ++k) {
+            const float4 p = part[r * nchunk + k];
+            t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        }
+        part[r * nchunk] = t;
+    }
+}
+
+// block = rows_pb rows x nchunk chunk-lanes (nchunk = ld / 4), PERSISTENT over row groups: a thread keeps ONE chunk of four
+// hidden units for every row it visits, so its slices of all five weights live in registers for the whole kernel (as
+// per-element global loads they made the kernel 3x slower than its memory traffic).  LDS: part[rows_pb][nchunk] | vec[rows_pb].
+__global__ __launch_bounds__(256) void front_fwd_kernel(int n, int h, int ld, int nchunk, int rows_pb, int ldw1,
+                                                        const float* __restrict__ x, const float* __restrict__ maskf,
+                                                        const float* __restrict__ wa, const float* __restrict__ ba,
+                                                        const float* __restrict__ wb, const float* __restrict__ bb,
+                                                        const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        float* __restrict__ me_h, float* __restrict__ x0,
+                                                        float* __restrict__ P, float* __restrict__ Q) {
+    extern __shared__ __attribute__((aligned(16))) float4 fl[];
+    float4* part = fl;
+    float4* vec = fl + (size_t)rows_pb * nchunk;
+    const int r = threadIdx.x / nchunk, c = threadIdx.x - r * nchunk;
+    const bool lane_on = r < rows_pb;
+    // this thread's units 4c .. 4c+3 of every weight (zero past H: the pad columns then come out as exact zeros)
+    float rwa[4][4], rba[4], rwb[4][4], rw1[4][8], rb1[4];
+    // (unconditional loads from a clamped unit, zeroed by a select afterwards: `ok ? load : 0` compiles to an exec-masked
+    //  branch with an immediate wait per load -- 72 serialized round trips to L2, 40 us)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = 4 * c + i, uc = min(u, h - 1);
+        const bool ok = lane_on && u < h;
+        const float vba = ba[uc], vb1 = b1[uc];
+        rba[i] = ok ? vba : 0.f;
+        rb1[i] = ok ? vb1 : 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float va = wa[(size_t)uc * 4 + f], vb = wb[(size_t)f * h + uc];
+            rwa[i][f] = ok ? va : 0.f;
+            rwb[i][f] = ok ? vb : 0.f;
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float v1 = w1[(size_t)uc * ldw1 + f];
+            rw1[i][f] = ok ? v1 : 0.f;
+        }
+    }
+    const float4 bb4 = make_float4(bb[0], bb[1], bb[2], bb[3]);
+    for (int row0 = blockIdx.x * rows_pb; row0 < n; row0 += gridDim.x * rows_pb) {
+        const int row = row0 + r;
+        const bool on = lane_on && row < n;
+        if (on) {
+            const float4 m = ld4f(maskf + (size_t)row * 4);
+            float hv[4];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);   // this chunk's share of me_h Wb^T
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = rba[i];
+                v = fmaf(rwa[i][0], m.x, v); v = fmaf(rwa[i][1], m.y, v); v = fmaf(rwa[i][2], m.z, v); v = fmaf(rwa[i][3], m.w, v);
+                v = fmaxf(v, 0.f);
+                hv[i] = v;
+                acc.x = fmaf(rwb[i][0], v, acc.x); acc.y = fmaf(rwb[i][1], v, acc.y);
+                acc.z = fmaf(rwb[i][2], v, acc.z); acc.w = fmaf(rwb[i][3], v, acc.w);
+            }
+            st4f(me_h + (size_t)row * ld + 4 * c, make_float4(hv[0], hv[1], hv[2], hv[3]));
+            part[r * nchunk + c] = acc;
+        }
+        __syncthreads();
+        row_sum(part, r, c, nchunk, on);   // fixed-order sum over the row's chunks, left in part[r * nchunk]
+        if (on && c == 0) {
+            const float4 s = part[r * nchunk];
+            const float4 xi = ld4f(x + (size_t)row * 4);
+            const float4 o = make_float4(xi.x + (s.x + bb4.x), xi.y + (s.y + bb4.y), xi.z + (s.z + bb4.z), xi.w + (s.w + bb4.w));
+            vec[r] = o;
+            st4f(x0 + (size_t)row * 4, o);
+        }
+        __syncthreads();
+        if (on) {
+            const float4 v = vec[r];
+            float p[4], q[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float a = rb1[i];
+                a = fmaf(rw1[i][0], v.x, a); a = fmaf(rw1[i][1], v.y, a); a = fmaf(rw1[i][2], v.z, a); a = fmaf(rw1[i][3], v.w, a);
+                float b = 0.f;
+                b = fmaf(rw1[i][4], v.x, b); b = fmaf(rw1[i][5], v.y, b); b = fmaf(rw1[i][6], v.z, b); b = fmaf(rw1[i][7], v.w, b);
+                p[i] = a;
+                q[i] = b;
+            }
+            st4f(P + (size_t)row * ld + 4 * c, make_float4(p[0], p[1], p[2], p[3]));
+            st4f(Q + (size_t)row * ld + 4 * c, make_float4(q[0], q[1], q[2], q[3]));
+        }
+        // (the next trip writes part[] only after its own first barrier has been passed by every reader of vec[]: part and
+        //  vec are disjoint, and part's readers (c == 0) are past the second barrier above)
+    }
+}
+
+__global__ __launch_bounds__(256) void front_bwd_kernel(int n, int h, int ld, int nchunk, int rows_pb, int ldw1,
+                                                        const float* __restrict__ dP, const float* __restrict__ dQ,
+                                                        const float* __restrict__ me_h, const float* __restrict__ w1,
+                                                        const float* __restrict__ wb, float* __restrict__ g0,
+                                                        float* __restrict__ dh) {
+    extern __shared__ __attribute__((aligned(16))) float4 fl[];
+    float4* part = fl;
+    float4* vec = fl + (size_t)rows_pb * nchunk;
+    const int r = threadIdx.x / nchunk, c = threadIdx.x - r * nchunk;
+    const bool lane_on = r < rows_pb;
+    float rwb[4][4], rw1[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // unconditional clamped loads + select (see front_fwd_kernel)
+        const int u = 4 * c + i, uc = min(u, h - 1);
+        const bool ok = lane_on && u < h;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float vb = wb[(size_t)f * h + uc];
+            rwb[i][f] = ok ? vb : 0.f;
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float v1 = w1[(size_t)uc * ldw1 + f];
+            rw1[i][f] = ok ? v1 : 0.f;
+        }
+    }
+    for (int row0 = blockIdx.x * rows_pb; row0 < n; row0 += gridDim.x * rows_pb) {
+        const int row = row0 + r;
+        const bool on = lane_on && row < n;
+        if (on) {
+            const float4 p4 = ld4f(dP + (size_t)row * ld + 4 * c), q4 = ld4f(dQ + (size_t)row * ld + 4 * c);
+            const float pv[4] = {p4.x, p4.y, p4.z, p4.w}, qv[4] = {q4.x, q4.y, q4.z, q4.w};
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc.x = fmaf(pv[i], rw1[i][0], acc.x); acc.y = fmaf(pv[i], rw1[i][1], acc.y);
+                acc.z = fmaf(pv[i], rw1[i][2], acc.z); acc.w = fmaf(pv[i], rw1[i][3], acc.w);
+                acc.x = fmaf(qv[i], rw1[i][4], acc.x); acc.y = fmaf(qv[i], rw1[i][5], acc.y);
+                acc.z = fmaf(qv[i], rw1[i][6], acc.z); acc.w = fmaf(qv[i], rw1[i][7], acc.w);
+            }
+            part[r * nchunk + c] = acc;
+        }
+        __syncthreads();
+        row_sum(part, r, c, nchunk, on);
+        if (on && c == 0) {
+            const float4 s = part[r * nchunk];
+            vec[r] = s;
+            st4f(g0 + (size_t)row * 4, s);
+        }
+        __syncthreads();
+        if (on) {
+            const float4 g = vec[r];
+            const float4 y = ld4f(me_h + (size_t)row * ld + 4 * c);
+            const float yv[4] = {y.x, y.y, y.z, y.w};
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = 0.f;
+                v = fmaf(g.x, rwb[i][0], v); v = fmaf(g.y, rwb[i][1], v); v = fmaf(g.z, rwb[i][2], v); v = fmaf(g.w, rwb[i][3], v);
+                o[i] = yv[i] > 0.f ? v : 0.f;
+            }
+            st4f(dh + (size_t)row * ld + 4 * c, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
+bool front_fused_ok(int f0, int h) {
+    static const bool off = getenv("PFN_NO_FUSED_FRONT") != nullptr;   // experiments / tests of the generic GEMM path
+    return !off && f0 == 4 && ld_of(h) / 4 <= 256;
+}
+
+static void front_shape(int h, int& ld, int& nchunk, int& rows_pb, size_t& lds) {
+    ld = ld_of(h);
+    nchunk = ld / 4;
+    rows_pb = 256 / nchunk;
+    lds = ((size_t)rows_pb * nchunk + rows_pb) * sizeof(float4);
+}
+
+int launch_front_fwd(int n, int h, int ldw1, const float* x, const float* maskf, const float* wa, const float* ba,
+                     const float* wb, const float* bb, const float* w1, const float* b1, float* me_h, float* x0, float* P,
+                     float* Q, hipStream_t s) {
+    if (n == 0) return PFN_OK;
+    int ld, nchunk, rows_pb;
+    size_t lds;
+    front_shape(h, ld, nchunk, rows_pb, lds);
+    ProfScope ps("front_fwd", 0.0, 0.0, s);
+    front_fwd_kernel<<<std::min((n + rows_pb - 1) / rows_pb, 8 * device_cus()), 256, lds, s>>>(n, h, ld, nchunk, rows_pb, ldw1, x, maskf, wa, ba, wb, bb, w1,
+                                                                   b1, me_h, x0, P, Q);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, const float* me_h, const float* w1,
+                     const float* wb, float* g0, float* dh, hipStream_t s) {
+    if (n == 0) return PFN_OK;
+    int ld, nchunk, rows_pb;
+    size_t lds;
+    front_shape(h, ld, nchunk, rows_pb, lds);
+    ProfScope ps("front_bwd", 0.0, 0.0, s);
+    front_bwd_kernel<<<std::min((n + rows_pb - 1) / rows_pb, 8 * device_cus()), 256, lds, s>>>(n, h, ld, nchunk, rows_pb, ldw1, dP, dQ, me_h, w1, wb, g0, dh);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+}  // namespace pfn

@@ -57,7 +57,9 @@ __host__ __device__ constexpr int t3_quads(int TA, int TB) { return TA * TB * 4 
 struct T3Task {
     short pair, ti, tj, flags;
     short wa, wb;          // 1: the operand is wide (a lane holds 4 adjacent columns); 0: narrow (lane c = column c)
-    int nsplit, block0;    // row splits of this task; first workgroup id
+    short gsize, gidx;     // tasks that share an operand form a group: its size (set on every member) and this task's index in it
+    int nsplit;            // row splits of this task (equal for the members of a group)
+    int block0;            // first workgroup id of the GROUP
     int part0;             // float4 offset of this task's first partial in the partial buffer
 };
 struct T3Args {
@@ -312,11 +314,31 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
 
 __global__ __launch_bounds__(T3_THREADS, 1) void gemm_tn_kernel(const T3Args a) {
     extern __shared__ __attribute__((aligned(16))) float4 t3_lds[];
-    // task of this workgroup: tasks own consecutive id ranges (block0 ascending)
+    // task and row split of this workgroup.  Groups own consecutive id ranges; inside a group the ids run
+    //     [chunk of 8 splits][member][split in chunk]
+    // so the workgroups of ONE row range of all members (the 4 pairs of a TAGConv share dY, dP / dQ of an EdgeAggregation
+    // share X) get ids that agree mod 8 and are dispatched together: workgroups are dealt round-robin to the 8 XCDs, each
+    // with its own L2, and the shared operand is then fetched from HBM once per XCD instead of once per member.
     int t = 0;
-    while (t + 1 < a.ntasks && (int)blockIdx.x >= a.task[t + 1].block0) ++t;
-    const T3Task tk = a.task[t];
-    const int bx = blockIdx.x - tk.block0;
+    for (;;) {
+        const int gs = a.task[t].gsize, nb = a.task[t].nsplit * gs;
+        if ((int)blockIdx.x < a.task[t].block0 + nb || t + gs >= a.ntasks) break;
+        t += gs;
+    }
+    const int local = blockIdx.x - a.task[t].block0, gs0 = a.task[t].gsize, ns0 = a.task[t].nsplit;
+    const int nfull = ns0 >> 3, tail = ns0 & 7;   // the last chunk holds the < 8 left-over splits, unpadded (ids stay dense:
+                                                  // padding ids would pin more work on some XCDs than on others)
+    int member, bx;
+    if (local < nfull * 8 * gs0) {
+        const int chunk = local / (8 * gs0), rem = local - chunk * 8 * gs0;
+        member = rem >> 3;
+        bx = 8 * chunk + (rem & 7);
+    } else {
+        const int l2 = local - nfull * 8 * gs0;
+        member = l2 / tail;
+        bx = 8 * nfull + (l2 - member * tail);
+    }
+    const T3Task tk = a.task[t + member];
     if (tk.wa && tk.wb) t3_body<4, 2>(a, tk, bx, t3_lds);
     else if (tk.wa) t3_body<4, 1>(a, tk, bx, t3_lds);
     else if (tk.wb) t3_body<1, 2>(a, tk, bx, t3_lds);
@@ -421,9 +443,28 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
             ta.pair[np_here++] = pr;
             ++p;
         }
+        // groups: consecutive single-tile tasks of the same shape that share A or B with the first of them (at most 8)
+        for (int t = 0; t < ta.ntasks;) {
+            int gsz = 1;
+            const TnPair& p0 = ta.pair[ta.task[t].pair];
+            const bool single = t + 1 >= ta.ntasks || ta.task[t + 1].pair != ta.task[t].pair;
+            static const bool no_group = getenv("PFN_TN_NOGROUP") != nullptr;   // experiments
+            while (!no_group && single && t + gsz < ta.ntasks && gsz < 8) {
+                const T3Task& nx = ta.task[t + gsz];
+                const TnPair& pn = ta.pair[nx.pair];
+                const bool nx_single = (t + gsz + 1 >= ta.ntasks || ta.task[t + gsz + 1].pair != nx.pair) && nx.pair != ta.task[t + gsz - 1].pair;
+                if (!nx_single || nx.wa != ta.task[t].wa || nx.wb != ta.task[t].wb || (pn.A != p0.A && pn.B != p0.B)) break;
+                ++gsz;
+            }
+            for (int k = 0; k < gsz; ++k) {
+                ta.task[t + k].gsize = (short)gsz;
+                ta.task[t + k].gidx = (short)k;
+            }
+            t += gsz;
+        }
         // row splits: about one workgroup per CU in total (two waves per SIMD), shared out in proportion to the tasks'
-        // cost per row; at least 64 rows per row group; when the partials would not fit the buffer the whole plan is scaled
-        // down (never a single task: one task left unsplit would take M rows on one CU)
+        // cost per row (equal inside a group); at least 64 rows per row group; when the partials would not fit the buffer the
+        // whole plan is scaled down (never a single task: one task left unsplit would take M rows on one CU)
         const int max_split = (int)std::max<int64_t>(1, M / (64 * T3_WAVES));
         int nblocks = 0;
         size_t part = 0;
@@ -432,15 +473,20 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
             part = 0;
             for (int t = 0; t < ta.ntasks; ++t) {
                 T3Task& tk = ta.task[t];
-                int ns = (int)(want * cost[t] / cost_total + 0.5);
-                ns = std::max(1, std::min(ns, max_split));
-                // an empty trailing range would leave its partial unwritten: shrink until every range holds rows
-                while (ns > 1 && round_up((M + ns - 1) / ns, T3_ROWS * T3_WAVES) * (ns - 1) >= M) --ns;
-                tk.nsplit = ns;
-                tk.block0 = nblocks;
+                if (tk.gidx == 0) {
+                    int ns = (int)(want * cost[t] / cost_total + 0.5);
+                    ns = std::max(1, std::min(ns, max_split));
+                    // an empty trailing range would leave its partial unwritten: shrink until every range holds rows
+                    while (ns > 1 && round_up((M + ns - 1) / ns, T3_ROWS * T3_WAVES) * (ns - 1) >= M) --ns;
+                    tk.nsplit = ns;
+                    tk.block0 = nblocks;
+                    nblocks += ns * tk.gsize;
+                } else {
+                    tk.nsplit = ta.task[t - tk.gidx].nsplit;
+                    tk.block0 = ta.task[t - tk.gidx].block0;
+                }
                 tk.part0 = (int)part;
-                nblocks += ns;
-                if (ns > 1) part += (size_t)ns * (tk.wb ? 2 : 1) * t3_quads(tk.wa ? 4 : 1, tk.wb ? 2 : 1) * 64;
+                if (tk.nsplit > 1) part += (size_t)tk.nsplit * (tk.wb ? 2 : 1) * t3_quads(tk.wa ? 4 : 1, tk.wb ? 2 : 1) * 64;
             }
             if (part <= cap_f4 || want < 2.0) break;
         }

@@ -272,7 +272,13 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
 #pragma unroll
                 for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + (m + 1) * 32 + c * 4);
             }
-            wait_a<NCH - 1>(a_cur[m]);
+            // (refills are issued per GROUP of four chunks, below: chunk m has 16 - (m & 3) younger loads)
+            switch (m & 3) {
+                case 0: wait_a<NCH - 1>(a_cur[m]); break;
+                case 1: wait_a<NCH - 2>(a_cur[m]); break;
+                case 2: wait_a<NCH - 3>(a_cur[m]); break;
+                default: wait_a<NCH - 4>(a_cur[m]); break;
+            }
             const f32x4 av = a_cur[m];
 #pragma unroll
             for (int i = 0; i < ((FAST && m == NFAST - 1) ? LS : 4); ++i) {
@@ -282,11 +288,19 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
                 for (int c = 0; c < NR; ++c) racc[c] = fmaf(av[i], r[c][i], racc[c]);
             }
         }
-        // chunk m consumed: refill it IN PLACE for the next piece.  Unconditional (the wait counts rely on exactly 17
-        // refills per piece), from a clamped always-valid address: k's past the row multiply zero B rows.
-        // Address = wave-uniform 64-bit base (SGPRs) + 32-bit per-lane offset.
-        const uint32_t kk = min(kh4 + 8u * m, (uint32_t)nkmax);
-        vload_x4(a_cur[m], nbase, nvoff + 4u * kk);
+        // chunks consumed: refill them IN PLACE for the next piece -- four at a time.  A 128-byte line of a row holds four
+        // consecutive chunks (32 bytes each: the two lane halves); refilled one by one they are requested ~600 cycles apart,
+        // and with 8 waves x 32 rows = 32 KB of distinct lines in flight per CU the line is evicted from L1 in between:
+        // every chunk load went back to L2 (4x the L2 -> L1 traffic).  Issued back to back the four requests meet in L1.
+        // Unconditional (the wait counts rely on exactly 17 refills per piece), from a clamped always-valid address: k's past
+        // the row multiply zero B rows.  Address = wave-uniform 64-bit base (SGPRs) + 32-bit per-lane offset.
+        if ((m & 3) == 3 || m == NCH - 1) {
+#pragma unroll
+            for (int mm = m & ~3; mm <= m; ++mm) {
+                const uint32_t kk = min(kh4 + 8u * mm, (uint32_t)nkmax);
+                vload_x4(a_cur[mm], nbase, nvoff + 4u * kk);
+            }
+        }
         __builtin_amdgcn_sched_barrier(0);
     }
 }

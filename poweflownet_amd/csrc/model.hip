@@ -80,7 +80,11 @@ struct Gate {
 // network's dW work at once instead of by 8 small launches competing with the input-gradient chain.  (Round 1 ran them
 // per layer on a second stream: measured 1-2 % over no overlap at all, and the sharing slowed the HBM-bound hops 2x.)
 // The price is memory: every layer's incoming gradient and dP / dQ stay alive until the end (sized for 288 GB).
-typedef std::vector<TnPair> PairList;
+struct Deferred {
+    std::vector<TnPair> pairs;
+    std::vector<DweJob> dwe;     // the dWe partial reductions of the EdgeAggregation layers, one launch for all
+};
+typedef Deferred PairList;
 
 // ---------------------------------------------------------------------------------- EdgeAggregation
 struct EaSaved { float *P, *Q, *S; };
@@ -101,9 +105,9 @@ static EaPack ea_pack(Packer& pk, int fi, int fe, int h, int fo, const float* w1
 
 static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
                       const float* w1, const float* b1, const float* b2, const EaPack& pw, float* out, int ldo,
-                      const Act& act, const EaSaved& sv, hipStream_t s) {
+                      const Act& act, const EaSaved& sv, hipStream_t s, bool pq_ready = false) {
     const int ld = ld_of(h);
-    {   // P = x W1[:, :Fi]^T + b1 ; Q = x W1[:, Fi:2Fi]^T
+    if (!pq_ready) {   // P = x W1[:, :Fi]^T + b1 ; Q = x W1[:, Fi:2Fi]^T   (layer 0: already written by the fused front)
         GemmArgs a = gemm_defaults(g.n, h, ld);
         a.ngroup = 2;
         a.C[0] = sv.P;
@@ -162,14 +166,16 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         PFN_TRY(launch_gemm_nt(a, s));
     }
     // weight gradients: dWe partials -> W1[:, 2Fi:], and three (dY, X) pairs
-    PFN_TRY(launch_dwe_reduce(sc.dWe, g.n > 0 ? edge_bwd_dst_blocks(g, ld) : 0, fe, ld, h, gw1, ldw1, 2 * fi, s));
+    const int dwe_blocks = g.n > 0 ? edge_bwd_dst_blocks(g, ld) : 0;
+    if (defer) defer->dwe.push_back(DweJob{sc.dWe, gw1, dwe_blocks, ldw1, 2 * fi, 0});
+    else PFN_TRY(launch_dwe_reduce(sc.dWe, dwe_blocks, fe, ld, h, gw1, ldw1, 2 * fi, s));
     const TnPair pairs[3] = {
         tn_pair(gout, ldgo, fo, sv.S, ld, h, gw2, h, 0, gb2, g.deg),      // dW2 ; db2 = sum_i deg_i gout_i
         tn_pair(sc.dP, ld, h, x, ldx, fi, gw1, ldw1, 0, gb1, nullptr),    // dW1[:, :Fi] ; db1 = sum_i dP_i
         tn_pair(sc.dQ, ld, h, x, ldx, fi, gw1, ldw1, fi, nullptr, nullptr),
     };
     if (defer) {
-        defer->insert(defer->end(), pairs, pairs + 3);
+        defer->pairs.insert(defer->pairs.end(), pairs, pairs + 3);
         return PFN_OK;
     }
     return launch_weight_grads(pairs, 3, g.n, sc.red, s);
@@ -279,8 +285,8 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
         }
     }
     // weight gradients need only gout and the saved hops
-    PairList local;
-    PairList& pairs = defer ? *defer : local;
+    std::vector<TnPair> local;
+    std::vector<TnPair>& pairs = defer ? defer->pairs : local;
     for (int k = 0; k <= K; ++k)
         pairs.push_back(tn_pair(gout, ldgo, cout, k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, gw[k], cin, 0,
                                 k == 0 ? gbias : nullptr, nullptr));
@@ -416,24 +422,30 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     // ... the same launch advances the dropout stream for this forward and converts pred_mask to float32
     PFN_TRY(pk.flush(s, drop ? rng : nullptr, pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0));
     // mask_embd(mask) + x   (networks/MPN.py:533,:537)
-    {
-        GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
-        a.C[0] = lo.me_h;
-        a.nterm = 1;
-        a.term[0] = term(lo.maskf, lo.ld0, lo.f0, mp.wa_t, 0);
-        a.bias = me[1];
-        a.act = ACT_RELU;
-        PFN_TRY(launch_gemm_nt(a, s));
-    }
-    {
-        GemmArgs a = gemm_defaults(lo.n, lo.f0, lo.ld0);
-        a.C[0] = lo.x0;
-        a.nterm = 1;
-        a.term[0] = term(lo.me_h, lo.ld, lo.h, mp.wb_t, 0);
-        a.bias = me[3];
-        a.resid = x;
-        a.ldr = lo.ld0;
-        PFN_TRY(launch_gemm_nt(a, s));
+    const bool fused_front = front_fused_ok(lo.f0, lo.h);
+    if (fused_front) {   // ... and the first EdgeAggregation's P | Q, all in one launch (front.hip)
+        PFN_TRY(launch_front_fwd(lo.n, lo.h, 2 * lo.f0 + lo.fe, x, lo.maskf, me[0], me[1], me[2], me[3], params[0], params[1],
+                                 lo.me_h, lo.x0, lo.ea[0].P, lo.ea[0].Q, s));
+    } else {
+        {
+            GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
+            a.C[0] = lo.me_h;
+            a.nterm = 1;
+            a.term[0] = term(lo.maskf, lo.ld0, lo.f0, mp.wa_t, 0);
+            a.bias = me[1];
+            a.act = ACT_RELU;
+            PFN_TRY(launch_gemm_nt(a, s));
+        }
+        {
+            GemmArgs a = gemm_defaults(lo.n, lo.f0, lo.ld0);
+            a.C[0] = lo.x0;
+            a.nterm = 1;
+            a.term[0] = term(lo.me_h, lo.ld, lo.h, mp.wb_t, 0);
+            a.bias = me[3];
+            a.resid = x;
+            a.ldr = lo.ld0;
+            PFN_TRY(launch_gemm_nt(a, s));
+        }
     }
     const float* cur = lo.x0;
     int ldc = lo.ld0, fcur = lo.f0, pi = 0;
@@ -451,7 +463,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         if (is_ea(i)) {
             const int fo = last ? lo.fo : lo.h;
             PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 3],
-                               mp.ea[i], y, ldy, act, lo.ea[i], s));
+                               mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0));
             pi += 4;
             fcur = fo;
         } else {
@@ -482,6 +494,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
     }
     if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)lo.e * lo.fe * sizeof(float), s));
     PairList pairs;                            // every weight-gradient pair of the network, launched once at the end
+    const bool fused_front = front_fused_ok(lo.f0, lo.h);
     const float* gcur = gout;
     int ldg = lo.ldo;
     for (int i = lo.nlayers - 1; i >= 0; --i) {
@@ -502,8 +515,10 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
             sc.dP = lo.dP[i];
             sc.dQ = lo.dQ[i];
             sc.dWe = lo.dWe[i];
-            PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], mp.ea[i], gcur, ldg, gate, gnext, ldi,
-                                grads[p0], grads[p0 + 1], grads[p0 + 2], grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs));
+            // (layer 0 with the fused front: its input gradient is formed together with mask_embd's, below)
+            PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], mp.ea[i], gcur, ldg, gate,
+                                (fused_front && i == 0) ? nullptr : gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2],
+                                grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
                                  grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg));
@@ -513,7 +528,10 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
     }
     // mask_embd backward: x0 = me_h Wb^T + bb + x ; me_h = relu(maskf Wa^T + ba)
     float* const* gme = grads + (nparams - 4);
-    {
+    if (fused_front) {   // g0 = dP0 W1i + dQ0 W1j and dh = (g0 Wb) [me_h > 0] in one launch (front.hip)
+        PFN_TRY(launch_front_bwd(lo.n, lo.h, 2 * lo.f0 + lo.fe, lo.dP[0], lo.dQ[0], lo.me_h, params[0], params[nparams - 2],
+                                 lo.gin[0], lo.dh, s));
+    } else {
         GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
         a.C[0] = lo.dh;
         a.nterm = 1;
@@ -522,9 +540,10 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         a.ldg = lo.ld;
         PFN_TRY(launch_gemm_nt(a, s));
     }
-    pairs.push_back(tn_pair(gcur, lo.ld0, lo.f0, lo.me_h, lo.ld, lo.h, gme[2], lo.h, 0, gme[3], nullptr));     // dWb, dbb
-    pairs.push_back(tn_pair(lo.dh, lo.ld, lo.h, lo.maskf, lo.ld0, lo.f0, gme[0], lo.f0, 0, gme[1], nullptr));  // dWa, dba
-    PFN_TRY(launch_weight_grads(pairs.data(), (int)pairs.size(), lo.n, lo.eas.red, s));
+    pairs.pairs.push_back(tn_pair(gcur, lo.ld0, lo.f0, lo.me_h, lo.ld, lo.h, gme[2], lo.h, 0, gme[3], nullptr));     // dWb, dbb
+    pairs.pairs.push_back(tn_pair(lo.dh, lo.ld, lo.h, lo.maskf, lo.ld0, lo.f0, gme[0], lo.f0, 0, gme[1], nullptr));  // dWa, dba
+    PFN_TRY(launch_dwe_reduce_multi(pairs.dwe.data(), (int)pairs.dwe.size(), lo.fe, lo.ld, lo.h, s));
+    PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s));
     if (gx) PFN_CHECK_HIP(hipMemcpyAsync(gx, gcur, (size_t)lo.n * lo.ld0 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return PFN_OK;
 }

@@ -218,9 +218,28 @@ struct EdgeBwdArgs {
 int edge_bwd_dst_blocks(const GraphView& g, int ld);   // number of dWe partials the dst walk emits (<= 1024)
 int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t* edge_index_unused, hipStream_t s);
 int launch_edge_attr_grad(const GraphView& g, const EdgeBwdArgs& a, hipStream_t s);
+// the same for several EdgeAggregation layers in one launch (all with the same fe / ld / h: the layers of one model)
+struct DweJob {
+    const float* partial;
+    float* gw1;
+    int nblocks, ldw, col0, pad_;
+};
+constexpr int DWE_MAX_JOBS = 16;
+struct DweJobs { DweJob job[DWE_MAX_JOBS]; };
+int launch_dwe_reduce_multi(const DweJob* jobs, int njobs, int fe, int ld, int h, hipStream_t s);
 // sums dWe partials [nblocks][fe][ld] into grad_w1[:, 2Fi + f]
 int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, float* grad_w1, int ldw, int col0,
                       hipStream_t s);
+
+// ------------------------------------------------------------------------------------- 4-wide front
+// front.hip: mask_embd + residual + the first EdgeAggregation's P | Q in one launch (forward), and the gradient w.r.t. x0 +
+// mask_embd's hidden-layer gradient in one launch (backward).  Only for nfeature_dim == 4 (what the reference asserts).
+bool front_fused_ok(int f0, int h);
+int launch_front_fwd(int n, int h, int ldw1, const float* x, const float* maskf, const float* wa, const float* ba,
+                     const float* wb, const float* bb, const float* w1, const float* b1, float* me_h, float* x0, float* P,
+                     float* Q, hipStream_t s);
+int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, const float* me_h, const float* w1,
+                     const float* wb, float* g0, float* dh, hipStream_t s);
 
 // ------------------------------------------------------------------------------------ small kernels
 int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t f,

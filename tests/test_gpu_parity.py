@@ -642,6 +642,36 @@ def test_train_mode_matches_oracle_fed_the_exported_masks(case, B, cfg):
         assert_close(m(dd), ref(data), RTOL, "eval out")
 
 
+def test_fused_front_equals_generic_gemm_path(tmp_path):
+    """front.hip (mask_embd + residual + layer-0 P|Q in one launch, and its mirror in backward) against the generic
+    tall-skinny GEMM path it replaces (PFN_NO_FUSED_FRONT=1, read once per process -> a child process): same output and
+    gradients up to fp32 summation order."""
+    import os
+    import subprocess
+    import sys
+    script = f"""
+import sys, torch
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+from poweflownet_amd.synth import make_batch
+torch.manual_seed(3)
+m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.0).to("cuda:0").eval()
+d = make_batch("118", 6, seed=4).to("cuda:0")
+d.x.requires_grad_(True)
+out = m(d)
+torch.nn.MSELoss()(out, d.y).backward()
+torch.save({{"out": out.detach().cpu(), "gx": d.x.grad.cpu(), "g": m.flat_grad().cpu()}}, sys.argv[1])
+"""
+    res = {}
+    for tag, env in (("fused", {}), ("generic", {"PFN_NO_FUSED_FRONT": "1"})):
+        path = str(tmp_path / f"{tag}.pt")
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=300)
+        res[tag] = torch.load(path)
+    assert_close(res["fused"]["out"], res["generic"]["out"], RTOL, "out")
+    assert_close(res["fused"]["gx"], res["generic"]["gx"], RTOL, "grad x")
+    assert_close(res["fused"]["g"], res["generic"]["g"], RTOL, "flat parameter gradient")
+
+
 def test_two_models_two_streams_two_threads_do_not_share_state():
     """The library holds no stream / event / device binding of its own (include/pfn_hip.h): two models, each on its own
     torch stream, driven (a) interleaved from one thread and (b) concurrently from two host threads, produce
