@@ -45,14 +45,6 @@ constexpr int KP = 8 * NCH;                     // 136 k's per piece: H = 129 is
 constexpr int NT_MAX_PIECES = 16;
 constexpr int NT_LDS_BYTES = 160 * 1024;
 
-// column plan of an output of `ld` (padded) columns: `remv` trailing columns (0 or 4) go to the VALU path when that
-// saves a whole MFMA quarter; `nq` 32-column MFMA quarters.
-__host__ __device__ inline void col_plan(int ld, int& remv, int& nq) {
-    const int m = ld & 31;
-    remv = (m != 0 && m <= 4) ? m : 0;
-    nq = (ld - remv + 31) / 32;
-}
-
 // ------------------------------------------------------------------------------------------------ pack
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     // the dropout stream advances once per forward, before any kernel of that forward reads it
@@ -63,28 +55,7 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
             a.maskf[i] = a.mask_dtype == 0 ? (float)static_cast<const int64_t*>(a.mask)[i] : static_cast<const float*>(a.mask)[i];
     }
     if ((int)blockIdx.y >= a.njobs) return;
-    const PackJob jb = a.job[blockIdx.y];
-    int remv, nq;
-    col_plan(jb.ld_out, remv, nq);
-    const int G = ((jb.K + 7) & ~7) >> 2;       // groups of four k's
-    const long main_floats = (long)nq * G * 128, total = main_floats + (long)G * 16;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int k, n;
-        if (i < main_floats) {
-            const int q = (int)(i / ((long)G * 128));
-            const int r = (int)(i - (long)q * G * 128);
-            k = 4 * (r >> 7) + (r & 3);
-            n = 32 * q + ((r & 127) >> 2);
-        } else {
-            const int r = (int)(i - main_floats);
-            k = 4 * (r >> 4) + (r & 3);
-            n = 32 * nq + ((r & 15) >> 2);
-        }
-        float v = 0.f;
-        if (k < jb.K && n < jb.ncols)
-            v = jb.trans ? jb.src[(size_t)(jb.wn0 + n) * jb.ldw + jb.wk0 + k] : jb.src[(size_t)(jb.wk0 + k) * jb.ldw + jb.wn0 + n];
-        jb.dst[i] = v;
-    }
+    pack_job_body(a.job[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
 size_t packed_floats(int K, int ld_out) {

@@ -419,14 +419,20 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     Packer pk(lo.packed);
     ModelPack mp;
     plan_pack(pk, lo.f0, lo.fe, lo.fo, lo.h, lo.L, lo.K, params, mp);
-    // ... the same launch advances the dropout stream for this forward and converts pred_mask to float32
-    PFN_TRY(pk.flush(s, drop ? rng : nullptr, pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0));
     // mask_embd(mask) + x   (networks/MPN.py:533,:537)
     const bool fused_front = front_fused_ok(lo.f0, lo.h);
-    if (fused_front) {   // ... and the first EdgeAggregation's P | Q, all in one launch (front.hip)
-        PFN_TRY(launch_front_fwd(lo.n, lo.h, 2 * lo.f0 + lo.fe, x, lo.maskf, me[0], me[1], me[2], me[3], params[0], params[1],
-                                 lo.me_h, lo.x0, lo.ea[0].P, lo.ea[0].Q, s));
+    if (fused_front) {
+        // ONE launch: the weight re-layout (which also advances the dropout stream for this forward) next to the front --
+        // pred_mask.float(), mask_embd, the residual add and the first EdgeAggregation's P | Q (front.hip)
+        FrontFwdArgs f;
+        f.n = lo.n; f.h = lo.h; f.ldw1 = 2 * lo.f0 + lo.fe; f.mask_dtype = mask_dtype;
+        f.x = x; f.mask = pred_mask;
+        f.wa = me[0]; f.ba = me[1]; f.wb = me[2]; f.bb = me[3]; f.w1 = params[0]; f.b1 = params[1];
+        f.maskf = lo.maskf; f.me_h = lo.me_h; f.x0 = lo.x0; f.P = lo.ea[0].P; f.Q = lo.ea[0].Q;
+        PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s));
     } else {
+        // ... the pack launch also advances the dropout stream for this forward and converts pred_mask to float32
+        PFN_TRY(pk.flush(s, drop ? rng : nullptr, pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0));
         {
             GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
             a.C[0] = lo.me_h;

@@ -110,6 +110,37 @@ struct PackArgs {
     int mask_dtype;          // 0: int64, 1: float32
 };
 size_t packed_floats(int K, int ld_out);
+// column plan of an output of `ld` (padded) columns: `remv` trailing columns (0 or 4) go to the VALU path when that
+// saves a whole MFMA quarter; `nq` 32-column MFMA quarters.
+__host__ __device__ inline void col_plan(int ld, int& remv, int& nq) {
+    const int m = ld & 31;
+    remv = (m != 0 && m <= 4) ? m : 0;
+    nq = (ld - remv + 31) / 32;
+}
+// one block's share (block bx of nbx) of one weight re-layout job
+__device__ inline void pack_job_body(const PackJob& jb, int bx, int nbx) {
+    int remv, nq;
+    col_plan(jb.ld_out, remv, nq);
+    const int G = ((jb.K + 7) & ~7) >> 2;       // groups of four k's
+    const long main_floats = (long)nq * G * 128, total = main_floats + (long)G * 16;
+    for (long i = (long)bx * blockDim.x + threadIdx.x; i < total; i += (long)nbx * blockDim.x) {
+        int k, n;
+        if (i < main_floats) {
+            const int q = (int)(i / ((long)G * 128));
+            const int r = (int)(i - (long)q * G * 128);
+            k = 4 * (r >> 7) + (r & 3);
+            n = 32 * q + ((r & 127) >> 2);
+        } else {
+            const int r = (int)(i - main_floats);
+            k = 4 * (r >> 4) + (r & 3);
+            n = 32 * nq + ((r & 15) >> 2);
+        }
+        float v = 0.f;
+        if (k < jb.K && n < jb.ncols)
+            v = jb.trans ? jb.src[(size_t)(jb.wn0 + n) * jb.ldw + jb.wk0 + k] : jb.src[(size_t)(jb.wk0 + k) * jb.ldw + jb.wn0 + n];
+        jb.dst[i] = v;
+    }
+}
 int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s, const void* mask = nullptr,
                 int mask_dtype = 0, float* maskf = nullptr, int64_t mask_count = 0);
 
@@ -235,9 +266,15 @@ int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, 
 // front.hip: mask_embd + residual + the first EdgeAggregation's P | Q in one launch (forward), and the gradient w.r.t. x0 +
 // mask_embd's hidden-layer gradient in one launch (backward).  Only for nfeature_dim == 4 (what the reference asserts).
 bool front_fused_ok(int f0, int h);
-int launch_front_fwd(int n, int h, int ldw1, const float* x, const float* maskf, const float* wa, const float* ba,
-                     const float* wb, const float* bb, const float* w1, const float* b1, float* me_h, float* x0, float* P,
-                     float* Q, hipStream_t s);
+struct FrontFwdArgs {
+    int n, h, ldw1, mask_dtype;            // mask_dtype 0: int64, 1: float32 (pred_mask as the caller holds it)
+    const float* x;
+    const void* mask;
+    const float *wa, *ba, *wb, *bb, *w1, *b1;
+    float *maskf, *me_h, *x0, *P, *Q;      // maskf: pred_mask.float() (networks/MPN.py:533), kept for the weight gradients
+};
+// the front AND the weight re-layout of a forward pass (independent of each other) in one launch; `rng_advance` as in launch_pack
+int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s);
 int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, const float* me_h, const float* w1,
                      const float* wb, float* g0, float* dh, hipStream_t s);
 
