@@ -187,6 +187,11 @@ int pfn_dropout_mask(const uint64_t* rng_state, int32_t layer, int64_t rows, int
 int pfn_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                    float lr, float beta1, float beta2, float eps, float weight_decay, int64_t* step,
                    void* stream);
+/* The same update with the five scalars {lr, beta1, beta2, eps, weight_decay} read from DEVICE memory (`hyper`, float[5]):
+ * a launch captured into a hipGraph then follows a learning-rate schedule (train.py:129,145: OneCycleLR) by a 20-byte copy
+ * into `hyper` between replays instead of a new capture.                                                              */
+int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
+                       const float* hyper, int64_t* step, void* stream);
 
 /* --------------------------------------------------------------------------------------- profiling
  * Optional HIP-event bracket around every kernel launch (same stream), aggregated per kernel class with

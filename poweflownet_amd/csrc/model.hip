@@ -671,9 +671,15 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ o, c
     }
 }
 
+// hp (optional): device {lr, beta1, beta2, eps, weight_decay} read instead of the by-value arguments, so that a captured
+// launch follows a learning-rate schedule without being captured again
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
-                                                    float b1, float b2, float eps, float wd, int64_t* step) {
+                                                    float b1, float b2, float eps, float wd, int64_t* step,
+                                                    const float* __restrict__ hp) {
+    if (hp) {
+        lr = hp[0]; b1 = hp[1]; b2 = hp[2]; eps = hp[3]; wd = hp[4];
+    }
     // step[0] = completed steps, step[1] = arrival counter: the last block to finish bumps the step and re-arms the
     // counter, so the whole update is ONE launch and stays hipGraph-replayable
     const float t = (float)(step[0] + 1);
@@ -986,7 +992,17 @@ int pfn_adamw_step(float* p, const float* g, float* m, float* v, int64_t count, 
     hipStream_t s = static_cast<hipStream_t>(stream);
     // one block per CU at most: every block ends with one atomic on the arrival counter (~12 ns each, serialised)
     const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 256));
-    adamw_kernel<<<nb, 256, 0, s>>>(p, g, m, v, count, lr, b1, b2, eps, wd, step);
+    adamw_kernel<<<nb, 256, 0, s>>>(p, g, m, v, count, lr, b1, b2, eps, wd, step, nullptr);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+int pfn_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t count, const float* hyper, int64_t* step,
+                       void* stream) {
+    PFN_CHECK_ARG(p && g && m && v && step && hyper, "pfn_adamw_step_dev: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int nb = (int)std::max<int64_t>(1, std::min<int64_t>((count + 255) / 256, 256));
+    adamw_kernel<<<nb, 256, 0, s>>>(p, g, m, v, count, 0.f, 0.f, 0.f, 0.f, 0.f, step, hyper);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

@@ -32,6 +32,25 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count = torch.zeros(2, dtype=torch.int64, device=flat.device)   # {steps done, arrival scratch}
         self._gather = None
+        # {lr, beta1, beta2, eps, weight_decay} live on the device: the update kernel reads them there, so a captured step
+        # follows a scheduler (OneCycleLR moves lr AND beta1) through a 20-byte copy instead of a re-capture
+        self.hyper = torch.zeros(5, dtype=torch.float32, device=flat.device)
+        self._hyper_host = None
+        self.sync_hyper()
+
+    def _hyper_now(self):
+        g = self.param_groups[0]
+        return (float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]))
+
+    def sync_hyper(self) -> None:
+        """Push the param group's scalars to the device when they changed (call it outside a stream capture: the captured
+        step itself contains no copy)."""
+        now = self._hyper_now()
+        if now != self._hyper_host:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FlatAdamW: hyper-parameters changed inside a stream capture")
+            self.hyper.copy_(torch.tensor(now, dtype=torch.float32))
+            self._hyper_host = now
 
     def _flat_grad(self) -> torch.Tensor:
         fg = self._model.flat_grad() if hasattr(self._model, "flat_grad") else None
@@ -53,12 +72,10 @@ class FlatAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
-        g = self.param_groups[0]
         grad = self._flat_grad()
         with torch.cuda.device(self.flat_param.device):
-            L.check(L.load().pfn_adamw_step(self.flat_param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
-                                            self.exp_avg_sq.data_ptr(), self.flat_param.numel(), float(g["lr"]),
-                                            float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
-                                            float(g["weight_decay"]), self.step_count.data_ptr(), L.stream_ptr()),
-                    "pfn_adamw_step")
+            self.sync_hyper()
+            L.check(L.load().pfn_adamw_step_dev(self.flat_param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.hyper.data_ptr(),
+                                                self.step_count.data_ptr(), L.stream_ptr()), "pfn_adamw_step_dev")
         return loss

@@ -61,8 +61,11 @@ class GraphedTrainStep:
         self.misses = 0
 
     def _hyper_key(self):
-        """Every optimiser scalar `pfn_adamw_step` receives BY VALUE (captured as a kernel argument): lr, betas (OneCycleLR
-        cycles beta1 together with lr), eps, weight_decay.  Any change re-captures."""
+        """Every optimiser scalar a captured update would hold BY VALUE (as a kernel argument): lr, betas (OneCycleLR
+        cycles beta1 together with lr), eps, weight_decay; any change re-captures.  `FlatAdamW` keeps them on the device
+        (`sync_hyper`), so its captured step follows a scheduler without a new capture: constant key."""
+        if hasattr(self.opt, "sync_hyper"):
+            return ("device-resident",)
         g = self.opt.param_groups[0]
         betas = tuple(float(b) for b in g.get("betas", ()))
         return (float(g["lr"]), betas, float(g.get("eps", 0.0)), float(g.get("weight_decay", 0.0)))
@@ -151,6 +154,8 @@ class GraphedTrainStep:
                     self.disabled = True
             return self._eager(data)
         self.misses = 0
+        if hasattr(self.opt, "sync_hyper"):
+            self.opt.sync_hyper()                                  # a scheduler moved lr / betas: 20 bytes to the device
         for k in ("x", "y", "pred_mask", "edge_attr"):
             getattr(self.static, k).copy_(getattr(data, k))
         self.graph.replay()
