@@ -239,7 +239,11 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
             for (int c = 0; c < NR; ++c) r[c] = r_nxt[c];
             if (m + 1 < NCH && (FAST ? m + 1 < NFAST : 8 * (m + 1) < klen)) {
 #pragma unroll
+#ifndef PFN_EXP_NOLDS   /* tools/ubench experiment switch: never defined in the product build */
                 for (int ct = 0; ct < CT; ++ct) b_nxt[ct] = *reinterpret_cast<const f32x4*>(Bt + ct * tile_floats + (m + 1) * 256);
+#else
+                for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(b_nxt[ct]));
+#endif
 #pragma unroll
                 for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + (m + 1) * 32 + c * 4);
             }
@@ -269,7 +273,11 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
 #pragma unroll
             for (int mm = m & ~3; mm <= m; ++mm) {
                 const uint32_t kk = min(kh4 + 8u * mm, (uint32_t)nkmax);
+#ifndef PFN_EXP_NOREFILL   /* experiment switch: every refill re-reads ONE cache line (the wave's first row) */
                 vload_x4(a_cur[mm], nbase, nvoff + 4u * kk);
+#else
+                vload_x4(a_cur[mm], nbase, 0u * (nvoff + kk));
+#endif
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -540,7 +548,11 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                     }
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
+#ifndef PFN_EXP_NOSTORE   /* experiment switch */
                         if (row[g] < a.M) vstore_x4(dst[g], f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+#else
+                        if (row[g] < 0) vstore_x4(dst[g], f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+#endif
                 }
             }
             if (rem_on) {
