@@ -487,21 +487,27 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                 const int col0 = 32 * (tile0 + ct) + (r32 & ~3);
                 if (tile0 + ct < a.nq && col0 < a.ldc) {
                     float v[4][4];
-                    float* dst[4];
-                    int row[4];
+                    // row / destination of register group g are recomputed where they are used (one multiply-add each):
+                    // kept in arrays they were 12 more registers alive through every epilogue stage -- with CT = 2 the
+                    // difference between spilling and not, and a spill reload anywhere in the kernel makes hipcc put an
+                    // s_waitcnt vmcnt(0) -- a drain of the 17 prefetched A chunks -- at the head of EVERY piece
+                    const int row_base = rbase + (r32 & 3) + 4 * kh;
+                    auto row_of = [&](int g) { return row_base + 8 * g; };
+                    auto dst_of = [&](int g) {
+                        const int rw_ = row_of(g);
+                        return C + (size_t)(rw_ < a.M ? rw_ : a.M - 1) * a.ldc + col0;
+                    };
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         float t[4] = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
                         quad_transpose(t, lane);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[g][e] = t[e];
-                        row[g] = rbase + (r32 & 3) + 8 * g + 4 * kh;
-                        dst[g] = C + (size_t)(row[g] < a.M ? row[g] : a.M - 1) * a.ldc + col0;
                     }
                     if (gf & 1) {   // accumulating launch (weights larger than LDS): rare, visible loads
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
-                            const float4 old = *reinterpret_cast<const float4*>(dst[g]);
+                            const float4 old = *reinterpret_cast<const float4*>(dst_of(g));
                             v[g][0] += old.x; v[g][1] += old.y; v[g][2] += old.z; v[g][3] += old.w;
                         }
                     }
@@ -531,10 +537,15 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
                         } else if (ep.act == ACT_DROPOUT_RELU) {
+                            // (opaque: the column group is loop-invariant per lane, and hipcc otherwise hoists the Philox
+                            //  rounds' invariant parts out of the tile loop -- per-lane values alive through the whole
+                            //  kernel, i.e. spills)
+                            uint32_t cgv = (uint32_t)(col0 >> 2);
+                            asm volatile("" : "+v"(cgv));
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 float u[4];
-                                dropout_uniform4(ep.dk, (uint32_t)row[g], (uint32_t)(col0 >> 2), u);
+                                dropout_uniform4(ep.dk, (uint32_t)row_of(g), cgv, u);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[g][e] = (u[e] >= ep.p_drop && v[g][e] > 0.f) ? v[g][e] * ep.keep_scale : 0.f;
                             }
@@ -549,9 +560,9 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #ifndef PFN_EXP_NOSTORE   /* experiment switch */
-                        if (row[g] < a.M) vstore_x4(dst[g], f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+                        if (row_of(g) < a.M) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
 #else
-                        if (row[g] < 0) vstore_x4(dst[g], f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+                        if (row_of(g) < 0) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
 #endif
                 }
             }
@@ -569,7 +580,11 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                     if (!raw) {
                         const f32x4 rcb = *reinterpret_cast<const f32x4*>(lds + a.bias_lds_off + rem_col);
                         float ud[4] = {1.f, 1.f, 1.f, 1.f};
-                        if (ep.act == ACT_DROPOUT_RELU) dropout_uniform4(ep.dk, (uint32_t)row, (uint32_t)(rem_col >> 2), ud);
+                        if (ep.act == ACT_DROPOUT_RELU) {
+                            uint32_t cgv = (uint32_t)(rem_col >> 2);
+                            asm volatile("" : "+v"(cgv));
+                            dropout_uniform4(ep.dk, (uint32_t)row, cgv, ud);
+                        }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             float x = v[e] + ((use_bias && !ep.has_rowscale) ? rcb[e] : 0.f);
