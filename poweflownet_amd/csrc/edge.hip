@@ -540,12 +540,20 @@ __global__ __launch_bounds__(1024) void dwe_reduce_kernel(const DweJobs jobs, in
     const size_t stride = (size_t)fe * ld;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (ok) {
+        // up to 16 partials of the lane's stride-64 subset are requested at once (two rounds of the four chains), then added in
+        // a fixed order: the kernel is a chain of dependent loads, not bandwidth
         int b = ty;
+        for (; b + 448 < nblocks; b += 512) {
+            const float a0 = p[(size_t)b * stride], a1 = p[(size_t)(b + 64) * stride], a2 = p[(size_t)(b + 128) * stride],
+                        a3 = p[(size_t)(b + 192) * stride], a4 = p[(size_t)(b + 256) * stride], a5 = p[(size_t)(b + 320) * stride],
+                        a6 = p[(size_t)(b + 384) * stride], a7 = p[(size_t)(b + 448) * stride];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+            s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+        }
         for (; b + 192 < nblocks; b += 256) {
-            s0 += p[(size_t)b * stride];
-            s1 += p[(size_t)(b + 64) * stride];
-            s2 += p[(size_t)(b + 128) * stride];
-            s3 += p[(size_t)(b + 192) * stride];
+            const float a0 = p[(size_t)b * stride], a1 = p[(size_t)(b + 64) * stride], a2 = p[(size_t)(b + 128) * stride],
+                        a3 = p[(size_t)(b + 192) * stride];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
         }
         for (; b < nblocks; b += 64) s0 += p[(size_t)b * stride];
     }

@@ -356,18 +356,20 @@ __global__ __launch_bounds__(256) void tn_combine_kernel(const T3Args a) {
     const int half = idx / (NQ * 64), Q = (idx >> 6) % NQ, lane = idx & 63;
     const float4* src = a.partial + tk.part0 + idx;
     const size_t stride = (size_t)nh * NQ * 64;
-    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
-    int b = 0;
-    for (; b + 1 < tk.nsplit; b += 2) {          // two independent chains, combined in a fixed order
-        const float4 p0 = src[(size_t)b * stride], p1 = src[(size_t)(b + 1) * stride];
-        s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
-        s1.x += p1.x; s1.y += p1.y; s1.z += p1.z; s1.w += p1.w;
+    // eight partials are REQUESTED at once (clamped index: a slot past the end re-reads the last partial and is dropped), then
+    // added in block order: the kernel is one dependent-latency chain, ~5 us when the loads went out two at a time
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int b = 0; b < tk.nsplit; b += 8) {
+        float4 pp[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) pp[u] = src[(size_t)min(b + u, tk.nsplit - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool k = b + u < tk.nsplit;
+            s.x = k ? s.x + pp[u].x : s.x; s.y = k ? s.y + pp[u].y : s.y;
+            s.z = k ? s.z + pp[u].z : s.z; s.w = k ? s.w + pp[u].w : s.w;
+        }
     }
-    if (b < tk.nsplit) {
-        const float4 p0 = src[(size_t)b * stride];
-        s0.x += p0.x; s0.y += p0.y; s0.z += p0.z; s0.w += p0.w;
-    }
-    const float4 s = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
     const TnPair& pr = a.pair[tk.pair];
     const int c = lane & 31, kh = lane >> 5;
     if (tk.wa && tk.wb) t3_emit<4, 2>(pr, tk, half, Q, s, c, kh, lane);

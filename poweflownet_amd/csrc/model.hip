@@ -651,14 +651,17 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ o, c
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        partial[blockIdx.x] = red[0];
-        __threadfence();
-        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        // hand-off to the last arriver without __threadfence() (an L2 write-back + L1 invalidate, ~3.5 us each on this
+        // multi-XCD part, and the kernel had two): the partial is stored WRITE-THROUGH (agent-scope atomic store = sc1), the
+        // store is drained, then the ticket is taken; the last arriver reads the partials with agent-scope atomic loads (sc1:
+        // served by L2 / memory, never by its L1)
+        __hip_atomic_store(partial + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_last = t == (int)gridDim.x - 1;
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     red[threadIdx.x] = threadIdx.x < gridDim.x ? __hip_atomic_load(partial + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
     __syncthreads();
     for (int off = 128; off > 0; off >>= 1) {

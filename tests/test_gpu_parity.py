@@ -237,6 +237,25 @@ def test_fused_mse_loss_matches_torch():
     assert_close(g1, a.grad, 1e-6, "grad")
 
 
+@pytest.mark.parametrize("rows", [15104, 414080])
+def test_fused_mse_loss_handoff_is_never_stale(rows):
+    """pfn_mse_loss sums per-block partials in the last-arriving block (write-through partial stores + ticket, no fence);
+    300 back-to-back calls on changing data at the benchmark sizes (59 / 256 blocks): a stale partial -- the previous call's
+    value -- would show up as a wrong loss."""
+    from poweflownet_amd.loss import MSELoss
+    torch.manual_seed(1)
+    fn = MSELoss()
+    y = torch.randn(rows, 4, device=DEV)
+    outs = [torch.randn(rows, 4, device=DEV) * (1.0 + 0.37 * i) for i in range(6)]
+    want = [((o.double() - y.double()) ** 2).mean().item() for o in outs]
+    got = []
+    for it in range(300):
+        got.append(fn(outs[it % 6], y))
+    torch.cuda.synchronize()
+    for it, g in enumerate(got):
+        assert abs(g.item() - want[it % 6]) <= 2e-6 * want[it % 6], (it, g.item(), want[it % 6])
+
+
 def test_g8_masked_l2_loss_matches_reference_goldens():
     """pfn_masked_l2_loss vs outputs of the reference's own Masked_L2_loss (tests/golden/g8_masked_l2.npz), through the
     dispatching class the train loop uses; then against the oracle on a full-size input."""
