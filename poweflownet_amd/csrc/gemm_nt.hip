@@ -248,12 +248,14 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
                 for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + (m + 1) * 32 + c * 4);
             }
             // (refills are issued per GROUP of four chunks, below: chunk m has 16 - (m & 3) younger loads)
+#ifndef PFN_EXP_NOWAIT   /* experiment switch */
             switch (m & 3) {
                 case 0: wait_a<NCH - 1>(a_cur[m]); break;
                 case 1: wait_a<NCH - 2>(a_cur[m]); break;
                 case 2: wait_a<NCH - 3>(a_cur[m]); break;
                 default: wait_a<NCH - 4>(a_cur[m]); break;
             }
+#endif
             const f32x4 av = a_cur[m];
 #pragma unroll
             for (int i = 0; i < ((FAST && m == NFAST - 1) ? LS : 4); ++i) {
@@ -280,7 +282,9 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
 #endif
             }
         }
+#ifndef PFN_EXP_NOSCHEDBAR   /* experiment switch */
         __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
