@@ -204,9 +204,11 @@ def main():
                 # that fails next to a live process group falls back to eager launches instead of taking the run down.
                 try:
                     g_opt = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_fb):
+                    # thread-local capture mode: a live RCCL process group has a watchdog thread that queries events; under
+                    # the default (global) mode its calls would invalidate the capture of this thread
+                    with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
                         fwd_bwd()
-                    with torch.cuda.graph(g_opt):
+                    with torch.cuda.graph(g_opt, capture_error_mode="thread_local"):
                         opt.step()
 
                     def step():
