@@ -83,7 +83,16 @@ def allreduce_gradients(model: torch.nn.Module, ordered_params=None) -> None:
     flat = model.flat_grad() if hasattr(model, "flat_grad") else None
     params = ordered_params if ordered_params is not None else (
         model._ordered_params() if hasattr(model, "_ordered_params") else list(model.parameters()))
-    in_place = flat is not None and _grads_are_views_of(flat, params)
+    # (the check walks every parameter; under hipGraph replay the flat buffer is the same tensor every step: remember the verdict)
+    key = None if flat is None else (flat.data_ptr(), flat.numel())
+    if key is not None and getattr(model, "_dp_inplace_key", None) == key:
+        in_place = True
+    else:
+        in_place = flat is not None and _grads_are_views_of(flat, params)
+        try:
+            model._dp_inplace_key = key if in_place else None
+        except Exception:
+            pass
     if not in_place:
         grads = [p.grad for p in params if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
