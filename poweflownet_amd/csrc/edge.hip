@@ -23,6 +23,7 @@ __device__ __forceinline__ float4 fma4(float a, float4 x, float4 acc) {
     acc.w = fmaf(a, x.w, acc.w);
     return acc;
 }
+__device__ __forceinline__ float4 mul4(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float4 sel4(bool k, float4 a, float4 b) { return make_float4(k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z, k ? a.w : b.w); }
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
@@ -219,24 +220,23 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
 // (node GEMMs) and a per-edge residue sum_f a_e[f] W1[:, 2Fi+f]; the second Linear commutes with the
 // segment sum, so only S[i] = sum_e relu(P[i] + Q[src] + residue) is formed per edge.
 // LDS holds the Fe residue columns of W1 (strided in the nn.Linear layout) for the whole block.
-template <int FE>
-__global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_stored, const int* __restrict__ rowptr,
-                                                       const int* __restrict__ nbr, const int* __restrict__ eid,
-                                                       const float* __restrict__ P, const float* __restrict__ Q,
-                                                       const float* __restrict__ ea, const float* __restrict__ w1,
-                                                       float* __restrict__ S, int ld, int h, int fi, int fe_rt) {
-    extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld]
-    const int fe = FE > 0 ? FE : fe_rt;
-    const int ldw = 2 * fi + fe;
-    for (int i = threadIdx.x; i < fe * ld; i += blockDim.x) {
-        const int f = i / ld, k = i - f * ld;
-        we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
+// The LAST layer's second Linear W2 [fo][h] (Fo <= 4) staged in LDS as w2s[4][ld], rows >= Fo and units >= H zero: the fused
+// last-layer kernels (edge_fwd_out_kernel, ds_row) read a thread's column chunk from there when they need it (held in 16
+// registers across the walks it cost two to three waves per SIMD of occupancy and made the fusion a wash)
+__device__ __forceinline__ void stage_w2(float* w2s, const float* __restrict__ w2, int h, int fo, int ld) {
+    for (int i = threadIdx.x; i < 4 * ld; i += blockDim.x) {
+        const int o = i / ld, k = i - o * ld;
+        w2s[i] = (o < fo && k < h) ? w2[(size_t)o * h + k] : 0.f;
     }
-    __syncthreads();
-    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = (int)(item / nchunk);
-    if (row >= n) return;
-    const int col = (int)(item - (long)row * nchunk) * 4;
+}
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
+
+// S[row][col..col+3] for one (row, column chunk): the walk over the row's incoming edges
+template <int FE>
+__device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored, const int* __restrict__ rowptr,
+                                                 const int* __restrict__ nbr, const int* __restrict__ eid,
+                                                 const float* __restrict__ P, const float* __restrict__ Q,
+                                                 const float* __restrict__ ea, const float* we, int ld, int fe) {
     const float4 p4 = ld4(P + (size_t)row * ld + col);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rowptr[row], end = rowptr[row + 1];
@@ -278,9 +278,83 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
             acc = add4(acc, relu4(v));
         }
     }
-    st4(S + (size_t)row * ld + col, acc);
+    return acc;
 }
 
+template <int FE>
+__global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_stored, const int* __restrict__ rowptr,
+                                                       const int* __restrict__ nbr, const int* __restrict__ eid,
+                                                       const float* __restrict__ P, const float* __restrict__ Q,
+                                                       const float* __restrict__ ea, const float* __restrict__ w1,
+                                                       float* __restrict__ S, int ld, int h, int fi, int fe_rt) {
+    extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld]
+    const int fe = FE > 0 ? FE : fe_rt;
+    const int ldw = 2 * fi + fe;
+    for (int i = threadIdx.x; i < fe * ld; i += blockDim.x) {
+        const int f = i / ld, k = i - f * ld;
+        we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
+    }
+    __syncthreads();
+    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = (int)(item / nchunk);
+    if (row >= n) return;
+    const int col = (int)(item - (long)row * nchunk) * 4;
+    st4(S + (size_t)row * ld + col, edge_sum_chunk<FE>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe));
+}
+
+// The network's LAST EdgeAggregation layer (Fo <= 4, no activation): the second Linear rides in the same launch.  Block =
+// rows_pb rows x nchunk chunk-lanes (the front's mapping, front.hip): a lane forms its S chunk, multiplies it with its W2
+// column chunk (registers), and the row's nchunk float4 partials are added in a FIXED two-level order:
+//   out[row][o] = sum_u S[row][u] W2[o][u] + deg[row] * b2[o]
+// S is still written (the backward pairs it with gout for dW2).  LDS: we[FE][ld] | part[rows_pb][nchunk] float4.
+template <int FE>
+__global__ __launch_bounds__(256) void edge_fwd_out_kernel(int n, int nchunk, int rows_pb, int e_stored,
+                                                           const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                           const int* __restrict__ eid, const float* __restrict__ P,
+                                                           const float* __restrict__ Q, const float* __restrict__ ea,
+                                                           const float* __restrict__ w1, float* __restrict__ S,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           const float* __restrict__ deg, float* __restrict__ out, int ld,
+                                                           int h, int fi, int fo) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* we = smem;
+    float* w2s = smem + FE * ld;
+    float4* part = reinterpret_cast<float4*>(smem + (FE + 4) * ld);
+    const int ldw = 2 * fi + FE;
+    for (int i = threadIdx.x; i < FE * ld; i += blockDim.x) {
+        const int f = i / ld, k = i - f * ld;
+        we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
+    }
+    stage_w2(w2s, w2, h, fo, ld);
+    const int r = threadIdx.x / nchunk, c = threadIdx.x - r * nchunk;
+    const int row = blockIdx.x * rows_pb + r, col = 4 * c;
+    const bool on = r < rows_pb && row < n;
+    __syncthreads();
+    if (on) {
+        const float4 s4 = edge_sum_chunk<FE>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, FE);
+        st4(S + (size_t)row * ld + col, s4);
+        float4 o;
+        o.x = dot4(s4, ld4(w2s + col));
+        o.y = dot4(s4, ld4(w2s + ld + col));
+        o.z = dot4(s4, ld4(w2s + 2 * ld + col));
+        o.w = dot4(s4, ld4(w2s + 3 * ld + col));
+        part[r * nchunk + c] = o;
+    }
+    __syncthreads();
+    row_sum(part, r, c, nchunk, on);   // (barriers inside: every thread calls it)
+    if (on && c == 0) {
+        const float4 t = part[r * nchunk];
+        const float d = deg[row];
+        float4 o;
+        o.x = fmaf(d, b2[0], t.x);
+        o.y = fo > 1 ? fmaf(d, b2[1], t.y) : 0.f;
+        o.z = fo > 2 ? fmaf(d, b2[2], t.z) : 0.f;
+        o.w = fo > 3 ? fmaf(d, b2[3], t.w) : 0.f;
+        st4(out + (size_t)row * 4, o);
+    }
+}
+
+bool edge_fwd_out_ok(int fe, int h, int fo, int ldo) { return fe == 2 && fo >= 1 && fo <= 4 && ldo == 4 && ld_of(h) / 4 <= 256; }
 int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
     if (g.n == 0) return PFN_OK;
     const int nchunk = a.ld / 4;
@@ -288,6 +362,15 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
     const int blocks = (int)((items + 255) / 256);
     const size_t lds = (size_t)a.fe * a.ld * sizeof(float);
     ProfScope ps("edge_fwd", 0.0, 0.0, s);
+    if (a.out) {   // last layer: S and out = S W2^T + deg b2 in one launch (edge_fwd_out_ok)
+        const int rows_pb = 256 / nchunk;
+        const size_t lds_out = lds + (size_t)4 * a.ld * sizeof(float) + (size_t)rows_pb * nchunk * sizeof(float4);
+        edge_fwd_out_kernel<2><<<(g.n + rows_pb - 1) / rows_pb, 256, lds_out, s>>>(
+            g.n, nchunk, rows_pb, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.edge_attr, a.w1, a.S, a.w2, a.b2,
+            g.deg, a.out, a.ld, a.h, a.fi, a.fo);
+        PFN_CHECK_LAUNCH();
+        return PFN_OK;
+    }
     if (a.fe == 2)
         edge_fwd_kernel<2><<<blocks, 256, lds, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q,
                                                     a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe);
@@ -308,25 +391,42 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
 // kernel SLOWER (492 -> 566 us at 6470rte x 64); two keep 8 waves per SIMD
 constexpr int BW_SLOTS = 2;
 
-template <int FE>
+// dS row chunk for the LAST EdgeAggregation layer (Fo <= 4): dS[row][col..col+3] = sum_o gout[row][o] * W2[o][col..col+3], formed
+// from the 16-byte gout row and the W2 column chunk in LDS instead of reading an N x H dS that a K = 4 GEMM wrote
+template <bool DSG>
+__device__ __forceinline__ float4 ds_row(const float* __restrict__ dS, int row, int ld, int col, const float* w2s) {
+    if (!DSG) return ld4(dS + (size_t)row * ld + col);
+    const float4 g = ld4(dS + (size_t)row * 4);          // gout row, ld 4 (columns >= Fo are zero-weighted)
+    int co = col;
+    asm volatile("" : "+v"(co));                         // re-read the chunk here: hoisted out of the walk it is 16 live VGPRs
+    float4 r = mul4(g.x, ld4(w2s + co));
+    r = fma4(g.y, ld4(w2s + ld + co), r);
+    r = fma4(g.z, ld4(w2s + 2 * ld + co), r);
+    r = fma4(g.w, ld4(w2s + 3 * ld + co), r);
+    return r;
+}
+
+template <int FE, bool DSG>
 __device__ __forceinline__ void edge_bwd_dst_body(int bid, int nblk, int n, int nchunk, int bdx, int bdy, int e_stored,
                                                            const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                            const int* __restrict__ eid, const float* __restrict__ P,
                                                            const float* __restrict__ Q, const float* __restrict__ dS,
                                                            const float* __restrict__ ea, const float* __restrict__ w1,
                                                            float* __restrict__ dP, float* __restrict__ dWe_partial,
-                                                           int ld, int h, int fi) {
+                                                           int ld, int h, int fi, const float* __restrict__ w2, int fo) {
     // Block = bdx column chunks x bdy rows (bdx * bdy <= 256, lanes run along the columns of one row, then the
     // next row); a thread keeps ONE column chunk for every row it visits, so the dWe partial sums stay in
     // registers across the block's whole row range and each block emits a single ordered partial.
     extern __shared__ __attribute__((aligned(16))) float smem[];   // we[FE][ld] | part[256][FE] float4
     float* we = smem;
     float4* part = reinterpret_cast<float4*>(smem + FE * ld);
+    float* w2s = smem + FE * ld + 256 * FE * 4;                    // (DSG only) W2 [4][ld]
     const int ldw = 2 * fi + FE;
     for (int i = threadIdx.x; i < FE * ld; i += blockDim.x) {
         const int f = i / ld, k = i - f * ld;
         we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
     }
+    if (DSG) stage_w2(w2s, w2, h, fo, ld);
     __syncthreads();
     const int ty = threadIdx.x / bdx, tx = threadIdx.x - ty * bdx;
     const bool active = ty < bdy;
@@ -341,7 +441,7 @@ __device__ __forceinline__ void edge_bwd_dst_body(int bid, int nblk, int n, int 
             for (int f = 0; f < FE; ++f) w4[f] = ld4(we + f * ld + col);
             for (int row = bid * bdy + ty; row < n; row += nblk * bdy) {
                 const float4 p4 = ld4(P + (size_t)row * ld + col);
-                const float4 g4 = ld4(dS + (size_t)row * ld + col);
+                const float4 g4 = ds_row<DSG>(dS, row, ld, col, w2s);
                 float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                 const int beg = rowptr[row], end = rowptr[row + 1];
                 // BW_SLOTS edge slots per trip (see hop_kernel): a slot past the row's end re-reads the last edge and
@@ -404,19 +504,22 @@ __device__ __forceinline__ void edge_bwd_dst_body(int bid, int nblk, int n, int 
     }
 }
 
-template <int FE>
+template <int FE, bool DSG>
 __device__ __forceinline__ void edge_bwd_src_body(int bid, int n, int nchunk, int e_stored,
                                                            const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                            const int* __restrict__ eid, const float* __restrict__ P,
                                                            const float* __restrict__ Q, const float* __restrict__ dS,
                                                            const float* __restrict__ ea, const float* __restrict__ w1,
-                                                           float* __restrict__ dQ, int ld, int h, int fi) {
+                                                           float* __restrict__ dQ, int ld, int h, int fi,
+                                                           const float* __restrict__ w2, int fo) {
     extern __shared__ __attribute__((aligned(16))) float we[];
     const int ldw = 2 * fi + FE;
     for (int i = threadIdx.x; i < FE * ld; i += blockDim.x) {
         const int f = i / ld, k = i - f * ld;
         we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
     }
+    float* w2s = we + FE * ld;                                     // (DSG only) W2 [4][ld]
+    if (DSG) stage_w2(w2s, w2, h, fo, ld);
     __syncthreads();
     const long item = (long)bid * blockDim.x + threadIdx.x;
     const int row = (int)(item / nchunk);
@@ -443,7 +546,7 @@ __device__ __forceinline__ void edge_bwd_src_body(int bid, int n, int nchunk, in
 #pragma unroll
         for (int u = 0; u < BW_SLOTS; ++u) {
             p_[u] = ld4(P + (size_t)d_[u] * ld + col);
-            g_[u] = ld4(dS + (size_t)d_[u] * ld + col);
+            g_[u] = ds_row<DSG>(dS, d_[u], ld, col, w2s);
 #pragma unroll
             for (int f = 0; f < FE; ++f) a_[u][f] = ea[(size_t)id_[u] * FE + f];
         }
@@ -465,7 +568,7 @@ __device__ __forceinline__ void edge_bwd_src_body(int bid, int n, int nchunk, in
 // One launch for both halves of the EdgeAggregation backward: blocks [0, nb_dst) walk the by-destination CSR (dP, dWe
 // partials; block-persistent), the rest walk the by-source CSR (dQ).  Both halves are latency-bound at small batches; in
 // one grid they overlap instead of paying two launch floors.
-template <int FE>
+template <int FE, bool DSG>
 __global__ __launch_bounds__(256) void edge_bwd_kernel(int nb_dst, int n, int nchunk, int bdx, int bdy, int e_stored,
                                                        const int* __restrict__ rp_in, const int* __restrict__ in_src,
                                                        const int* __restrict__ in_eid, const int* __restrict__ rp_out,
@@ -474,12 +577,14 @@ __global__ __launch_bounds__(256) void edge_bwd_kernel(int nb_dst, int n, int nc
                                                        const float* __restrict__ dS, const float* __restrict__ ea,
                                                        const float* __restrict__ w1, float* __restrict__ dP,
                                                        float* __restrict__ dQ, float* __restrict__ dWe_partial, int ld, int h,
-                                                       int fi) {
+                                                       int fi, const float* __restrict__ w2, int fo) {
+    // DSG: `dS` is the layer's N x 4 output gradient and dS rows are formed on the fly from it and W2 (ds_row)
     if ((int)blockIdx.x < nb_dst)
-        edge_bwd_dst_body<FE>(blockIdx.x, nb_dst, n, nchunk, bdx, bdy, e_stored, rp_in, in_src, in_eid, P, Q, dS, ea, w1, dP,
-                              dWe_partial, ld, h, fi);
+        edge_bwd_dst_body<FE, DSG>(blockIdx.x, nb_dst, n, nchunk, bdx, bdy, e_stored, rp_in, in_src, in_eid, P, Q, dS, ea, w1,
+                                   dP, dWe_partial, ld, h, fi, w2, fo);
     else
-        edge_bwd_src_body<FE>(blockIdx.x - nb_dst, n, nchunk, e_stored, rp_out, out_dst, out_eid, P, Q, dS, ea, w1, dQ, ld, h, fi);
+        edge_bwd_src_body<FE, DSG>(blockIdx.x - nb_dst, n, nchunk, e_stored, rp_out, out_dst, out_eid, P, Q, dS, ea, w1, dQ, ld,
+                                   h, fi, w2, fo);
 }
 
 static void dst_block_shape(int ld, int& bdx, int& bdy) {
@@ -499,14 +604,20 @@ static int launch_edge_bwd_fe(const GraphView& g, const EdgeBwdArgs& a, hipStrea
     const int nchunk = a.ld / 4;
     int bdx, bdy;
     dst_block_shape(a.ld, bdx, bdy);
-    const size_t lds_dst = (size_t)FE * a.ld * sizeof(float) + (size_t)256 * FE * sizeof(float4);
+    const size_t lds_dst = (size_t)FE * a.ld * sizeof(float) + (size_t)256 * FE * sizeof(float4) +
+                           (a.gout ? (size_t)4 * a.ld * sizeof(float) : 0);
     const int nb_dst = edge_bwd_dst_blocks(g, a.ld);
     const long items = (long)g.n * nchunk;
     const int nb_src = (int)((items + 255) / 256);
     ProfScope ps("edge_bwd", 0.0, 0.0, s);
-    edge_bwd_kernel<FE><<<nb_dst + nb_src, 256, lds_dst, s>>>(nb_dst, g.n, nchunk, bdx, bdy, g.e_stored, g.rowptr_in, g.in_src,
-                                                             g.in_eid, g.rowptr_out, g.out_dst, g.out_eid, a.P, a.Q, a.dS,
-                                                             a.edge_attr, a.w1, a.dP, a.dQ, a.dWe_partial, a.ld, a.h, a.fi);
+    if (a.gout)
+        edge_bwd_kernel<FE, true><<<nb_dst + nb_src, 256, lds_dst, s>>>(
+            nb_dst, g.n, nchunk, bdx, bdy, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, g.rowptr_out, g.out_dst, g.out_eid, a.P,
+            a.Q, a.gout, a.edge_attr, a.w1, a.dP, a.dQ, a.dWe_partial, a.ld, a.h, a.fi, a.w2, a.fo);
+    else
+        edge_bwd_kernel<FE, false><<<nb_dst + nb_src, 256, lds_dst, s>>>(
+            nb_dst, g.n, nchunk, bdx, bdy, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, g.rowptr_out, g.out_dst, g.out_eid, a.P,
+            a.Q, a.dS, a.edge_attr, a.w1, a.dP, a.dQ, a.dWe_partial, a.ld, a.h, a.fi, nullptr, 0);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

@@ -24,31 +24,6 @@ namespace pfn {
 __device__ __forceinline__ float4 ld4f(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4f(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// Sum of a row's nchunk float4 partials in a FIXED order, in two levels (a single thread walking all 33 was a chain of 33
-// dependent LDS reads, ~1 us per row group): lanes c < 8 each add the partials c, c + 8, c + 16, ... in that order, then lane 0
-// adds the eight sub-sums in lane order.  Called by every thread of the block (two barriers inside); result in part[r * nchunk].
-__device__ __forceinline__ void row_sum(float4* part, int r, int c, int nchunk, bool on) {
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (on && c < 8) {
-        for (int k = c; k < nchunk; k += 8) {
-            const float4 p = part[r * nchunk + k];
-            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
-        }
-    }
-    __syncthreads();
-    if (on && c < 8) part[r * nchunk + c] = s;
-    __syncthreads();
-    if (on && c == 0) {
-        float4 t = part[r * nchunk];
-        const int m = nchunk < 8 ? nchunk : 8;
-        for (int k = 1; k < m; ++k) {
-            const float4 p = part[r * nchunk + k];
-            t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
-        }
-        part[r * nchunk] = t;
-    }
-}
-
 // block = rows_pb rows x nchunk chunk-lanes (nchunk = ld / 4), PERSISTENT over row groups: a thread keeps ONE chunk of four
 // hidden units for every row it visits, so its slices of all five weights live in registers for the whole kernel (as
 // per-element global loads they made the kernel 3x slower than its memory traffic).  LDS: part[rows_pb][nchunk] | vec[rows_pb].

@@ -103,8 +103,13 @@ static EaPack ea_pack(Packer& pk, int fi, int fe, int h, int fo, const float* w1
     return p;
 }
 
+static bool back_fused_ok() {
+    static const bool off = getenv("PFN_NO_FUSED_BACK") != nullptr;   // A/B switch: the last layer's fused kernels
+    return !off;
+}
+
 static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
-                      const float* w1, const float* b1, const float* b2, const EaPack& pw, float* out, int ldo,
+                      const float* w1, const float* b1, const float* w2, const float* b2, const EaPack& pw, float* out, int ldo,
                       const Act& act, const EaSaved& sv, hipStream_t s, bool pq_ready = false) {
     const int ld = ld_of(h);
     if (!pq_ready) {   // P = x W1[:, :Fi]^T + b1 ; Q = x W1[:, Fi:2Fi]^T   (layer 0: already written by the fused front)
@@ -119,11 +124,19 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
         a.bias_group = 0;
         PFN_TRY(launch_gemm_nt(a, s));
     }
+    // the network's last layer (Fo <= 4, no activation): the second Linear rides in the edge walk's launch (edge_fwd_out_kernel)
+    const bool out_in_walk = w2 && act.act == ACT_NONE && edge_fwd_out_ok(fe, h, fo, ldo) && back_fused_ok();
     {
         EdgeFwdArgs e{sv.P, sv.Q, ea, w1, sv.S, ld, h, fi, fe};
+        if (out_in_walk) {
+            e.out = out;
+            e.w2 = w2;
+            e.b2 = b2;
+            e.fo = fo;
+        }
         PFN_TRY(launch_edge_fwd(g, e, s));
     }
-    {   // out = S W2^T + deg * b2   (the second Linear commutes with the segment sum)
+    if (!out_in_walk) {   // out = S W2^T + deg * b2   (the second Linear commutes with the segment sum)
         GemmArgs a = gemm_defaults(g.n, fo, ldo);
         a.C[0] = out;
         a.nterm = 1;
@@ -140,11 +153,14 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
 }
 
 static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
-                       const float* w1, const EaPack& pw, const float* gout, int ldgo, const Gate& gate, float* gx,
+                       const float* w1, const float* w2, const EaPack& pw, const float* gout, int ldgo, const Gate& gate, float* gx,
                        int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
                        const EaScratch& sc, hipStream_t s, PairList* defer) {
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
-    {   // dS = gout W2
+    // the network's last layer (Fo <= 4): the walks form dS rows from the 16-byte gout rows themselves (edge.hip ds_row), so
+    // the K = 4 GEMM that would write N x H (and the walks' re-read of it) goes away
+    const bool ds_in_walk = w2 && fo <= 4 && ldgo == 4 && !gea && back_fused_ok();
+    if (!ds_in_walk) {   // dS = gout W2
         GemmArgs a = gemm_defaults(g.n, h, ld);
         a.C[0] = sc.dS;
         a.nterm = 1;
@@ -152,6 +168,11 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         PFN_TRY(launch_gemm_nt(a, s));
     }
     EdgeBwdArgs e{sv.P, sv.Q, sc.dS, ea, w1, sc.dP, sc.dQ, sc.dWe, gea, ld, h, fi, fe};
+    if (ds_in_walk) {
+        e.gout = gout;
+        e.w2 = w2;
+        e.fo = fo;
+    }
     PFN_TRY(launch_edge_bwd(g, e, nullptr, s));
     if (gea) PFN_TRY(launch_edge_attr_grad(g, e, s));
     if (gx) {   // dx = dP W1[:, :Fi] + dQ W1[:, Fi:2Fi], gated by the producing layer's activation
@@ -468,8 +489,8 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         const int ldy = last ? lo.ldo : lo.ld;
         if (is_ea(i)) {
             const int fo = last ? lo.fo : lo.h;
-            PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 3],
-                               mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0));
+            PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
+                               params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0));
             pi += 4;
             fcur = fo;
         } else {
@@ -522,7 +543,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
             sc.dQ = lo.dQ[i];
             sc.dWe = lo.dWe[i];
             // (layer 0 with the fused front: its input gradient is formed together with mask_embd's, below)
-            PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], mp.ea[i], gcur, ldg, gate,
+            PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], params[p0 + 2], mp.ea[i], gcur, ldg, gate,
                                 (fused_front && i == 0) ? nullptr : gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2],
                                 grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs));
         } else {
@@ -834,7 +855,7 @@ int pfn_edge_aggr_forward(const void* gws, int64_t n, int64_t e, int fi, int fe,
     Packer pk(w.packed);
     const EaPack pw = ea_pack(pk, fi, fe, h, fo, w1, w2);
     PFN_TRY(pk.flush(s));
-    return ea_forward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, b1, b2, pw, out, (int)ldo, Act{}, w.sv, s);
+    return ea_forward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, b1, w2, b2, pw, out, (int)ldo, Act{}, w.sv, s);
 }
 
 int pfn_edge_aggr_backward(const void* gws, int64_t n, int64_t e, int fi, int fe, int h, int fo, const float* x,
@@ -856,7 +877,7 @@ int pfn_edge_aggr_backward(const void* gws, int64_t n, int64_t e, int fi, int fe
     if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)e * fe * sizeof(float), s));
     Packer pk(w.packed);                       // images were filled by the forward call on the same workspace
     const EaPack pw = ea_pack(pk, fi, fe, h, fo, w1, w2);
-    return ea_backward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, pw, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gw1, gb1, gw2,
+    return ea_backward(g, fi, fe, h, fo, x, (int)ldx, ea, w1, w2, pw, gout, (int)ldgo, Gate{}, gx, (int)ldgx, gw1, gb1, gw2,
                        gb2, gea, w.sv, w.sc, s, nullptr);
 }
 

@@ -224,6 +224,31 @@ bool fused_hops_fit(int seg, int ld, int n);
 int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s);
 
 // S[i] = sum_{e -> i} relu(P[i] + Q[src(e)] + sum_f a_e[f] * W1[:, 2Fi + f])
+// Sum of a row's nchunk float4 partials in a FIXED order, in two levels (a single thread walking all 33 was a chain of 33
+// dependent LDS reads, ~1 us per row group): lanes c < 8 each add the partials c, c + 8, c + 16, ... in that order, then lane 0
+// adds the eight sub-sums in lane order.  Called by every thread of the block (two barriers inside); result in part[r * nchunk].
+__device__ __forceinline__ void row_sum(float4* part, int r, int c, int nchunk, bool on) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on && c < 8) {
+        for (int k = c; k < nchunk; k += 8) {
+            const float4 p = part[r * nchunk + k];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+    }
+    __syncthreads();
+    if (on && c < 8) part[r * nchunk + c] = s;
+    __syncthreads();
+    if (on && c == 0) {
+        float4 t = part[r * nchunk];
+        const int m = nchunk < 8 ? nchunk : 8;
+        for (int k = 1; k < m; ++k) {
+            const float4 p = part[r * nchunk + k];
+            t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        }
+        part[r * nchunk] = t;
+    }
+}
+
 struct EdgeFwdArgs {
     const float* P;
     const float* Q;
@@ -231,7 +256,13 @@ struct EdgeFwdArgs {
     const float* w1;
     float* S;
     int ld, h, fi, fe;
+    // last layer only (edge_fwd_out_ok): out[N][4] = S W2^T + deg b2 is formed in the same launch
+    float* out = nullptr;
+    const float* w2 = nullptr;
+    const float* b2 = nullptr;
+    int fo = 0;
 };
+bool edge_fwd_out_ok(int fe, int h, int fo, int ldo);
 int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s);
 
 struct EdgeBwdArgs {
@@ -245,6 +276,10 @@ struct EdgeBwdArgs {
     float* dWe_partial;   // [edge_bwd_dst_blocks][fe][ld] partial sums of a_e[f] * dh_e
     float* grad_edge_attr;  // optional [e_stored][fe]
     int ld, h, fi, fe;
+    // last layer (Fo <= 4, N x 4 output gradient): dS rows are formed inside the walks from gout and W2 [fo][h]; dS is unused
+    const float* gout = nullptr;
+    const float* w2 = nullptr;
+    int fo = 0;
 };
 int edge_bwd_dst_blocks(const GraphView& g, int ld);   // number of dWe partials the dst walk emits (<= 1024)
 int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t* edge_index_unused, hipStream_t s);
