@@ -285,7 +285,7 @@ def main():
         event_pair_overhead_us = round(1e3 * rep.pop("__event_pair_overhead", {"ms": 0.0})["ms"], 3)
         for name, r in rep.items():
             cnt = max(r["count"], 1)
-            avg_s = 1e-3 * r["ms"] / cnt
+            avg_s = max(1e-3 * r["ms"] / cnt, 1e-9)   # (a kernel shorter than the subtracted event-pair overhead reads 0)
             row = {"launches_per_step": r["count"] / args.profile_steps, "avg_us": round(1e6 * avg_s, 3),
                    "ms_per_step": round(r["ms"] / args.profile_steps, 4)}
             if name in ab:

@@ -1,0 +1,514 @@
+// EdgeAggregation for batches of SMALL graphs (the metric configuration: case118 x 128), graph-resident in LDS.
+//
+// A batch of disjoint graphs of `seg` nodes each (pfn_graph_segments) never sends a message across a graph boundary, and the
+// edge walk acts on every hidden column independently.  So a workgroup that owns the rows of whole graphs AND one 32-column
+// quarter of the hidden width can run the node GEMM that produces its P | Q columns, keep them in LDS, and walk the edges
+// right there -- what the generic path does as two or three launches with an N x H round trip through HBM between them
+// (networks/MPN.py:17-21,:28: per-edge Linear -> ReLU -> Linear -> sum, restructured per node as in edge.hip):
+//
+//   forward   P | Q quarter = x W1i^T + b1 | x W1j^T   (MFMA, one 32 x 32 tile per wave)      \  ea_seg_fwd_kernel
+//             S[i] = sum_{e -> i} relu(P[i] + Q[src e] + a_e We)                (LDS walk)     /  (was gemm_nt + edge_fwd)
+//   backward  dS quarter = gout W2                         (MFMA; last layer: from the 16-byte gout rows, VALU)   \
+//             dP[i] = sum_{e -> i} dh_e, dWe partials ; dQ[j] = sum_{e: src = j} dh_e          (LDS walks)          /  ea_seg_bwd_kernel
+//                                                                                               (was gemm_nt + edge_bwd)
+// P, Q, S, dP, dQ are still written to HBM: the backward pass and the weight gradients read them.  The MFMA tiles use the
+// same packed weight images and the same k order as gemm_nt and the walks the same edge order as edge.hip, so the results
+// are bit-identical to the generic path except for the order of the dWe partial sums.
+// With 128 graphs x 4 quarters = 512 workgroups (two per CU, 4 waves per SIMD) a launch is ~one MFMA tile and one short
+// LDS walk per wave deep.  Graphs whose rows do not fit (ea_seg_fit) take the generic kernels.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "pfn_internal.hpp"
+
+namespace pfn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SG_THREADS = 512;
+constexpr int SG_WAVES = SG_THREADS / 64;
+constexpr int SG_TW = 36;            // LDS tile row stride (floats): 32 quarter columns + up to 4 trailing VALU columns
+constexpr int SG_GC = 9;             // eight-wide k chunks per register batch (two batches cover H = 129 -> K8 = 136)
+constexpr int SG_MAX_ROWS = 128;     // rows of whole graphs per workgroup (4 row tiles: one MFMA task per wave at most)
+constexpr int SG_LDS_BYTES = 78 * 1024;   // two workgroups per CU
+
+__device__ __forceinline__ float4 sg_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void sg_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+struct SegCsr {      // one adjacency slice in LDS: rp[rows + 1] (relative), nb[cap] (row index inside the block), ea[cap] (a_e)
+    int* rp;
+    int* nb;
+    float2* ea;
+    bool in_lds;
+    int e0;
+};
+
+// The block's slice of one CSR (by destination or by source) goes to LDS once; `ea_slot` = the edge attributes already in slot
+// order (SlotEa, gathered once per forward), so the chain is two loads deep: rowptr, then indices | attributes
+__device__ __forceinline__ void stage_csr(SegCsr& c, int r0, int rows, int cap, const int* __restrict__ rowptr,
+                                          const int* __restrict__ nbr, const float* __restrict__ ea_slot) {
+#ifdef SG_EXP_NOSTAGE
+    c.e0 = 0; c.in_lds = true;
+    for (int i = threadIdx.x; i <= rows; i += SG_THREADS) c.rp[i] = 0;
+    return;
+#endif
+    c.e0 = rowptr[r0];
+    const int ne = rowptr[r0 + rows] - c.e0;
+    c.in_lds = ne <= cap;
+    for (int i = threadIdx.x; i <= rows; i += SG_THREADS) c.rp[i] = rowptr[r0 + i] - c.e0;
+    if (c.in_lds) {
+        for (int i = threadIdx.x; i < ne; i += SG_THREADS) {
+            c.nb[i] = nbr[c.e0 + i] - r0;
+            c.ea[i] = reinterpret_cast<const float2*>(ea_slot)[c.e0 + i];
+        }
+    }
+}
+__device__ __forceinline__ void csr_slot(const SegCsr& c, int p, int r0, const int* __restrict__ nbr, const float* __restrict__ ea_slot,
+                                         int& ls, float2& a2) {
+    if (c.in_lds) {
+        ls = c.nb[p];
+        a2 = c.ea[p];
+    } else {   // a block with more edges than the LDS slice holds: indices from global memory
+        ls = nbr[c.e0 + p] - r0;
+        a2 = reinterpret_cast<const float2*>(ea_slot)[c.e0 + p];
+    }
+}
+
+// One 32 x 32 MFMA tile (+ up to 4 trailing VALU columns) of  A[rows r_first..][0..K) * image quarter q, written to an LDS tile.
+//   A     : row-major, lda floats per row; the lane's row is clamped to r_last (results of clamped rows land in pad rows)
+//   Bp    : packed image (pack_job_body): quarter q, group g = k / 4 -> Bp[(q * G + g) * 128 + col * 4 + (k & 3)], then the trailing
+//           columns at Bp[nq * G * 128 + g * 16 + c * 4 + (k & 3)]
+// The k order (chunk m, step i: lane half kh supplies k = 8m + 4kh + i) is gemm_nt's, so the sums are bit-identical to it.
+// Split in two so that the first batch of operand loads can be in flight while the block stages its adjacency slice.
+struct SegTile {
+    const float* arow;
+    const float* bq;
+    int K8, kmax;
+    f32x4 av[SG_GC], bv[SG_GC];
+};
+__device__ __forceinline__ void seg_tile_load(SegTile& t, int m0, int kh) {
+#pragma unroll
+    for (int mm = 0; mm < SG_GC; ++mm) {
+        const int mc = min(m0 + mm, (t.K8 >> 3) - 1);                // clamped: chunks past K8 are loaded but not multiplied
+#ifndef SG_EXP_NOLOAD
+        t.av[mm] = *reinterpret_cast<const f32x4*>(t.arow + min(8 * mc + 4 * kh, t.kmax));
+        t.bv[mm] = *reinterpret_cast<const f32x4*>(t.bq + (size_t)(2 * mc + kh) * 128);
+#else
+        t.av[mm] = f32x4{1.f * mc, 2.f, 3.f, 4.f};
+        t.bv[mm] = f32x4{1.f * kh, 2.f, 3.f, 4.f};
+#endif
+    }
+}
+__device__ __forceinline__ void seg_tile_begin(SegTile& t, const float* __restrict__ A, int lda, int K, int r_first, int r_last,
+                                               const float* __restrict__ Bp, int q, int lane) {
+    const int r32 = lane & 31, kh = lane >> 5;
+    t.K8 = (K + 7) & ~7;
+    const int G = t.K8 >> 2;
+    t.arow = A + (size_t)min(r_first + r32, r_last) * lda;
+    t.bq = Bp + (size_t)q * G * 128 + r32 * 4;
+    t.kmax = lda - 4;
+    seg_tile_load(t, 0, kh);
+}
+__device__ __forceinline__ void seg_tile_finish(SegTile& t, int q, const float* __restrict__ bias, int ncols, float* tile,
+                                                int trow0, int lane) {
+    const int r32 = lane & 31, kh = lane >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int m0 = 0;;) {
+#pragma unroll
+        for (int mm = 0; mm < SG_GC; ++mm) {
+            if (8 * (m0 + mm) < t.K8) {
+#pragma unroll
+#ifndef SG_EXP_NOMFMA   /* tools/ubench experiment switches (results wrong by design): never defined in the product build */
+                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.av[mm][i], t.bv[mm][i], acc, 0, 0, 0);
+#else
+                for (int i = 0; i < 4; ++i) acc[i] += t.av[mm][i] * t.bv[mm][i];
+#endif
+            }
+        }
+        m0 += SG_GC;
+        if (8 * m0 >= t.K8) break;
+        seg_tile_load(t, m0, kh);
+    }
+    // accumulator register 4g + e of lane (r32, kh) = row 8g + 4kh + e, column r32
+    const int col = 32 * q + r32;
+    const float cb = (bias && col < ncols) ? bias[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[(size_t)(trow0 + 8 * (j >> 2) + 4 * kh + (j & 3)) * SG_TW + r32] = acc[j] + cb;
+}
+
+// The up to 4 trailing columns (H = 129 = 4 * 32 + 1) never get an MFMA tile: the LAST quarter's block forms them as VALU dot
+// products with all its threads right after the tiles: thread = (row tid >> 2, k part tid & 3); part j adds the
+// k groups j, j + 4, ... in order, the four parts are added by a fixed xor tree.  Two images (P and Q) share the row loads.
+//   tile1[row][32 + c] = sum_k A[row][k] * image1_rem[k][c] (+ bias),   tile2 likewise (no bias) when Bp2 != null
+__device__ __forceinline__ void seg_rem_cols(const float* __restrict__ A, int lda, int K, int r0, int rows,
+                                             const float* __restrict__ Bp1, const float* __restrict__ Bp2, int nq, int nreal,
+                                             const float* __restrict__ bias, float* tile1, float* tile2) {
+    const int lr = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const int G = ((K + 7) & ~7) >> 2;
+    const float* arow = A + (size_t)(r0 + min(lr, rows - 1)) * lda;
+    const size_t roff = (size_t)nq * G * 128;
+    const int gmax = (lda >> 2) - 1;                                 // k groups past the row multiply zero image rows
+    float acc1[4] = {0.f, 0.f, 0.f, 0.f}, acc2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (nreal == 1) {   // H = 128 + 1: five k groups per batch, all loads of a batch requested before the first multiply
+        for (int g0 = part; g0 < G; g0 += 20) {
+            float4 xa[5], w1[5], w2[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int g = min(g0 + 4 * j, G - 1);
+                xa[j] = sg_ld4(arow + 4 * min(g, gmax));
+                w1[j] = sg_ld4(Bp1 + roff + (size_t)g * 16);
+                w2[j] = Bp2 ? sg_ld4(Bp2 + roff + (size_t)g * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                if (g0 + 4 * j < G) {
+                    acc1[0] = fmaf(xa[j].w, w1[j].w, fmaf(xa[j].z, w1[j].z, fmaf(xa[j].y, w1[j].y, fmaf(xa[j].x, w1[j].x, acc1[0]))));
+                    acc2[0] = fmaf(xa[j].w, w2[j].w, fmaf(xa[j].z, w2[j].z, fmaf(xa[j].y, w2[j].y, fmaf(xa[j].x, w2[j].x, acc2[0]))));
+                }
+            }
+        }
+    } else {
+        for (int g = part; g < G; g += 4) {
+            const float4 xa = sg_ld4(arow + 4 * min(g, gmax));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (c < nreal) {
+                    const float4 w = sg_ld4(Bp1 + roff + (size_t)g * 16 + c * 4);
+                    acc1[c] = fmaf(xa.w, w.w, fmaf(xa.z, w.z, fmaf(xa.y, w.y, fmaf(xa.x, w.x, acc1[c]))));
+                    if (Bp2) {
+                        const float4 w2 = sg_ld4(Bp2 + roff + (size_t)g * 16 + c * 4);
+                        acc2[c] = fmaf(xa.w, w2.w, fmaf(xa.z, w2.z, fmaf(xa.y, w2.y, fmaf(xa.x, w2.x, acc2[c]))));
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float v1 = acc1[c], v2 = acc2[c];
+        v1 += __shfl_xor(v1, 1);
+        v1 += __shfl_xor(v1, 2);
+        v2 += __shfl_xor(v2, 1);
+        v2 += __shfl_xor(v2, 2);
+        if (part == 0 && lr < rows) {   // (columns past the real ones: zero, like every pad column)
+            tile1[(size_t)lr * SG_TW + 32 + c] = c < nreal ? v1 + (bias ? bias[32 * nq + c] : 0.f) : 0.f;
+            if (tile2) tile2[(size_t)lr * SG_TW + 32 + c] = c < nreal ? v2 : 0.f;
+        }
+    }
+}
+
+// column-slice geometry shared by the kernels: block y = q covers the 32-column quarter q (up to 8 float4 chunks); the LAST
+// quarter's block also owns the `remv` trailing columns (one more chunk, LDS tile columns 32..35)
+struct SegCols {
+    int q, nq, remv, cw, col0;   // cw = float4 chunks of this block's slice
+    bool rem;                    // this block owns the trailing columns
+};
+__device__ __forceinline__ SegCols seg_cols(int ld) {
+    SegCols c;
+    col_plan(ld, c.remv, c.nq);
+    c.q = blockIdx.y;
+    c.rem = c.remv > 0 && c.q == c.nq - 1;
+    c.col0 = 32 * c.q;
+    c.cw = min(8, (ld - c.remv - c.col0) >> 2) + (c.rem ? 1 : 0);
+    return c;
+}
+// LDS tile column of chunk lc / its global column
+__device__ __forceinline__ int seg_tcol(const SegCols& c, int lc) { return (c.rem && lc == c.cw - 1) ? 32 : 4 * lc; }
+__device__ __forceinline__ int seg_gcol(const SegCols& c, int lc) { return (c.rem && lc == c.cw - 1) ? 32 * c.nq : c.col0 + 4 * lc; }
+// global column of LDS tile column t (0..31: the quarter; 32..35: the trailing columns), -1: not in this block
+__device__ __forceinline__ int seg_col_of_tile(const SegCols& c, int t) { return t < 32 ? c.col0 + t : (c.rem && t - 32 < c.remv ? 32 * c.nq + t - 32 : -1); }
+
+// residue columns of W1 for the slice: we[f][tile column] = W1[col][2Fi + f] (zero past H)
+__device__ __forceinline__ void stage_we(float* s_we, const SegCols& c, const float* __restrict__ w1, int h, int fi) {
+    const int ldw = 2 * fi + 2;
+    for (int i = threadIdx.x; i < 2 * SG_TW; i += SG_THREADS) {
+        const int f = i / SG_TW, t = i - f * SG_TW;
+        const int col = seg_col_of_tile(c, t);
+        s_we[i] = (col >= 0 && col < h) ? w1[(size_t)col * ldw + 2 * fi + f] : 0.f;
+    }
+}
+
+__device__ __forceinline__ float4 sg_add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sg_fma4(float a, float4 x, float4 acc) {
+    return make_float4(fmaf(a, x.x, acc.x), fmaf(a, x.y, acc.y), fmaf(a, x.z, acc.z), fmaf(a, x.w, acc.w));
+}
+__device__ __forceinline__ float4 sg_relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
+
+// LDS carve-up (floats): tiles first (16-byte aligned), then the CSR slices
+struct SegLds {
+    float* P;
+    float* Q;
+    float* D;      // backward only: dS
+    float* we;     // [2][SG_TW]
+    float* w2s;    // backward, last layer only: W2 slice [4][SG_TW]
+    float4* part;  // backward only: dWe partials [8 waves][16 chunk lanes][2]
+    SegCsr in, out;
+};
+__device__ __forceinline__ SegLds seg_lds(float* base, int trows, int rows_pb, int cap, bool bwd) {
+    SegLds l;
+    float* p = base;
+    l.P = p; p += (size_t)trows * SG_TW;
+    l.Q = p; p += (size_t)trows * SG_TW;
+    l.D = p; if (bwd) p += (size_t)trows * SG_TW;
+    l.we = p; p += 2 * SG_TW;
+    l.w2s = p; if (bwd) p += 4 * SG_TW;
+    l.part = reinterpret_cast<float4*>(p); if (bwd) p += 8 * 16 * 2 * 4;
+    l.in.ea = reinterpret_cast<float2*>(p); p += 2 * cap;
+    l.out.ea = reinterpret_cast<float2*>(p); if (bwd) p += 2 * cap;
+    int* ip = reinterpret_cast<int*>(p);
+    l.in.rp = ip; ip += rows_pb + 1;
+    l.in.nb = ip; ip += cap;
+    l.out.rp = ip; if (bwd) ip += rows_pb + 1;
+    l.out.nb = ip;
+    return l;
+}
+static size_t seg_lds_bytes(int trows, int rows_pb, int cap, bool bwd) {
+    size_t f = (size_t)(bwd ? 3 : 2) * trows * SG_TW + 2 * SG_TW + (bwd ? 4 * SG_TW + 8 * 16 * 2 * 4 : 0) + (size_t)(bwd ? 2 : 1) * 2 * cap;
+    size_t i = (size_t)(bwd ? 2 : 1) * (rows_pb + 1 + cap);
+    return (f + i) * 4 + 16;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                       const EaSegFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sg_smem[];
+    const SegLds l = seg_lds(sg_smem, trows, rows_pb, cap, false);
+    const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0);
+    const SegCols sc = seg_cols(a.ld);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ---- P | Q tiles: task t = (row tile t >> 1, P or Q); the first task's operands are requested before the block stages
+    // its adjacency slice (three dependent loads deep), so both latencies overlap
+    const int nrt = (rows + 31) >> 5;
+    const bool mfma_on = wave < 2 * nrt;   // (rows <= SG_MAX_ROWS = 128: at most one task per wave)
+    SegTile tl;
+    if (mfma_on) seg_tile_begin(tl, a.x, a.ldx, a.K, r0 + 32 * (wave >> 1), r0 + rows - 1, (wave & 1) ? a.Bj : a.Bi, sc.q, lane);
+    SegCsr cin = l.in;
+    stage_csr(cin, r0, rows, cap, rowptr, nbr, a.ea_in);
+    stage_we(l.we, sc, a.w1, a.h, a.fi);
+    if (mfma_on) seg_tile_finish(tl, sc.q, (wave & 1) ? nullptr : a.b1, a.h, (wave & 1) ? l.Q : l.P, 32 * (wave >> 1), lane);
+    // (after the tiles: the operand registers are free again, and the rows are in L2 / L1 from the tile loads)
+    if (sc.rem) seg_rem_cols(a.x, a.ldx, a.K, r0, rows, a.Bi, a.Bj, sc.nq, min(sc.remv, a.h - 32 * sc.nq), a.b1, l.P, l.Q);
+    __syncthreads();
+    // ---- P, Q out (the backward pass recomputes the pre-activation from them), and the walk
+    for (int it = threadIdx.x; it < rows * sc.cw; it += SG_THREADS) {
+        const int lr = it / sc.cw, lc = it - lr * sc.cw;
+        const int tc = seg_tcol(sc, lc), gc = seg_gcol(sc, lc);
+        const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tc);
+        const size_t o = (size_t)(r0 + lr) * a.ld + gc;
+        sg_st4(a.P + o, p4);
+        sg_st4(a.Q + o, sg_ld4(l.Q + (size_t)lr * SG_TW + tc));
+        const float4 w0 = sg_ld4(l.we + tc), w1 = sg_ld4(l.we + SG_TW + tc);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifndef SG_EXP_NOWALK
+        const int beg = cin.rp[lr], end = cin.rp[lr + 1];
+#else
+        const int beg = 0, end = 0;
+#endif
+        for (int p = beg; p < end; ++p) {
+            int ls;
+            float2 a2;
+            csr_slot(cin, p, r0, nbr, a.ea_in, ls, a2);
+            float4 v = sg_add4(p4, sg_ld4(l.Q + (size_t)ls * SG_TW + tc));
+            v = sg_fma4(a2.x, w0, v);
+            v = sg_fma4(a2.y, w1, v);
+            acc = sg_add4(acc, sg_relu4(v));
+        }
+        sg_st4(a.S + o, acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <bool DSG>
+__global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __restrict__ rp_in, const int* __restrict__ in_src,
+                       const int* __restrict__ rp_out, const int* __restrict__ out_dst, const EaSegBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sg_smem[];
+    const SegLds l = seg_lds(sg_smem, trows, rows_pb, cap, true);
+    const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0);
+    const SegCols sc = seg_cols(a.ld);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // ---- dS slice: the MFMA waves request their operands first (the staging below is several dependent loads deep)
+    const int nrt = (rows + 31) >> 5;
+    const bool mfma_on = !DSG && wave < nrt;
+    SegTile tl;
+    if (mfma_on) seg_tile_begin(tl, a.gout, a.ldgo, a.fo, r0 + 32 * wave, r0 + rows - 1, a.Bd, sc.q, lane);
+    SegCsr cin = l.in, cout = l.out;
+    stage_csr(cin, r0, rows, cap, rp_in, in_src, a.ea_in);
+    stage_csr(cout, r0, rows, cap, rp_out, out_dst, a.ea_out);
+    stage_we(l.we, sc, a.w1, a.h, a.fi);
+    // ---- P, Q slices -> LDS
+    for (int it = threadIdx.x; it < rows * sc.cw; it += SG_THREADS) {
+        const int lr = it / sc.cw, lc = it - lr * sc.cw;
+        const int tc = seg_tcol(sc, lc);
+        const size_t o = (size_t)(r0 + lr) * a.ld + seg_gcol(sc, lc);
+        sg_st4(l.P + (size_t)lr * SG_TW + tc, sg_ld4(a.P + o));
+        sg_st4(l.Q + (size_t)lr * SG_TW + tc, sg_ld4(a.Q + o));
+    }
+    if (DSG) {   // last layer: dS[row][u] = sum_o gout[row][o] W2[o][u] from the 16-byte gout rows (edge.hip ds_row)
+        for (int i = threadIdx.x; i < 4 * SG_TW; i += SG_THREADS) {
+            const int o = i / SG_TW, t = i - o * SG_TW;
+            const int col = seg_col_of_tile(sc, t);
+            l.w2s[i] = (o < a.fo && col >= 0 && col < a.h) ? a.w2[(size_t)o * a.h + col] : 0.f;
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < rows * sc.cw; it += SG_THREADS) {
+            const int lr = it / sc.cw, lc = it - lr * sc.cw;
+            const int tc = seg_tcol(sc, lc);
+            const float4 g = sg_ld4(a.gout + (size_t)(r0 + lr) * 4);
+            const float4 x0 = sg_ld4(l.w2s + tc);
+            float4 r = make_float4(g.x * x0.x, g.x * x0.y, g.x * x0.z, g.x * x0.w);
+            r = sg_fma4(g.y, sg_ld4(l.w2s + SG_TW + tc), r);
+            r = sg_fma4(g.z, sg_ld4(l.w2s + 2 * SG_TW + tc), r);
+            r = sg_fma4(g.w, sg_ld4(l.w2s + 3 * SG_TW + tc), r);
+            sg_st4(l.D + (size_t)lr * SG_TW + tc, r);
+        }
+    } else {
+        if (mfma_on) seg_tile_finish(tl, sc.q, nullptr, a.h, l.D, 32 * wave, lane);
+        if (sc.rem) seg_rem_cols(a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, min(sc.remv, a.h - 32 * sc.nq), nullptr, l.D, nullptr);
+    }
+    __syncthreads();
+    // ---- walks.  Thread = (chunk lane lc = tid % CL, row lane ty = tid / CL), CL = 8 (16 in the block that also owns the trailing
+    // columns): a thread keeps ONE column chunk for all its rows, so the dWe partial sums stay in registers and the block emits
+    // one ordered partial per column.
+    const int cl_shift = sc.cw <= 8 ? 3 : 4, CL = 1 << cl_shift, RL = SG_THREADS >> cl_shift;
+    const int lc = threadIdx.x & (CL - 1), ty = threadIdx.x >> cl_shift;
+    const bool col_on = lc < sc.cw;
+    const int tc = col_on ? seg_tcol(sc, lc) : 0, gc = col_on ? seg_gcol(sc, lc) : 0;
+    const float4 w0 = sg_ld4(l.we + tc), w1 = sg_ld4(l.we + SG_TW + tc);
+    float4 dwe0 = make_float4(0.f, 0.f, 0.f, 0.f), dwe1 = dwe0;
+    if (col_on) {
+        for (int lr = ty; lr < rows; lr += RL) {
+            // by destination: dP[i] = sum_{e -> i} dh_e ; dWe[f] += a_e[f] dh_e
+            {
+                const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tc), g4 = sg_ld4(l.D + (size_t)lr * SG_TW + tc);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int beg = cin.rp[lr], end = cin.rp[lr + 1];
+                for (int p = beg; p < end; ++p) {
+                    int ls;
+                    float2 a2;
+                    csr_slot(cin, p, r0, in_src, a.ea_in, ls, a2);
+                    float4 v = sg_add4(p4, sg_ld4(l.Q + (size_t)ls * SG_TW + tc));
+                    v = sg_fma4(a2.x, w0, v);
+                    v = sg_fma4(a2.y, w1, v);
+                    float4 dh;
+                    dh.x = v.x > 0.f ? g4.x : 0.f;
+                    dh.y = v.y > 0.f ? g4.y : 0.f;
+                    dh.z = v.z > 0.f ? g4.z : 0.f;
+                    dh.w = v.w > 0.f ? g4.w : 0.f;
+                    acc = sg_add4(acc, dh);
+                    dwe0 = sg_fma4(a2.x, dh, dwe0);
+                    dwe1 = sg_fma4(a2.y, dh, dwe1);
+                }
+                sg_st4(a.dP + (size_t)(r0 + lr) * a.ld + gc, acc);
+            }
+            // by source: dQ[j] = sum_{e: src(e) = j} dh_e
+            {
+                const float4 q4 = sg_ld4(l.Q + (size_t)lr * SG_TW + tc);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int beg = cout.rp[lr], end = cout.rp[lr + 1];
+                for (int p = beg; p < end; ++p) {
+                    int ld_;
+                    float2 a2;
+                    csr_slot(cout, p, r0, out_dst, a.ea_out, ld_, a2);
+                    float4 v = sg_add4(sg_ld4(l.P + (size_t)ld_ * SG_TW + tc), q4);
+                    v = sg_fma4(a2.x, w0, v);
+                    v = sg_fma4(a2.y, w1, v);
+                    const float4 g4 = sg_ld4(l.D + (size_t)ld_ * SG_TW + tc);
+                    acc.x += v.x > 0.f ? g4.x : 0.f;
+                    acc.y += v.y > 0.f ? g4.y : 0.f;
+                    acc.z += v.z > 0.f ? g4.z : 0.f;
+                    acc.w += v.w > 0.f ? g4.w : 0.f;
+                }
+                sg_st4(a.dQ + (size_t)(r0 + lr) * a.ld + gc, acc);
+            }
+        }
+    }
+    // ordered reduction of the dWe partials over the row lanes: inside a wave by a fixed xor tree over the lanes that share a
+    // chunk (lane bits above cl_shift), then over the 8 waves in wave order -> the block's partial [2][ld]
+    for (int off = 32; off >= CL; off >>= 1) {
+        dwe0.x += __shfl_xor(dwe0.x, off); dwe0.y += __shfl_xor(dwe0.y, off); dwe0.z += __shfl_xor(dwe0.z, off); dwe0.w += __shfl_xor(dwe0.w, off);
+        dwe1.x += __shfl_xor(dwe1.x, off); dwe1.y += __shfl_xor(dwe1.y, off); dwe1.z += __shfl_xor(dwe1.z, off); dwe1.w += __shfl_xor(dwe1.w, off);
+    }
+    if (lane < CL) {
+        l.part[(wave * 16 + lane) * 2] = dwe0;
+        l.part[(wave * 16 + lane) * 2 + 1] = dwe1;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * CL) {
+        const int f = threadIdx.x >> cl_shift, c2 = threadIdx.x & (CL - 1);
+        if (c2 < sc.cw) {
+            float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int w = 0; w < SG_WAVES; ++w) s = sg_add4(s, l.part[(w * 16 + c2) * 2 + f]);
+            sg_st4(a.dWe_partial + ((size_t)blockIdx.x * 2 + f) * a.ld + seg_gcol(sc, c2), s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+struct SegPlan { int rows_pb, trows, cap, nblocks, ny; };
+static bool seg_plan(int seg, int n, int ld, SegPlan& p) {
+    if (seg <= 0 || seg > SG_MAX_ROWS || n <= 0 || n % seg != 0) return false;
+    const int gpb = std::max(1, SG_MAX_ROWS / seg);
+    p.rows_pb = gpb * seg;
+    p.trows = (p.rows_pb + 31) / 32 * 32;
+    p.cap = p.rows_pb * 4;
+    p.nblocks = (n + p.rows_pb - 1) / p.rows_pb;
+    int remv, nq;
+    col_plan(ld, remv, nq);
+    p.ny = nq;   // one block column per 32-column quarter
+    return p.ny >= 1 && p.nblocks <= 1024 && seg_lds_bytes(p.trows, p.rows_pb, p.cap, true) <= (size_t)SG_LDS_BYTES;
+}
+bool ea_seg_fit(int seg, int n, int fe, int ld) {
+    static const bool off = getenv("PFN_NO_SEG_EA") != nullptr;   // A/B switch: the generic gemm_nt + edge kernels
+    SegPlan p;
+    return !off && fe == 2 && seg_plan(seg, n, ld, p);
+}
+int ea_seg_blocks(int seg, int n, int ld) {
+    SegPlan p;
+    return seg_plan(seg, n, ld, p) ? p.nblocks : 0;
+}
+
+int launch_ea_seg_fwd(const GraphView& g, const EaSegFwdArgs& a, int seg, hipStream_t s) {
+    SegPlan p;
+    if (!seg_plan(seg, g.n, a.ld, p)) {
+        set_error("ea_seg_fwd: %d-row graphs do not fit", seg);
+        return PFN_EINVAL;
+    }
+    static std::atomic<uint64_t> raised{0};
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(ea_seg_fwd_kernel), SG_LDS_BYTES, raised));
+    ProfScope ps("ea_seg_fwd", 0.0, 0.0, s);
+    ea_seg_fwd_kernel<<<dim3(p.nblocks, p.ny), SG_THREADS, seg_lds_bytes(p.trows, p.rows_pb, p.cap, false), s>>>(
+        g.n, p.rows_pb, p.trows, p.cap, g.rowptr_in, g.in_src, a);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStream_t s) {
+    SegPlan p;
+    if (!seg_plan(seg, g.n, a.ld, p)) {
+        set_error("ea_seg_bwd: %d-row graphs do not fit", seg);
+        return PFN_EINVAL;
+    }
+    const size_t lds = seg_lds_bytes(p.trows, p.rows_pb, p.cap, true);
+    const bool dsg = a.Bd == nullptr;
+    static std::atomic<uint64_t> raised0{0}, raised1{0};
+    ProfScope ps("ea_seg_bwd", 0.0, 0.0, s);
+    if (dsg) {
+        PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(ea_seg_bwd_kernel<true>), SG_LDS_BYTES, raised1));
+        ea_seg_bwd_kernel<true><<<dim3(p.nblocks, p.ny), SG_THREADS, lds, s>>>(g.n, p.rows_pb, p.trows, p.cap, g.rowptr_in, g.in_src,
+                                                                             g.rowptr_out, g.out_dst, a);
+    } else {
+        PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(ea_seg_bwd_kernel<false>), SG_LDS_BYTES, raised0));
+        ea_seg_bwd_kernel<false><<<dim3(p.nblocks, p.ny), SG_THREADS, lds, s>>>(g.n, p.rows_pb, p.trows, p.cap, g.rowptr_in, g.in_src,
+                                                                              g.rowptr_out, g.out_dst, a);
+    }
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+}  // namespace pfn

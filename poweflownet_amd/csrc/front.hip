@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256) void front_pack_kernel(const FrontFwdArgs f, c
     extern __shared__ __attribute__((aligned(16))) float4 fl[];
     // the dropout stream advances once per forward, before any kernel of that forward reads it
     if (pa.rng_advance && blockIdx.x == 0 && threadIdx.x == 0) pa.rng_advance[1] += 1;
+    slot_ea_body(pa.slot_ea, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
     if ((int)blockIdx.x < nb_front) {
         front_fwd_body(f, blockIdx.x, nb_front, ld, nchunk, rows_pb, fl);
         return;
@@ -206,7 +207,8 @@ static void front_shape(int h, int& ld, int& nchunk, int& rows_pb, size_t& lds) 
     lds = ((size_t)rows_pb * nchunk + rows_pb) * sizeof(float4);
 }
 
-int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s) {
+int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s,
+                          const SlotEa* slot_ea) {
     if (f.mask_dtype != 0 && f.mask_dtype != 1) {
         set_error("pred_mask dtype code %d unsupported (0: int64, 1: float32)", f.mask_dtype);
         return PFN_EINVAL;
@@ -215,6 +217,7 @@ int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs,
     size_t lds;
     front_shape(f.h, ld, nchunk, rows_pb, lds);
     PackArgs pa;
+    if (slot_ea) pa.slot_ea = *slot_ea;
     pa.njobs = std::min(njobs, PACK_MAX_JOBS);
     pa.rng_advance = rng_advance;
     pa.mask = nullptr;

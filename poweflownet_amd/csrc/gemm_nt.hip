@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
         for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < a.mask_count; i += nthr)
             a.maskf[i] = a.mask_dtype == 0 ? (float)static_cast<const int64_t*>(a.mask)[i] : static_cast<const float*>(a.mask)[i];
     }
+    slot_ea_body(a.slot_ea, ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x,
+                 (int64_t)gridDim.x * gridDim.y * blockDim.x);
     if ((int)blockIdx.y >= a.njobs) return;
     pack_job_body(a.job[blockIdx.y], blockIdx.x, gridDim.x);
 }
@@ -66,13 +68,14 @@ size_t packed_floats(int K, int ld_out) {
 }
 
 int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s, const void* mask, int mask_dtype,
-                float* maskf, int64_t mask_count) {
+                float* maskf, int64_t mask_count, const SlotEa* slot_ea) {
     if (mask && mask_dtype != 0 && mask_dtype != 1) {
         set_error("pred_mask dtype code %d unsupported (0: int64, 1: float32)", mask_dtype);
         return PFN_EINVAL;
     }
-    for (int j0 = 0; j0 < njobs || (j0 == 0 && mask); j0 += PACK_MAX_JOBS) {
+    for (int j0 = 0; j0 < njobs || (j0 == 0 && (mask || slot_ea)); j0 += PACK_MAX_JOBS) {
         PackArgs a;
+        if (j0 == 0 && slot_ea) a.slot_ea = *slot_ea;
         a.njobs = std::max(0, std::min(PACK_MAX_JOBS, njobs - j0));
         a.rng_advance = j0 == 0 ? rng_advance : nullptr;
         const bool rider = j0 == 0 && mask != nullptr && mask_count > 0;
@@ -87,7 +90,7 @@ int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream
         }
         const int bx = (int)std::min<long>(std::max<long>(1, (biggest + 255) / 256), 64);
         ProfScope ps("pack_weights", 0.0, 0.0, s);
-        if (a.njobs == 0 && !rider) continue;
+        if (a.njobs == 0 && !rider && !a.slot_ea.ea_in) continue;
         pack_weights_kernel<<<dim3(bx, std::max(1, a.njobs)), 256, 0, s>>>(a);
         PFN_CHECK_LAUNCH();
     }

@@ -57,8 +57,8 @@ struct Packer {
         return dst ? dst : reinterpret_cast<const float*>(0x10);   // non-null sentinel while measuring
     }
     int flush(hipStream_t s, uint64_t* rng_advance = nullptr, const void* mask = nullptr, int mask_dtype = 0,
-              float* maskf = nullptr, int64_t mask_count = 0) {
-        return launch_pack(jobs.data(), (int)jobs.size(), rng_advance, s, mask, mask_dtype, maskf, mask_count);
+              float* maskf = nullptr, int64_t mask_count = 0, const SlotEa* slot_ea = nullptr) {
+        return launch_pack(jobs.data(), (int)jobs.size(), rng_advance, s, mask, mask_dtype, maskf, mask_count, slot_ea);
     }
 };
 
@@ -110,9 +110,15 @@ static bool back_fused_ok() {
 
 static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
                       const float* w1, const float* b1, const float* w2, const float* b2, const EaPack& pw, float* out, int ldo,
-                      const Act& act, const EaSaved& sv, hipStream_t s, bool pq_ready = false) {
+                      const Act& act, const EaSaved& sv, hipStream_t s, bool pq_ready = false, int seg = 0,
+                      const float* ea_in = nullptr) {
     const int ld = ld_of(h);
-    if (!pq_ready) {   // P = x W1[:, :Fi]^T + b1 ; Q = x W1[:, Fi:2Fi]^T   (layer 0: already written by the fused front)
+    // batches of small graphs: the P | Q GEMM and the edge walk in one launch, graph-resident in LDS (ea_seg.hip)
+    const bool seg_walk = !pq_ready && ea_in && ea_seg_fit(seg, g.n, fe, ld);
+    if (seg_walk) {
+        EaSegFwdArgs e{x, pw.w1i_t, pw.w1j_t, b1, w1, ea_in, sv.P, sv.Q, sv.S, ldx, fi, ld, h, fi};
+        PFN_TRY(launch_ea_seg_fwd(g, e, seg, s));
+    } else if (!pq_ready) {   // P = x W1[:, :Fi]^T + b1 ; Q = x W1[:, Fi:2Fi]^T   (layer 0: already written by the fused front)
         GemmArgs a = gemm_defaults(g.n, h, ld);
         a.ngroup = 2;
         a.C[0] = sv.P;
@@ -125,8 +131,8 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
         PFN_TRY(launch_gemm_nt(a, s));
     }
     // the network's last layer (Fo <= 4, no activation): the second Linear rides in the edge walk's launch (edge_fwd_out_kernel)
-    const bool out_in_walk = w2 && act.act == ACT_NONE && edge_fwd_out_ok(fe, h, fo, ldo) && back_fused_ok();
-    {
+    const bool out_in_walk = !seg_walk && w2 && act.act == ACT_NONE && edge_fwd_out_ok(fe, h, fo, ldo) && back_fused_ok();
+    if (!seg_walk) {
         EdgeFwdArgs e{sv.P, sv.Q, ea, w1, sv.S, ld, h, fi, fe};
         if (out_in_walk) {
             e.out = out;
@@ -155,12 +161,20 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
 static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
                        const float* w1, const float* w2, const EaPack& pw, const float* gout, int ldgo, const Gate& gate, float* gx,
                        int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
-                       const EaScratch& sc, hipStream_t s, PairList* defer) {
+                       const EaScratch& sc, hipStream_t s, PairList* defer, int seg = 0, const float* ea_in = nullptr,
+                       const float* ea_out = nullptr) {
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
+    // batches of small graphs: the dS GEMM and both backward walks in one launch, graph-resident in LDS (ea_seg.hip)
+    const bool seg_walk = !gea && ea_in && ea_out && ea_seg_fit(seg, g.n, fe, ld) && (fo > 4 || ldgo == 4);
+    if (seg_walk) {
+        const bool last = fo <= 4 && ldgo == 4;
+        EaSegBwdArgs e{gout, last ? nullptr : pw.w2_d, w2, sv.P, sv.Q, ea_in, ea_out, w1, sc.dP, sc.dQ, sc.dWe, ldgo, fo, ld, h, fi};
+        PFN_TRY(launch_ea_seg_bwd(g, e, seg, s));
+    }
     // the network's last layer (Fo <= 4): the walks form dS rows from the 16-byte gout rows themselves (edge.hip ds_row), so
     // the K = 4 GEMM that would write N x H (and the walks' re-read of it) goes away
-    const bool ds_in_walk = w2 && fo <= 4 && ldgo == 4 && !gea && back_fused_ok();
-    if (!ds_in_walk) {   // dS = gout W2
+    const bool ds_in_walk = !seg_walk && w2 && fo <= 4 && ldgo == 4 && !gea && back_fused_ok();
+    if (!seg_walk && !ds_in_walk) {   // dS = gout W2
         GemmArgs a = gemm_defaults(g.n, h, ld);
         a.C[0] = sc.dS;
         a.nterm = 1;
@@ -173,7 +187,7 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         e.w2 = w2;
         e.fo = fo;
     }
-    PFN_TRY(launch_edge_bwd(g, e, nullptr, s));
+    if (!seg_walk) PFN_TRY(launch_edge_bwd(g, e, nullptr, s));
     if (gea) PFN_TRY(launch_edge_attr_grad(g, e, s));
     if (gx) {   // dx = dP W1[:, :Fi] + dQ W1[:, Fi:2Fi], gated by the producing layer's activation
         GemmArgs a = gemm_defaults(g.n, fi, ldgx);
@@ -187,7 +201,7 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         PFN_TRY(launch_gemm_nt(a, s));
     }
     // weight gradients: dWe partials -> W1[:, 2Fi:], and three (dY, X) pairs
-    const int dwe_blocks = g.n > 0 ? edge_bwd_dst_blocks(g, ld) : 0;
+    const int dwe_blocks = g.n > 0 ? (seg_walk ? ea_seg_blocks(seg, g.n, ld) : edge_bwd_dst_blocks(g, ld)) : 0;
     if (defer) defer->dwe.push_back(DweJob{sc.dWe, gw1, dwe_blocks, ldw1, 2 * fi, 0});
     else PFN_TRY(launch_dwe_reduce(sc.dWe, dwe_blocks, fe, ld, h, gw1, ldw1, 2 * fi, s));
     const TnPair pairs[3] = {
@@ -321,6 +335,7 @@ struct Layout {
     int n, e, f0, fe, fo, h, L, K, ld, ld0, ldo, nlayers;
     // forward-saved
     float *maskf, *me_h, *x0, *packed;
+    float *ea_in, *ea_out;       // edge attributes in CSR slot order (Fe = 2; SlotEa), filled once per forward
     size_t packed_floats;
     std::vector<float*> y;       // per layer output (post-activation); last = nullptr (caller's out)
     std::vector<EaSaved> ea;     // per EA layer
@@ -387,6 +402,8 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     }
     lo.packed = cv.take<float>(lo.packed_floats);
     lo.maskf = cv.take<float>((size_t)n * lo.ld0);
+    lo.ea_in = cv.take<float>((size_t)4 * e + 4);
+    lo.ea_out = cv.take<float>((size_t)4 * e + 4);
     lo.me_h = cv.take<float>(nld);
     lo.x0 = cv.take<float>((size_t)n * lo.ld0);
     lo.y.assign(lo.nlayers, nullptr);
@@ -440,6 +457,13 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     Packer pk(lo.packed);
     ModelPack mp;
     plan_pack(pk, lo.f0, lo.fe, lo.fo, lo.h, lo.L, lo.K, params, mp);
+    // batches of small graphs (ea_seg.hip): the edge attributes go to CSR slot order once, riding in the pack launch
+    SlotEa se;
+    const bool seg_ea = ea_seg_fit(seg, lo.n, lo.fe, lo.ld);
+    if (seg_ea) {
+        se.rowptr_in = g.rowptr_in; se.in_eid = g.in_eid; se.out_eid = g.out_eid; se.ea = edge_attr;
+        se.ea_in = lo.ea_in; se.ea_out = lo.ea_out; se.n = g.n; se.e_stored = g.e_stored;
+    }
     // mask_embd(mask) + x   (networks/MPN.py:533,:537)
     const bool fused_front = front_fused_ok(lo.f0, lo.h);
     if (fused_front) {
@@ -450,10 +474,10 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         f.x = x; f.mask = pred_mask;
         f.wa = me[0]; f.ba = me[1]; f.wb = me[2]; f.bb = me[3]; f.w1 = params[0]; f.b1 = params[1];
         f.maskf = lo.maskf; f.me_h = lo.me_h; f.x0 = lo.x0; f.P = lo.ea[0].P; f.Q = lo.ea[0].Q;
-        PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s));
+        PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s, seg_ea ? &se : nullptr));
     } else {
         // ... the pack launch also advances the dropout stream for this forward and converts pred_mask to float32
-        PFN_TRY(pk.flush(s, drop ? rng : nullptr, pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0));
+        PFN_TRY(pk.flush(s, drop ? rng : nullptr, pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0, seg_ea ? &se : nullptr));
         {
             GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
             a.C[0] = lo.me_h;
@@ -490,7 +514,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         if (is_ea(i)) {
             const int fo = last ? lo.fo : lo.h;
             PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
-                               params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0));
+                               params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0, seg, seg_ea ? lo.ea_in : nullptr));
             pi += 4;
             fcur = fo;
         } else {
@@ -545,7 +569,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
             // (layer 0 with the fused front: its input gradient is formed together with mask_embd's, below)
             PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], params[p0 + 2], mp.ea[i], gcur, ldg, gate,
                                 (fused_front && i == 0) ? nullptr : gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2],
-                                grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs));
+                                grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs, seg, lo.ea_in, lo.ea_out));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
                                  grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg));

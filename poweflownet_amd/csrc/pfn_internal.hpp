@@ -99,8 +99,32 @@ struct PackJob {
     int ldw, wk0, wn0, trans, K, ncols, ld_out, pad_;
 };
 constexpr int PACK_MAX_JOBS = 64;
+// optional rider of the pack launches: the edge attributes gathered ONCE per forward into CSR slot order (by destination and by
+// source), Fe = 2 -- the graph-resident EdgeAggregation kernels (ea_seg.hip) then stage a block's attributes with one
+// coalesced load instead of an index load followed by a dependent gather in each of their eight launches per step
+struct SlotEa {
+    const int* rowptr_in = nullptr;   // [n + 1]: rowptr_in[n] = number of slots
+    const int* in_eid = nullptr;
+    const int* out_eid = nullptr;
+    const float* ea = nullptr;        // [e_stored][2]
+    float* ea_in = nullptr;           // [slots][2], null: no rider
+    float* ea_out = nullptr;
+    int n = 0, e_stored = 0;
+};
+__device__ inline void slot_ea_body(const SlotEa& se, int64_t gtid, int64_t nthr) {
+    if (!se.ea_in) return;
+    const int nslot = se.rowptr_in[se.n];
+    for (int64_t i = gtid; i < nslot; i += nthr) {
+        int a = se.in_eid[i], b = se.out_eid[i];
+        a = a >= se.e_stored ? a - se.e_stored : a;
+        b = b >= se.e_stored ? b - se.e_stored : b;
+        reinterpret_cast<float2*>(se.ea_in)[i] = *reinterpret_cast<const float2*>(se.ea + (size_t)a * 2);
+        reinterpret_cast<float2*>(se.ea_out)[i] = *reinterpret_cast<const float2*>(se.ea + (size_t)b * 2);
+    }
+}
 struct PackArgs {
     PackJob job[PACK_MAX_JOBS];
+    SlotEa slot_ea;
     int njobs;
     uint64_t* rng_advance;   // device {seed, offset}: offset += 1 (dropout stream), or null
     // optional rider (one launch floor less per forward): pred_mask -> float32, spread over all blocks of the launch
@@ -142,7 +166,7 @@ __device__ inline void pack_job_body(const PackJob& jb, int bx, int nbx) {
     }
 }
 int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s, const void* mask = nullptr,
-                int mask_dtype = 0, float* maskf = nullptr, int64_t mask_count = 0);
+                int mask_dtype = 0, float* maskf = nullptr, int64_t mask_count = 0, const SlotEa* slot_ea = nullptr);
 
 // C[g] (M x ldc) = sum over terms t with t.group == g of  A_t (M x K_t) * B_t (K_t x ncols)  + epilogue,
 // B_t given as a packed image (Bp).
@@ -265,6 +289,40 @@ struct EdgeFwdArgs {
 bool edge_fwd_out_ok(int fe, int h, int fo, int ldo);
 int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s);
 
+// EdgeAggregation for batches of small graphs, graph-resident in LDS (ea_seg.hip): the node GEMM of one 32-column quarter and
+// the edge walk over it in ONE launch per direction.  `seg` = nodes per graph (pfn_graph_segments); ea_seg_fit() says whether
+// the rows of whole graphs fit (else: gemm_nt + edge_fwd / edge_bwd).  Fe = 2 only.
+struct EaSegFwdArgs {
+    const float* x;        // layer input, N x ldx, K = Fi real columns
+    const float* Bi;       // packed images (ld_out = ld) of W1[:, :Fi]^T and W1[:, Fi:2Fi]^T
+    const float* Bj;
+    const float* b1;
+    const float* w1;       // raw W1 [H][2Fi + 2] (residue columns)
+    const float* ea_in;    // edge attributes in by-destination CSR slot order (SlotEa)
+    float* P;
+    float* Q;
+    float* S;
+    int ldx, K, ld, h, fi;
+};
+struct EaSegBwdArgs {
+    const float* gout;     // N x ldgo gradient of the layer output, Fo real columns
+    const float* Bd;       // packed image (ld_out = ld) of W2 (Fo -> H), or null: last layer (Fo <= 4, ldgo == 4), dS from `w2` on the fly
+    const float* w2;       // raw W2 [Fo][H]
+    const float* P;
+    const float* Q;
+    const float* ea_in;    // edge attributes in CSR slot order (SlotEa), by destination / by source
+    const float* ea_out;
+    const float* w1;
+    float* dP;
+    float* dQ;
+    float* dWe_partial;    // [ea_seg_blocks][2][ld]
+    int ldgo, fo, ld, h, fi;
+};
+bool ea_seg_fit(int seg, int n, int fe, int ld);
+int ea_seg_blocks(int seg, int n, int ld);
+int launch_ea_seg_fwd(const GraphView& g, const EaSegFwdArgs& a, int seg, hipStream_t s);
+int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStream_t s);
+
 struct EdgeBwdArgs {
     const float* P;
     const float* Q;
@@ -309,7 +367,8 @@ struct FrontFwdArgs {
     float *maskf, *me_h, *x0, *P, *Q;      // maskf: pred_mask.float() (networks/MPN.py:533), kept for the weight gradients
 };
 // the front AND the weight re-layout of a forward pass (independent of each other) in one launch; `rng_advance` as in launch_pack
-int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s);
+int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s,
+                          const SlotEa* slot_ea = nullptr);
 int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, const float* me_h, const float* w1,
                      const float* wb, float* g0, float* dh, hipStream_t s);
 
