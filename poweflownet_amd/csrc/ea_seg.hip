@@ -30,7 +30,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int SG_THREADS = 512;
 constexpr int SG_WAVES = SG_THREADS / 64;
 constexpr int SG_TW = 36;            // LDS tile row stride (floats): 32 quarter columns + up to 4 trailing VALU columns
-constexpr int SG_GC = 9;             // eight-wide k chunks per register batch (two batches cover H = 129 -> K8 = 136)
 constexpr int SG_MAX_ROWS = 128;     // rows of whole graphs per workgroup (4 row tiles: one MFMA task per wave at most)
 constexpr int SG_LDS_BYTES = 78 * 1024;   // two workgroups per CU
 
@@ -76,64 +75,78 @@ __device__ __forceinline__ void csr_slot(const SegCsr& c, int p, int r0, const i
     }
 }
 
-// One 32 x 32 MFMA tile (+ up to 4 trailing VALU columns) of  A[rows r_first..][0..K) * image quarter q, written to an LDS tile.
-//   A     : row-major, lda floats per row; the lane's row is clamped to r_last (results of clamped rows land in pad rows)
-//   Bp    : packed image (pack_job_body): quarter q, group g = k / 4 -> Bp[(q * G + g) * 128 + col * 4 + (k & 3)], then the trailing
-//           columns at Bp[nq * G * 128 + g * 16 + c * 4 + (k & 3)]
+// One 32 x 32 MFMA tile of  A[rows r_first..][0..K) * image quarter q  (K <= 136: one piece), written to an LDS tile.
+//   A  : row-major, lda floats per row, straight from global memory into registers (17 float4 per lane, all requested at once);
+//        the lane's row is clamped to r_last (results of clamped rows land in pad rows of the tile)
+//   B  : the quarter of the packed image (pack_job_body: group g = k / 4 -> [(q * G + g) * 128 + col * 4 + (k & 3)]), copied
+//        ONCE per block into LDS by LDS-DMA and shared by the row-tile waves (as per-lane register fragments every wave pulled its
+//        own 17 KB copy through L1: 11 of the kernel's 33 us)
 // The k order (chunk m, step i: lane half kh supplies k = 8m + 4kh + i) is gemm_nt's, so the sums are bit-identical to it.
-// Split in two so that the first batch of operand loads can be in flight while the block stages its adjacency slice.
-struct SegTile {
-    const float* arow;
-    const float* bq;
-    int K8, kmax;
-    f32x4 av[SG_GC], bv[SG_GC];
-};
-__device__ __forceinline__ void seg_tile_load(SegTile& t, int m0, int kh) {
+constexpr int SG_NCH = 17;           // eight-wide k chunks: K8 <= 136
+struct SegA { f32x4 av[SG_NCH]; };
+__device__ __forceinline__ void seg_load_a(SegA& t, const float* __restrict__ A, int lda, int K8, int r_first, int r_last, int lane) {
+    const int r32 = lane & 31, kh = lane >> 5;
+    const float* arow = A + (size_t)min(r_first + r32, r_last) * lda;
+    const int kmax = lda - 4;
 #pragma unroll
-    for (int mm = 0; mm < SG_GC; ++mm) {
-        const int mc = min(m0 + mm, (t.K8 >> 3) - 1);                // clamped: chunks past K8 are loaded but not multiplied
-#ifndef SG_EXP_NOLOAD
-        t.av[mm] = *reinterpret_cast<const f32x4*>(t.arow + min(8 * mc + 4 * kh, t.kmax));
-        t.bv[mm] = *reinterpret_cast<const f32x4*>(t.bq + (size_t)(2 * mc + kh) * 128);
+    for (int m = 0; m < SG_NCH; ++m) {
+        const int mc = min(m, (K8 >> 3) - 1);                        // clamped: chunks past K8 are loaded but not multiplied
+#ifndef SG_EXP_NOLOAD   /* tools/ubench experiment switches (results wrong by design): never defined in the product build */
+        t.av[m] = *reinterpret_cast<const f32x4*>(arow + min(8 * mc + 4 * kh, kmax));
 #else
-        t.av[mm] = f32x4{1.f * mc, 2.f, 3.f, 4.f};
-        t.bv[mm] = f32x4{1.f * kh, 2.f, 3.f, 4.f};
+        t.av[m] = f32x4{1.f * mc, 2.f, 3.f, 4.f};
 #endif
     }
 }
-__device__ __forceinline__ void seg_tile_begin(SegTile& t, const float* __restrict__ A, int lda, int K, int r_first, int r_last,
-                                               const float* __restrict__ Bp, int q, int lane) {
-    const int r32 = lane & 31, kh = lane >> 5;
-    t.K8 = (K + 7) & ~7;
-    const int G = t.K8 >> 2;
-    t.arow = A + (size_t)min(r_first + r32, r_last) * lda;
-    t.bq = Bp + (size_t)q * G * 128 + r32 * 4;
-    t.kmax = lda - 4;
-    seg_tile_load(t, 0, kh);
+// One 1 KiB LDS-DMA (64 lanes x 16 bytes; LDS destination = wave-uniform base + lane * 16); inline asm as in gemm_nt.hip: hidden
+// from the compiler, waited for by hand (seg_dma_wait) before the barrier that publishes the copy
+__device__ __forceinline__ void seg_dma_1k(const char* g, float* lds_dst) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)lds_dst));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(m0v)
+        : "memory");
 }
-__device__ __forceinline__ void seg_tile_finish(SegTile& t, int q, const float* __restrict__ bias, int ncols, float* tile,
-                                                int trow0, int lane) {
+__device__ __forceinline__ void seg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// quarter q of a packed image (G * 128 floats, whole KiBs) -> LDS, the 1 KiB pieces dealt round-robin to the 8 waves
+__device__ __forceinline__ void seg_copy_b(float* dst, const float* __restrict__ Bp, int q, int K8, int wave, int lane) {
+    const int nfl = (K8 >> 2) * 128;
+    const char* src = reinterpret_cast<const char*>(Bp + (size_t)q * nfl) + lane * 16;
+    for (int off = wave * 256; off < nfl; off += SG_WAVES * 256) seg_dma_1k(src + (size_t)off * 4, dst + off);
+}
+__device__ __forceinline__ f32x16 seg_mma(const SegA& t, const float* bl, int K8, int lane) {
     const int r32 = lane & 31, kh = lane >> 5;
+    const float* bp = bl + kh * 128 + r32 * 4;
     f32x16 acc;
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    for (int m0 = 0;;) {
+    f32x4 b = *reinterpret_cast<const f32x4*>(bp);
 #pragma unroll
-        for (int mm = 0; mm < SG_GC; ++mm) {
-            if (8 * (m0 + mm) < t.K8) {
+    for (int m = 0; m < SG_NCH; ++m) {
+        if (8 * m < K8) {
+            f32x4 bn = b;
+            if (8 * (m + 1) < K8) bn = *reinterpret_cast<const f32x4*>(bp + (m + 1) * 256);
 #pragma unroll
-#ifndef SG_EXP_NOMFMA   /* tools/ubench experiment switches (results wrong by design): never defined in the product build */
-                for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.av[mm][i], t.bv[mm][i], acc, 0, 0, 0);
+#ifndef SG_EXP_NOMFMA
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.av[m][i], b[i], acc, 0, 0, 0);
 #else
-                for (int i = 0; i < 4; ++i) acc[i] += t.av[mm][i] * t.bv[mm][i];
+            for (int i = 0; i < 4; ++i) acc[i] += t.av[m][i] * b[i];
 #endif
-            }
+            b = bn;
         }
-        m0 += SG_GC;
-        if (8 * m0 >= t.K8) break;
-        seg_tile_load(t, m0, kh);
     }
-    // accumulator register 4g + e of lane (r32, kh) = row 8g + 4kh + e, column r32
+    return acc;
+}
+// accumulator register 4g + e of lane (r32, kh) = row 8g + 4kh + e, column r32
+__device__ __forceinline__ void seg_store_tile(const f32x16& acc, int q, const float* __restrict__ bias, int ncols, float* tile,
+                                               int trow0, int lane) {
+    const int r32 = lane & 31, kh = lane >> 5;
     const int col = 32 * q + r32;
     const float cb = (bias && col < ncols) ? bias[col] : 0.f;
 #pragma unroll
@@ -245,6 +258,8 @@ struct SegLds {
     float* D;      // backward only: dS
     float* we;     // [2][SG_TW]
     float* w2s;    // backward, last layer only: W2 slice [4][SG_TW]
+    float* B0;     // forward: the quarter of W1i^T | W1j^T (2 x 34 x 128 floats); backward: the quarter of W2 -- ALIASES the dS tile
+    float* B1;
     float4* part;  // backward only: dWe partials [8 waves][16 chunk lanes][2]
     SegCsr in, out;
 };
@@ -254,6 +269,8 @@ __device__ __forceinline__ SegLds seg_lds(float* base, int trows, int rows_pb, i
     l.P = p; p += (size_t)trows * SG_TW;
     l.Q = p; p += (size_t)trows * SG_TW;
     l.D = p; if (bwd) p += (size_t)trows * SG_TW;
+    l.B0 = bwd ? l.D : p; if (!bwd) p += SG_NCH * 256;
+    l.B1 = p; if (!bwd) p += SG_NCH * 256;
     l.we = p; p += 2 * SG_TW;
     l.w2s = p; if (bwd) p += 4 * SG_TW;
     l.part = reinterpret_cast<float4*>(p); if (bwd) p += 8 * 16 * 2 * 4;
@@ -267,7 +284,7 @@ __device__ __forceinline__ SegLds seg_lds(float* base, int trows, int rows_pb, i
     return l;
 }
 static size_t seg_lds_bytes(int trows, int rows_pb, int cap, bool bwd) {
-    size_t f = (size_t)(bwd ? 3 : 2) * trows * SG_TW + 2 * SG_TW + (bwd ? 4 * SG_TW + 8 * 16 * 2 * 4 : 0) + (size_t)(bwd ? 2 : 1) * 2 * cap;
+    size_t f = (size_t)(bwd ? 3 : 2) * trows * SG_TW + (bwd ? 0 : 2 * SG_NCH * 256) + 2 * SG_TW + (bwd ? 4 * SG_TW + 8 * 16 * 2 * 4 : 0) + (size_t)(bwd ? 2 : 1) * 2 * cap;
     size_t i = (size_t)(bwd ? 2 : 1) * (rows_pb + 1 + cap);
     return (f + i) * 4 + 16;
 }
@@ -285,12 +302,20 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     // its adjacency slice (three dependent loads deep), so both latencies overlap
     const int nrt = (rows + 31) >> 5;
     const bool mfma_on = wave < 2 * nrt;   // (rows <= SG_MAX_ROWS = 128: at most one task per wave)
-    SegTile tl;
-    if (mfma_on) seg_tile_begin(tl, a.x, a.ldx, a.K, r0 + 32 * (wave >> 1), r0 + rows - 1, (wave & 1) ? a.Bj : a.Bi, sc.q, lane);
+    const int K8 = (a.K + 7) & ~7;
+    SegA ta;
+    if (mfma_on) seg_load_a(ta, a.x, a.ldx, K8, r0 + 32 * (wave >> 1), r0 + rows - 1, lane);
+    seg_copy_b(l.B0, a.Bi, sc.q, K8, wave, lane);
+    seg_copy_b(l.B1, a.Bj, sc.q, K8, wave, lane);
     SegCsr cin = l.in;
     stage_csr(cin, r0, rows, cap, rowptr, nbr, a.ea_in);
     stage_we(l.we, sc, a.w1, a.h, a.fi);
-    if (mfma_on) seg_tile_finish(tl, sc.q, (wave & 1) ? nullptr : a.b1, a.h, (wave & 1) ? l.Q : l.P, 32 * (wave >> 1), lane);
+    seg_dma_wait();
+    __syncthreads();
+    if (mfma_on) {
+        const f32x16 acc = seg_mma(ta, (wave & 1) ? l.B1 : l.B0, K8, lane);
+        seg_store_tile(acc, sc.q, (wave & 1) ? nullptr : a.b1, a.h, (wave & 1) ? l.Q : l.P, 32 * (wave >> 1), lane);
+    }
     // (after the tiles: the operand registers are free again, and the rows are in L2 / L1 from the tile loads)
     if (sc.rem) seg_rem_cols(a.x, a.ldx, a.K, r0, rows, a.Bi, a.Bj, sc.nq, min(sc.remv, a.h - 32 * sc.nq), a.b1, l.P, l.Q);
     __syncthreads();
@@ -300,8 +325,10 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         const int tc = seg_tcol(sc, lc), gc = seg_gcol(sc, lc);
         const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tc);
         const size_t o = (size_t)(r0 + lr) * a.ld + gc;
+#ifndef SG_EXP_NOSTORE
         sg_st4(a.P + o, p4);
         sg_st4(a.Q + o, sg_ld4(l.Q + (size_t)lr * SG_TW + tc));
+#endif
         const float4 w0 = sg_ld4(l.we + tc), w1 = sg_ld4(l.we + SG_TW + tc);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifndef SG_EXP_NOWALK
@@ -318,7 +345,11 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             v = sg_fma4(a2.y, w1, v);
             acc = sg_add4(acc, sg_relu4(v));
         }
+#ifndef SG_EXP_NOSTORE
         sg_st4(a.S + o, acc);
+#else
+        if (acc.x == 123.456f) sg_st4(a.S + o, acc);
+#endif
     }
 }
 
@@ -335,8 +366,10 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     // ---- dS slice: the MFMA waves request their operands first (the staging below is several dependent loads deep)
     const int nrt = (rows + 31) >> 5;
     const bool mfma_on = !DSG && wave < nrt;
-    SegTile tl;
-    if (mfma_on) seg_tile_begin(tl, a.gout, a.ldgo, a.fo, r0 + 32 * wave, r0 + rows - 1, a.Bd, sc.q, lane);
+    const int K8 = (a.fo + 7) & ~7;
+    SegA ta;
+    if (mfma_on) seg_load_a(ta, a.gout, a.ldgo, K8, r0 + 32 * wave, r0 + rows - 1, lane);
+    if (!DSG) seg_copy_b(l.B0, a.Bd, sc.q, K8, wave, lane);
     SegCsr cin = l.in, cout = l.out;
     stage_csr(cin, r0, rows, cap, rp_in, in_src, a.ea_in);
     stage_csr(cout, r0, rows, cap, rp_out, out_dst, a.ea_out);
@@ -368,7 +401,13 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             sg_st4(l.D + (size_t)lr * SG_TW + tc, r);
         }
     } else {
-        if (mfma_on) seg_tile_finish(tl, sc.q, nullptr, a.h, l.D, 32 * wave, lane);
+        // (the W2 quarter sits where the dS tile goes: every wave is done reading it before the first one writes)
+        seg_dma_wait();
+        __syncthreads();
+        f32x16 acc;
+        if (mfma_on) acc = seg_mma(ta, l.B0, K8, lane);
+        __syncthreads();
+        if (mfma_on) seg_store_tile(acc, sc.q, nullptr, a.h, l.D, 32 * wave, lane);
         if (sc.rem) seg_rem_cols(a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, min(sc.remv, a.h - 32 * sc.nq), nullptr, l.D, nullptr);
     }
     __syncthreads();
@@ -461,7 +500,9 @@ static bool seg_plan(int seg, int n, int ld, SegPlan& p) {
     int remv, nq;
     col_plan(ld, remv, nq);
     p.ny = nq;   // one block column per 32-column quarter
-    return p.ny >= 1 && p.nblocks <= 1024 && seg_lds_bytes(p.trows, p.rows_pb, p.cap, true) <= (size_t)SG_LDS_BYTES;
+    return p.ny >= 1 && ld <= 8 * SG_NCH &&   // (one k piece: every layer width of the model is <= ld)
+           p.nblocks <= 1024 && seg_lds_bytes(p.trows, p.rows_pb, p.cap, true) <= (size_t)SG_LDS_BYTES &&
+           seg_lds_bytes(p.trows, p.rows_pb, p.cap, false) <= (size_t)SG_LDS_BYTES;
 }
 bool ea_seg_fit(int seg, int n, int fe, int ld) {
     static const bool off = getenv("PFN_NO_SEG_EA") != nullptr;   // A/B switch: the generic gemm_nt + edge kernels
