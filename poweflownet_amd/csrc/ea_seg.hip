@@ -81,7 +81,7 @@ __device__ __forceinline__ void csr_slot(const SegCsr& c, int p, int r0, const i
 //   B  : the quarter of the packed image (pack_job_body: group g = k / 4 -> [(q * G + g) * 128 + col * 4 + (k & 3)]), copied
 //        ONCE per block into LDS by LDS-DMA and shared by the row-tile waves (as per-lane register fragments every wave pulled its
 //        own 17 KB copy through L1: 11 of the kernel's 33 us)
-// The k order (chunk m, step i: lane half kh supplies k = 8m + 4kh + i) is gemm_nt's, so the sums are bit-identical to it.
+// The k order (chunk m, step i: lane half kh supplies k = 8m + 4kh + i) is gemm_nt's, so the tile sums are bit-identical to it.
 constexpr int SG_NCH = 17;           // eight-wide k chunks: K8 <= 136
 struct SegA { f32x4 av[SG_NCH]; };
 __device__ __forceinline__ void seg_load_a(SegA& t, const float* __restrict__ A, int lda, int K8, int r_first, int r_last, int lane) {
@@ -120,7 +120,10 @@ __device__ __forceinline__ void seg_copy_b(float* dst, const float* __restrict__
     const char* src = reinterpret_cast<const char*>(Bp + (size_t)q * nfl) + lane * 16;
     for (int off = wave * 256; off < nfl; off += SG_WAVES * 256) seg_dma_1k(src + (size_t)off * 4, dst + off);
 }
-__device__ __forceinline__ f32x16 seg_mma(const SegA& t, const float* bl, int K8, int lane) {
+// (one accumulator chain: a second, independent one changed nothing -- the MFMA pipe is shared by 2-4 waves per SIMD here, and
+//  tools/ubench/mfma_peak.hip reaches 147 TF with a single dependent chain per wave)
+template <bool FULL>   // FULL: K8 == 136, all 17 chunks live -> straight-line code (the per-chunk guards cost ~50 SGPRs of branch state)
+__device__ __forceinline__ f32x16 seg_mma_t(const SegA& t, const float* bl, int K8, int lane) {
     const int r32 = lane & 31, kh = lane >> 5;
     const float* bp = bl + kh * 128 + r32 * 4;
     f32x16 acc;
@@ -129,9 +132,9 @@ __device__ __forceinline__ f32x16 seg_mma(const SegA& t, const float* bl, int K8
     f32x4 b = *reinterpret_cast<const f32x4*>(bp);
 #pragma unroll
     for (int m = 0; m < SG_NCH; ++m) {
-        if (8 * m < K8) {
+        if (FULL || 8 * m < K8) {
             f32x4 bn = b;
-            if (8 * (m + 1) < K8) bn = *reinterpret_cast<const f32x4*>(bp + (m + 1) * 256);
+            if (FULL ? m + 1 < SG_NCH : 8 * (m + 1) < K8) bn = *reinterpret_cast<const f32x4*>(bp + (m + 1) * 256);
 #pragma unroll
 #ifndef SG_EXP_NOMFMA
             for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.av[m][i], b[i], acc, 0, 0, 0);
@@ -142,6 +145,9 @@ __device__ __forceinline__ f32x16 seg_mma(const SegA& t, const float* bl, int K8
         }
     }
     return acc;
+}
+__device__ __forceinline__ f32x16 seg_mma(const SegA& t, const float* bl, int K8, int lane) {
+    return K8 == 8 * SG_NCH ? seg_mma_t<true>(t, bl, K8, lane) : seg_mma_t<false>(t, bl, K8, lane);
 }
 // accumulator register 4g + e of lane (r32, kh) = row 8g + 4kh + e, column r32
 __device__ __forceinline__ void seg_store_tile(const f32x16& acc, int q, const float* __restrict__ bias, int ncols, float* tile,
@@ -157,6 +163,7 @@ __device__ __forceinline__ void seg_store_tile(const f32x16& acc, int q, const f
 // products with all its threads right after the tiles: thread = (row tid >> 2, k part tid & 3); part j adds the
 // k groups j, j + 4, ... in order, the four parts are added by a fixed xor tree.  Two images (P and Q) share the row loads.
 //   tile1[row][32 + c] = sum_k A[row][k] * image1_rem[k][c] (+ bias),   tile2 likewise (no bias) when Bp2 != null
+template <bool TWO>
 __device__ __forceinline__ void seg_rem_cols(const float* __restrict__ A, int lda, int K, int r0, int rows,
                                              const float* __restrict__ Bp1, const float* __restrict__ Bp2, int nq, int nreal,
                                              const float* __restrict__ bias, float* tile1, float* tile2) {
@@ -166,22 +173,21 @@ __device__ __forceinline__ void seg_rem_cols(const float* __restrict__ A, int ld
     const size_t roff = (size_t)nq * G * 128;
     const int gmax = (lda >> 2) - 1;                                 // k groups past the row multiply zero image rows
     float acc1[4] = {0.f, 0.f, 0.f, 0.f}, acc2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (nreal == 1) {   // H = 128 + 1: five k groups per batch, all loads of a batch requested before the first multiply
-        for (int g0 = part; g0 < G; g0 += 20) {
-            float4 xa[5], w1[5], w2[5];
+    if (nreal == 1) {   // H = 128 + 1: three k groups per batch, all loads of a batch requested before the first multiply
+        for (int g0 = part; g0 < G; g0 += 12) {
+            float4 xa[3], w1[3], w2[3];
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
+            for (int j = 0; j < 3; ++j) {
                 const int g = min(g0 + 4 * j, G - 1);
-                xa[j] = sg_ld4(arow + 4 * min(g, gmax));
+                const float4 v = sg_ld4(arow + 4 * min(g, gmax));
+                xa[j] = g0 + 4 * j < G ? v : make_float4(0.f, 0.f, 0.f, 0.f);   // (past G: zeroed by a select, no divergent branch)
                 w1[j] = sg_ld4(Bp1 + roff + (size_t)g * 16);
-                w2[j] = Bp2 ? sg_ld4(Bp2 + roff + (size_t)g * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (TWO) w2[j] = sg_ld4(Bp2 + roff + (size_t)g * 16);
             }
 #pragma unroll
-            for (int j = 0; j < 5; ++j) {
-                if (g0 + 4 * j < G) {
-                    acc1[0] = fmaf(xa[j].w, w1[j].w, fmaf(xa[j].z, w1[j].z, fmaf(xa[j].y, w1[j].y, fmaf(xa[j].x, w1[j].x, acc1[0]))));
-                    acc2[0] = fmaf(xa[j].w, w2[j].w, fmaf(xa[j].z, w2[j].z, fmaf(xa[j].y, w2[j].y, fmaf(xa[j].x, w2[j].x, acc2[0]))));
-                }
+            for (int j = 0; j < 3; ++j) {
+                acc1[0] = fmaf(xa[j].w, w1[j].w, fmaf(xa[j].z, w1[j].z, fmaf(xa[j].y, w1[j].y, fmaf(xa[j].x, w1[j].x, acc1[0]))));
+                if (TWO) acc2[0] = fmaf(xa[j].w, w2[j].w, fmaf(xa[j].z, w2[j].z, fmaf(xa[j].y, w2[j].y, fmaf(xa[j].x, w2[j].x, acc2[0]))));
             }
         }
     } else {
@@ -192,7 +198,7 @@ __device__ __forceinline__ void seg_rem_cols(const float* __restrict__ A, int ld
                 if (c < nreal) {
                     const float4 w = sg_ld4(Bp1 + roff + (size_t)g * 16 + c * 4);
                     acc1[c] = fmaf(xa.w, w.w, fmaf(xa.z, w.z, fmaf(xa.y, w.y, fmaf(xa.x, w.x, acc1[c]))));
-                    if (Bp2) {
+                    if (TWO) {
                         const float4 w2 = sg_ld4(Bp2 + roff + (size_t)g * 16 + c * 4);
                         acc2[c] = fmaf(xa.w, w2.w, fmaf(xa.z, w2.z, fmaf(xa.y, w2.y, fmaf(xa.x, w2.x, acc2[c]))));
                     }
@@ -209,7 +215,7 @@ __device__ __forceinline__ void seg_rem_cols(const float* __restrict__ A, int ld
         v2 += __shfl_xor(v2, 2);
         if (part == 0 && lr < rows) {   // (columns past the real ones: zero, like every pad column)
             tile1[(size_t)lr * SG_TW + 32 + c] = c < nreal ? v1 + (bias ? bias[32 * nq + c] : 0.f) : 0.f;
-            if (tile2) tile2[(size_t)lr * SG_TW + 32 + c] = c < nreal ? v2 : 0.f;
+            if (TWO) tile2[(size_t)lr * SG_TW + 32 + c] = c < nreal ? v2 : 0.f;
         }
     }
 }
@@ -317,7 +323,7 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         seg_store_tile(acc, sc.q, (wave & 1) ? nullptr : a.b1, a.h, (wave & 1) ? l.Q : l.P, 32 * (wave >> 1), lane);
     }
     // (after the tiles: the operand registers are free again, and the rows are in L2 / L1 from the tile loads)
-    if (sc.rem) seg_rem_cols(a.x, a.ldx, a.K, r0, rows, a.Bi, a.Bj, sc.nq, min(sc.remv, a.h - 32 * sc.nq), a.b1, l.P, l.Q);
+    if (sc.rem) seg_rem_cols<true>(a.x, a.ldx, a.K, r0, rows, a.Bi, a.Bj, sc.nq, min(sc.remv, a.h - 32 * sc.nq), a.b1, l.P, l.Q);
     __syncthreads();
     // ---- P, Q out (the backward pass recomputes the pre-activation from them), and the walk
     for (int it = threadIdx.x; it < rows * sc.cw; it += SG_THREADS) {
@@ -408,7 +414,7 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         if (mfma_on) acc = seg_mma(ta, l.B0, K8, lane);
         __syncthreads();
         if (mfma_on) seg_store_tile(acc, sc.q, nullptr, a.h, l.D, 32 * wave, lane);
-        if (sc.rem) seg_rem_cols(a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, min(sc.remv, a.h - 32 * sc.nq), nullptr, l.D, nullptr);
+        if (sc.rem) seg_rem_cols<false>(a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, min(sc.remv, a.h - 32 * sc.nq), nullptr, l.D, nullptr);
     }
     __syncthreads();
     // ---- walks.  Thread = (chunk lane lc = tid % CL, row lane ty = tid / CL), CL = 8 (16 in the block that also owns the trailing
@@ -490,7 +496,7 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
 
 // ------------------------------------------------------------------------------------------------ host
 struct SegPlan { int rows_pb, trows, cap, nblocks, ny; };
-static bool seg_plan(int seg, int n, int ld, SegPlan& p) {
+static bool seg_plan(int seg, int n, int ld, SegPlan& p, bool bwd_limits = true) {
     if (seg <= 0 || seg > SG_MAX_ROWS || n <= 0 || n % seg != 0) return false;
     const int gpb = std::max(1, SG_MAX_ROWS / seg);
     p.rows_pb = gpb * seg;
@@ -501,13 +507,19 @@ static bool seg_plan(int seg, int n, int ld, SegPlan& p) {
     col_plan(ld, remv, nq);
     p.ny = nq;   // one block column per 32-column quarter
     return p.ny >= 1 && ld <= 8 * SG_NCH &&   // (one k piece: every layer width of the model is <= ld)
-           p.nblocks <= 1024 && seg_lds_bytes(p.trows, p.rows_pb, p.cap, true) <= (size_t)SG_LDS_BYTES &&
+           (!bwd_limits || p.nblocks <= 1024) &&   // (the dWe partial buffer holds 1024 row blocks)
+           seg_lds_bytes(p.trows, p.rows_pb, p.cap, true) <= (size_t)SG_LDS_BYTES &&
            seg_lds_bytes(p.trows, p.rows_pb, p.cap, false) <= (size_t)SG_LDS_BYTES;
 }
-bool ea_seg_fit(int seg, int n, int fe, int ld) {
+// `bwd`: the backward kernel's dWe partial buffer bounds the number of row blocks; the forward kernel has no such bound (a big
+// inference batch takes it, and a training batch beyond the bound pairs it with the generic backward: P, Q, S mean the same)
+bool ea_seg_fit(int seg, int n, int fe, int ld, bool bwd) {
     static const bool off = getenv("PFN_NO_SEG_EA") != nullptr;   // A/B switch: the generic gemm_nt + edge kernels
     SegPlan p;
-    return !off && fe == 2 && seg_plan(seg, n, ld, p);
+    // Only in the latency regime: with a few blocks per CU a launch is one MFMA tile and one walk deep and the saved launches
+    // and HBM round trips win (case118 x 128: -5 % of the step); with many blocks per CU the weight-stationary persistent
+    // gemm_nt amortises its prologue and is the faster GEMM (case118 x 2048 inference: 3.39 vs 3.11 ms, measured)
+    return !off && fe == 2 && seg_plan(seg, n, ld, p, bwd) && (long)p.nblocks * p.ny <= 4L * device_cus();
 }
 int ea_seg_blocks(int seg, int n, int ld) {
     SegPlan p;
@@ -516,7 +528,7 @@ int ea_seg_blocks(int seg, int n, int ld) {
 
 int launch_ea_seg_fwd(const GraphView& g, const EaSegFwdArgs& a, int seg, hipStream_t s) {
     SegPlan p;
-    if (!seg_plan(seg, g.n, a.ld, p)) {
+    if (!seg_plan(seg, g.n, a.ld, p, false)) {
         set_error("ea_seg_fwd: %d-row graphs do not fit", seg);
         return PFN_EINVAL;
     }

@@ -114,7 +114,7 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
                       const float* ea_in = nullptr) {
     const int ld = ld_of(h);
     // batches of small graphs: the P | Q GEMM and the edge walk in one launch, graph-resident in LDS (ea_seg.hip)
-    const bool seg_walk = !pq_ready && ea_in && ea_seg_fit(seg, g.n, fe, ld);
+    const bool seg_walk = !pq_ready && ea_in && ea_seg_fit(seg, g.n, fe, ld, false);
     if (seg_walk) {
         EaSegFwdArgs e{x, pw.w1i_t, pw.w1j_t, b1, w1, ea_in, sv.P, sv.Q, sv.S, ldx, fi, ld, h, fi};
         PFN_TRY(launch_ea_seg_fwd(g, e, seg, s));
@@ -165,7 +165,7 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
                        const float* ea_out = nullptr) {
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
     // batches of small graphs: the dS GEMM and both backward walks in one launch, graph-resident in LDS (ea_seg.hip)
-    const bool seg_walk = !gea && ea_in && ea_out && ea_seg_fit(seg, g.n, fe, ld) && (fo > 4 || ldgo == 4);
+    const bool seg_walk = !gea && ea_in && ea_out && ea_seg_fit(seg, g.n, fe, ld, true) && (fo > 4 || ldgo == 4);
     if (seg_walk) {
         const bool last = fo <= 4 && ldgo == 4;
         EaSegBwdArgs e{gout, last ? nullptr : pw.w2_d, w2, sv.P, sv.Q, ea_in, ea_out, w1, sc.dP, sc.dQ, sc.dWe, ldgo, fo, ld, h, fi};
@@ -260,6 +260,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
                         const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx, float* const* gw,
                         float* gbias, const float* xk, const TagScratch& sc, hipStream_t s, PairList* defer, int seg = 0) {
     const size_t stride = (size_t)g.n * ldx;
+    float* hk = sc.G;
     if (gx) {
         if (ldgx != ldx) {
             set_error("TAGConv backward: grad_x stride %d != x stride %d", ldgx, ldx);
@@ -271,12 +272,12 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             // one output instead of K + 1 (measured 607 vs 754 us for the GEMM at 414 k nodes) and no Horner pass.
             const size_t gstride = (size_t)g.n * ldgo;
             if (fused_hops_fit(seg, ldgo, g.n)) {
-                FusedHopsArgs fh{gout, sc.G, nullptr, nullptr, nullptr, 1.f, gstride, ldgo, K, 0, seg, 1};
+                FusedHopsArgs fh{gout, hk, nullptr, nullptr, nullptr, 1.f, gstride, ldgo, K, 0, seg, 1};
                 PFN_TRY(launch_fused_hops(g, fh, s));
             } else {
                 const float* prev = gout;
                 for (int k = 1; k <= K; ++k) {
-                    HopArgs hp{prev, nullptr, sc.G + (size_t)(k - 1) * gstride, nullptr, 1.f, ldgo, 1, 1};
+                    HopArgs hp{prev, nullptr, hk + (size_t)(k - 1) * gstride, nullptr, 1.f, ldgo, 1, 1};
                     PFN_TRY(launch_hop(g, hp, s));
                     prev = hp.y;
                 }
@@ -285,7 +286,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             a.C[0] = gx;
             a.nterm = K + 1;
             for (int k = 0; k <= K; ++k)
-                a.term[k] = term(k == 0 ? gout : sc.G + (size_t)(k - 1) * gstride, ldgo, cout, pw.wd[k], 0);
+                a.term[k] = term(k == 0 ? gout : hk + (size_t)(k - 1) * gstride, ldgo, cout, pw.wd[k], 0);
             a.gate = gate.y;
             a.ldg = gate.ld;
             a.gate_scale = gate.scale;
@@ -459,7 +460,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     plan_pack(pk, lo.f0, lo.fe, lo.fo, lo.h, lo.L, lo.K, params, mp);
     // batches of small graphs (ea_seg.hip): the edge attributes go to CSR slot order once, riding in the pack launch
     SlotEa se;
-    const bool seg_ea = ea_seg_fit(seg, lo.n, lo.fe, lo.ld);
+    const bool seg_ea = ea_seg_fit(seg, lo.n, lo.fe, lo.ld, false);
     if (seg_ea) {
         se.rowptr_in = g.rowptr_in; se.in_eid = g.in_eid; se.out_eid = g.out_eid; se.ea = edge_attr;
         se.ea_in = lo.ea_in; se.ea_out = lo.ea_out; se.n = g.n; se.e_stored = g.e_stored;

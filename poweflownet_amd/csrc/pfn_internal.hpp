@@ -318,7 +318,7 @@ struct EaSegBwdArgs {
     float* dWe_partial;    // [ea_seg_blocks][2][ld]
     int ldgo, fo, ld, h, fi;
 };
-bool ea_seg_fit(int seg, int n, int fe, int ld);
+bool ea_seg_fit(int seg, int n, int fe, int ld, bool bwd);
 int ea_seg_blocks(int seg, int n, int ld);
 int launch_ea_seg_fwd(const GraphView& g, const EaSegFwdArgs& a, int seg, hipStream_t s);
 int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStream_t s);

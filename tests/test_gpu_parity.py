@@ -481,30 +481,47 @@ def test_model_vs_oracle_seeded(case, B, cfg):
 
 
 def test_fused_lds_hops_match_generic_path():
-    """Batches with `ptr` take the LDS-resident multi-hop path; without it the per-hop kernels.  Same results."""
+    """Batches with `ptr` take the graph-resident LDS kernels (fused hops, ea_seg); without it the generic per-hop / GEMM /
+    edge kernels.  Same output to 1e-6;
+    the gradients are two different fp32 formulations of a sum with cancellation (untrained weights: a ReLU mask within the
+    forward rounding error of zero may differ between them and moves a weight gradient by up to a few 1e-4 of its largest
+    entry, see test_config2_full_size_vs_oracle), so EACH path is held against the float64 oracle: within 5e-4 of the largest
+    entry or 3x the fp32 oracle's own error."""
     torch.manual_seed(3)
-    m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 3, 0.0).to(DEV).eval()
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 3, 3, 0.0).eval()
     with torch.no_grad():
-        for mod in m.layers:
-            if isinstance(mod, TAGConv):
+        for mod in ref.layers:
+            if hasattr(mod, "lins"):
                 mod.bias.normal_(std=0.1)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 3, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
     for case, B in (("118", 6), ("14", 37)):
-        d = make_batch(case, B).to(DEV)
+        data = make_batch(case, B)
+        ref.zero_grad()
+        torch.nn.MSELoss()(ref(data), data.y).backward()
+        g32 = [q.grad.clone() for q in ref.parameters()]
+        _, g64 = _fp64_truth(ref, data)
+        d = data.to(DEV)
         out_f = m(d)
         assert m._graphs._graph.seg_nodes == {"118": 118, "14": 14}[case]
-        loss = out_f.square().mean()
         m.zero_grad()
-        loss.backward()
+        torch.nn.MSELoss()(out_f, d.y).backward()
         gf = [p.grad.clone() for p in m.parameters()]
         d2 = d.clone()
         del d2.__dict__["ptr"]; d2._keys.remove("ptr")
         out_g = m(d2)
         assert m._graphs._graph.seg_nodes == 0
         m.zero_grad()
-        out_g.square().mean().backward()
+        torch.nn.MSELoss()(out_g, d2.y).backward()
         assert_close(out_f, out_g, 1e-6, "out")
-        for a, p in zip(gf, m.parameters()):
-            assert_close(a, p.grad, 1e-6, "grad")
+        for (k, p), a, q, t in zip(m.named_parameters(), gf, g32, g64):
+            scale = t.abs().max().item()
+            e_ref = (q.double() - t).abs().max().item()
+            for tag, g in (("graph-resident", a), ("generic", p.grad)):
+                e = (g.cpu().double() - t).abs().max().item()
+                record(f"{case}: grad.{k} ({tag}) vs fp64 (fp32 oracle: {e_ref / max(scale, 1e-300):.2e})", e, scale, GRAD_FULL_RTOL)
+                assert e <= max(GRAD_FULL_RTOL * scale, 3 * e_ref), (case, k, tag, e, e_ref, scale)
     # a hint that the edges contradict is rejected on device: 5 graphs of 14 nodes claimed to be 7 graphs of 10
     d = make_batch("14", 5).to(DEV)
     d.ptr = torch.arange(0, 71, 10, device=DEV)
