@@ -41,7 +41,7 @@ struct SegCsr {      // one adjacency slice in LDS: rp[rows + 1] (relative), nb[
     int* nb;
     float2* ea;
     bool in_lds;
-    int e0;
+    int e0, ne;
 };
 
 // The block's slice of one CSR (by destination or by source) goes to LDS once; `ea_slot` = the edge attributes already in slot
@@ -49,12 +49,13 @@ struct SegCsr {      // one adjacency slice in LDS: rp[rows + 1] (relative), nb[
 __device__ __forceinline__ void stage_csr(SegCsr& c, int r0, int rows, int cap, const int* __restrict__ rowptr,
                                           const int* __restrict__ nbr, const float* __restrict__ ea_slot) {
 #ifdef SG_EXP_NOSTAGE
-    c.e0 = 0; c.in_lds = true;
+    c.e0 = 0; c.in_lds = true; c.ne = 0;
     for (int i = threadIdx.x; i <= rows; i += SG_THREADS) c.rp[i] = 0;
     return;
 #endif
     c.e0 = rowptr[r0];
     const int ne = rowptr[r0 + rows] - c.e0;
+    c.ne = ne;
     c.in_lds = ne <= cap;
     for (int i = threadIdx.x; i <= rows; i += SG_THREADS) c.rp[i] = rowptr[r0 + i] - c.e0;
     if (c.in_lds) {
@@ -342,14 +343,43 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
 #else
         const int beg = 0, end = 0;
 #endif
-        for (int p = beg; p < end; ++p) {
-            int ls;
-            float2 a2;
-            csr_slot(cin, p, r0, nbr, a.ea_in, ls, a2);
-            float4 v = sg_add4(p4, sg_ld4(l.Q + (size_t)ls * SG_TW + tc));
-            v = sg_fma4(a2.x, w0, v);
-            v = sg_fma4(a2.y, w1, v);
-            acc = sg_add4(acc, sg_relu4(v));
+        if (cin.in_lds) {   // four slots per trip (slots past the row's end re-read its last edge and are not added): the walk is a
+            const int last = end - 1;   // chain of dependent LDS reads (index -> tile), four independent chains at a time
+            for (int p = beg; p < end; p += 4) {
+                int s_[4];
+                float2 a_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = min(p + u, last);
+                    s_[u] = cin.nb[q];
+                    a_[u] = cin.ea[q];
+                }
+                float4 q_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q_[u] = sg_ld4(l.Q + (size_t)s_[u] * SG_TW + tc);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float4 v = sg_add4(p4, q_[u]);
+                    v = sg_fma4(a_[u].x, w0, v);
+                    v = sg_fma4(a_[u].y, w1, v);
+                    const float4 r = sg_add4(acc, sg_relu4(v));
+                    const bool k = p + u < end;
+                    acc.x = k ? r.x : acc.x;
+                    acc.y = k ? r.y : acc.y;
+                    acc.z = k ? r.z : acc.z;
+                    acc.w = k ? r.w : acc.w;
+                }
+            }
+        } else {
+            for (int p = beg; p < end; ++p) {
+                int ls;
+                float2 a2;
+                csr_slot(cin, p, r0, nbr, a.ea_in, ls, a2);
+                float4 v = sg_add4(p4, sg_ld4(l.Q + (size_t)ls * SG_TW + tc));
+                v = sg_fma4(a2.x, w0, v);
+                v = sg_fma4(a2.y, w1, v);
+                acc = sg_add4(acc, sg_relu4(v));
+            }
         }
 #ifndef SG_EXP_NOSTORE
         sg_st4(a.S + o, acc);
@@ -360,6 +390,105 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
 }
 
 // ------------------------------------------------------------------------------------------------ backward
+// One row's two backward walks for one column chunk:
+//   by destination: dP[i] = sum_{e -> i} dh_e, dWe[f] += a_e[f] dh_e ;  by source: dQ[j] = sum_{e: src(e) = j} dh_e
+//   dh_e = dS[dst e] where the recomputed pre-activation P[dst] + Q[src] + a_e We is > 0
+// BOTH walks advance together, two slots each per trip (slots past a row's end re-read the block's last slot and contribute an
+// exact zero): the walk is a chain of dependent LDS reads (index -> tile), and four independent chains per trip instead of one
+// cut it from 9.2 to ~4 us per launch.  Sums stay in slot (= edge id) order.
+__device__ __forceinline__ void seg_bwd_row(const SegLds& l, const SegCsr& cin, const SegCsr& cout, int lr, int tc, float4 w0,
+                                            float4 w1, float4& accP, float4& accQ, float4& dwe0, float4& dwe1) {
+    const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tc), q4 = sg_ld4(l.Q + (size_t)lr * SG_TW + tc);
+    const float4 g4 = sg_ld4(l.D + (size_t)lr * SG_TW + tc);
+    accP = make_float4(0.f, 0.f, 0.f, 0.f);
+    accQ = accP;
+    const int b1 = cin.rp[lr], e1 = cin.rp[lr + 1], b2 = cout.rp[lr], e2 = cout.rp[lr + 1];
+    const int nit = max(e1 - b1, e2 - b2);
+    const int last1 = cin.ne - 1, last2 = cout.ne - 1;     // (nit > 0 implies both lists are non-empty for an undirected batch;
+    for (int t = 0; t < nit; t += 2) {                     //  a clamped -1 is excluded by the max below)
+        int s_[2], d_[2];
+        float2 ai[2], ao[2];
+        bool ki[2], ko[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pi = max(min(b1 + t + u, last1), 0), po = max(min(b2 + t + u, last2), 0);
+            ki[u] = b1 + t + u < e1;
+            ko[u] = b2 + t + u < e2;
+            s_[u] = cin.nb[pi];
+            ai[u] = cin.ea[pi];
+            d_[u] = cout.nb[po];
+            ao[u] = cout.ea[po];
+        }
+        float4 qs[2], pd[2], gd[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            qs[u] = sg_ld4(l.Q + (size_t)s_[u] * SG_TW + tc);
+            pd[u] = sg_ld4(l.P + (size_t)d_[u] * SG_TW + tc);
+            gd[u] = sg_ld4(l.D + (size_t)d_[u] * SG_TW + tc);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            float4 v = sg_add4(p4, qs[u]);
+            v = sg_fma4(ai[u].x, w0, v);
+            v = sg_fma4(ai[u].y, w1, v);
+            float4 dh;
+            dh.x = (ki[u] && v.x > 0.f) ? g4.x : 0.f;
+            dh.y = (ki[u] && v.y > 0.f) ? g4.y : 0.f;
+            dh.z = (ki[u] && v.z > 0.f) ? g4.z : 0.f;
+            dh.w = (ki[u] && v.w > 0.f) ? g4.w : 0.f;
+            accP = sg_add4(accP, dh);
+            dwe0 = sg_fma4(ai[u].x, dh, dwe0);
+            dwe1 = sg_fma4(ai[u].y, dh, dwe1);
+            float4 z = sg_add4(pd[u], q4);
+            z = sg_fma4(ao[u].x, w0, z);
+            z = sg_fma4(ao[u].y, w1, z);
+            accQ.x += (ko[u] && z.x > 0.f) ? gd[u].x : 0.f;
+            accQ.y += (ko[u] && z.y > 0.f) ? gd[u].y : 0.f;
+            accQ.z += (ko[u] && z.z > 0.f) ? gd[u].z : 0.f;
+            accQ.w += (ko[u] && z.w > 0.f) ? gd[u].w : 0.f;
+        }
+    }
+}
+// the same with the indices read from global memory (a block with more edges than its LDS slice holds)
+__device__ __forceinline__ void seg_bwd_row_slow(const SegLds& l, const SegCsr& cin, const SegCsr& cout, int lr, int tc, int r0,
+                                                 const int* __restrict__ in_src, const int* __restrict__ out_dst,
+                                                 const float* __restrict__ ea_in, const float* __restrict__ ea_out, float4 w0,
+                                                 float4 w1, float4& accP, float4& accQ, float4& dwe0, float4& dwe1) {
+    const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tc), q4 = sg_ld4(l.Q + (size_t)lr * SG_TW + tc);
+    const float4 g4 = sg_ld4(l.D + (size_t)lr * SG_TW + tc);
+    accP = make_float4(0.f, 0.f, 0.f, 0.f);
+    accQ = accP;
+    for (int p = cin.rp[lr]; p < cin.rp[lr + 1]; ++p) {
+        int ls;
+        float2 a2;
+        csr_slot(cin, p, r0, in_src, ea_in, ls, a2);
+        float4 v = sg_add4(p4, sg_ld4(l.Q + (size_t)ls * SG_TW + tc));
+        v = sg_fma4(a2.x, w0, v);
+        v = sg_fma4(a2.y, w1, v);
+        float4 dh;
+        dh.x = v.x > 0.f ? g4.x : 0.f;
+        dh.y = v.y > 0.f ? g4.y : 0.f;
+        dh.z = v.z > 0.f ? g4.z : 0.f;
+        dh.w = v.w > 0.f ? g4.w : 0.f;
+        accP = sg_add4(accP, dh);
+        dwe0 = sg_fma4(a2.x, dh, dwe0);
+        dwe1 = sg_fma4(a2.y, dh, dwe1);
+    }
+    for (int p = cout.rp[lr]; p < cout.rp[lr + 1]; ++p) {
+        int ld_;
+        float2 a2;
+        csr_slot(cout, p, r0, out_dst, ea_out, ld_, a2);
+        float4 v = sg_add4(sg_ld4(l.P + (size_t)ld_ * SG_TW + tc), q4);
+        v = sg_fma4(a2.x, w0, v);
+        v = sg_fma4(a2.y, w1, v);
+        const float4 gd = sg_ld4(l.D + (size_t)ld_ * SG_TW + tc);
+        accQ.x += v.x > 0.f ? gd.x : 0.f;
+        accQ.y += v.y > 0.f ? gd.y : 0.f;
+        accQ.z += v.z > 0.f ? gd.z : 0.f;
+        accQ.w += v.w > 0.f ? gd.w : 0.f;
+    }
+}
+
 template <bool DSG>
 __global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __restrict__ rp_in, const int* __restrict__ in_src,
@@ -381,7 +510,11 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     stage_csr(cout, r0, rows, cap, rp_out, out_dst, a.ea_out);
     stage_we(l.we, sc, a.w1, a.h, a.fi);
     // ---- P, Q slices -> LDS
+#ifndef SG_EXP_NOPQ
     for (int it = threadIdx.x; it < rows * sc.cw; it += SG_THREADS) {
+#else
+    for (int it = threadIdx.x; it < rows * sc.cw && rows > 100000; it += SG_THREADS) {
+#endif
         const int lr = it / sc.cw, lc = it - lr * sc.cw;
         const int tc = seg_tcol(sc, lc);
         const size_t o = (size_t)(r0 + lr) * a.ld + seg_gcol(sc, lc);
@@ -417,75 +550,52 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         if (sc.rem) seg_rem_cols<false>(a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, min(sc.remv, a.h - 32 * sc.nq), nullptr, l.D, nullptr);
     }
     __syncthreads();
-    // ---- walks.  Thread = (chunk lane lc = tid % CL, row lane ty = tid / CL), CL = 8 (16 in the block that also owns the trailing
-    // columns): a thread keeps ONE column chunk for all its rows, so the dWe partial sums stay in registers and the block emits
-    // one ordered partial per column.
-    const int cl_shift = sc.cw <= 8 ? 3 : 4, CL = 1 << cl_shift, RL = SG_THREADS >> cl_shift;
-    const int lc = threadIdx.x & (CL - 1), ty = threadIdx.x >> cl_shift;
-    const bool col_on = lc < sc.cw;
-    const int tc = col_on ? seg_tcol(sc, lc) : 0, gc = col_on ? seg_gcol(sc, lc) : 0;
-    const float4 w0 = sg_ld4(l.we + tc), w1 = sg_ld4(l.we + SG_TW + tc);
-    float4 dwe0 = make_float4(0.f, 0.f, 0.f, 0.f), dwe1 = dwe0;
-    if (col_on) {
-        for (int lr = ty; lr < rows; lr += RL) {
-            // by destination: dP[i] = sum_{e -> i} dh_e ; dWe[f] += a_e[f] dh_e
-            {
-                const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tc), g4 = sg_ld4(l.D + (size_t)lr * SG_TW + tc);
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int beg = cin.rp[lr], end = cin.rp[lr + 1];
-                for (int p = beg; p < end; ++p) {
-                    int ls;
-                    float2 a2;
-                    csr_slot(cin, p, r0, in_src, a.ea_in, ls, a2);
-                    float4 v = sg_add4(p4, sg_ld4(l.Q + (size_t)ls * SG_TW + tc));
-                    v = sg_fma4(a2.x, w0, v);
-                    v = sg_fma4(a2.y, w1, v);
-                    float4 dh;
-                    dh.x = v.x > 0.f ? g4.x : 0.f;
-                    dh.y = v.y > 0.f ? g4.y : 0.f;
-                    dh.z = v.z > 0.f ? g4.z : 0.f;
-                    dh.w = v.w > 0.f ? g4.w : 0.f;
-                    acc = sg_add4(acc, dh);
-                    dwe0 = sg_fma4(a2.x, dh, dwe0);
-                    dwe1 = sg_fma4(a2.y, dh, dwe1);
-                }
-                sg_st4(a.dP + (size_t)(r0 + lr) * a.ld + gc, acc);
-            }
-            // by source: dQ[j] = sum_{e: src(e) = j} dh_e
-            {
-                const float4 q4 = sg_ld4(l.Q + (size_t)lr * SG_TW + tc);
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                const int beg = cout.rp[lr], end = cout.rp[lr + 1];
-                for (int p = beg; p < end; ++p) {
-                    int ld_;
-                    float2 a2;
-                    csr_slot(cout, p, r0, out_dst, a.ea_out, ld_, a2);
-                    float4 v = sg_add4(sg_ld4(l.P + (size_t)ld_ * SG_TW + tc), q4);
-                    v = sg_fma4(a2.x, w0, v);
-                    v = sg_fma4(a2.y, w1, v);
-                    const float4 g4 = sg_ld4(l.D + (size_t)ld_ * SG_TW + tc);
-                    acc.x += v.x > 0.f ? g4.x : 0.f;
-                    acc.y += v.y > 0.f ? g4.y : 0.f;
-                    acc.z += v.z > 0.f ? g4.z : 0.f;
-                    acc.w += v.w > 0.f ? g4.w : 0.f;
-                }
-                sg_st4(a.dQ + (size_t)(r0 + lr) * a.ld + gc, acc);
-            }
+    // ---- walks.  Thread = (chunk lane lc = tid & 7, row lane ty = tid >> 3): a thread keeps ONE column chunk for all its rows, so
+    // the dWe partial sums stay in registers and the block emits one ordered partial per column.  The block that also owns the
+    // trailing columns walks that ninth chunk in a second, short pass (thread = row): as a ninth lane it halved the row lanes and
+    // made those blocks -- the launch's critical path -- twice as long.
+    auto walk_rows = [&](int lr0, int lr_step, int tc, int gc, float4& dwe0, float4& dwe1) {
+        const float4 w0 = sg_ld4(l.we + tc), w1 = sg_ld4(l.we + SG_TW + tc);
+        for (int lr = lr0; lr < rows; lr += lr_step) {
+            float4 accP, accQ;
+            if (cin.in_lds && cout.in_lds)
+                seg_bwd_row(l, cin, cout, lr, tc, w0, w1, accP, accQ, dwe0, dwe1);
+            else
+                seg_bwd_row_slow(l, cin, cout, lr, tc, r0, in_src, out_dst, a.ea_in, a.ea_out, w0, w1, accP, accQ, dwe0, dwe1);
+#ifndef SG_EXP_NOSTORE
+            sg_st4(a.dP + (size_t)(r0 + lr) * a.ld + gc, accP);
+            sg_st4(a.dQ + (size_t)(r0 + lr) * a.ld + gc, accQ);
+#else
+            if (accP.x == 123.456f) sg_st4(a.dP + (size_t)(r0 + lr) * a.ld + gc, accP);
+            if (accQ.x == 123.456f) sg_st4(a.dQ + (size_t)(r0 + lr) * a.ld + gc, accQ);
+#endif
         }
-    }
-    // ordered reduction of the dWe partials over the row lanes: inside a wave by a fixed xor tree over the lanes that share a
-    // chunk (lane bits above cl_shift), then over the 8 waves in wave order -> the block's partial [2][ld]
-    for (int off = 32; off >= CL; off >>= 1) {
-        dwe0.x += __shfl_xor(dwe0.x, off); dwe0.y += __shfl_xor(dwe0.y, off); dwe0.z += __shfl_xor(dwe0.z, off); dwe0.w += __shfl_xor(dwe0.w, off);
-        dwe1.x += __shfl_xor(dwe1.x, off); dwe1.y += __shfl_xor(dwe1.y, off); dwe1.z += __shfl_xor(dwe1.z, off); dwe1.w += __shfl_xor(dwe1.w, off);
-    }
-    if (lane < CL) {
+    };
+    const int cwm = sc.cw - (sc.rem ? 1 : 0);             // chunks of the 32-column quarter itself (<= 8)
+    const int lc = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    float4 dwe0 = make_float4(0.f, 0.f, 0.f, 0.f), dwe1 = dwe0, rwe0 = dwe0, rwe1 = dwe0;
+#ifndef SG_EXP_NOWALK
+    if (lc < cwm) walk_rows(ty, SG_THREADS / 8, 4 * lc, sc.col0 + 4 * lc, dwe0, dwe1);
+    if (sc.rem) walk_rows(threadIdx.x, SG_THREADS, 32, 32 * sc.nq, rwe0, rwe1);
+#endif
+    // ordered reduction of the dWe partials over the row lanes: inside a wave by a fixed xor tree (over the lanes that share a chunk:
+    // lane bits 3..5; all six bits for the trailing chunk), then over the 8 waves in wave order -> the block's partial [2][ld]
+    auto xor_sum = [&](float4& v, int off) {
+        v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off); v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+    };
+    for (int off = 32; off >= 8; off >>= 1) { xor_sum(dwe0, off); xor_sum(dwe1, off); }
+    if (sc.rem)
+        for (int off = 32; off >= 1; off >>= 1) { xor_sum(rwe0, off); xor_sum(rwe1, off); }
+    if (lane < 8) {
         l.part[(wave * 16 + lane) * 2] = dwe0;
         l.part[(wave * 16 + lane) * 2 + 1] = dwe1;
+    } else if (lane == 8) {
+        l.part[(wave * 16 + 8) * 2] = rwe0;
+        l.part[(wave * 16 + 8) * 2 + 1] = rwe1;
     }
     __syncthreads();
-    if (threadIdx.x < 2 * CL) {
-        const int f = threadIdx.x >> cl_shift, c2 = threadIdx.x & (CL - 1);
+    if (threadIdx.x < 32) {
+        const int f = threadIdx.x >> 4, c2 = threadIdx.x & 15;
         if (c2 < sc.cw) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int w = 0; w < SG_WAVES; ++w) s = sg_add4(s, l.part[(w * 16 + c2) * 2 + f]);

@@ -3,7 +3,7 @@
 # the timings mean something): where do the microseconds of a launch go?   gpurun -- tools/ubench/run_ea_seg_exp.sh
 R=$GRAFT_REPO_ROOT; C=$R/poweflownet_amd/csrc; cd $C
 export TMPDIR=/tmp
-for v in BASE NOMFMA NOWALK NOSTAGE NOLOAD NOSTORE "NOLOAD -DSG_EXP_NOMFMA" "NOLOAD -DSG_EXP_NOMFMA -DSG_EXP_NOSTAGE -DSG_EXP_NOWALK" "NOLOAD -DSG_EXP_NOMFMA -DSG_EXP_NOSTAGE -DSG_EXP_NOWALK -DSG_EXP_NOSTORE"; do
+for v in BASE NOMFMA NOLOAD NOWALK NOSTORE NOSTAGE NOPQ "NOWALK -DSG_EXP_NOSTORE -DSG_EXP_NOPQ -DSG_EXP_NOSTAGE" "NOWALK -DSG_EXP_NOSTORE -DSG_EXP_NOPQ -DSG_EXP_NOSTAGE -DSG_EXP_NOMFMA -DSG_EXP_NOLOAD"; do
   d=/tmp/exp_$(echo $v | tr -d ' -' ); mkdir -p $d
   cp -r $R/poweflownet_amd $R/bench.py $R/oracle $R/include $R/BASELINE.json $d/ 2>/dev/null
   ( cd $d/poweflownet_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DSG_EXP_$v -c ea_seg.hip -o ea_seg.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC graph.o edge.o gemm.o gemm_nt.o front.o ea_seg.o model.o physics.o prof.o -o libpfn_hip.so ) || exit 1
