@@ -1,0 +1,89 @@
+// MFMA tile building blocks of the graph-resident EdgeAggregation kernels (ea_seg.hip): A fragments in registers, one weight
+// quarter in LDS (LDS-DMA), one 32 x 32 fp32 tile per wave.
+#pragma once
+#include "pfn_internal.hpp"
+
+namespace pfn {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int SG_WAVES = 8;          // waves that share one seg_copy_b (ea_seg.hip: 512-thread blocks)
+
+// One 32 x 32 MFMA tile of  A[rows r_first..][0..K) * image quarter q  (K <= 136: one piece), written to an LDS tile.
+//   A  : row-major, lda floats per row, straight from global memory into registers (17 float4 per lane, all requested at once);
+//        the lane's row is clamped to r_last (results of clamped rows land in pad rows of the tile)
+//   B  : the quarter of the packed image (pack_job_body: group g = k / 4 -> [(q * G + g) * 128 + col * 4 + (k & 3)]), copied
+//        ONCE per block into LDS by LDS-DMA and shared by the row-tile waves (as per-lane register fragments every wave pulled its
+//        own 17 KB copy through L1: 11 of the kernel's 33 us)
+// The k order (chunk m, step i: lane half kh supplies k = 8m + 4kh + i) is gemm_nt's, so the tile sums are bit-identical to it.
+constexpr int SG_NCH = 17;           // eight-wide k chunks: K8 <= 136
+struct SegA { f32x4 av[SG_NCH]; };
+__device__ __forceinline__ void seg_load_a(SegA& t, const float* __restrict__ A, int lda, int K8, int r_first, int r_last, int lane) {
+    const int r32 = lane & 31, kh = lane >> 5;
+    const float* arow = A + (size_t)min(r_first + r32, r_last) * lda;
+    const int kmax = lda - 4;
+#pragma unroll
+    for (int m = 0; m < SG_NCH; ++m) {
+        const int mc = min(m, (K8 >> 3) - 1);                        // clamped: chunks past K8 are loaded but not multiplied
+#ifndef SG_EXP_NOLOAD   /* tools/ubench experiment switches (results wrong by design): never defined in the product build */
+        t.av[m] = *reinterpret_cast<const f32x4*>(arow + min(8 * mc + 4 * kh, kmax));
+#else
+        t.av[m] = f32x4{1.f * mc, 2.f, 3.f, 4.f};
+#endif
+    }
+}
+// One 1 KiB LDS-DMA (64 lanes x 16 bytes; LDS destination = wave-uniform base + lane * 16); inline asm as in gemm_nt.hip: hidden
+// from the compiler, waited for by hand (seg_dma_wait) before the barrier that publishes the copy
+__device__ __forceinline__ void seg_dma_1k(const char* g, float* lds_dst) {
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)((__attribute__((address_space(3))) float*)lds_dst));
+    uint32_t keep;
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(g), "s"(m0v)
+        : "memory");
+}
+__device__ __forceinline__ void seg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// quarter q of a packed image (G * 128 floats, whole KiBs) -> LDS, the 1 KiB pieces dealt round-robin to the block's waves
+__device__ __forceinline__ void seg_copy_b(float* dst, const float* __restrict__ Bp, int q, int K8, int wave, int lane,
+                                           int nwaves = SG_WAVES) {
+    const int nfl = (K8 >> 2) * 128;
+    const char* src = reinterpret_cast<const char*>(Bp + (size_t)q * nfl) + lane * 16;
+    for (int off = wave * 256; off < nfl; off += nwaves * 256) seg_dma_1k(src + (size_t)off * 4, dst + off);
+}
+// (one accumulator chain: a second, independent one changed nothing -- the MFMA pipe is shared by 2-4 waves per SIMD here, and
+//  tools/ubench/mfma_peak.hip reaches 147 TF with a single dependent chain per wave)
+template <bool FULL>   // FULL: K8 == 136, all 17 chunks live -> straight-line code (the per-chunk guards cost ~50 SGPRs of branch state)
+__device__ __forceinline__ f32x16 seg_mma_t(const SegA& t, const float* bl, int K8, int lane) {
+    const int r32 = lane & 31, kh = lane >> 5;
+    const float* bp = bl + kh * 128 + r32 * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    f32x4 b = *reinterpret_cast<const f32x4*>(bp);
+#pragma unroll
+    for (int m = 0; m < SG_NCH; ++m) {
+        if (FULL || 8 * m < K8) {
+            f32x4 bn = b;
+            if (FULL ? m + 1 < SG_NCH : 8 * (m + 1) < K8) bn = *reinterpret_cast<const f32x4*>(bp + (m + 1) * 256);
+#pragma unroll
+#ifndef SG_EXP_NOMFMA
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.av[m][i], b[i], acc, 0, 0, 0);
+#else
+            for (int i = 0; i < 4; ++i) acc[i] += t.av[m][i] * b[i];
+#endif
+            b = bn;
+        }
+    }
+    return acc;
+}
+__device__ __forceinline__ f32x16 seg_mma(const SegA& t, const float* bl, int K8, int lane) {
+    return K8 == 8 * SG_NCH ? seg_mma_t<true>(t, bl, K8, lane) : seg_mma_t<false>(t, bl, K8, lane);
+}
+
+}  // namespace pfn
