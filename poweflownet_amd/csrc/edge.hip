@@ -155,9 +155,29 @@ __global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_
             const int beg = s_rp[lr], end = s_rp[lr + 1];
             const float di = s_dinv[lr];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int p = beg; p < end; ++p) {
-                const int ls = nb_in_lds ? s_nb[p] : nbr[e0 + p] - r0;
-                acc = fma4(s_dinv[ls] * di, ld4(cur + (size_t)ls * tld + 4 * lc), acc);
+            if (nb_in_lds) {   // four slots per trip (see hop_kernel): index -> (dinv, row) is a chain of dependent LDS reads
+                const int last = end - 1;
+                for (int p = beg; p < end; p += 4) {
+                    int s_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s_[u] = s_nb[min(p + u, last)];
+                    float w_[4];
+                    float4 v_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        w_[u] = s_dinv[s_[u]] * di;
+                        v_[u] = ld4(cur + (size_t)s_[u] * tld + 4 * lc);
+                    }
+                    acc = fma4(w_[0], v_[0], acc);
+                    acc = sel4(p + 1 < end, fma4(w_[1], v_[1], acc), acc);
+                    acc = sel4(p + 2 < end, fma4(w_[2], v_[2], acc), acc);
+                    acc = sel4(p + 3 < end, fma4(w_[3], v_[3], acc), acc);
+                }
+            } else {
+                for (int p = beg; p < end; ++p) {
+                    const int ls = nbr[e0 + p] - r0;
+                    acc = fma4(s_dinv[ls] * di, ld4(cur + (size_t)ls * tld + 4 * lc), acc);
+                }
             }
             const size_t o = (size_t)(r0 + lr) * a.ld + 4 * (c0 + lc);
             if (addp) acc = add4(acc, ld4(addp + o));
