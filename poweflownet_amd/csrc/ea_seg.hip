@@ -567,7 +567,7 @@ int launch_ea_seg_fwd(const GraphView& g, const EaSegFwdArgs& a, int seg, hipStr
     }
     static std::atomic<uint64_t> raised{0};
     PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(ea_seg_fwd_kernel), SG_LDS_BYTES, raised));
-    ProfScope ps("ea_seg_fwd", 0.0, 0.0, s);
+    ProfScope ps("ea_seg_fwd", 0.0, 4.0 * g.n * (double)a.K * a.h, s);   // (the P | Q GEMM's flops; the walk is LDS work)
     ea_seg_fwd_kernel<<<dim3(p.nblocks, p.ny), SG_THREADS, seg_lds_bytes(p.trows, p.rows_pb, p.cap, false), s>>>(
         g.n, p.rows_pb, p.trows, p.cap, g.rowptr_in, g.in_src, a);
     PFN_CHECK_LAUNCH();
@@ -583,7 +583,7 @@ int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStr
     const size_t lds = seg_lds_bytes(p.trows, p.rows_pb, p.cap, true);
     const bool dsg = a.Bd == nullptr;
     static std::atomic<uint64_t> raised0{0}, raised1{0};
-    ProfScope ps("ea_seg_bwd", 0.0, 0.0, s);
+    ProfScope ps("ea_seg_bwd", 0.0, a.Bd ? 2.0 * g.n * (double)a.fo * a.h : 0.0, s);
     if (dsg) {
         PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(ea_seg_bwd_kernel<true>), SG_LDS_BYTES, raised1));
         ea_seg_bwd_kernel<true><<<dim3(p.nblocks, p.ny), SG_THREADS, lds, s>>>(g.n, p.rows_pb, p.trows, p.cap, g.rowptr_in, g.in_src,
