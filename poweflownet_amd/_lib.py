@@ -30,11 +30,11 @@ class MpnConfig(C.Structure):
     """struct pfn_mpn_config."""
     _fields_ = [("nfeature_dim", C.c_int32), ("efeature_dim", C.c_int32), ("output_dim", C.c_int32),
                 ("hidden_dim", C.c_int32), ("n_gnn_layers", C.c_int32), ("K", C.c_int32),
-                ("dropout_rate", C.c_float), ("training", C.c_int32)]
+                ("dropout_rate", C.c_float), ("training", C.c_int32), ("need_backward", C.c_int32)]
 
 
 _lib = None
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def load() -> C.CDLL:

@@ -25,6 +25,12 @@ __device__ __forceinline__ float4 fma4(float a, float4 x, float4 acc) {
 }
 __device__ __forceinline__ float4 mul4(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
 __device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ unsigned char relu_bits(float4 v) {   // bit i = component i > 0 (the edge stage's ReLU mask)
+    return (unsigned char)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
+}
+__device__ __forceinline__ float4 mask4(unsigned m, float4 g) {   // g where the mask bit is set, else 0
+    return make_float4((m & 1) ? g.x : 0.f, (m & 2) ? g.y : 0.f, (m & 4) ? g.z : 0.f, (m & 8) ? g.w : 0.f);
+}
 __device__ __forceinline__ float4 sel4(bool k, float4 a, float4 b) { return make_float4(k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z, k ? a.w : b.w); }
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
 
@@ -252,12 +258,19 @@ __device__ __forceinline__ void stage_w2(float* w2s, const float* __restrict__ w
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
 
 // S[row][col..col+3] for one (row, column chunk): the walk over the row's incoming edges
-template <int FE>
+template <int FE, bool MASK>   // MASK: also save the ReLU masks (EdgeFwdArgs::mask) -- a backward pass will follow
 __device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored, const int* __restrict__ rowptr,
                                                  const int* __restrict__ nbr, const int* __restrict__ eid,
                                                  const float* __restrict__ P, const float* __restrict__ Q,
-                                                 const float* __restrict__ ea, const float* we, int ld, int fe) {
+                                                 const float* __restrict__ ea, const float* we, int ld, int fe,
+                                                 unsigned* __restrict__ mask, const int* __restrict__ rp4) {
     const float4 p4 = ld4(P + (size_t)row * ld + col);
+    // this (row, chunk)'s run of mask dwords (EdgeFwdArgs::mask): one dword per trip of four slots
+    unsigned* mrun = nullptr;
+    if (MASK) {
+        const int b4 = rp4[row];
+        mrun = mask + (size_t)b4 * (ld >> 2) + (size_t)(col >> 2) * (rp4[row + 1] - b4);
+    }
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     const int beg = rowptr[row], end = rowptr[row + 1];
     if (FE == 2) {
@@ -280,13 +293,16 @@ __device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored,
                 q_[u] = ld4(Q + (size_t)s_[u] * ld + col);
                 a_[u] = *reinterpret_cast<const float2*>(ea + (size_t)id_[u] * 2);
             }
+            unsigned mword = 0u;
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 float4 v = add4(p4, q_[u]);
                 v = fma4(a_[u].x, w0, v);
                 v = fma4(a_[u].y, w1, v);
                 acc = sel4(p + u < end, add4(acc, relu4(v)), acc);
+                if (MASK) mword |= (p + u < end ? (unsigned)relu_bits(v) : 0u) << (8 * u);
             }
+            if (MASK) mrun[(p - beg) >> 2] = mword;
         }
     } else {
         for (int p = beg; p < end; ++p) {
@@ -296,17 +312,19 @@ __device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored,
             float4 v = add4(p4, ld4(Q + (size_t)s * ld + col));
             for (int f = 0; f < fe; ++f) v = fma4(ea[(size_t)id * fe + f], ld4(we + f * ld + col), v);
             acc = add4(acc, relu4(v));
+            if (MASK) reinterpret_cast<unsigned char*>(mrun)[p - beg] = relu_bits(v);   // (generic Fe: byte by byte)
         }
     }
     return acc;
 }
 
-template <int FE>
+template <int FE, bool MASK>
 __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_stored, const int* __restrict__ rowptr,
                                                        const int* __restrict__ nbr, const int* __restrict__ eid,
                                                        const float* __restrict__ P, const float* __restrict__ Q,
                                                        const float* __restrict__ ea, const float* __restrict__ w1,
-                                                       float* __restrict__ S, int ld, int h, int fi, int fe_rt) {
+                                                       float* __restrict__ S, int ld, int h, int fi, int fe_rt,
+                                                       unsigned* __restrict__ mask, const int* __restrict__ rp4) {
     extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld]
     const int fe = FE > 0 ? FE : fe_rt;
     const int ldw = 2 * fi + fe;
@@ -319,7 +337,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
     const int row = (int)(item / nchunk);
     if (row >= n) return;
     const int col = (int)(item - (long)row * nchunk) * 4;
-    st4(S + (size_t)row * ld + col, edge_sum_chunk<FE>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe));
+    st4(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, rp4));
 }
 
 // The network's LAST EdgeAggregation layer (Fo <= 4, no activation): the second Linear rides in the same launch.  Block =
@@ -327,7 +345,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
 // column chunk (registers), and the row's nchunk float4 partials are added in a FIXED two-level order:
 //   out[row][o] = sum_u S[row][u] W2[o][u] + deg[row] * b2[o]
 // S is still written (the backward pairs it with gout for dW2).  LDS: we[FE][ld] | part[rows_pb][nchunk] float4.
-template <int FE>
+template <int FE, bool MASK>
 __global__ __launch_bounds__(256) void edge_fwd_out_kernel(int n, int nchunk, int rows_pb, int e_stored,
                                                            const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                            const int* __restrict__ eid, const float* __restrict__ P,
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(256) void edge_fwd_out_kernel(int n, int nchunk, in
                                                            const float* __restrict__ w1, float* __restrict__ S,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
                                                            const float* __restrict__ deg, float* __restrict__ out, int ld,
-                                                           int h, int fi, int fo) {
+                                                           int h, int fi, int fo, unsigned* __restrict__ mask, const int* __restrict__ rp4) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* we = smem;
     float* w2s = smem + FE * ld;
@@ -351,7 +369,7 @@ __global__ __launch_bounds__(256) void edge_fwd_out_kernel(int n, int nchunk, in
     const bool on = r < rows_pb && row < n;
     __syncthreads();
     if (on) {
-        const float4 s4 = edge_sum_chunk<FE>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, FE);
+        const float4 s4 = edge_sum_chunk<FE, MASK>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, FE, mask, rp4);
         st4(S + (size_t)row * ld + col, s4);
         float4 o;
         o.x = dot4(s4, ld4(w2s + col));
@@ -385,18 +403,26 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
     if (a.out) {   // last layer: S and out = S W2^T + deg b2 in one launch (edge_fwd_out_ok)
         const int rows_pb = 256 / nchunk;
         const size_t lds_out = lds + (size_t)4 * a.ld * sizeof(float) + (size_t)rows_pb * nchunk * sizeof(float4);
-        edge_fwd_out_kernel<2><<<(g.n + rows_pb - 1) / rows_pb, 256, lds_out, s>>>(
-            g.n, nchunk, rows_pb, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.edge_attr, a.w1, a.S, a.w2, a.b2,
-            g.deg, a.out, a.ld, a.h, a.fi, a.fo);
+        const dim3 grid_out((g.n + rows_pb - 1) / rows_pb);
+        if (a.mask)
+            edge_fwd_out_kernel<2, true><<<grid_out, 256, lds_out, s>>>(g.n, nchunk, rows_pb, g.e_stored, g.rowptr_in, g.in_src, g.in_eid,
+                                                                      a.P, a.Q, a.edge_attr, a.w1, a.S, a.w2, a.b2, g.deg, a.out, a.ld,
+                                                                      a.h, a.fi, a.fo, a.mask, g.rp4);
+        else
+            edge_fwd_out_kernel<2, false><<<grid_out, 256, lds_out, s>>>(g.n, nchunk, rows_pb, g.e_stored, g.rowptr_in, g.in_src, g.in_eid,
+                                                                       a.P, a.Q, a.edge_attr, a.w1, a.S, a.w2, a.b2, g.deg, a.out, a.ld,
+                                                                       a.h, a.fi, a.fo, nullptr, nullptr);
         PFN_CHECK_LAUNCH();
         return PFN_OK;
     }
-    if (a.fe == 2)
-        edge_fwd_kernel<2><<<blocks, 256, lds, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q,
-                                                    a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe);
-    else
-        edge_fwd_kernel<0><<<blocks, 256, lds, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q,
-                                                    a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe);
+#define PFN_EDGE_FWD(FE_, M_)                                                                                                  \
+    edge_fwd_kernel<FE_, M_><<<blocks, 256, lds, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q,          \
+                                                      a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe, a.mask, g.rp4)
+    if (a.fe == 2 && a.mask) PFN_EDGE_FWD(2, true);
+    else if (a.fe == 2) PFN_EDGE_FWD(2, false);
+    else if (a.mask) PFN_EDGE_FWD(0, true);
+    else PFN_EDGE_FWD(0, false);
+#undef PFN_EDGE_FWD
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
@@ -585,6 +611,137 @@ __device__ __forceinline__ void edge_bwd_src_body(int bid, int n, int nchunk, in
     st4(dQ + (size_t)row * ld + col, acc);
 }
 
+// ---- the same two walks reading the forward pass's ReLU masks (Fe = 2): dh_e = dS[dst e] where the saved mask bit is set.
+// Nothing is recomputed, so P, Q, the residue weights and (in the by-source half) the edge attributes are never touched: the
+// kernel gathers dS rows only.  Four slots per trip again (no Q rows to hold).
+template <bool DSG>
+__device__ __forceinline__ void edge_bwd_dst_body_mask(int bid, int nblk, int n, int nchunk, int bdx, int bdy, int e_stored,
+                                                       const int* __restrict__ rowptr, const int* __restrict__ eid,
+                                                       const float* __restrict__ dS, const float* __restrict__ ea,
+                                                       const unsigned* __restrict__ mask, const int* __restrict__ rp4,
+                                                       float* __restrict__ dP,
+                                                       float* __restrict__ dWe_partial, int ld, int h,
+                                                       const float* __restrict__ w2, int fo) {
+    constexpr int FE = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // (we[FE][ld] unused) | part[256][FE] float4 | w2s
+    float4* part = reinterpret_cast<float4*>(smem + FE * ld);
+    float* w2s = smem + FE * ld + 256 * FE * 4;
+    if (DSG) stage_w2(w2s, w2, h, fo, ld);
+    __syncthreads();
+    const int ty = threadIdx.x / bdx, tx = threadIdx.x - ty * bdx;
+    const bool active = ty < bdy;
+    for (int c0 = 0; c0 < nchunk; c0 += bdx) {
+        const int c = c0 + tx, col = 4 * c;
+        float4 dwe[FE];
+#pragma unroll
+        for (int f = 0; f < FE; ++f) dwe[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active && c < nchunk) {
+            for (int row = bid * bdy + ty; row < n; row += nblk * bdy) {
+                const float4 g4 = ds_row<DSG>(dS, row, ld, col, w2s);
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int beg = rowptr[row], end = rowptr[row + 1];
+                const int b4 = rp4[row];
+                const unsigned* mrun = mask + (size_t)b4 * nchunk + (size_t)c * (rp4[row + 1] - b4);
+                for (int p = beg; p < end; p += 4) {
+                    const int last = end - 1;
+                    const unsigned mword = mrun[(p - beg) >> 2];     // (bytes of slots past the row's end are zero)
+                    unsigned m_[4];
+                    float2 a_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int q = min(p + u, last);
+                        m_[u] = (mword >> (8 * u)) & 0xffu;
+                        const int id = eid[q];
+                        a_[u] = *reinterpret_cast<const float2*>(ea + (size_t)(id >= e_stored ? id - e_stored : id) * 2);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float4 dh = mask4(m_[u], g4);
+                        acc = add4(acc, dh);
+                        dwe[0] = fma4(a_[u].x, dh, dwe[0]);
+                        dwe[1] = fma4(a_[u].y, dh, dwe[1]);
+                    }
+                }
+                st4(dP + (size_t)row * ld + col, acc);
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int f = 0; f < FE; ++f) part[threadIdx.x * FE + f] = dwe[f];
+        }
+        __syncthreads();
+        if (ty == 0 && c < nchunk) {
+            float4 sum[FE];
+#pragma unroll
+            for (int f = 0; f < FE; ++f) sum[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int y = 0; y < bdy; ++y) {
+#pragma unroll
+                for (int f = 0; f < FE; ++f) sum[f] = add4(sum[f], part[(y * bdx + tx) * FE + f]);
+            }
+#pragma unroll
+            for (int f = 0; f < FE; ++f) st4(dWe_partial + ((size_t)bid * FE + f) * ld + col, sum[f]);
+        }
+        __syncthreads();
+    }
+}
+
+template <bool DSG>
+__device__ __forceinline__ void edge_bwd_src_body_mask(int bid, int n, int nchunk, const int* __restrict__ rowptr,
+                                                       const int* __restrict__ nbr, const int* __restrict__ out_mbase,
+                                                       const int* __restrict__ out_ml4k, const float* __restrict__ dS,
+                                                       const unsigned* __restrict__ mask,
+                                                       float* __restrict__ dQ, int ld, int h, const float* __restrict__ w2,
+                                                       int fo) {
+    extern __shared__ __attribute__((aligned(16))) float we[];
+    float* w2s = we + 2 * ld;
+    if (DSG) stage_w2(w2s, w2, h, fo, ld);
+    __syncthreads();
+    const long item = (long)bid * blockDim.x + threadIdx.x;
+    const int row = (int)(item / nchunk);
+    if (row >= n) return;
+    const int c = (int)(item - (long)row * nchunk), col = 4 * c;
+    const unsigned char* mbytes = reinterpret_cast<const unsigned char*>(mask);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = rowptr[row], end = rowptr[row + 1];
+    for (int p = beg; p < end; p += 4) {
+        const int last = end - 1;
+        int d_[4];
+        unsigned m_[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = min(p + u, last);
+            d_[u] = nbr[q];
+            const int l4k = out_ml4k[q];                             // (ceil(deg_dst / 4) << 16) | position among dst's incoming edges
+            const size_t at = ((size_t)out_mbase[q] * nchunk + (size_t)c * (l4k >> 16)) * 4 + (l4k & 0xffff);
+            m_[u] = p + u < end ? mbytes[at] : 0u;
+        }
+        float4 g_[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) g_[u] = ds_row<DSG>(dS, d_[u], ld, col, w2s);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = add4(acc, mask4(m_[u], g_[u]));
+    }
+    st4(dQ + (size_t)row * ld + col, acc);
+}
+
+template <bool DSG>
+__global__ __launch_bounds__(256) void edge_bwd_mask_kernel(int nb_dst, int n, int nchunk, int bdx, int bdy, int e_stored,
+                                                            const int* __restrict__ rp_in, const int* __restrict__ in_eid,
+                                                            const int* __restrict__ rp_out, const int* __restrict__ out_dst,
+                                                            const int* __restrict__ out_mbase, const int* __restrict__ out_ml4k,
+                                                            const int* __restrict__ rp4, const float* __restrict__ dS,
+                                                            const float* __restrict__ ea, const unsigned* __restrict__ mask,
+                                                            float* __restrict__ dP, float* __restrict__ dQ,
+                                                            float* __restrict__ dWe_partial, int ld, int h,
+                                                            const float* __restrict__ w2, int fo) {
+    if ((int)blockIdx.x < nb_dst)
+        edge_bwd_dst_body_mask<DSG>(blockIdx.x, nb_dst, n, nchunk, bdx, bdy, e_stored, rp_in, in_eid, dS, ea, mask, rp4, dP,
+                                    dWe_partial, ld, h, w2, fo);
+    else
+        edge_bwd_src_body_mask<DSG>(blockIdx.x - nb_dst, n, nchunk, rp_out, out_dst, out_mbase, out_ml4k, dS, mask, dQ, ld, h, w2,
+                                    fo);
+}
+
 // One launch for both halves of the EdgeAggregation backward: blocks [0, nb_dst) walk the by-destination CSR (dP, dWe
 // partials; block-persistent), the rest walk the by-source CSR (dQ).  Both halves are latency-bound at small batches; in
 // one grid they overlap instead of paying two launch floors.
@@ -630,6 +787,20 @@ static int launch_edge_bwd_fe(const GraphView& g, const EdgeBwdArgs& a, hipStrea
     const long items = (long)g.n * nchunk;
     const int nb_src = (int)((items + 255) / 256);
     ProfScope ps("edge_bwd", 0.0, 0.0, s);
+    if (FE == 2 && a.mask) {
+        if (a.gout)
+            edge_bwd_mask_kernel<true><<<nb_dst + nb_src, 256, lds_dst, s>>>(nb_dst, g.n, nchunk, bdx, bdy, g.e_stored, g.rowptr_in,
+                                                                           g.in_eid, g.rowptr_out, g.out_dst, g.out_mbase, g.out_ml4k,
+                                                                           g.rp4, a.gout, a.edge_attr, a.mask, a.dP, a.dQ,
+                                                                           a.dWe_partial, a.ld, a.h, a.w2, a.fo);
+        else
+            edge_bwd_mask_kernel<false><<<nb_dst + nb_src, 256, lds_dst, s>>>(nb_dst, g.n, nchunk, bdx, bdy, g.e_stored, g.rowptr_in,
+                                                                            g.in_eid, g.rowptr_out, g.out_dst, g.out_mbase, g.out_ml4k,
+                                                                            g.rp4, a.dS, a.edge_attr, a.mask, a.dP, a.dQ,
+                                                                            a.dWe_partial, a.ld, a.h, nullptr, 0);
+        PFN_CHECK_LAUNCH();
+        return PFN_OK;
+    }
     if (a.gout)
         edge_bwd_kernel<FE, true><<<nb_dst + nb_src, 256, lds_dst, s>>>(
             nb_dst, g.n, nchunk, bdx, bdy, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, g.rowptr_out, g.out_dst, g.out_eid, a.P,

@@ -60,6 +60,10 @@ GraphView graph_view(void* ws, int64_t n, int64_t e) {
     g.in_eid = c.take<int>(2 * e + 1);
     g.out_dst = c.take<int>(2 * e + 1);
     g.out_eid = c.take<int>(2 * e + 1);
+    g.rp4 = c.take<int>(n + 1);
+    g.out_mbase = c.take<int>(2 * e + 1);
+    g.out_ml4k = c.take<int>(2 * e + 1);
+    g.slot_of_eid = c.take<int>(2 * e + 1);
     g.cur_in = c.take<int>(n + 1);
     g.cur_out = c.take<int>(n + 1);
     g.deg = c.take<float>(n + 1);
@@ -89,15 +93,17 @@ __global__ __launch_bounds__(256) void graph_hist_kernel(const int64_t* __restri
 // Pass 2 (single block): decide `directed`, form in/out degrees, exclusive-scan them into the two
 // rowptr arrays, emit deg / deg^-1/2, and clear the histograms so pass 3 can reuse them as cursors.
 __global__ __launch_bounds__(1024) void graph_scan_kernel(int n, int e, int mode, int* cnt_dst, int* cnt_src,
-                                                          int* rowptr_in, int* rowptr_out, float* deg, float* dinv,
+                                                          int* rowptr_in, int* rowptr_out, int* rp4, float* deg, float* dinv,
                                                           int* flags) {
-    __shared__ int wsum_in[16], wsum_out[16];
-    __shared__ int carry_in, carry_out;
+    // rp4: prefix sum of ceil(in-degree / 4) -- the row offsets (in dwords per column chunk) of the edge stage's ReLU masks
+    __shared__ int wsum_in[16], wsum_out[16], wsum_4[16];
+    __shared__ int carry_in, carry_out, carry_4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int directed = (mode == 1) ? 1 : (mode == 0 ? 0 : (e > 0 && flags[3] == 0));
     if (tid == 0) {
         carry_in = 0;
         carry_out = 0;
+        carry_4 = 0;
         flags[0] = directed;
         flags[1] = directed ? 2 * e : e;
     }
@@ -114,39 +120,46 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int n, int e, int mode
             deg[i] = (float)di;
             dinv[i] = di > 0 ? 1.0f / sqrtf((float)di) : 0.0f;
         }
-        int si = di, so = dout;   // inclusive wave scan
+        const int d4 = (di + 3) >> 2;
+        int si = di, so = dout, s4 = d4;   // inclusive wave scan
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
-            const int ti = __shfl_up(si, off), to = __shfl_up(so, off);
+            const int ti = __shfl_up(si, off), to = __shfl_up(so, off), t4 = __shfl_up(s4, off);
             if (lane >= off) {
                 si += ti;
                 so += to;
+                s4 += t4;
             }
         }
         if (lane == 63) {
             wsum_in[wave] = si;
             wsum_out[wave] = so;
+            wsum_4[wave] = s4;
         }
         __syncthreads();
-        int pre_in = carry_in, pre_out = carry_out;
+        int pre_in = carry_in, pre_out = carry_out, pre_4 = carry_4;
         for (int w = 0; w < wave; ++w) {
             pre_in += wsum_in[w];
             pre_out += wsum_out[w];
+            pre_4 += wsum_4[w];
         }
         if (i < n) {
             rowptr_in[i] = pre_in + si - di;
             rowptr_out[i] = pre_out + so - dout;
+            rp4[i] = pre_4 + s4 - d4;
         }
         __syncthreads();
         if (tid == 1023) {
             carry_in = pre_in + si;
             carry_out = pre_out + so;
+            carry_4 = pre_4 + s4;
         }
         __syncthreads();
     }
     if (tid == 0) {
         rowptr_in[n] = carry_in;
         rowptr_out[n] = carry_out;
+        rp4[n] = carry_4;
     }
 }
 
@@ -240,6 +253,27 @@ size_t pfn_graph_workspace_bytes(int64_t n, int64_t e) {
     return graph_view(nullptr, n, e).bytes;
 }
 
+// where the backward by-source walk finds an edge's ReLU mask (see EdgeFwdArgs::mask): by-destination slot per edge id first (edge
+// ids are unique per directed edge), then per by-source slot the destination row's mask offset and the edge's position in it
+__global__ __launch_bounds__(256) void graph_slot_of_eid_kernel(int n, const int* __restrict__ rowptr_in,
+                                                                const int* __restrict__ in_eid, int* __restrict__ slot_of_eid) {
+    const int nslot = rowptr_in[n];
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nslot; p += gridDim.x * blockDim.x) slot_of_eid[in_eid[p]] = p;
+}
+__global__ __launch_bounds__(256) void graph_mask_index_kernel(int n, const int* __restrict__ rowptr_in,
+                                                               const int* __restrict__ rowptr_out, const int* __restrict__ out_dst,
+                                                               const int* __restrict__ out_eid, const int* __restrict__ slot_of_eid,
+                                                               const int* __restrict__ rp4, int* __restrict__ out_mbase,
+                                                               int* __restrict__ out_ml4k) {
+    const int nslot = rowptr_out[n];
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nslot; p += gridDim.x * blockDim.x) {
+        const int d = out_dst[p];
+        const int k = slot_of_eid[out_eid[p]] - rowptr_in[d];       // position of the edge among d's incoming edges
+        out_mbase[p] = rp4[d];
+        out_ml4k[p] = ((rp4[d + 1] - rp4[d]) << 16) | (k & 0xffff);
+    }
+}
+
 int pfn_graph_build(const int64_t* edge_index, int64_t e, int64_t n, int mode, void* ws, size_t ws_bytes,
                     void* stream) {
     PFN_CHECK_ARG(n >= 0 && e >= 0, "pfn_graph_build: negative sizes");
@@ -262,7 +296,7 @@ int pfn_graph_build(const int64_t* edge_index, int64_t e, int64_t n, int mode, v
         graph_hist_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.cur_in, g.cur_out, g.flags);
         PFN_CHECK_LAUNCH();
     }
-    graph_scan_kernel<<<1, 1024, 0, s>>>(in, ie, mode, g.cur_in, g.cur_out, g.rowptr_in, g.rowptr_out, g.deg, g.dinv,
+    graph_scan_kernel<<<1, 1024, 0, s>>>(in, ie, mode, g.cur_in, g.cur_out, g.rowptr_in, g.rowptr_out, g.rp4, g.deg, g.dinv,
                                          g.flags);
     PFN_CHECK_LAUNCH();
     if (ie > 0) {
@@ -272,6 +306,12 @@ int pfn_graph_build(const int64_t* edge_index, int64_t e, int64_t n, int mode, v
         PFN_CHECK_LAUNCH();
         graph_sort_rows_kernel<<<(2 * in + 255) / 256, 256, 0, s>>>(in, g.rowptr_in, g.rowptr_out, g.in_src, g.in_eid,
                                                                    g.out_dst, g.out_eid);
+        PFN_CHECK_LAUNCH();
+        const int sblocks = (int)std::min<int64_t>((2 * e + 255) / 256, 2048);
+        graph_slot_of_eid_kernel<<<sblocks, 256, 0, s>>>(in, g.rowptr_in, g.in_eid, g.slot_of_eid);
+        PFN_CHECK_LAUNCH();
+        graph_mask_index_kernel<<<sblocks, 256, 0, s>>>(in, g.rowptr_in, g.rowptr_out, g.out_dst, g.out_eid, g.slot_of_eid, g.rp4,
+                                                        g.out_mbase, g.out_ml4k);
         PFN_CHECK_LAUNCH();
     }
     return PFN_OK;

@@ -111,7 +111,7 @@ static bool back_fused_ok() {
 static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
                       const float* w1, const float* b1, const float* w2, const float* b2, const EaPack& pw, float* out, int ldo,
                       const Act& act, const EaSaved& sv, hipStream_t s, bool pq_ready = false, int seg = 0,
-                      const float* ea_in = nullptr) {
+                      const float* ea_in = nullptr, unsigned* relu_mask = nullptr) {
     const int ld = ld_of(h);
     // batches of small graphs: the P | Q GEMM and the edge walk in one launch, graph-resident in LDS (ea_seg.hip)
     const bool seg_walk = !pq_ready && ea_in && ea_seg_fit(seg, g.n, fe, ld, false);
@@ -134,6 +134,7 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
     const bool out_in_walk = !seg_walk && w2 && act.act == ACT_NONE && edge_fwd_out_ok(fe, h, fo, ldo) && back_fused_ok();
     if (!seg_walk) {
         EdgeFwdArgs e{sv.P, sv.Q, ea, w1, sv.S, ld, h, fi, fe};
+        e.mask = relu_mask;   // (a backward pass will follow: it reads the masks instead of recomputing the pre-activations)
         if (out_in_walk) {
             e.out = out;
             e.w2 = w2;
@@ -162,7 +163,7 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
                        const float* w1, const float* w2, const EaPack& pw, const float* gout, int ldgo, const Gate& gate, float* gx,
                        int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
                        const EaScratch& sc, hipStream_t s, PairList* defer, int seg = 0, const float* ea_in = nullptr,
-                       const float* ea_out = nullptr) {
+                       const float* ea_out = nullptr, const unsigned* relu_mask = nullptr) {
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
     // batches of small graphs: the dS GEMM and both backward walks in one launch, graph-resident in LDS (ea_seg.hip)
     const bool seg_walk = !gea && ea_in && ea_out && ea_seg_fit(seg, g.n, fe, ld, true) && (fo > 4 || ldgo == 4);
@@ -182,6 +183,7 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         PFN_TRY(launch_gemm_nt(a, s));
     }
     EdgeBwdArgs e{sv.P, sv.Q, sc.dS, ea, w1, sc.dP, sc.dQ, sc.dWe, gea, ld, h, fi, fe};
+    if (!gea && fe == 2) e.mask = relu_mask;   // written by this layer's generic forward walk (ea_fwd_saves_mask)
     if (ds_in_walk) {
         e.gout = gout;
         e.w2 = w2;
@@ -337,6 +339,7 @@ struct Layout {
     // forward-saved
     float *maskf, *me_h, *x0, *packed;
     float *ea_in, *ea_out;       // edge attributes in CSR slot order (Fe = 2; SlotEa), filled once per forward
+    std::vector<unsigned*> relu_mask;   // per EA layer: the edge stage's ReLU masks (EdgeFwdArgs::mask; need_backward)
     size_t packed_floats;
     std::vector<float*> y;       // per layer output (post-activation); last = nullptr (caller's out)
     std::vector<EaSaved> ea;     // per EA layer
@@ -424,12 +427,14 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     lo.dP.assign(lo.nlayers, nullptr);
     lo.dQ.assign(lo.nlayers, nullptr);
     lo.dWe.assign(lo.nlayers, nullptr);
+    lo.relu_mask.assign(lo.nlayers, nullptr);
     for (int i = 0; i < lo.nlayers; ++i) {
         lo.gin[i] = cv.take<float>(i == 0 ? (size_t)n * lo.ld0 : nld);
         if (is_ea(i)) {
             lo.dP[i] = cv.take<float>(nld);
             lo.dQ[i] = cv.take<float>(nld);
             lo.dWe[i] = cv.take<float>((size_t)1025 * lo.fe * lo.ld);
+            lo.relu_mask[i] = cv.take<unsigned>(mask_dwords((size_t)n, (size_t)e, lo.ld));
         }
     }
     lo.dh = cv.take<float>(nld);
@@ -445,6 +450,14 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     lo.tags.red = lo.eas.red;
     lo.bytes = cv.off;
     return PFN_OK;
+}
+
+// Does layer i's forward edge walk save its ReLU masks?  Only the generic walk does (the graph-resident kernels pair with a
+// graph-resident backward that keeps its tiles in LDS), only when a backward pass was announced, Fe = 2.  Forward and backward
+// evaluate the same predicate.
+static bool ea_fwd_saves_mask(const pfn_mpn_config& c, const Layout& lo, bool seg_ea, bool fused_front, int i) {
+    const bool generic_walk = !seg_ea || (fused_front && i == 0);
+    return c.need_backward != 0 && lo.fe == 2 && generic_walk;
 }
 
 static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
@@ -515,7 +528,8 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         if (is_ea(i)) {
             const int fo = last ? lo.fo : lo.h;
             PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
-                               params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0, seg, seg_ea ? lo.ea_in : nullptr));
+                               params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0, seg, seg_ea ? lo.ea_in : nullptr,
+                               ea_fwd_saves_mask(c, lo, seg_ea, fused_front, i) ? lo.relu_mask[i] : nullptr));
             pi += 4;
             fcur = fo;
         } else {
@@ -547,6 +561,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
     if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)lo.e * lo.fe * sizeof(float), s));
     PairList pairs;                            // every weight-gradient pair of the network, launched once at the end
     const bool fused_front = front_fused_ok(lo.f0, lo.h);
+    const bool seg_ea = ea_seg_fit(seg, lo.n, lo.fe, lo.ld, false);   // (as in model_forward)
     const float* gcur = gout;
     int ldg = lo.ldo;
     for (int i = lo.nlayers - 1; i >= 0; --i) {
@@ -570,7 +585,8 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
             // (layer 0 with the fused front: its input gradient is formed together with mask_embd's, below)
             PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], params[p0 + 2], mp.ea[i], gcur, ldg, gate,
                                 (fused_front && i == 0) ? nullptr : gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2],
-                                grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs, seg, lo.ea_in, lo.ea_out));
+                                grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs, seg, lo.ea_in, lo.ea_out,
+                                ea_fwd_saves_mask(c, lo, seg_ea, fused_front, i) ? lo.relu_mask[i] : nullptr));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
                                  grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg));

@@ -80,6 +80,10 @@ struct GraphView {
     int* in_eid;
     int* out_dst;
     int* out_eid;
+    int* rp4;         // [n+1] prefix sum of ceil(in-degree / 4): row offsets of the edge stage's ReLU masks (EdgeFwdArgs::mask)
+    int* out_mbase;   // [2*e_stored] per by-source slot: rp4[dst], and (ceil(deg_dst / 4) << 16) | position of the edge among dst's
+    int* out_ml4k;    //              incoming edges -- where the by-source half of the backward walk finds the edge's mask byte
+    int* slot_of_eid; // [2*e_stored] build scratch: by-destination slot of edge id
     int* cur_in;      // [n] scratch: histogram, then fill cursor
     int* cur_out;     // [n]
     float* deg;       // [n] in-degree (multiplicity kept)
@@ -273,6 +277,13 @@ __device__ __forceinline__ void row_sum(float4* part, int r, int c, int nchunk, 
     }
 }
 
+// ReLU masks of the edge stage: one byte per (incoming edge, float4 column chunk), bit i = pre-activation of column 4c + i > 0.
+// Written by the forward walk when a backward pass will follow, read by the backward walks INSTEAD of recomputing
+// P[dst] + Q[src] + a_e We: they then gather dS rows only (a third of the gathers).  Layout: destination row i owns
+// nchunk * L4_i dwords at dword offset rp4[i] * nchunk, L4_i = ceil(deg_i / 4); chunk c's run of L4_i dwords holds the bytes of
+// the row's incoming edges in slot order, so the thread (i, c) of a walk writes / reads ONE whole dword per trip of four
+// slots (byte stores into slot-major records made the forward walk 23 % slower).  Size: mask_dwords(n, e, ld).
+__host__ __device__ inline size_t mask_dwords(size_t n, size_t e_stored, int ld) { return (n + e_stored / 2 + 2) * (size_t)(ld / 4); }
 struct EdgeFwdArgs {
     const float* P;
     const float* Q;
@@ -280,6 +291,7 @@ struct EdgeFwdArgs {
     const float* w1;
     float* S;
     int ld, h, fi, fe;
+    unsigned* mask = nullptr;        // optional, mask_dwords(n, e, ld) dwords
     // last layer only (edge_fwd_out_ok): out[N][4] = S W2^T + deg b2 is formed in the same launch
     float* out = nullptr;
     const float* w2 = nullptr;
@@ -338,6 +350,7 @@ struct EdgeBwdArgs {
     const float* gout = nullptr;
     const float* w2 = nullptr;
     int fo = 0;
+    const unsigned* mask = nullptr;        // the forward walk's ReLU masks (Fe = 2): P, Q and the residue weights are not read
 };
 int edge_bwd_dst_blocks(const GraphView& g, int ld);   // number of dWe partials the dst walk emits (<= 1024)
 int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t* edge_index_unused, hipStream_t s);

@@ -273,6 +273,9 @@ class _MpnFn(torch.autograd.Function):
     def forward(ctx, model, graph, x, pred_mask, edge_attr, *params):
         lib = L.load()
         cfg = model._config()
+        # (autograd records this call only when grad mode was on at `apply`: inside forward it is always off, and
+        #  ctx.needs_input_grad ignores torch.no_grad())
+        cfg.need_backward = 1 if (model._grad_mode_at_apply and any(ctx.needs_input_grad)) else 0
         n = x.shape[0]
         fo = model.output_dim
         out = torch.empty(n, _padded(fo), dtype=torch.float32, device=x.device)
@@ -372,7 +375,7 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
     # ------------------------------------------------------------------------------------- plumbing
     def _config(self) -> L.MpnConfig:
         return L.MpnConfig(self.nfeature_dim, self.efeature_dim, self.output_dim, self.hidden_dim, self.n_gnn_layers,
-                           self.K, float(self.dropout_rate), 1 if self.training else 0)
+                           self.K, float(self.dropout_rate), 1 if self.training else 0, 0)
 
     def _ordered_params(self):
         """The C ABI's parameter table order (include/pfn_hip.h)."""
@@ -433,6 +436,7 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
             nseg = int(ptr.numel()) - 1 if torch.is_tensor(ptr) else 0
             seg_hint = x.shape[0] // nseg if nseg > 0 and x.shape[0] % nseg == 0 else 0
             graph = self._graphs.get(edge_index, x.shape[0], -1, seg_hint)   # is_directed + undirect_graph (:539)
+            self._grad_mode_at_apply = torch.is_grad_enabled()
             return _MpnFn.apply(self, graph, x, mask, edge_features, *self._ordered_params())
 
 
