@@ -183,7 +183,7 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         PFN_TRY(launch_gemm_nt(a, s));
     }
     EdgeBwdArgs e{sv.P, sv.Q, sc.dS, ea, w1, sc.dP, sc.dQ, sc.dWe, gea, ld, h, fi, fe};
-    if (!gea && fe == 2) e.mask = relu_mask;   // written by this layer's generic forward walk (ea_fwd_saves_mask)
+    if (!gea && fe == 2) e.mask = relu_mask;   // written by this layer's generic forward walk (ea_saves_mask)
     if (ds_in_walk) {
         e.gout = gout;
         e.w2 = w2;
@@ -452,12 +452,13 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     return PFN_OK;
 }
 
-// Does layer i's forward edge walk save its ReLU masks?  Only the generic walk does (the graph-resident kernels pair with a
-// graph-resident backward that keeps its tiles in LDS), only when a backward pass was announced, Fe = 2.  Forward and backward
-// evaluate the same predicate.
-static bool ea_fwd_saves_mask(const pfn_mpn_config& c, const Layout& lo, bool seg_ea, bool fused_front, int i) {
-    const bool generic_walk = !seg_ea || (fused_front && i == 0);
-    return c.need_backward != 0 && lo.fe == 2 && generic_walk;
+// Does layer i's forward edge walk save its ReLU masks?  When a backward pass was announced, Fe = 2, the layer's forward walk is
+// the generic one (the graph-resident forward does not write masks), and the backward pass will run the generic walks too (the
+// graph-resident backward keeps its tiles in LDS and recomputes: masks bought nothing there).  Forward and backward evaluate
+// the same predicate.
+static bool ea_saves_mask(const pfn_mpn_config& c, const Layout& lo, int seg, bool fused_front, int i) {
+    const bool generic_fwd = !ea_seg_fit(seg, lo.n, lo.fe, lo.ld, false) || (fused_front && i == 0);
+    return c.need_backward != 0 && lo.fe == 2 && generic_fwd && !ea_seg_fit(seg, lo.n, lo.fe, lo.ld, true);
 }
 
 static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
@@ -529,7 +530,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
             const int fo = last ? lo.fo : lo.h;
             PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
                                params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0, seg, seg_ea ? lo.ea_in : nullptr,
-                               ea_fwd_saves_mask(c, lo, seg_ea, fused_front, i) ? lo.relu_mask[i] : nullptr));
+                               ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr));
             pi += 4;
             fcur = fo;
         } else {
@@ -561,7 +562,6 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
     if (gea) PFN_CHECK_HIP(hipMemsetAsync(gea, 0, (size_t)lo.e * lo.fe * sizeof(float), s));
     PairList pairs;                            // every weight-gradient pair of the network, launched once at the end
     const bool fused_front = front_fused_ok(lo.f0, lo.h);
-    const bool seg_ea = ea_seg_fit(seg, lo.n, lo.fe, lo.ld, false);   // (as in model_forward)
     const float* gcur = gout;
     int ldg = lo.ldo;
     for (int i = lo.nlayers - 1; i >= 0; --i) {
@@ -586,7 +586,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
             PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], params[p0 + 2], mp.ea[i], gcur, ldg, gate,
                                 (fused_front && i == 0) ? nullptr : gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2],
                                 grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs, seg, lo.ea_in, lo.ea_out,
-                                ea_fwd_saves_mask(c, lo, seg_ea, fused_front, i) ? lo.relu_mask[i] : nullptr));
+                                ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
                                  grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg));
