@@ -750,15 +750,35 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     const float t = (float)(step[0] + 1);
     const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
     const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float gi = g[i];
-        float pi = p[i] * (1.f - lr * wd);               // decoupled weight decay
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    auto upd = [&](float& pi, float gi, float& mi, float& vi) {
+        pi *= (1.f - lr * wd);                           // decoupled weight decay
+        mi = b1 * mi + (1.f - b1) * gi;
+        vi = b2 * vi + (1.f - b2) * gi * gi;
+        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+        pi -= step_size * (mi / denom);
+    };
+    // 16 bytes per lane and array when the four flat buffers allow it (they are whole allocations: 256-byte aligned); the
+    // update is a chain of dependent loads per element otherwise (10 us for 355 k parameters, 2x its memory time)
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const int64_t n4 = vec ? n >> 2 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+        const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+        upd(p4.x, g4.x, m4.x, v4.x);
+        upd(p4.y, g4.y, m4.y, v4.y);
+        upd(p4.z, g4.z, m4.z, v4.z);
+        upd(p4.w, g4.w, m4.w, v4.w);
+        reinterpret_cast<float4*>(p)[i] = p4;
+        reinterpret_cast<float4*>(m)[i] = m4;
+        reinterpret_cast<float4*>(v)[i] = v4;
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float pi = p[i], mi = m[i], vi = v[i];
+        upd(pi, g[i], mi, vi);
+        p[i] = pi;
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
-        p[i] = pi - step_size * (mi / denom);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
