@@ -1,5 +1,6 @@
 #!/bin/bash
-# ReLU masks in the generic backward walks: tests, then configs 2 (generic path forced), 3, 4, wide, hub
+# One GPU session: the -m gpu tests, then the benches of configs 2 (also with the generic kernels forced), 3, 4 and 4-hub.
+#   gpurun --timeout 2400 -- bash tools/gpu_check.sh     (results under gpurun_out/t/)
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/t; mkdir -p $O
 export HSA_ENABLE_IPC_MODE_LEGACY=0
