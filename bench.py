@@ -54,7 +54,7 @@ def parse():
     return ap.parse_args()
 
 
-def alg_bytes(n, e, h, fe, K=3):
+def alg_bytes(n, e, h, fe, K=3, train=True):
     """Algorithmic bytes per launch of the gather/segment-sum kernel classes (4-byte elements and indices; logical
     inputs once, one gathered row per directed edge, output once -- the convention of SURVEY.md 8d)."""
     return {
@@ -63,9 +63,11 @@ def alg_bytes(n, e, h, fe, K=3):
         # K hops in one launch (rows LDS-resident between hops): the algorithmic work is still K x B_sa(H)
         "fused_hops_fwd": K * 4.0 * (e * h + e + n * h + (n + 1)),
         "fused_hops_bwd": K * 4.0 * (e * h + e + n * h + (n + 1)),
-        "edge_fwd": 4.0 * (n * h + e * h + e * fe + e + (n + 1) + n * h),
-        # one launch: the by-destination half (dP, dWe) + the by-source half (dQ)
-        "edge_bwd": 4.0 * (2 * n * h + e * h + e * fe + e + (n + 1) + n * h) + 4.0 * (n * h + 2 * e * h + e * fe + e + (n + 1) + n * h),
+        # training: the forward walk also saves one ReLU-mask byte per (edge, float4 chunk) ...
+        "edge_fwd": 4.0 * (n * h + e * h + e * fe + e + (n + 1) + n * h) + (e * ((h + 3) // 4) if train else 0),
+        # ... and the backward walks (one launch: the by-destination half -> dP, dWe; the by-source half -> dQ) read the masks
+        # instead of recomputing: dS once + its row gathered once per edge, the masks twice, indices, two outputs
+        "edge_bwd": 4.0 * (n * h + e * fe + e + (n + 1) + n * h) + 4.0 * (e * h + 3 * e + (n + 1) + n * h) + 2.0 * e * ((h + 3) // 4),
     }
 
 
@@ -280,7 +282,7 @@ def main():
     if rank == 0 and args.profile_steps > 0:
         L.profile_enable(False)
         rep = L.profile_report(reset=True)
-        ab = alg_bytes(n_nodes, e_eff, h, 2, K)
+        ab = alg_bytes(n_nodes, e_eff, h, 2, K, train)
         # every event-pair interval has had the live-measured interval of an EMPTY pair subtracted by the library
         event_pair_overhead_us = round(1e3 * rep.pop("__event_pair_overhead", {"ms": 0.0})["ms"], 3)
         for name, r in rep.items():
