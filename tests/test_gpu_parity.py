@@ -456,7 +456,12 @@ def test_g7_batch_equals_concat_of_singles():
 
 
 @pytest.mark.parametrize("case,B,cfg", [("14", 32, (129, 4, 3)), ("118", 16, (129, 4, 3)), ("118", 4, (129, 6, 6)),
-                                        ("118", 3, (64, 2, 3)), ("14", 5, (512, 3, 2))])
+                                        ("118", 3, (64, 2, 3)), ("14", 5, (512, 3, 2)),
+                                        # hidden widths that walk the column plans of the graph-resident kernels (ea_seg.hip):
+                                        # 33 / 36 -> one quarter + 1 / 4 trailing columns, 100 -> three quarters + 4, 132 -> four
+                                        # + 4 real trailing columns, 136 -> five quarters, the last one 8 columns wide, K8 = 136
+                                        ("118", 3, (33, 3, 2)), ("14", 20, (36, 3, 2)), ("118", 3, (100, 3, 2)),
+                                        ("14", 20, (132, 3, 2)), ("118", 3, (136, 3, 2))])
 def test_model_vs_oracle_seeded(case, B, cfg):
     torch.manual_seed(1234)
     h, L_, K = cfg
