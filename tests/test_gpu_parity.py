@@ -534,6 +534,30 @@ def test_fused_lds_hops_match_generic_path():
     assert m._graphs._graph.seg_nodes == 0
 
 
+def test_graph_resident_kernels_with_more_edges_than_their_lds_slices():
+    """Dense small graphs (16 nodes, 100 stored = 200 directed edges each): a workgroup of the graph-resident kernels owns 8
+    graphs = 1,600 edge slots, more than its LDS adjacency slice holds (4 per row), so the walks read indices and attributes
+    from global memory (csr_slot / seg_bwd_row_slow).  Output and all gradients against the CPU oracle."""
+    from poweflownet_amd.data import Batch
+    from poweflownet_amd.synth import make_graph, make_topology
+    torch.manual_seed(11)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    topo = make_topology(16, 100, 0)
+    data = Batch.from_data_list([make_graph(16, 100, seed=50 + b, edge_index=topo) for b in range(21)])
+    out_ref = ref(data)
+    torch.nn.MSELoss()(out_ref, data.y).backward()
+    dd = data.to(DEV)
+    out = m(dd)
+    assert m._graphs._graph.seg_nodes == 16
+    assert_close(out, out_ref, RTOL, "out")
+    torch.nn.MSELoss()(out, dd.y).backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, RTOL, f"grad.{k}")
+
+
 def test_edge_cases_empty_edges_and_isolated_nodes():
     from poweflownet_amd.data import Data
     torch.manual_seed(0)
