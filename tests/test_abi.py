@@ -103,3 +103,10 @@ def test_constructor_surface():
         bad = make_batch("14", 1)
         bad.x = torch.zeros(14, 6)
         m(bad)
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" hook: compiles every HIP source (incremental make) and checks the library's ABI version
+    against the Python mirror's."""
+    import __graft_entry__
+    __graft_entry__.build()
