@@ -25,6 +25,21 @@
 
 namespace pfn {
 
+// tools/ubench experiment switch (never defined in the product build): wall-clock (100 MHz) timestamps of the backward kernel's
+// phases, one record per workgroup of the LAST launch, read back with pfn_debug_seg_ts()
+#ifdef SG_EXP_TS
+__device__ unsigned long long sg_ts[4096 * 8];
+#define SG_TS(slot)                                                                                                   \
+    do {                                                                                                              \
+        if (threadIdx.x == 0) {                                                                                       \
+            const int b_ = blockIdx.y * gridDim.x + blockIdx.x;                                                       \
+            if (b_ < 4096) sg_ts[b_ * 8 + (slot)] = wall_clock64();                                                   \
+        }                                                                                                             \
+    } while (0)
+#else
+#define SG_TS(slot) do { } while (0)
+#endif
+
 constexpr int SG_THREADS = 512;
 constexpr int SG_TW = 36;            // LDS tile row stride (floats): 32 quarter columns + up to 4 trailing VALU columns
 constexpr int SG_MAX_ROWS = 128;     // rows of whole graphs per workgroup (4 row tiles: one MFMA task per wave at most)
@@ -42,24 +57,36 @@ struct SegCsr {      // one adjacency slice in LDS: rp[rows + 1] (relative), nb[
 };
 
 // The block's slice of one CSR (by destination or by source) goes to LDS once; `ea_slot` = the edge attributes already in slot
-// order (SlotEa, gathered once per forward), so the chain is two loads deep: rowptr, then indices | attributes
-__device__ __forceinline__ void stage_csr(SegCsr& c, int r0, int rows, int cap, const int* __restrict__ rowptr,
-                                          const int* __restrict__ nbr, const float* __restrict__ ea_slot) {
+// order (SlotEa, gathered once per forward), so the chain is two loads deep: rowptr, then indices | attributes.
+// Issue / commit are split so that EVERY global load of a kernel's prologue is requested before its first LDS store: written
+// as load-store loops, each store waited for all loads before it (VMEM returns in order) and the next loop's loads went out
+// only then -- eight serial round trips, 8.4 of ea_seg_bwd's 25 us (phase timestamps, tools/ubench/run_ea_seg_ts.sh).
+// rows + 1 <= 129 and cap <= 512 = SG_THREADS: one row pointer and one slot per thread.
+struct CsrRegs { int rp, nb; float2 ea; };
+__device__ __forceinline__ void csr_issue1(SegCsr& c, CsrRegs& r, int r0, int rows, const int* __restrict__ rowptr) {
+    c.e0 = rowptr[r0];
+    c.ne = rowptr[r0 + rows] - c.e0;
+    r.rp = (int)threadIdx.x <= rows ? rowptr[r0 + threadIdx.x] : 0;
+}
+__device__ __forceinline__ void csr_issue2(SegCsr& c, CsrRegs& r, int cap, const int* __restrict__ nbr,
+                                           const float* __restrict__ ea_slot) {
+    c.in_lds = c.ne <= cap;
+    r.nb = 0;
+    r.ea = make_float2(0.f, 0.f);
+    if (c.in_lds && (int)threadIdx.x < c.ne) {
+        r.nb = nbr[c.e0 + threadIdx.x];
+        r.ea = reinterpret_cast<const float2*>(ea_slot)[c.e0 + threadIdx.x];
+    }
+}
+__device__ __forceinline__ void csr_commit(const SegCsr& c, const CsrRegs& r, int r0, int rows) {
 #ifdef SG_EXP_NOSTAGE
-    c.e0 = 0; c.in_lds = true; c.ne = 0;
-    for (int i = threadIdx.x; i <= rows; i += SG_THREADS) c.rp[i] = 0;
+    if ((int)threadIdx.x <= rows) c.rp[threadIdx.x] = 0;
     return;
 #endif
-    c.e0 = rowptr[r0];
-    const int ne = rowptr[r0 + rows] - c.e0;
-    c.ne = ne;
-    c.in_lds = ne <= cap;
-    for (int i = threadIdx.x; i <= rows; i += SG_THREADS) c.rp[i] = rowptr[r0 + i] - c.e0;
-    if (c.in_lds) {
-        for (int i = threadIdx.x; i < ne; i += SG_THREADS) {
-            c.nb[i] = nbr[c.e0 + i] - r0;
-            c.ea[i] = reinterpret_cast<const float2*>(ea_slot)[c.e0 + i];
-        }
+    if ((int)threadIdx.x <= rows) c.rp[threadIdx.x] = r.rp - c.e0;
+    if (c.in_lds && (int)threadIdx.x < c.ne) {
+        c.nb[threadIdx.x] = r.nb - r0;
+        c.ea[threadIdx.x] = r.ea;
     }
 }
 __device__ __forceinline__ void csr_slot(const SegCsr& c, int p, int r0, const int* __restrict__ nbr, const float* __restrict__ ea_slot,
@@ -84,47 +111,51 @@ __device__ __forceinline__ void seg_store_tile(const f32x16& acc, int q, const f
 }
 
 // The up to 4 trailing columns (H = 129 = 4 * 32 + 1) never get an MFMA tile: the LAST quarter's block forms them as VALU dot
-// products with all its threads right after the tiles: thread = (row tid >> 2, k part tid & 3); part j adds the
-// k groups j, j + 4, ... in order, the four parts are added by a fixed xor tree.  Two images (P and Q) share the row loads.
-//   tile1[row][32 + c] = sum_k A[row][k] * image1_rem[k][c] (+ bias),   tile2 likewise (no bias) when Bp2 != null
-template <bool TWO>
-__device__ __forceinline__ void seg_rem_cols(const float* __restrict__ A, int lda, int K, int r0, int rows,
+// products, thread t = (row t >> PL2, k part t & (2^PL2 - 1)); a part adds its k groups in order (NB groups per batch, all loads
+// of a batch requested before the first multiply), the parts are added by a fixed xor tree.  Two images (P and Q) share the row
+// loads.  v1[c] = sum_k A[row][k] * image1_rem[k][c], v2 likewise; seg_rem_store drops them into tile columns 32.. (+ bias).
+// Forward: all 512 threads (4 parts per row) while the MFMA operands are in flight; backward: the four waves without a tile
+// (2 parts per row) while the other four multiply.
+template <bool TWO, int PL2, int NB>
+__device__ __forceinline__ void seg_rem_dots(int t, const float* __restrict__ A, int lda, int K, int r0, int rows,
                                              const float* __restrict__ Bp1, const float* __restrict__ Bp2, int nq, int nreal,
-                                             const float* __restrict__ bias, float* tile1, float* tile2) {
-    const int lr = threadIdx.x >> 2, part = threadIdx.x & 3;
+                                             float (&v1)[4], float (&v2)[4]) {
+    constexpr int PARTS = 1 << PL2;
+    const int lr = t >> PL2, part = t & (PARTS - 1);
     const int G = ((K + 7) & ~7) >> 2;
     const float* arow = A + (size_t)(r0 + min(lr, rows - 1)) * lda;
     const size_t roff = (size_t)nq * G * 128;
     const int gmax = (lda >> 2) - 1;                                 // k groups past the row multiply zero image rows
-    float acc1[4] = {0.f, 0.f, 0.f, 0.f}, acc2[4] = {0.f, 0.f, 0.f, 0.f};
-    if (nreal == 1) {   // H = 128 + 1: three k groups per batch, all loads of a batch requested before the first multiply
-        for (int g0 = part; g0 < G; g0 += 12) {
-            float4 xa[3], w1[3], w2[3];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int g = min(g0 + 4 * j, G - 1);
+    for (int c = 0; c < 4; ++c) v1[c] = v2[c] = 0.f;
+    if (nreal == 1) {   // H = 128 + 1
+        for (int g0 = part; g0 < G; g0 += NB * PARTS) {
+            float4 xa[NB], w1[NB], w2[TWO ? NB : 1];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int g = min(g0 + PARTS * j, G - 1);
                 const float4 v = sg_ld4(arow + 4 * min(g, gmax));
-                xa[j] = g0 + 4 * j < G ? v : make_float4(0.f, 0.f, 0.f, 0.f);   // (past G: zeroed by a select, no divergent branch)
+                xa[j] = g0 + PARTS * j < G ? v : make_float4(0.f, 0.f, 0.f, 0.f);   // (past G: zeroed by a select, no divergent branch)
                 w1[j] = sg_ld4(Bp1 + roff + (size_t)g * 16);
                 if (TWO) w2[j] = sg_ld4(Bp2 + roff + (size_t)g * 16);
             }
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                acc1[0] = fmaf(xa[j].w, w1[j].w, fmaf(xa[j].z, w1[j].z, fmaf(xa[j].y, w1[j].y, fmaf(xa[j].x, w1[j].x, acc1[0]))));
-                if (TWO) acc2[0] = fmaf(xa[j].w, w2[j].w, fmaf(xa[j].z, w2[j].z, fmaf(xa[j].y, w2[j].y, fmaf(xa[j].x, w2[j].x, acc2[0]))));
+            for (int j = 0; j < NB; ++j) {
+                v1[0] = fmaf(xa[j].w, w1[j].w, fmaf(xa[j].z, w1[j].z, fmaf(xa[j].y, w1[j].y, fmaf(xa[j].x, w1[j].x, v1[0]))));
+                if (TWO) v2[0] = fmaf(xa[j].w, w2[j].w, fmaf(xa[j].z, w2[j].z, fmaf(xa[j].y, w2[j].y, fmaf(xa[j].x, w2[j].x, v2[0]))));
             }
         }
     } else {
-        for (int g = part; g < G; g += 4) {
+        for (int g = part; g < G; g += PARTS) {
             const float4 xa = sg_ld4(arow + 4 * min(g, gmax));
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 if (c < nreal) {
                     const float4 w = sg_ld4(Bp1 + roff + (size_t)g * 16 + c * 4);
-                    acc1[c] = fmaf(xa.w, w.w, fmaf(xa.z, w.z, fmaf(xa.y, w.y, fmaf(xa.x, w.x, acc1[c]))));
+                    v1[c] = fmaf(xa.w, w.w, fmaf(xa.z, w.z, fmaf(xa.y, w.y, fmaf(xa.x, w.x, v1[c]))));
                     if (TWO) {
                         const float4 w2 = sg_ld4(Bp2 + roff + (size_t)g * 16 + c * 4);
-                        acc2[c] = fmaf(xa.w, w2.w, fmaf(xa.z, w2.z, fmaf(xa.y, w2.y, fmaf(xa.x, w2.x, acc2[c]))));
+                        v2[c] = fmaf(xa.w, w2.w, fmaf(xa.z, w2.z, fmaf(xa.y, w2.y, fmaf(xa.x, w2.x, v2[c]))));
                     }
                 }
             }
@@ -132,14 +163,22 @@ __device__ __forceinline__ void seg_rem_cols(const float* __restrict__ A, int ld
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        float v1 = acc1[c], v2 = acc2[c];
-        v1 += __shfl_xor(v1, 1);
-        v1 += __shfl_xor(v1, 2);
-        v2 += __shfl_xor(v2, 1);
-        v2 += __shfl_xor(v2, 2);
-        if (part == 0 && lr < rows) {   // (columns past the real ones: zero, like every pad column)
-            tile1[(size_t)lr * SG_TW + 32 + c] = c < nreal ? v1 + (bias ? bias[32 * nq + c] : 0.f) : 0.f;
-            if (TWO) tile2[(size_t)lr * SG_TW + 32 + c] = c < nreal ? v2 : 0.f;
+#pragma unroll
+        for (int off = 1; off < PARTS; off <<= 1) {
+            v1[c] += __shfl_xor(v1[c], off);
+            if (TWO) v2[c] += __shfl_xor(v2[c], off);
+        }
+    }
+}
+template <bool TWO, int PL2>
+__device__ __forceinline__ void seg_rem_store(int t, int rows, int nq, int nreal, const float* __restrict__ bias,
+                                              const float (&v1)[4], const float (&v2)[4], float* tile1, float* tile2) {
+    const int lr = t >> PL2, part = t & ((1 << PL2) - 1);
+    if (part == 0 && lr < rows) {   // (columns past the real ones: zero, like every pad column)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            tile1[(size_t)lr * SG_TW + 32 + c] = c < nreal ? v1[c] + (bias ? bias[32 * nq + c] : 0.f) : 0.f;
+            if (TWO) tile2[(size_t)lr * SG_TW + 32 + c] = c < nreal ? v2[c] : 0.f;
         }
     }
 }
@@ -153,7 +192,9 @@ struct SegCols {
 __device__ __forceinline__ SegCols seg_cols(int ld) {
     SegCols c;
     col_plan(ld, c.remv, c.nq);
-    c.q = blockIdx.y;
+    // (reversed: the last quarter's block, which also owns the trailing columns and is the launch's critical path, is dispatched
+    //  first -- the second half of a launch's workgroups reaches its first barrier ~3.6 us later than the first half, measured)
+    c.q = c.nq - 1 - (int)blockIdx.y;
     c.rem = c.remv > 0 && c.q == c.nq - 1;
     c.col0 = 32 * c.q;
     c.cw = min(8, (ld - c.remv - c.col0) >> 2) + (c.rem ? 1 : 0);
@@ -165,14 +206,16 @@ __device__ __forceinline__ int seg_gcol(const SegCols& c, int lc) { return (c.re
 // global column of LDS tile column t (0..31: the quarter; 32..35: the trailing columns), -1: not in this block
 __device__ __forceinline__ int seg_col_of_tile(const SegCols& c, int t) { return t < 32 ? c.col0 + t : (c.rem && t - 32 < c.remv ? 32 * c.nq + t - 32 : -1); }
 
-// residue columns of W1 for the slice: we[f][tile column] = W1[col][2Fi + f] (zero past H)
-__device__ __forceinline__ void stage_we(float* s_we, const SegCols& c, const float* __restrict__ w1, int h, int fi) {
-    const int ldw = 2 * fi + 2;
-    for (int i = threadIdx.x; i < 2 * SG_TW; i += SG_THREADS) {
-        const int f = i / SG_TW, t = i - f * SG_TW;
-        const int col = seg_col_of_tile(c, t);
-        s_we[i] = (col >= 0 && col < h) ? w1[(size_t)col * ldw + 2 * fi + f] : 0.f;
-    }
+// residue columns of W1 for the slice: we[f][tile column] = W1[col][2Fi + f] (zero past H); 2 * SG_TW = 72 values, one per thread
+__device__ __forceinline__ float we_issue(const SegCols& c, const float* __restrict__ w1, int h, int fi) {
+    const int i = threadIdx.x, ldw = 2 * fi + 2;
+    if (i >= 2 * SG_TW) return 0.f;
+    const int f = i / SG_TW, t = i - f * SG_TW;
+    const int col = seg_col_of_tile(c, t);
+    return (col >= 0 && col < h) ? w1[(size_t)col * ldw + 2 * fi + f] : 0.f;
+}
+__device__ __forceinline__ void we_commit(float* s_we, float v) {
+    if (threadIdx.x < 2 * SG_TW) s_we[threadIdx.x] = v;
 }
 
 __device__ __forceinline__ float4 sg_add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
@@ -230,6 +273,7 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // ---- P | Q tiles: task t = (row tile t >> 1, P or Q); the first task's operands are requested before the block stages
     // its adjacency slice (three dependent loads deep), so both latencies overlap
+    SG_TS(0);
     const int nrt = (rows + 31) >> 5;
     const bool mfma_on = wave < 2 * nrt;   // (rows <= SG_MAX_ROWS = 128: at most one task per wave)
     const int K8 = (a.K + 7) & ~7;
@@ -238,17 +282,27 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     seg_copy_b(l.B0, a.Bi, sc.q, K8, wave, lane);
     seg_copy_b(l.B1, a.Bj, sc.q, K8, wave, lane);
     SegCsr cin = l.in;
-    stage_csr(cin, r0, rows, cap, rowptr, nbr, a.ea_in);
-    stage_we(l.we, sc, a.w1, a.h, a.fi);
+    CsrRegs cri;
+    csr_issue1(cin, cri, r0, rows, rowptr);
+    const float wev = we_issue(sc, a.w1, a.h, a.fi);
+    csr_issue2(cin, cri, cap, nbr, a.ea_in);
+    csr_commit(cin, cri, r0, rows);
+    we_commit(l.we, wev);
+    if (sc.rem) {   // the trailing columns, while the tiles' operands are in flight (tile columns 32..: the tiles write 0..31)
+        float v1[4], v2[4];
+        const int nreal = min(sc.remv, a.h - 32 * sc.nq);
+        seg_rem_dots<true, 2, 3>(threadIdx.x, a.x, a.ldx, a.K, r0, rows, a.Bi, a.Bj, sc.nq, nreal, v1, v2);
+        seg_rem_store<true, 2>(threadIdx.x, rows, sc.nq, nreal, a.b1, v1, v2, l.P, l.Q);
+    }
     seg_dma_wait();
     __syncthreads();
+    SG_TS(1);
     if (mfma_on) {
         const f32x16 acc = seg_mma(ta, (wave & 1) ? l.B1 : l.B0, K8, lane);
         seg_store_tile(acc, sc.q, (wave & 1) ? nullptr : a.b1, a.h, (wave & 1) ? l.Q : l.P, 32 * (wave >> 1), lane);
     }
-    // (after the tiles: the operand registers are free again, and the rows are in L2 / L1 from the tile loads)
-    if (sc.rem) seg_rem_cols<true>(a.x, a.ldx, a.K, r0, rows, a.Bi, a.Bj, sc.nq, min(sc.remv, a.h - 32 * sc.nq), a.b1, l.P, l.Q);
     __syncthreads();
+    SG_TS(2);
     // ---- P, Q out (the backward pass recomputes the pre-activation from them), and the walk
     for (int it = threadIdx.x; it < rows * sc.cw; it += SG_THREADS) {
         const int lr = it / sc.cw, lc = it - lr * sc.cw;
@@ -310,6 +364,8 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         if (acc.x == 123.456f) sg_st4(a.S + o, acc);
 #endif
     }
+    SG_TS(3);
+    SG_TS(4);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
@@ -372,6 +428,74 @@ __device__ __forceinline__ void seg_bwd_row(const SegLds& l, const SegCsr& cin, 
         }
     }
 }
+// One direction only (the trailing chunk's second pass gives a row's two walks to two threads), four slots per trip
+__device__ __forceinline__ void seg_bwd_row_dst(const SegLds& l, const SegCsr& cin, int lr, int tc, float4 w0, float4 w1,
+                                                float4& accP, float4& dwe0, float4& dwe1) {
+    const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tc), g4 = sg_ld4(l.D + (size_t)lr * SG_TW + tc);
+    accP = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = cin.rp[lr], end = cin.rp[lr + 1], last = end - 1;
+    for (int p = beg; p < end; p += 4) {
+        int s_[4];
+        float2 ai[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = min(p + u, last);
+            s_[u] = cin.nb[q];
+            ai[u] = cin.ea[q];
+        }
+        float4 qs[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) qs[u] = sg_ld4(l.Q + (size_t)s_[u] * SG_TW + tc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 v = sg_add4(p4, qs[u]);
+            v = sg_fma4(ai[u].x, w0, v);
+            v = sg_fma4(ai[u].y, w1, v);
+            const bool k = p + u < end;
+            float4 dh;
+            dh.x = (k && v.x > 0.f) ? g4.x : 0.f;
+            dh.y = (k && v.y > 0.f) ? g4.y : 0.f;
+            dh.z = (k && v.z > 0.f) ? g4.z : 0.f;
+            dh.w = (k && v.w > 0.f) ? g4.w : 0.f;
+            accP = sg_add4(accP, dh);
+            dwe0 = sg_fma4(ai[u].x, dh, dwe0);
+            dwe1 = sg_fma4(ai[u].y, dh, dwe1);
+        }
+    }
+}
+__device__ __forceinline__ void seg_bwd_row_src(const SegLds& l, const SegCsr& cout, int lr, int tc, float4 w0, float4 w1,
+                                                float4& accQ) {
+    const float4 q4 = sg_ld4(l.Q + (size_t)lr * SG_TW + tc);
+    accQ = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int beg = cout.rp[lr], end = cout.rp[lr + 1], last = end - 1;
+    for (int p = beg; p < end; p += 4) {
+        int d_[4];
+        float2 ao[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int q = min(p + u, last);
+            d_[u] = cout.nb[q];
+            ao[u] = cout.ea[q];
+        }
+        float4 pd[4], gd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pd[u] = sg_ld4(l.P + (size_t)d_[u] * SG_TW + tc);
+            gd[u] = sg_ld4(l.D + (size_t)d_[u] * SG_TW + tc);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            float4 z = sg_add4(pd[u], q4);
+            z = sg_fma4(ao[u].x, w0, z);
+            z = sg_fma4(ao[u].y, w1, z);
+            const bool k = p + u < end;
+            accQ.x += (k && z.x > 0.f) ? gd[u].x : 0.f;
+            accQ.y += (k && z.y > 0.f) ? gd[u].y : 0.f;
+            accQ.z += (k && z.z > 0.f) ? gd[u].z : 0.f;
+            accQ.w += (k && z.w > 0.f) ? gd[u].w : 0.f;
+        }
+    }
+}
 // the same with the indices read from global memory (a block with more edges than its LDS slice holds)
 __device__ __forceinline__ void seg_bwd_row_slow(const SegLds& l, const SegCsr& cin, const SegCsr& cout, int lr, int tc, int r0,
                                                  const int* __restrict__ in_src, const int* __restrict__ out_dst,
@@ -421,6 +545,7 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0);
     const SegCols sc = seg_cols(a.ld);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    SG_TS(0);
     // ---- dS slice: the MFMA waves request their operands first (the staging below is several dependent loads deep)
     const int nrt = (rows + 31) >> 5;
     const bool mfma_on = !DSG && wave < nrt;
@@ -429,21 +554,46 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     if (mfma_on) seg_load_a(ta, a.gout, a.ldgo, K8, r0 + 32 * wave, r0 + rows - 1, lane);
     if (!DSG) seg_copy_b(l.B0, a.Bd, sc.q, K8, wave, lane);
     SegCsr cin = l.in, cout = l.out;
-    stage_csr(cin, r0, rows, cap, rp_in, in_src, a.ea_in);
-    stage_csr(cout, r0, rows, cap, rp_out, out_dst, a.ea_out);
-    stage_we(l.we, sc, a.w1, a.h, a.fi);
-    // ---- P, Q slices -> LDS
+    CsrRegs cri, cro;
+    csr_issue1(cin, cri, r0, rows, rp_in);
+    csr_issue1(cout, cro, r0, rows, rp_out);
+    const float wev = we_issue(sc, a.w1, a.h, a.fi);
+    // P, Q slices (rows * cw <= 1152 items: three per thread at most), requested with everything else
+    float4 pv[3], qv[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int it = threadIdx.x + j * SG_THREADS;
+        pv[j] = qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #ifndef SG_EXP_NOPQ
-    for (int it = threadIdx.x; it < rows * sc.cw; it += SG_THREADS) {
-#else
-    for (int it = threadIdx.x; it < rows * sc.cw && rows > 100000; it += SG_THREADS) {
+        if (it < rows * sc.cw) {
+            const int lr = it / sc.cw, lc = it - lr * sc.cw;
+            const size_t o = (size_t)(r0 + lr) * a.ld + seg_gcol(sc, lc);
+            pv[j] = sg_ld4(a.P + o);
+            qv[j] = sg_ld4(a.Q + o);
+        }
 #endif
-        const int lr = it / sc.cw, lc = it - lr * sc.cw;
-        const int tc = seg_tcol(sc, lc);
-        const size_t o = (size_t)(r0 + lr) * a.ld + seg_gcol(sc, lc);
-        sg_st4(l.P + (size_t)lr * SG_TW + tc, sg_ld4(a.P + o));
-        sg_st4(l.Q + (size_t)lr * SG_TW + tc, sg_ld4(a.Q + o));
     }
+    csr_issue2(cin, cri, cap, in_src, a.ea_in);
+    csr_issue2(cout, cro, cap, out_dst, a.ea_out);
+    csr_commit(cin, cri, r0, rows);
+    csr_commit(cout, cro, r0, rows);
+    we_commit(l.we, wev);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int it = threadIdx.x + j * SG_THREADS;
+        if (it < rows * sc.cw) {
+            const int lr = it / sc.cw, lc = it - lr * sc.cw;
+            const int tc = seg_tcol(sc, lc);
+            sg_st4(l.P + (size_t)lr * SG_TW + tc, pv[j]);
+            sg_st4(l.Q + (size_t)lr * SG_TW + tc, qv[j]);
+        }
+    }
+    // the trailing columns of dS: VALU dot products on the four waves that carry no tile (rows <= 128), in the shadow of the
+    // prologue's loads; kept in registers until the dS tile exists (it is still the weight quarter)
+    float v1[4], v2[4];
+    const int nreal = min(sc.remv, a.h - 32 * sc.nq);
+    const bool rem_helper = !DSG && sc.rem && wave >= 4;
+    if (rem_helper) seg_rem_dots<false, 1, 5>(threadIdx.x - 256, a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, nreal, v1, v2);
     if (DSG) {   // last layer: dS[row][u] = sum_o gout[row][o] W2[o][u] from the 16-byte gout rows (edge.hip ds_row)
         for (int i = threadIdx.x; i < 4 * SG_TW; i += SG_THREADS) {
             const int o = i / SG_TW, t = i - o * SG_TW;
@@ -466,16 +616,18 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         // (the W2 quarter sits where the dS tile goes: every wave is done reading it before the first one writes)
         seg_dma_wait();
         __syncthreads();
+        SG_TS(1);
         f32x16 acc;
         if (mfma_on) acc = seg_mma(ta, l.B0, K8, lane);
         __syncthreads();
         if (mfma_on) seg_store_tile(acc, sc.q, nullptr, a.h, l.D, 32 * wave, lane);
-        if (sc.rem) seg_rem_cols<false>(a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, min(sc.remv, a.h - 32 * sc.nq), nullptr, l.D, nullptr);
+        else if (rem_helper) seg_rem_store<false, 1>(threadIdx.x - 256, rows, sc.nq, nreal, nullptr, v1, v2, l.D, nullptr);
     }
     __syncthreads();
+    SG_TS(2);
     // ---- walks.  Thread = (chunk lane lc = tid & 7, row lane ty = tid >> 3): a thread keeps ONE column chunk for all its rows, so
     // the dWe partial sums stay in registers and the block emits one ordered partial per column.  The block that also owns the
-    // trailing columns walks that ninth chunk in a second, short pass (thread = row): as a ninth lane it halved the row lanes and
+    // trailing columns walks that ninth chunk in a second, short pass (two threads per row, one per direction): as a ninth lane it halved the row lanes and
     // made those blocks -- the launch's critical path -- twice as long.
     auto walk_rows = [&](int lr0, int lr_step, int tc, int gc, float4& dwe0, float4& dwe1) {
         const float4 w0 = sg_ld4(l.we + tc), w1 = sg_ld4(l.we + SG_TW + tc);
@@ -499,8 +651,26 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     float4 dwe0 = make_float4(0.f, 0.f, 0.f, 0.f), dwe1 = dwe0, rwe0 = dwe0, rwe1 = dwe0;
 #ifndef SG_EXP_NOWALK
     if (lc < cwm) walk_rows(ty, SG_THREADS / 8, 4 * lc, sc.col0 + 4 * lc, dwe0, dwe1);
-    if (sc.rem) walk_rows(threadIdx.x, SG_THREADS, 32, 32 * sc.nq, rwe0, rwe1);
+    if (sc.rem) {   // the trailing chunk: a row's two walks go to two threads (t >> 1 = row, t & 1 = direction)
+        const int lr = threadIdx.x >> 1, gc = 32 * sc.nq;
+        if (lr < rows) {
+            if (cin.in_lds && cout.in_lds) {
+                const float4 w0 = sg_ld4(l.we + 32), w1 = sg_ld4(l.we + SG_TW + 32);
+                float4 acc;
+                if (threadIdx.x & 1) {
+                    seg_bwd_row_src(l, cout, lr, 32, w0, w1, acc);
+                    sg_st4(a.dQ + (size_t)(r0 + lr) * a.ld + gc, acc);
+                } else {
+                    seg_bwd_row_dst(l, cin, lr, 32, w0, w1, acc, rwe0, rwe1);
+                    sg_st4(a.dP + (size_t)(r0 + lr) * a.ld + gc, acc);
+                }
+            } else if (!(threadIdx.x & 1)) {
+                walk_rows(lr, SG_THREADS, 32, gc, rwe0, rwe1);
+            }
+        }
+    }
 #endif
+    SG_TS(3);
     // ordered reduction of the dWe partials over the row lanes: inside a wave by a fixed xor tree (over the lanes that share a chunk:
     // lane bits 3..5; all six bits for the trailing chunk), then over the 8 waves in wave order -> the block's partial [2][ld]
     auto xor_sum = [&](float4& v, int off) {
@@ -525,6 +695,7 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             sg_st4(a.dWe_partial + ((size_t)blockIdx.x * 2 + f) * a.ld + seg_gcol(sc, c2), s);
         }
     }
+    SG_TS(4);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -598,3 +769,9 @@ int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStr
 }
 
 }  // namespace pfn
+
+#ifdef SG_EXP_TS
+extern "C" int pfn_debug_seg_ts(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::sg_ts), (size_t)n * sizeof(unsigned long long));
+}
+#endif
