@@ -271,14 +271,15 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0);
     const SegCols sc = seg_cols(a.ld);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // ---- P | Q tiles: task t = (row tile t >> 1, P or Q); the first task's operands are requested before the block stages
-    // its adjacency slice (three dependent loads deep), so both latencies overlap
+    // ---- P | Q tiles: wave w < 4 owns row tile w and multiplies its ONE A fragment with both weight quarters (P, then Q); as two
+    // waves per row tile every fragment was fetched twice, and the prologue is bound by the bytes it pulls through L2 -> L1.
+    // (rows <= SG_MAX_ROWS = 128: waves 4..7 carry no tile)
     SG_TS(0);
     const int nrt = (rows + 31) >> 5;
-    const bool mfma_on = wave < 2 * nrt;   // (rows <= SG_MAX_ROWS = 128: at most one task per wave)
+    const bool mfma_on = wave < nrt;
     const int K8 = (a.K + 7) & ~7;
     SegA ta;
-    if (mfma_on) seg_load_a(ta, a.x, a.ldx, K8, r0 + 32 * (wave >> 1), r0 + rows - 1, lane);
+    if (mfma_on) seg_load_a(ta, a.x, a.ldx, K8, r0 + 32 * wave, r0 + rows - 1, lane);
     seg_copy_b(l.B0, a.Bi, sc.q, K8, wave, lane);
     seg_copy_b(l.B1, a.Bj, sc.q, K8, wave, lane);
     SegCsr cin = l.in;
@@ -288,8 +289,8 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     csr_issue2(cin, cri, cap, nbr, a.ea_in);
     csr_commit(cin, cri, r0, rows);
     we_commit(l.we, wev);
-    if (sc.rem) {   // the trailing columns, while the tiles' operands are in flight (tile columns 32..: the tiles write 0..31)
-        float v1[4], v2[4];
+    if (sc.rem) {   // the trailing columns (tile columns 32..: the tiles write 0..31), in the shadow of the operand loads; all 512
+        float v1[4], v2[4];   // threads, four k parts per row (on waves 4..7 alone, two parts per row, it took 2 us longer)
         const int nreal = min(sc.remv, a.h - 32 * sc.nq);
         seg_rem_dots<true, 2, 3>(threadIdx.x, a.x, a.ldx, a.K, r0, rows, a.Bi, a.Bj, sc.nq, nreal, v1, v2);
         seg_rem_store<true, 2>(threadIdx.x, rows, sc.nq, nreal, a.b1, v1, v2, l.P, l.Q);
@@ -298,8 +299,10 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     __syncthreads();
     SG_TS(1);
     if (mfma_on) {
-        const f32x16 acc = seg_mma(ta, (wave & 1) ? l.B1 : l.B0, K8, lane);
-        seg_store_tile(acc, sc.q, (wave & 1) ? nullptr : a.b1, a.h, (wave & 1) ? l.Q : l.P, 32 * (wave >> 1), lane);
+        const f32x16 accp = seg_mma(ta, l.B0, K8, lane);
+        seg_store_tile(accp, sc.q, a.b1, a.h, l.P, 32 * wave, lane);
+        const f32x16 accq = seg_mma(ta, l.B1, K8, lane);
+        seg_store_tile(accq, sc.q, nullptr, a.h, l.Q, 32 * wave, lane);
     }
     __syncthreads();
     SG_TS(2);
