@@ -142,14 +142,45 @@ __global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_
     // from global memory (three dependent latencies per item) would dominate everything else
     const int e0 = rowptr[r0], e1 = rowptr[r0 + rows];
     const bool nb_in_lds = e1 - e0 <= nbr_cap;
-    for (int i = threadIdx.x; i <= rows; i += FH_THREADS) s_rp[i] = rowptr[r0 + i] - e0;
-    for (int i = threadIdx.x; i < rows; i += FH_THREADS) s_dinv[i] = dinv[r0 + i];
-    if (nb_in_lds)
-        for (int i = threadIdx.x; i < e1 - e0; i += FH_THREADS) s_nb[i] = nbr[e0 + i] - r0;
     const float* first = a.transpose ? a.G + (size_t)a.K * a.stride : a.x0;
-    for (int i = threadIdx.x; i < items; i += FH_THREADS) {
-        const int lr = i / cwh, lc = i - lr * cwh;
-        st4(cur + (size_t)lr * tld + 4 * lc, ld4(first + (size_t)(r0 + lr) * a.ld + 4 * (c0 + lc)));
+    if (rows < FH_THREADS && items <= 4 * FH_THREADS && e1 - e0 <= FH_THREADS) {
+        // Small blocks (the metric configuration: one graph, ~1,300 items): EVERY global load of the prologue is requested before
+        // the first LDS store.  As load-store loops each store waited for all loads before it (VMEM returns in order) and the next
+        // loop's loads went out only then: four serial round trips before the first hop (cf. ea_seg.hip).
+        const int t = threadIdx.x;
+        const int rpv = t <= rows ? rowptr[r0 + t] : 0;
+        const float dv = t < rows ? dinv[r0 + t] : 0.f;
+        float4 tv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = t + j * FH_THREADS;
+            tv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < items) {
+                const int lr = i / cwh, lc = i - lr * cwh;
+                tv[j] = ld4(first + (size_t)(r0 + lr) * a.ld + 4 * (c0 + lc));
+            }
+        }
+        const int nbv = (nb_in_lds && t < e1 - e0) ? nbr[e0 + t] : 0;   // (second level: needs e0)
+        if (t <= rows) s_rp[t] = rpv - e0;
+        if (t < rows) s_dinv[t] = dv;
+        if (nb_in_lds && t < e1 - e0) s_nb[t] = nbv - r0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = t + j * FH_THREADS;
+            if (i < items) {
+                const int lr = i / cwh, lc = i - lr * cwh;
+                st4(cur + (size_t)lr * tld + 4 * lc, tv[j]);
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i <= rows; i += FH_THREADS) s_rp[i] = rowptr[r0 + i] - e0;
+        for (int i = threadIdx.x; i < rows; i += FH_THREADS) s_dinv[i] = dinv[r0 + i];
+        if (nb_in_lds)
+            for (int i = threadIdx.x; i < e1 - e0; i += FH_THREADS) s_nb[i] = nbr[e0 + i] - r0;
+        for (int i = threadIdx.x; i < items; i += FH_THREADS) {
+            const int lr = i / cwh, lc = i - lr * cwh;
+            st4(cur + (size_t)lr * tld + 4 * lc, ld4(first + (size_t)(r0 + lr) * a.ld + 4 * (c0 + lc)));
+        }
     }
     __syncthreads();
     for (int k = 1; k <= a.K; ++k) {
