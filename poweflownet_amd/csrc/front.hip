@@ -88,7 +88,7 @@ __device__ __forceinline__ void front_fwd_body(const FrontFwdArgs& a, int bid, i
         row_sum(part, r, c, nchunk, on);   // fixed-order sum over the row's chunks, left in part[r * nchunk]
         if (on && c == 0) {
             const float4 s = part[r * nchunk];
-            const float4 xi = ld4f(a.x + (size_t)row * 4);
+            const float4 xi = ld4f(a.x + (size_t)row * 4);   // (requested at the top of the trip instead: no gain at 128 graphs, 4-8 % slower at 2048)
             const float4 o = make_float4(xi.x + (s.x + bb4.x), xi.y + (s.y + bb4.y), xi.z + (s.z + bb4.z), xi.w + (s.w + bb4.w));
             vec[r] = o;
             st4f(a.x0 + (size_t)row * 4, o);
@@ -158,6 +158,8 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(int n, int h, int ld, in
     for (int row0 = blockIdx.x * rows_pb; row0 < n; row0 += gridDim.x * rows_pb) {
         const int row = row0 + r;
         const bool on = lane_on && row < n;
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);   // (requested with dP / dQ, used after the row sum's barriers)
+        if (on) y = ld4f(me_h + (size_t)row * ld + 4 * c);
         if (on) {
             const float4 p4 = ld4f(dP + (size_t)row * ld + 4 * c), q4 = ld4f(dQ + (size_t)row * ld + 4 * c);
             const float pv[4] = {p4.x, p4.y, p4.z, p4.w}, qv[4] = {q4.x, q4.y, q4.z, q4.w};
@@ -181,7 +183,6 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(int n, int h, int ld, in
         __syncthreads();
         if (on) {
             const float4 g = vec[r];
-            const float4 y = ld4f(me_h + (size_t)row * ld + 4 * c);
             const float yv[4] = {y.x, y.y, y.z, y.w};
             float o[4];
 #pragma unroll
