@@ -598,22 +598,34 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     const bool rem_helper = !DSG && sc.rem && wave >= 4;
     if (rem_helper) seg_rem_dots<false, 1, 5>(threadIdx.x - 256, a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, nreal, v1, v2);
     if (DSG) {   // last layer: dS[row][u] = sum_o gout[row][o] W2[o][u] from the 16-byte gout rows (edge.hip ds_row)
+        // (the gout rows are requested BEFORE the barrier that publishes the W2 slice: behind it they were one more exposed round trip)
+        float4 gv[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int it = threadIdx.x + j * SG_THREADS;
+            gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (it < rows * sc.cw) gv[j] = sg_ld4(a.gout + (size_t)(r0 + it / sc.cw) * 4);
+        }
         for (int i = threadIdx.x; i < 4 * SG_TW; i += SG_THREADS) {
             const int o = i / SG_TW, t = i - o * SG_TW;
             const int col = seg_col_of_tile(sc, t);
             l.w2s[i] = (o < a.fo && col >= 0 && col < a.h) ? a.w2[(size_t)o * a.h + col] : 0.f;
         }
         __syncthreads();
-        for (int it = threadIdx.x; it < rows * sc.cw; it += SG_THREADS) {
-            const int lr = it / sc.cw, lc = it - lr * sc.cw;
-            const int tc = seg_tcol(sc, lc);
-            const float4 g = sg_ld4(a.gout + (size_t)(r0 + lr) * 4);
-            const float4 x0 = sg_ld4(l.w2s + tc);
-            float4 r = make_float4(g.x * x0.x, g.x * x0.y, g.x * x0.z, g.x * x0.w);
-            r = sg_fma4(g.y, sg_ld4(l.w2s + SG_TW + tc), r);
-            r = sg_fma4(g.z, sg_ld4(l.w2s + 2 * SG_TW + tc), r);
-            r = sg_fma4(g.w, sg_ld4(l.w2s + 3 * SG_TW + tc), r);
-            sg_st4(l.D + (size_t)lr * SG_TW + tc, r);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int it = threadIdx.x + j * SG_THREADS;
+            if (it < rows * sc.cw) {
+                const int lr = it / sc.cw, lc = it - lr * sc.cw;
+                const int tc = seg_tcol(sc, lc);
+                const float4 g = gv[j];
+                const float4 x0 = sg_ld4(l.w2s + tc);
+                float4 r = make_float4(g.x * x0.x, g.x * x0.y, g.x * x0.z, g.x * x0.w);
+                r = sg_fma4(g.y, sg_ld4(l.w2s + SG_TW + tc), r);
+                r = sg_fma4(g.z, sg_ld4(l.w2s + 2 * SG_TW + tc), r);
+                r = sg_fma4(g.w, sg_ld4(l.w2s + 3 * SG_TW + tc), r);
+                sg_st4(l.D + (size_t)lr * SG_TW + tc, r);
+            }
         }
     } else {
         // (the W2 quarter sits where the dS tile goes: every wave is done reading it before the first one writes)

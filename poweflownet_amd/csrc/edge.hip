@@ -289,21 +289,32 @@ __device__ __forceinline__ void stage_w2(float* w2s, const float* __restrict__ w
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x))); }
 
 // S[row][col..col+3] for one (row, column chunk): the walk over the row's incoming edges
+// What a (row, chunk) walk needs before its first edge: requested BEFORE the barrier that publishes the block's residue weights
+// (behind it these loads were one more serial round trip; a load cannot move across __syncthreads by itself)
+struct EdgeRowHead { float4 p4; int beg, end, b4, b4n; };
+template <bool MASK>
+__device__ __forceinline__ EdgeRowHead edge_row_head(int row, int col, const int* __restrict__ rowptr, const float* __restrict__ P,
+                                                     int ld, const int* __restrict__ rp4) {
+    EdgeRowHead hd;
+    hd.p4 = ld4(P + (size_t)row * ld + col);
+    hd.beg = rowptr[row];
+    hd.end = rowptr[row + 1];
+    hd.b4 = MASK ? rp4[row] : 0;
+    hd.b4n = MASK ? rp4[row + 1] : 0;
+    return hd;
+}
 template <int FE, bool MASK>   // MASK: also save the ReLU masks (EdgeFwdArgs::mask) -- a backward pass will follow
 __device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored, const int* __restrict__ rowptr,
                                                  const int* __restrict__ nbr, const int* __restrict__ eid,
                                                  const float* __restrict__ P, const float* __restrict__ Q,
                                                  const float* __restrict__ ea, const float* we, int ld, int fe,
-                                                 unsigned* __restrict__ mask, const int* __restrict__ rp4) {
-    const float4 p4 = ld4(P + (size_t)row * ld + col);
+                                                 unsigned* __restrict__ mask, const EdgeRowHead& hd) {
+    const float4 p4 = hd.p4;
     // this (row, chunk)'s run of mask dwords (EdgeFwdArgs::mask): one dword per trip of four slots
     unsigned* mrun = nullptr;
-    if (MASK) {
-        const int b4 = rp4[row];
-        mrun = mask + (size_t)b4 * (ld >> 2) + (size_t)(col >> 2) * (rp4[row + 1] - b4);
-    }
+    if (MASK) mrun = mask + (size_t)hd.b4 * (ld >> 2) + (size_t)(col >> 2) * (hd.b4n - hd.b4);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int beg = rowptr[row], end = rowptr[row + 1];
+    const int beg = hd.beg, end = hd.end;
     if (FE == 2) {
         // four edge slots per trip (see hop_kernel): indices first, then all gathers, then the sums in edge-id order
         const float4 w0 = ld4(we + col), w1 = ld4(we + ld + col);
@@ -359,16 +370,18 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
     extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld]
     const int fe = FE > 0 ? FE : fe_rt;
     const int ldw = 2 * fi + fe;
+    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = (int)(item / nchunk);
+    const int col = (int)(item - (long)row * nchunk) * 4;
+    EdgeRowHead hd;
+    if (row < n) hd = edge_row_head<MASK>(row, col, rowptr, P, ld, rp4);
     for (int i = threadIdx.x; i < fe * ld; i += blockDim.x) {
         const int f = i / ld, k = i - f * ld;
         we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
     }
     __syncthreads();
-    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const int row = (int)(item / nchunk);
     if (row >= n) return;
-    const int col = (int)(item - (long)row * nchunk) * 4;
-    st4(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, rp4));
+    st4(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, hd));
 }
 
 // The network's LAST EdgeAggregation layer (Fo <= 4, no activation): the second Linear rides in the same launch.  Block =
@@ -398,9 +411,11 @@ __global__ __launch_bounds__(256) void edge_fwd_out_kernel(int n, int nchunk, in
     const int r = threadIdx.x / nchunk, c = threadIdx.x - r * nchunk;
     const int row = blockIdx.x * rows_pb + r, col = 4 * c;
     const bool on = r < rows_pb && row < n;
+    EdgeRowHead hd;
+    if (on) hd = edge_row_head<MASK>(row, col, rowptr, P, ld, rp4);
     __syncthreads();
     if (on) {
-        const float4 s4 = edge_sum_chunk<FE, MASK>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, FE, mask, rp4);
+        const float4 s4 = edge_sum_chunk<FE, MASK>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, FE, mask, hd);
         st4(S + (size_t)row * ld + col, s4);
         float4 o;
         o.x = dot4(s4, ld4(w2s + col));
