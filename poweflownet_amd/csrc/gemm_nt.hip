@@ -291,9 +291,31 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
     }
 }
 
+// tools/ubench experiment switch (never defined in the product build): wall-clock (100 MHz) timestamps of one workgroup's phases
+// -- kernel start, first barrier passed, first flush begins, end -- of the LAST launch, read back with pfn_debug_nt_ts()
+#ifdef NT_EXP_TS
+__device__ unsigned long long nt_ts[4096 * 4];
+#define NT_TS_DECL unsigned long long ts0_ = wall_clock64(), ts1_ = 0, ts2_ = 0
+#define NT_TS1 ts1_ = wall_clock64()
+#define NT_TS2 do { if (ts2_ == 0) ts2_ = wall_clock64(); } while (0)
+#define NT_TS_END                                                                                                   \
+    do {                                                                                                            \
+        const int b_ = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
+        if (tid == 0 && b_ < 4096) {                                                                                \
+            nt_ts[b_ * 4] = ts0_; nt_ts[b_ * 4 + 1] = ts1_; nt_ts[b_ * 4 + 2] = ts2_; nt_ts[b_ * 4 + 3] = wall_clock64(); \
+        }                                                                                                           \
+    } while (0)
+#else
+#define NT_TS_DECL
+#define NT_TS1
+#define NT_TS2
+#define NT_TS_END
+#endif
+
 template <int CT>
 __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    NT_TS_DECL;
     constexpr int CTE = CT > 0 ? CT : 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -362,6 +384,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     }
     dma_wait();
     __syncthreads();   // the only barrier: from here on the waves run free
+    NT_TS1;
     if (rt >= nrt || !(mfma_on || rem_on)) return;
 
     EpiCfg ep;
@@ -455,6 +478,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
             nt_multiply<CT, NR, NFAST, LS>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax);
         }
         if (flush_after) {
+            NT_TS2;
             // ---- flush straight from registers: acc[q] of lane (r32, kh) is D[row (q&3) + 8 (q>>2) + 4 kh][col r32];
             // after the quad transpose lane (u = r32 >> 2, j = r32 & 3) holds, for register group g, row
             // rbase + j + 8 g + 4 kh and the four columns col0 .. col0 + 3
@@ -633,11 +657,15 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
             done = true;
         }
     }
-    if (done) return;
+    if (done) {
+        NT_TS_END;
+        return;
+    }
     if (a.kuni == KP && nr == 0) rounds(integral_constant<int, NCH>{}, I0{}, I4{});
     else if (a.kuni == KP && nr == 1) rounds(integral_constant<int, NCH>{}, I1{}, I4{});
     else if (a.kuni == KP - 8 && nr == 0) rounds(integral_constant<int, NCH - 1>{}, I0{}, I4{});
     else if constexpr (CT < 2) rounds(I0{}, I4{}, I4{});
+    NT_TS_END;
     // CT == 2 exists only for the straight-line variants (the launcher never pairs it with the generic one: two tiles plus
     // four trailing columns plus per-chunk guards do not fit the register file without spills)
 }
@@ -789,3 +817,9 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace pfn
+
+#ifdef NT_EXP_TS
+extern "C" int pfn_debug_nt_ts(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::nt_ts), (size_t)n * sizeof(unsigned long long));
+}
+#endif

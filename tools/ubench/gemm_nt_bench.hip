@@ -9,6 +9,9 @@
 #include "../../poweflownet_amd/csrc/pfn_internal.hpp"
 using namespace pfn;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+#ifdef NT_EXP_TS
+extern "C" int pfn_debug_nt_ts(unsigned long long*, int);
+#endif
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 15104, K = argc > 2 ? atoi(argv[2]) : 129, N = argc > 3 ? atoi(argv[3]) : 129;
     const int nterm = argc > 4 ? atoi(argv[4]) : 1, ngroup = argc > 5 ? atoi(argv[5]) : 1, iters = argc > 6 ? atoi(argv[6]) : 20;
@@ -54,5 +57,23 @@ int main(int argc, char** argv) {
             ref *= (ngroup > 1 ? 1 : nterm); putchar(fabs(ref - hC[(size_t)r * ldc + c]) > 1e-3 ? 'X' : '.'); } putchar('\n'); }
     }
     printf("M=%d K=%d N=%d nterm=%d ngroup=%d : %.2f us  %.1f TFLOP/s  (spot max err %.2e)\n", M, K, N, nterm, ngroup, us, flops / us * 1e-6, maxerr);
+#ifdef NT_EXP_TS   /* built against a -DNT_EXP_TS library (tools/ubench/run_gemm_nt_ts.sh): phase timestamps of the LAST launch */
+    {
+        static unsigned long long ts[4096 * 4];
+        CK(hipDeviceSynchronize());
+        pfn_debug_nt_ts(ts, 4096 * 4);
+        unsigned long long t0 = ~0ull;
+        int nb = 0;
+        for (int b = 0; b < 4096; ++b) if (ts[b * 4 + 3] != 0) { nb = b + 1; if (ts[b * 4] < t0) t0 = ts[b * 4]; }
+        double s0 = 0, s1 = 0, s2 = 0, s3 = 0, m0 = 0, m3 = 0; int cnt = 0;
+        for (int b = 0; b < nb; ++b) {
+            if (ts[b * 4 + 3] == 0) continue;
+            const double a0 = (ts[b * 4] - t0) * 0.01, a1 = (ts[b * 4 + 1] - t0) * 0.01, a2 = (ts[b * 4 + 2] - t0) * 0.01, a3 = (ts[b * 4 + 3] - t0) * 0.01;
+            s0 += a0; s1 += a1 - a0; s2 += a2 - a1; s3 += a3 - a2; if (a0 > m0) m0 = a0; if (a3 > m3) m3 = a3; ++cnt;
+        }
+        printf("    %d workgroups: start mean %.2f max %.2f | to first barrier %.2f | multiply %.2f | flush %.2f | last end %.2f us\n", cnt,
+               s0 / cnt, m0, s1 / cnt, s2 / cnt, s3 / cnt, m3);
+    }
+#endif
     return 0;
 }
