@@ -977,7 +977,8 @@ int launch_edge_attr_grad(const GraphView& g, const EdgeBwdArgs& a, hipStream_t 
         set_error("edge feature width %d > %d", a.fe, PFN_MAX_FE);
         return PFN_EINVAL;
     }
-    PFN_CHECK_HIP(hipMemsetAsync(a.grad_edge_attr, 0, (size_t)g.e_stored * a.fe * sizeof(float), s));
+    // ACCUMULATES into grad_edge_attr (every EdgeAggregation layer of a model adds its share): the caller zeroes it once per
+    // backward pass (pfn_mpn_backward, pfn_edge_aggr_backward).  A memset here made the model-level gradient the LAST layer's alone.
     const long waves = 2l * g.e_stored;   // upper bound on effective edges
     const int blocks = (int)((waves * 64 + 255) / 256);
     edge_attr_grad_kernel<<<blocks, 256, 0, s>>>(g.e_stored, g.rowptr_in, g.in_src, g.in_eid, g.n, a.P, a.Q, a.dS,

@@ -558,6 +558,34 @@ def test_graph_resident_kernels_with_more_edges_than_their_lds_slices():
         assert_close(p.grad, q.grad, RTOL, f"grad.{k}")
 
 
+@pytest.mark.parametrize("with_ptr", [True, False])
+def test_model_input_and_edge_attr_gradients_vs_oracle(with_ptr):
+    """Gradients with respect to x AND edge_attr through the whole model (pfn_mpn_backward's optional outputs).  The edge-attribute
+    gradient needs the recomputing backward walks, whatever the forward pass ran: with `ptr` the graph-resident forward kernels
+    (their P | Q must be in memory for it), without it the generic forward walks that also saved ReLU masks nobody reads."""
+    torch.manual_seed(21)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    data = make_batch("118", 5, seed=9)
+    data.x.requires_grad_(True)
+    data.edge_attr.requires_grad_(True)
+    torch.nn.MSELoss()(ref(data), data.y).backward()
+    dd = data.clone().to(DEV)
+    if not with_ptr:
+        del dd.__dict__["ptr"]; dd._keys.remove("ptr")
+    dd.x = dd.x.detach().requires_grad_(True)
+    dd.edge_attr = dd.edge_attr.detach().requires_grad_(True)
+    out = m(dd)
+    assert (m._graphs._graph.seg_nodes == 118) == with_ptr
+    torch.nn.MSELoss()(out, dd.y).backward()
+    assert_close(dd.x.grad, data.x.grad, RTOL, "grad x")
+    assert_close(dd.edge_attr.grad, data.edge_attr.grad, RTOL, "grad edge_attr")
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, RTOL, f"grad.{k}")
+
+
 def test_edge_cases_empty_edges_and_isolated_nodes():
     from poweflownet_amd.data import Data
     torch.manual_seed(0)
