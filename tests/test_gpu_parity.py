@@ -586,6 +586,26 @@ def test_model_input_and_edge_attr_gradients_vs_oracle(with_ptr):
         assert_close(p.grad, q.grad, RTOL, f"grad.{k}")
 
 
+@pytest.mark.parametrize("fe", [1, 3])
+def test_model_with_other_edge_feature_widths_vs_oracle(fe):
+    """efeature_dim != 2 through the WHOLE model: the generic-width edge walks (runtime Fe), no ReLU masks, no graph-resident
+    kernels -- the recomputing backward walks at model level."""
+    torch.manual_seed(31 + fe)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, fe, 4, 64, 3, 2, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, fe, 4, 64, 3, 2, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    data = make_batch("14", 6, seed=2)
+    data.edge_attr = torch.randn(data.edge_index.shape[1], fe)
+    torch.nn.MSELoss()(ref(data), data.y).backward()
+    dd = data.to(DEV)
+    out = m(dd)
+    assert_close(out, ref(data), RTOL, "out")
+    torch.nn.MSELoss()(out, dd.y).backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, RTOL, f"grad.{k}")
+
+
 def test_edge_cases_empty_edges_and_isolated_nodes():
     from poweflownet_amd.data import Data
     torch.manual_seed(0)
