@@ -875,43 +875,8 @@ int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t*, hi
 // dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered: 4 interleaved lanes, then a fixed tree), for up to
 // DWE_MAX_JOBS EdgeAggregation layers in one launch (blockIdx.y = layer)
 __global__ __launch_bounds__(1024) void dwe_reduce_kernel(const DweJobs jobs, int fe, int ld, int h) {
-    // block = 16 output elements x 64 partial lanes; every lane sums its stride-64 subset with four independent
-    // chains, then a fixed-order tree over the lanes -> deterministic
     __shared__ float red[64][17];
-    const DweJob jb = jobs.job[blockIdx.y];
-    const int nblocks = jb.nblocks;
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + tx;
-    const bool ok = i < fe * h;
-    const int f = ok ? i / h : 0, k = ok ? i - f * h : 0;
-    const float* p = jb.partial + (size_t)f * ld + k;
-    const size_t stride = (size_t)fe * ld;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (ok) {
-        // up to 16 partials of the lane's stride-64 subset are requested at once (two rounds of the four chains), then added in
-        // a fixed order: the kernel is a chain of dependent loads, not bandwidth
-        int b = ty;
-        for (; b + 448 < nblocks; b += 512) {
-            const float a0 = p[(size_t)b * stride], a1 = p[(size_t)(b + 64) * stride], a2 = p[(size_t)(b + 128) * stride],
-                        a3 = p[(size_t)(b + 192) * stride], a4 = p[(size_t)(b + 256) * stride], a5 = p[(size_t)(b + 320) * stride],
-                        a6 = p[(size_t)(b + 384) * stride], a7 = p[(size_t)(b + 448) * stride];
-            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-            s0 += a4; s1 += a5; s2 += a6; s3 += a7;
-        }
-        for (; b + 192 < nblocks; b += 256) {
-            const float a0 = p[(size_t)b * stride], a1 = p[(size_t)(b + 64) * stride], a2 = p[(size_t)(b + 128) * stride],
-                        a3 = p[(size_t)(b + 192) * stride];
-            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
-        }
-        for (; b < nblocks; b += 64) s0 += p[(size_t)b * stride];
-    }
-    red[ty][tx] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    for (int off = 32; off > 0; off >>= 1) {
-        if (ty < off) red[ty][tx] += red[ty + off][tx];
-        __syncthreads();
-    }
-    if (ty == 0 && ok) jb.gw1[(size_t)k * jb.ldw + jb.col0 + f] = red[0][tx];
+    dwe_reduce_body<64>(jobs.job[blockIdx.y], blockIdx.x, fe, ld, h, red);
 }
 
 int launch_dwe_reduce_multi(const DweJob* jobs, int njobs, int fe, int ld, int h, hipStream_t s) {

@@ -312,8 +312,15 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     for (int Q = 0; Q < NQ; ++Q) mine[Q * 64 + lane] = v[Q];
 }
 
-__global__ __launch_bounds__(T3_THREADS, 1) void gemm_tn_kernel(const T3Args a) {
+__global__ __launch_bounds__(T3_THREADS, 1) void gemm_tn_kernel(const T3Args a, const DweRide ride) {
     extern __shared__ __attribute__((aligned(16))) float4 t3_lds[];
+    if ((int)blockIdx.x >= a.nblocks) {   // riders: the dWe partial reductions of the same backward pass (edge.hip), 17 blocks per layer
+        const int r = blockIdx.x - a.nblocks, bx_per = (ride.fe * ride.h + 15) / 16;
+        const int job = r / bx_per;
+        if (job < ride.njobs) dwe_reduce_body<T3_THREADS / 16>(ride.jobs.job[job], r - job * bx_per, ride.fe, ride.ld, ride.h,
+                                                               reinterpret_cast<float (*)[17]>(t3_lds));
+        return;
+    }
     // task and row split of this workgroup.  Groups own consecutive id ranges; inside a group the ids run
     //     [chunk of 8 splits][member][split in chunk]
     // so the workgroups of ONE row range of all members (the 4 pairs of a TAGConv share dY, dP / dQ of an EdgeAggregation
@@ -385,7 +392,7 @@ size_t reduce_ws_floats(int64_t M, int max_na, int max_nb, int max_pairs) {
     return T3_MAX_PARTIAL_F4 * 4 + 256;
 }
 
-int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s) {
+int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s, const DweRide* ride) {
     if (npairs == 0 || M == 0) {
         // no rows: every gradient is an empty sum
         for (int p = 0; p < npairs; ++p) {
@@ -401,6 +408,7 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
     PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_tn_kernel), T3_LDS_BYTES, lds_raised));
     static const int want_env = getenv("PFN_TN_BLOCKS") ? atoi(getenv("PFN_TN_BLOCKS")) : 0;   // tuning aid
     const int ncu = device_cus();
+    bool ride_done = false;
     int p = 0;
     while (p < npairs) {
         T3Args ta;
@@ -499,7 +507,14 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
         ta.nblocks = nblocks;
         {
             ProfScope ps("gemm_tn", bytes, flops, s);
-            gemm_tn_kernel<<<nblocks, T3_THREADS, T3_LDS_BYTES, s>>>(ta);
+            DweRide rd;
+            int extra = 0;
+            if (ride && !ride_done && ride->njobs > 0) {   // (the first launch of the pass carries the riders)
+                rd = *ride;
+                extra = ride->njobs * ((ride->fe * ride->h + 15) / 16);
+                ride_done = true;
+            }
+            gemm_tn_kernel<<<nblocks + extra, T3_THREADS, T3_LDS_BYTES, s>>>(ta, rd);
             PFN_CHECK_LAUNCH();
         }
         bool any_split = false;

@@ -610,8 +610,17 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
     }
     pairs.pairs.push_back(tn_pair(gcur, lo.ld0, lo.f0, lo.me_h, lo.ld, lo.h, gme[2], lo.h, 0, gme[3], nullptr));     // dWb, dbb
     pairs.pairs.push_back(tn_pair(lo.dh, lo.ld, lo.h, lo.maskf, lo.ld0, lo.f0, gme[0], lo.f0, 0, gme[1], nullptr));  // dWa, dba
-    PFN_TRY(launch_dwe_reduce_multi(pairs.dwe.data(), (int)pairs.dwe.size(), lo.fe, lo.ld, lo.h, s));
-    PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s));
+    // the dWe partial reductions ride in the weight-gradient launch (independent work, one launch floor less)
+    if ((int)pairs.dwe.size() <= DWE_MAX_JOBS && lo.n > 0 && !pairs.pairs.empty()) {
+        DweRide ride;
+        ride.njobs = (int)pairs.dwe.size();
+        for (int j = 0; j < ride.njobs; ++j) ride.jobs.job[j] = pairs.dwe[j];
+        ride.fe = lo.fe; ride.ld = lo.ld; ride.h = lo.h;
+        PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s, &ride));
+    } else {
+        PFN_TRY(launch_dwe_reduce_multi(pairs.dwe.data(), (int)pairs.dwe.size(), lo.fe, lo.ld, lo.h, s));
+        PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s));
+    }
     if (gx) PFN_CHECK_HIP(hipMemcpyAsync(gx, gcur, (size_t)lo.n * lo.ld0 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return PFN_OK;
 }

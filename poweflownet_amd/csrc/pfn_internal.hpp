@@ -216,7 +216,7 @@ struct ReduceWs {
     size_t floats;
 };
 size_t reduce_ws_floats(int64_t M, int max_na, int max_nb, int max_pairs);
-int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s);
+int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s, const struct DweRide* ride = nullptr);
 
 // ------------------------------------------------------------------------------------- edge kernels
 // y[i] = (add ? add[i] : 0) + dinv[i] * sum_{e in row i} dinv[nbr(e)] * x[nbr(e)]   (normalize)
@@ -363,6 +363,51 @@ struct DweJob {
 };
 constexpr int DWE_MAX_JOBS = 16;
 struct DweJobs { DweJob job[DWE_MAX_JOBS]; };
+// dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered: interleaved chains per lane, then a fixed tree): one block's
+// share, block = 16 output elements x LANES partial lanes (LANES = blockDim.x / 16: 64 in dwe_reduce_kernel, 32 when the work
+// rides in the gemm_tn launch).  `red`: LANES x 17 floats of LDS.  Every thread of the block calls it (barriers inside).
+template <int LANES>
+__device__ inline void dwe_reduce_body(const DweJob& jb, int bx, int fe, int ld, int h, float (*red)[17]) {
+    const int nblocks = jb.nblocks;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = bx * 16 + tx;
+    const bool ok = i < fe * h;
+    const int f = ok ? i / h : 0, k = ok ? i - f * h : 0;
+    const float* p = jb.partial + (size_t)f * ld + k;
+    const size_t stride = (size_t)fe * ld;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (ok) {
+        // up to 8 partials of the lane's stride-LANES subset are requested at once, then added in a fixed order: the kernel is
+        // a chain of dependent loads, not bandwidth
+        int b = ty;
+        for (; b + 7 * LANES < nblocks; b += 8 * LANES) {
+            const float a0 = p[(size_t)b * stride], a1 = p[(size_t)(b + LANES) * stride], a2 = p[(size_t)(b + 2 * LANES) * stride],
+                        a3 = p[(size_t)(b + 3 * LANES) * stride], a4 = p[(size_t)(b + 4 * LANES) * stride],
+                        a5 = p[(size_t)(b + 5 * LANES) * stride], a6 = p[(size_t)(b + 6 * LANES) * stride],
+                        a7 = p[(size_t)(b + 7 * LANES) * stride];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+            s0 += a4; s1 += a5; s2 += a6; s3 += a7;
+        }
+        for (; b + 3 * LANES < nblocks; b += 4 * LANES) {
+            const float a0 = p[(size_t)b * stride], a1 = p[(size_t)(b + LANES) * stride], a2 = p[(size_t)(b + 2 * LANES) * stride],
+                        a3 = p[(size_t)(b + 3 * LANES) * stride];
+            s0 += a0; s1 += a1; s2 += a2; s3 += a3;
+        }
+        for (; b < nblocks; b += LANES) s0 += p[(size_t)b * stride];
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    for (int off = LANES / 2; off > 0; off >>= 1) {
+        if (ty < off) red[ty][tx] += red[ty + off][tx];
+        __syncthreads();
+    }
+    if (ty == 0 && ok) jb.gw1[(size_t)k * jb.ldw + jb.col0 + f] = red[0][tx];
+}
+// the dWe reductions of a backward pass riding in the gemm_tn launch (independent work, one launch floor less per step)
+struct DweRide {
+    DweJobs jobs;
+    int njobs = 0, fe = 0, ld = 0, h = 0;
+};
 int launch_dwe_reduce_multi(const DweJob* jobs, int njobs, int fe, int ld, int h, hipStream_t s);
 // sums dWe partials [nblocks][fe][ld] into grad_w1[:, 2Fi + f]
 int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, float* grad_w1, int ldw, int col0,
