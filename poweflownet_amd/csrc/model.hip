@@ -755,6 +755,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                     float b1, float b2, float eps, float wd, int64_t* step,
                                                     const float* __restrict__ hp) {
+    // 16 bytes per lane and array when the four flat buffers allow it (they are whole allocations: 256-byte aligned); the
+    // update is a chain of dependent loads per element otherwise (10 us for 355 k parameters, 2x its memory time).  A thread's
+    // FIRST four-element group is requested before the hyper-parameters are even read: their load -> powf chain and this load
+    // were two serial round trips.
+    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
+    const int64_t n4 = vec ? n >> 2 : 0;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (int64_t)gridDim.x * blockDim.x;
+    float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = p4, v4 = p4, g4 = p4;
+    if (i0 < n4) {
+        p4 = reinterpret_cast<float4*>(p)[i0];
+        m4 = reinterpret_cast<float4*>(m)[i0];
+        v4 = reinterpret_cast<float4*>(v)[i0];
+        g4 = reinterpret_cast<const float4*>(g)[i0];
+    }
     if (hp) {
         lr = hp[0]; b1 = hp[1]; b2 = hp[2]; eps = hp[3]; wd = hp[4];
     }
@@ -770,14 +785,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
         pi -= step_size * (mi / denom);
     };
-    // 16 bytes per lane and array when the four flat buffers allow it (they are whole allocations: 256-byte aligned); the
-    // update is a chain of dependent loads per element otherwise (10 us for 355 k parameters, 2x its memory time)
-    const bool vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
-                       reinterpret_cast<uintptr_t>(v)) & 15) == 0;
-    const int64_t n4 = vec ? n >> 2 : 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
-        const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    for (int64_t i = i0; i < n4; i += stride) {
+        if (i != i0) {
+            p4 = reinterpret_cast<float4*>(p)[i];
+            m4 = reinterpret_cast<float4*>(m)[i];
+            v4 = reinterpret_cast<float4*>(v)[i];
+            g4 = reinterpret_cast<const float4*>(g)[i];
+        }
         upd(p4.x, g4.x, m4.x, v4.x);
         upd(p4.y, g4.y, m4.y, v4.y);
         upd(p4.z, g4.z, m4.z, v4.z);
