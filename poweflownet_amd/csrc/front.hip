@@ -113,6 +113,90 @@ __device__ __forceinline__ void front_fwd_body(const FrontFwdArgs& a, int bid, i
     }
 }
 
+// ---- one ROW PER WAVE (H <= 256: a row's <= 64 four-unit chunks are the lanes of one wave).  The row sums become a fixed xor tree
+// of DPP / permute shuffles: no LDS, no barrier, so every wave runs its own chain of loads and 32 of them per CU hide each
+// other's latency.  Used for small batches (front_row_per_wave); the block-per-row-group body above remains for wider models
+// and large batches.
+__device__ __forceinline__ float4 wave_sum4(float4 v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v.x += __shfl_xor(v.x, off);
+        v.y += __shfl_xor(v.y, off);
+        v.z += __shfl_xor(v.z, off);
+        v.w += __shfl_xor(v.w, off);
+    }
+    return v;
+}
+__device__ __forceinline__ void front_fwd_wave_body(const FrontFwdArgs& a, int bid, int nblk, int ld, int nchunk) {
+    const int n = a.n, h = a.h, ldw1 = a.ldw1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane;
+    const bool lane_on = c < nchunk;
+    float rwa[4][4], rba[4], rwb[4][4], rw1[4][8], rb1[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // unconditional clamped loads + select (see front_fwd_body)
+        const int u = 4 * c + i, uc = min(u, h - 1);
+        const bool ok = lane_on && u < h;
+        const float vba = a.ba[uc], vb1 = a.b1[uc];
+        rba[i] = ok ? vba : 0.f;
+        rb1[i] = ok ? vb1 : 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float va = a.wa[(size_t)uc * 4 + f], vb = a.wb[(size_t)f * h + uc];
+            rwa[i][f] = ok ? va : 0.f;
+            rwb[i][f] = ok ? vb : 0.f;
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float v1 = a.w1[(size_t)uc * ldw1 + f];
+            rw1[i][f] = ok ? v1 : 0.f;
+        }
+    }
+    const float4 bb4 = make_float4(a.bb[0], a.bb[1], a.bb[2], a.bb[3]);
+    const int wpb = blockDim.x >> 6;
+    for (int row = bid * wpb + wave; row < n; row += nblk * wpb) {
+        float4 m;                                   // pred_mask.float() (networks/MPN.py:533); every lane reads the same 16 / 32 bytes
+        if (a.mask_dtype == 0) {
+            const int64_t* mp = static_cast<const int64_t*>(a.mask) + (size_t)row * 4;
+            m = make_float4((float)mp[0], (float)mp[1], (float)mp[2], (float)mp[3]);
+        } else {
+            m = ld4f(static_cast<const float*>(a.mask) + (size_t)row * 4);
+        }
+        const float4 xi = ld4f(a.x + (size_t)row * 4);
+        float hv[4];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);   // this chunk's share of me_h Wb^T (zero in lanes past the row)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = rba[i];
+            v = fmaf(rwa[i][0], m.x, v); v = fmaf(rwa[i][1], m.y, v); v = fmaf(rwa[i][2], m.z, v); v = fmaf(rwa[i][3], m.w, v);
+            v = fmaxf(v, 0.f);
+            hv[i] = v;
+            acc.x = fmaf(rwb[i][0], v, acc.x); acc.y = fmaf(rwb[i][1], v, acc.y);
+            acc.z = fmaf(rwb[i][2], v, acc.z); acc.w = fmaf(rwb[i][3], v, acc.w);
+        }
+        if (lane_on) st4f(a.me_h + (size_t)row * ld + 4 * c, make_float4(hv[0], hv[1], hv[2], hv[3]));
+        const float4 s4 = wave_sum4(acc);            // fixed butterfly: every lane ends with the same, deterministic sum
+        const float4 o = make_float4(xi.x + (s4.x + bb4.x), xi.y + (s4.y + bb4.y), xi.z + (s4.z + bb4.z), xi.w + (s4.w + bb4.w));
+        if (lane == 0) {
+            st4f(a.maskf + (size_t)row * 4, m);
+            st4f(a.x0 + (size_t)row * 4, o);
+        }
+        if (lane_on) {
+            float pv[4], qv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float pa = rb1[i];
+                pa = fmaf(rw1[i][0], o.x, pa); pa = fmaf(rw1[i][1], o.y, pa); pa = fmaf(rw1[i][2], o.z, pa); pa = fmaf(rw1[i][3], o.w, pa);
+                float qb = 0.f;
+                qb = fmaf(rw1[i][4], o.x, qb); qb = fmaf(rw1[i][5], o.y, qb); qb = fmaf(rw1[i][6], o.z, qb); qb = fmaf(rw1[i][7], o.w, qb);
+                pv[i] = pa;
+                qv[i] = qb;
+            }
+            st4f(a.P + (size_t)row * ld + 4 * c, make_float4(pv[0], pv[1], pv[2], pv[3]));
+            st4f(a.Q + (size_t)row * ld + 4 * c, make_float4(qv[0], qv[1], qv[2], qv[3]));
+        }
+    }
+}
+
 // Blocks [0, nb_front) run the front, the rest the weight re-layout jobs of the same forward pass (block p -> job p / pack_bx,
 // share p % pack_bx): two independent pieces of work, one launch floor (~5 us) less per step.
 __global__ __launch_bounds__(256) void front_pack_kernel(const FrontFwdArgs f, const PackArgs pa, int nb_front, int pack_bx,
@@ -122,7 +206,8 @@ __global__ __launch_bounds__(256) void front_pack_kernel(const FrontFwdArgs f, c
     if (pa.rng_advance && blockIdx.x == 0 && threadIdx.x == 0) pa.rng_advance[1] += 1;
     slot_ea_body(pa.slot_ea, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
     if ((int)blockIdx.x < nb_front) {
-        front_fwd_body(f, blockIdx.x, nb_front, ld, nchunk, rows_pb, fl);
+        if (rows_pb == 0) front_fwd_wave_body(f, blockIdx.x, nb_front, ld, nchunk);   // (rows_pb == 0: one row per wave)
+        else front_fwd_body(f, blockIdx.x, nb_front, ld, nchunk, rows_pb, fl);
         return;
     }
     const int p = blockIdx.x - nb_front, job = p / pack_bx;
@@ -196,11 +281,71 @@ __global__ __launch_bounds__(256) void front_bwd_kernel(int n, int h, int ld, in
     }
 }
 
+// one row per wave (see front_fwd_wave_body)
+__global__ __launch_bounds__(256) void front_bwd_wave_kernel(int n, int h, int ld, int nchunk, int ldw1,
+                                                             const float* __restrict__ dP, const float* __restrict__ dQ,
+                                                             const float* __restrict__ me_h, const float* __restrict__ w1,
+                                                             const float* __restrict__ wb, float* __restrict__ g0,
+                                                             float* __restrict__ dh) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane;
+    const bool lane_on = c < nchunk;
+    float rwb[4][4], rw1[4][8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = 4 * c + i, uc = min(u, h - 1);
+        const bool ok = lane_on && u < h;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float vb = wb[(size_t)f * h + uc];
+            rwb[i][f] = ok ? vb : 0.f;
+        }
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            const float v1 = w1[(size_t)uc * ldw1 + f];
+            rw1[i][f] = ok ? v1 : 0.f;
+        }
+    }
+    const int wpb = blockDim.x >> 6, cc = lane_on ? c : 0;   // (lanes past the row re-read chunk 0: zero weights, nothing stored)
+    for (int row = blockIdx.x * wpb + wave; row < n; row += gridDim.x * wpb) {
+        const float4 p4 = ld4f(dP + (size_t)row * ld + 4 * cc), q4 = ld4f(dQ + (size_t)row * ld + 4 * cc);
+        const float4 y = ld4f(me_h + (size_t)row * ld + 4 * cc);
+        const float pv[4] = {p4.x, p4.y, p4.z, p4.w}, qv[4] = {q4.x, q4.y, q4.z, q4.w};
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            acc.x = fmaf(pv[i], rw1[i][0], acc.x); acc.y = fmaf(pv[i], rw1[i][1], acc.y);
+            acc.z = fmaf(pv[i], rw1[i][2], acc.z); acc.w = fmaf(pv[i], rw1[i][3], acc.w);
+            acc.x = fmaf(qv[i], rw1[i][4], acc.x); acc.y = fmaf(qv[i], rw1[i][5], acc.y);
+            acc.z = fmaf(qv[i], rw1[i][6], acc.z); acc.w = fmaf(qv[i], rw1[i][7], acc.w);
+        }
+        const float4 g = wave_sum4(acc);
+        if (lane == 0) st4f(g0 + (size_t)row * 4, g);
+        if (lane_on) {
+            const float yv[4] = {y.x, y.y, y.z, y.w};
+            float o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float v = 0.f;
+                v = fmaf(g.x, rwb[i][0], v); v = fmaf(g.y, rwb[i][1], v); v = fmaf(g.z, rwb[i][2], v); v = fmaf(g.w, rwb[i][3], v);
+                o[i] = yv[i] > 0.f ? v : 0.f;
+            }
+            st4f(dh + (size_t)row * ld + 4 * c, make_float4(o[0], o[1], o[2], o[3]));
+        }
+    }
+}
+
 bool front_fused_ok(int f0, int h) {
     static const bool off = getenv("PFN_NO_FUSED_FRONT") != nullptr;   // experiments / tests of the generic GEMM path
     return !off && f0 == 4 && ld_of(h) / 4 <= 256;
 }
 
+// One row per wave pays in the latency regime only (case118 x 128 = 15 k rows: 25.9 -> 21.4 us forward); with hundreds of
+// thousands of rows the half-empty waves (33 of 64 lanes at H = 129) cost more than the barriers of the block version
+// (6470rte x 64: backward 182 -> 247 us, measured), which stays for those sizes.
+static bool front_row_per_wave(int nchunk, int n) {
+    static const bool off = getenv("PFN_FRONT_BLOCK_ROWS") != nullptr;   // A/B switch: the block-per-row-group kernels
+    return !off && nchunk <= 64 && n <= 32768;
+}
 static void front_shape(int h, int& ld, int& nchunk, int& rows_pb, size_t& lds) {
     ld = ld_of(h);
     nchunk = ld / 4;
@@ -231,7 +376,12 @@ int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs,
         biggest = std::max<long>(biggest, (long)packed_floats(jobs[j].K, jobs[j].ld_out));
     }
     const int pack_bx = (int)std::min<long>(std::max<long>(1, (biggest + 255) / 256), 64);
-    const int nb_front = f.n > 0 ? std::min((f.n + rows_pb - 1) / rows_pb, 8 * device_cus()) : 0;
+    const bool per_wave = front_row_per_wave(nchunk, f.n);
+    if (per_wave) {   // one row per wave: four rows per 256-thread block, no LDS
+        rows_pb = 0;
+        lds = 0;
+    }
+    const int nb_front = f.n > 0 ? std::min((f.n + (per_wave ? 4 : rows_pb) - 1) / (per_wave ? 4 : rows_pb), 8 * device_cus()) : 0;
     const int nblocks = nb_front + pack_bx * pa.njobs;
     if (nblocks > 0 || rng_advance) {
         ProfScope ps("front_fwd+pack", 0.0, 0.0, s);
@@ -249,6 +399,11 @@ int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, c
     size_t lds;
     front_shape(h, ld, nchunk, rows_pb, lds);
     ProfScope ps("front_bwd", 0.0, 0.0, s);
+    if (front_row_per_wave(nchunk, n)) {
+        front_bwd_wave_kernel<<<std::min((n + 3) / 4, 8 * device_cus()), 256, 0, s>>>(n, h, ld, nchunk, ldw1, dP, dQ, me_h, w1, wb, g0, dh);
+        PFN_CHECK_LAUNCH();
+        return PFN_OK;
+    }
     front_bwd_kernel<<<std::min((n + rows_pb - 1) / rows_pb, 8 * device_cus()), 256, lds, s>>>(n, h, ld, nchunk, rows_pb, ldw1, dP, dQ, me_h, w1, wb, g0, dh);
     PFN_CHECK_LAUNCH();
     return PFN_OK;

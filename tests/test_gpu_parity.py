@@ -760,7 +760,7 @@ def test_fused_front_and_back_equal_generic_gemm_path(tmp_path):
     walks (edge_fwd_out_kernel: out = S W2^T + deg b2 inside the edge walk; edge_bwd ds_row: dS rows formed from gout and
     W2 inside the walks) and the graph-resident EdgeAggregation kernels (ea_seg.hip: node GEMM + edge walk per 32-column
     quarter in one launch) against the generic tall-skinny GEMM + edge kernels they replace (PFN_NO_FUSED_FRONT=1 /
-    PFN_NO_FUSED_BACK=1 / PFN_NO_SEG_EA=1, read once per process -> child processes): same output and gradients up to fp32 summation
+    PFN_NO_FUSED_BACK=1 / PFN_NO_SEG_EA=1; PFN_FRONT_BLOCK_ROWS=1 = the front's block-per-row-group kernels instead of one row per wave; read once per process -> child processes): same output and gradients up to fp32 summation
     order."""
     import os
     import subprocess
@@ -781,12 +781,13 @@ torch.save({{"out": out.detach().cpu(), "gx": d.x.grad.cpu(), "g": m.flat_grad()
     res = {}
     variants = (("fused", {}), ("no_front", {"PFN_NO_FUSED_FRONT": "1"}), ("no_back", {"PFN_NO_FUSED_BACK": "1"}),
                 ("no_seg", {"PFN_NO_SEG_EA": "1"}), ("no_seg_no_back", {"PFN_NO_SEG_EA": "1", "PFN_NO_FUSED_BACK": "1"}),
+                ("front_block_rows", {"PFN_FRONT_BLOCK_ROWS": "1"}),
                 ("generic", {"PFN_NO_FUSED_FRONT": "1", "PFN_NO_FUSED_BACK": "1", "PFN_NO_SEG_EA": "1"}))
     for tag, env in variants:
         path = str(tmp_path / f"{tag}.pt")
         subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=300)
         res[tag] = torch.load(path)
-    for tag in ("fused", "no_front", "no_back", "no_seg", "no_seg_no_back"):
+    for tag in ("fused", "no_front", "no_back", "no_seg", "no_seg_no_back", "front_block_rows"):
         assert_close(res[tag]["out"], res["generic"]["out"], RTOL, f"{tag}: out")
         assert_close(res[tag]["gx"], res["generic"]["gx"], RTOL, f"{tag}: grad x")
         assert_close(res[tag]["g"], res["generic"]["g"], RTOL, f"{tag}: flat parameter gradient")
