@@ -334,6 +334,54 @@ __global__ __launch_bounds__(256) void front_bwd_wave_kernel(int n, int h, int l
     }
 }
 
+// out[row][o] = sum_u S[row][u] W2[o][u] + deg[row] b2[o]  for the network's LAST EdgeAggregation layer (Fo <= 4), one row per wave:
+// what remains of that layer's second Linear when the graph-resident kernel formed S (a K = 129 -> N = 4 gemm_nt launch took
+// 9.4 us at case118 x 128: the matrix cores have nothing to do there)
+__global__ __launch_bounds__(256) void lin_out4_wave_kernel(int n, int h, int ld, int nchunk, int fo, const float* __restrict__ S,
+                                                            const float* __restrict__ w2, const float* __restrict__ b2,
+                                                            const float* __restrict__ deg, float* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c = lane;
+    const bool lane_on = c < nchunk;
+    float rw[4][4];   // rw[o][i] = W2[o][4c + i]
+#pragma unroll
+    for (int o = 0; o < 4; ++o) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = 4 * c + i;
+            const float v = w2[(size_t)min(o, fo - 1) * h + min(u, h - 1)];
+            rw[o][i] = (lane_on && o < fo && u < h) ? v : 0.f;
+        }
+    }
+    const float4 bv = make_float4(b2[0], fo > 1 ? b2[1] : 0.f, fo > 2 ? b2[2] : 0.f, fo > 3 ? b2[3] : 0.f);
+    const int wpb = blockDim.x >> 6, cc = lane_on ? c : 0;
+    for (int row = blockIdx.x * wpb + wave; row < n; row += gridDim.x * wpb) {
+        const float4 s4 = ld4f(S + (size_t)row * ld + 4 * cc);
+        const float d = deg[row];
+        float4 acc;
+        acc.x = fmaf(s4.w, rw[0][3], fmaf(s4.z, rw[0][2], fmaf(s4.y, rw[0][1], s4.x * rw[0][0])));
+        acc.y = fmaf(s4.w, rw[1][3], fmaf(s4.z, rw[1][2], fmaf(s4.y, rw[1][1], s4.x * rw[1][0])));
+        acc.z = fmaf(s4.w, rw[2][3], fmaf(s4.z, rw[2][2], fmaf(s4.y, rw[2][1], s4.x * rw[2][0])));
+        acc.w = fmaf(s4.w, rw[3][3], fmaf(s4.z, rw[3][2], fmaf(s4.y, rw[3][1], s4.x * rw[3][0])));
+        const float4 t = wave_sum4(acc);
+        if (lane == 0)
+            st4f(out + (size_t)row * 4, make_float4(fmaf(d, bv.x, t.x), fo > 1 ? fmaf(d, bv.y, t.y) : 0.f,
+                                                    fo > 2 ? fmaf(d, bv.z, t.z) : 0.f, fo > 3 ? fmaf(d, bv.w, t.w) : 0.f));
+    }
+}
+bool lin_out4_ok(int h, int fo, int ldo, int n) {
+    static const bool off = getenv("PFN_NO_FUSED_BACK") != nullptr;   // (the last layer's special kernels share one A/B switch)
+    return !off && fo >= 1 && fo <= 4 && ldo == 4 && ld_of(h) / 4 <= 64 && n <= 32768;
+}
+int launch_lin_out4(int n, int h, int fo, const float* S, const float* w2, const float* b2, const float* deg, float* out,
+                    hipStream_t s) {
+    if (n == 0) return PFN_OK;
+    const int ld = ld_of(h);
+    ProfScope ps("lin_out4", 0.0, 0.0, s);
+    lin_out4_wave_kernel<<<std::min((n + 3) / 4, 8 * device_cus()), 256, 0, s>>>(n, h, ld, ld / 4, fo, S, w2, b2, deg, out);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
 bool front_fused_ok(int f0, int h) {
     static const bool off = getenv("PFN_NO_FUSED_FRONT") != nullptr;   // experiments / tests of the generic GEMM path
     return !off && f0 == 4 && ld_of(h) / 4 <= 256;

@@ -143,7 +143,9 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
         }
         PFN_TRY(launch_edge_fwd(g, e, s));
     }
-    if (!out_in_walk) {   // out = S W2^T + deg * b2   (the second Linear commutes with the segment sum)
+    if (!out_in_walk && w2 && act.act == ACT_NONE && lin_out4_ok(h, fo, ldo, g.n)) {
+        PFN_TRY(launch_lin_out4(g.n, h, fo, sv.S, w2, b2, g.deg, out, s));   // the last layer at small batches: one row per wave
+    } else if (!out_in_walk) {   // out = S W2^T + deg * b2   (the second Linear commutes with the segment sum)
         GemmArgs a = gemm_defaults(g.n, fo, ldo);
         a.C[0] = out;
         a.nterm = 1;

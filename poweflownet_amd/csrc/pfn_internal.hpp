@@ -417,6 +417,10 @@ int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, 
 // front.hip: mask_embd + residual + the first EdgeAggregation's P | Q in one launch (forward), and the gradient w.r.t. x0 +
 // mask_embd's hidden-layer gradient in one launch (backward).  Only for nfeature_dim == 4 (what the reference asserts).
 bool front_fused_ok(int f0, int h);
+// the last layer's second Linear (Fo <= 4) as one row per wave, for small batches (front.hip)
+bool lin_out4_ok(int h, int fo, int ldo, int n);
+int launch_lin_out4(int n, int h, int fo, const float* S, const float* w2, const float* b2, const float* deg, float* out,
+                    hipStream_t s);
 struct FrontFwdArgs {
     int n, h, ldw1, mask_dtype;            // mask_dtype 0: int64, 1: float32 (pred_mask as the caller holds it)
     const float* x;
