@@ -153,15 +153,21 @@ __device__ __forceinline__ void front_fwd_wave_body(const FrontFwdArgs& a, int b
     }
     const float4 bb4 = make_float4(a.bb[0], a.bb[1], a.bb[2], a.bb[3]);
     const int wpb = blockDim.x >> 6;
-    for (int row = bid * wpb + wave; row < n; row += nblk * wpb) {
-        float4 m;                                   // pred_mask.float() (networks/MPN.py:533); every lane reads the same 16 / 32 bytes
+    auto load_row = [&](int row, float4& m, float4& xi) {   // pred_mask.float() (networks/MPN.py:533) and x: every lane reads the same bytes
         if (a.mask_dtype == 0) {
             const int64_t* mp = static_cast<const int64_t*>(a.mask) + (size_t)row * 4;
             m = make_float4((float)mp[0], (float)mp[1], (float)mp[2], (float)mp[3]);
         } else {
             m = ld4f(static_cast<const float*>(a.mask) + (size_t)row * 4);
         }
-        const float4 xi = ld4f(a.x + (size_t)row * 4);
+        xi = ld4f(a.x + (size_t)row * 4);
+    };
+    float4 m_n = make_float4(0.f, 0.f, 0.f, 0.f), xi_n = m_n;
+    const int row_first = bid * wpb + wave;
+    if (row_first < n) load_row(row_first, m_n, xi_n);
+    for (int row = row_first; row < n; row += nblk * wpb) {
+        const float4 m = m_n, xi = xi_n;
+        if (row + nblk * wpb < n) load_row(row + nblk * wpb, m_n, xi_n);   // the next row's inputs, in flight during this row
         float hv[4];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);   // this chunk's share of me_h Wb^T (zero in lanes past the row)
 #pragma unroll
@@ -306,9 +312,20 @@ __global__ __launch_bounds__(256) void front_bwd_wave_kernel(int n, int h, int l
         }
     }
     const int wpb = blockDim.x >> 6, cc = lane_on ? c : 0;   // (lanes past the row re-read chunk 0: zero weights, nothing stored)
-    for (int row = blockIdx.x * wpb + wave; row < n; row += gridDim.x * wpb) {
-        const float4 p4 = ld4f(dP + (size_t)row * ld + 4 * cc), q4 = ld4f(dQ + (size_t)row * ld + 4 * cc);
-        const float4 y = ld4f(me_h + (size_t)row * ld + 4 * cc);
+    const int step = gridDim.x * wpb, row_first = blockIdx.x * wpb + wave;
+    float4 p_n = make_float4(0.f, 0.f, 0.f, 0.f), q_n = p_n, y_n = p_n;
+    if (row_first < n) {
+        p_n = ld4f(dP + (size_t)row_first * ld + 4 * cc);
+        q_n = ld4f(dQ + (size_t)row_first * ld + 4 * cc);
+        y_n = ld4f(me_h + (size_t)row_first * ld + 4 * cc);
+    }
+    for (int row = row_first; row < n; row += step) {
+        const float4 p4 = p_n, q4 = q_n, y = y_n;
+        if (row + step < n) {   // the next row's inputs, in flight during this row
+            p_n = ld4f(dP + (size_t)(row + step) * ld + 4 * cc);
+            q_n = ld4f(dQ + (size_t)(row + step) * ld + 4 * cc);
+            y_n = ld4f(me_h + (size_t)(row + step) * ld + 4 * cc);
+        }
         const float pv[4] = {p4.x, p4.y, p4.z, p4.w}, qv[4] = {q4.x, q4.y, q4.z, q4.w};
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
