@@ -250,8 +250,26 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
     int cw = (nchunk + cs - 1) / cs;
     cw = std::min(cw, max_cw);
     cs = (nchunk + cw - 1) / cw;
+    // Big batches (several rounds of workgroups anyway): a block's tiles stay under HALF of the LDS, so that two workgroups
+    // share a CU and the loads / stores of one overlap the LDS hops of the other (case118 x 2048: 197 -> 144 us per launch
+    // with 2 slices of 17 float4 columns; narrower slices lose it again to partly used cache lines: 165 / 181 us at 3 / 4).
+    size_t budget = (size_t)FH_LDS_BYTES, lds_cap = (size_t)160 * 1024;
+    {
+        const size_t half = (size_t)FH_LDS_BYTES / 2;
+        const int half_cw = (int)((half - (size_t)(2 * a.seg + 1) * sizeof(int)) / per_chunk_graph);
+        static const bool off = getenv("PFN_FH_ONE_PER_CU") != nullptr;   // experiments
+        if (!off && (long)ngraphs * cs >= 2L * device_cus() && half_cw >= 8) {
+            budget = half;
+            lds_cap /= 2;
+            if (cw > half_cw) {
+                cs = (nchunk + half_cw - 1) / half_cw;
+                cw = (nchunk + cs - 1) / cs;
+                cs = (nchunk + cw - 1) / cw;
+            }
+        }
+    }
     // whole graphs per block: as many as fit the two LDS tiles, but keep >= ~2 blocks per CU worth of parallelism
-    int gpb = (int)((size_t)FH_LDS_BYTES / ((size_t)2 * a.seg * cw * 4 * sizeof(float) + (size_t)2 * a.seg * sizeof(int)));
+    int gpb = (int)(budget / ((size_t)2 * a.seg * cw * 4 * sizeof(float) + (size_t)2 * a.seg * sizeof(int)));
     gpb = std::max(1, gpb);
     while (gpb > 1 && (long)((ngraphs + gpb - 1) / gpb) * cs < want) --gpb;
     const int rows_pb = gpb * a.seg;
@@ -259,11 +277,10 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
     const size_t fixed = tile_bytes + (size_t)(2 * rows_pb + 1) * sizeof(int);
     // neighbour list: what the slice's rows need (average degree is small), capped by what is left of 160 KiB / blocks per CU
     const size_t want_nb = (size_t)rows_pb * 16 * sizeof(int);
-    const size_t lds_cap = (size_t)160 * 1024;
-    const size_t lds_total = std::min(lds_cap, fixed + want_nb);
+    const size_t lds_total = std::max(fixed, std::min(lds_cap, fixed + want_nb));
     const int nbr_cap = (int)((lds_total - fixed) / sizeof(int));
     static std::atomic<uint64_t> lds_raised{0};
-    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(fused_hops_kernel), (int)lds_cap, lds_raised));
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(fused_hops_kernel), 160 * 1024, lds_raised));
     const bool adjt = a.adjt < 0 ? a.transpose != 0 : a.adjt != 0;
     ProfScope ps((a.transpose || adjt) ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
     fused_hops_kernel<<<dim3((g.n + rows_pb - 1) / rows_pb, cs), FH_THREADS, lds_total, s>>>(
