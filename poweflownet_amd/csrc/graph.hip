@@ -54,6 +54,7 @@ GraphView graph_view(void* ws, int64_t n, int64_t e) {
     g.n = (int)n;
     g.e_stored = (int)e;
     g.flags = c.take<int>(64);
+    g.scan_sums = c.take<int>(3 * GRAPH_SCAN_BLOCKS);
     g.rowptr_in = c.take<int>(n + 1);
     g.rowptr_out = c.take<int>(n + 1);
     g.in_src = c.take<int>(2 * e + 1);
@@ -90,31 +91,96 @@ __global__ __launch_bounds__(256) void graph_hist_kernel(const int64_t* __restri
     }
 }
 
-// Pass 2 (single block): decide `directed`, form in/out degrees, exclusive-scan them into the two
-// rowptr arrays, emit deg / deg^-1/2, and clear the histograms so pass 3 can reuse them as cursors.
-__global__ __launch_bounds__(1024) void graph_scan_kernel(int n, int e, int mode, int* cnt_dst, int* cnt_src,
-                                                          int* rowptr_in, int* rowptr_out, int* rp4, float* deg, float* dinv,
-                                                          int* flags) {
-    // rp4: prefix sum of ceil(in-degree / 4) -- the row offsets (in dwords per column chunk) of the edge stage's ReLU masks
-    __shared__ int wsum_in[16], wsum_out[16], wsum_4[16];
-    __shared__ int carry_in, carry_out, carry_4;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int directed = (mode == 1) ? 1 : (mode == 0 ? 0 : (e > 0 && flags[3] == 0));
-    if (tid == 0) {
-        carry_in = 0;
-        carry_out = 0;
-        carry_4 = 0;
-        flags[0] = directed;
-        flags[1] = directed ? 2 * e : e;
+// Pass 2 (two launches over the same tiling: block b owns rows [b * tile, (b + 1) * tile), tile a multiple of 1024, at most
+// GRAPH_SCAN_BLOCKS blocks): decide `directed`, form in/out degrees, exclusive-scan them into the two rowptr arrays (and
+// rp4 = prefix of ceil(in-degree / 4), the row offsets in dwords per column chunk of the edge stage's ReLU masks), emit
+// deg / deg^-1/2, and clear the histograms so pass 3 can reuse them as cursors.  First the per-block totals, then every
+// block adds up the totals before it and scans its own rows.  (One 1024-thread block walking all rows was 0.8 ms at
+// 414 k nodes -- most of a cold-topology build.)
+__device__ __forceinline__ void degrees_of(int directed, int cd, int cs, int& di, int& dout) {
+    di = directed ? cd + cs : cd;
+    dout = directed ? cd + cs : cs;
+}
+__device__ __forceinline__ int scan_directed(int mode, int e, const int* flags) {
+    return (mode == 1) ? 1 : (mode == 0 ? 0 : (e > 0 && flags[3] == 0));
+}
+// sum over the block of three ints per thread -> every thread gets the totals (two barriers)
+__device__ __forceinline__ void block_sum3(int& a, int& b, int& c, int* red /* [3][16] */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        a += __shfl_xor(a, off);
+        b += __shfl_xor(b, off);
+        c += __shfl_xor(c, off);
+    }
+    __syncthreads();   // (red may still be read from a previous call)
+    if (lane == 0) {
+        red[wave] = a;
+        red[16 + wave] = b;
+        red[32 + wave] = c;
     }
     __syncthreads();
-    for (int base = 0; base < n; base += 1024) {
+    a = b = c = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) {
+        a += red[w];
+        b += red[16 + w];
+        c += red[32 + w];
+    }
+}
+__global__ __launch_bounds__(1024) void graph_scan_sums_kernel(int n, int e, int mode, int tile, const int* __restrict__ cnt_dst,
+                                                               const int* __restrict__ cnt_src, const int* __restrict__ flags,
+                                                               int* __restrict__ bsum) {
+    __shared__ int red[48];
+    const int directed = scan_directed(mode, e, flags);
+    const int r0 = blockIdx.x * tile, r1 = min(n, r0 + tile);
+    int a = 0, b = 0, c = 0;
+    for (int i = r0 + threadIdx.x; i < r1; i += 1024) {
+        int di, dout;
+        degrees_of(directed, cnt_dst[i], cnt_src[i], di, dout);
+        a += di;
+        b += dout;
+        c += (di + 3) >> 2;
+    }
+    block_sum3(a, b, c, red);
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = a;
+        bsum[GRAPH_SCAN_BLOCKS + blockIdx.x] = b;
+        bsum[2 * GRAPH_SCAN_BLOCKS + blockIdx.x] = c;
+    }
+}
+__global__ __launch_bounds__(1024) void graph_scan_kernel(int n, int e, int mode, int tile, int* cnt_dst, int* cnt_src,
+                                                          int* rowptr_in, int* rowptr_out, int* rp4, float* deg, float* dinv,
+                                                          int* flags, const int* __restrict__ bsum) {
+    __shared__ int wsum_in[16], wsum_out[16], wsum_4[16], red[48];
+    __shared__ int carry_in, carry_out, carry_4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int directed = scan_directed(mode, e, flags);
+    {
+        // totals of the blocks before this one (at most GRAPH_SCAN_BLOCKS = blockDim.x of them: one per thread)
+        int a = 0, b = 0, c = 0;
+        if (tid < (int)blockIdx.x) {
+            a = bsum[tid];
+            b = bsum[GRAPH_SCAN_BLOCKS + tid];
+            c = bsum[2 * GRAPH_SCAN_BLOCKS + tid];
+        }
+        block_sum3(a, b, c, red);
+        if (tid == 0) {
+            carry_in = a;
+            carry_out = b;
+            carry_4 = c;
+            if (blockIdx.x == 0) {
+                flags[0] = directed;
+                flags[1] = directed ? 2 * e : e;
+            }
+        }
+    }
+    __syncthreads();
+    const int r0 = blockIdx.x * tile, r1 = min(n, r0 + tile);
+    for (int base = r0; base < r1; base += 1024) {
         const int i = base + tid;
         int di = 0, dout = 0;
-        if (i < n) {
-            const int cd = cnt_dst[i], cs = cnt_src[i];
-            di = directed ? cd + cs : cd;
-            dout = directed ? cd + cs : cs;
+        if (i < r1) {
+            degrees_of(directed, cnt_dst[i], cnt_src[i], di, dout);
             cnt_dst[i] = 0;
             cnt_src[i] = 0;
             deg[i] = (float)di;
@@ -143,7 +209,7 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int n, int e, int mode
             pre_out += wsum_out[w];
             pre_4 += wsum_4[w];
         }
-        if (i < n) {
+        if (i < r1) {
             rowptr_in[i] = pre_in + si - di;
             rowptr_out[i] = pre_out + so - dout;
             rp4[i] = pre_4 + s4 - d4;
@@ -156,7 +222,7 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int n, int e, int mode
         }
         __syncthreads();
     }
-    if (tid == 0) {
+    if (tid == 0 && blockIdx.x == gridDim.x - 1) {
         rowptr_in[n] = carry_in;
         rowptr_out[n] = carry_out;
         rp4[n] = carry_4;
@@ -296,9 +362,15 @@ int pfn_graph_build(const int64_t* edge_index, int64_t e, int64_t n, int mode, v
         graph_hist_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.cur_in, g.cur_out, g.flags);
         PFN_CHECK_LAUNCH();
     }
-    graph_scan_kernel<<<1, 1024, 0, s>>>(in, ie, mode, g.cur_in, g.cur_out, g.rowptr_in, g.rowptr_out, g.rp4, g.deg, g.dinv,
-                                         g.flags);
-    PFN_CHECK_LAUNCH();
+    {
+        const int tile = 1024 * std::max(1, (in + 1024 * GRAPH_SCAN_BLOCKS - 1) / (1024 * GRAPH_SCAN_BLOCKS));
+        const int nb = std::max(1, (in + tile - 1) / tile);
+        graph_scan_sums_kernel<<<nb, 1024, 0, s>>>(in, ie, mode, tile, g.cur_in, g.cur_out, g.flags, g.scan_sums);
+        PFN_CHECK_LAUNCH();
+        graph_scan_kernel<<<nb, 1024, 0, s>>>(in, ie, mode, tile, g.cur_in, g.cur_out, g.rowptr_in, g.rowptr_out, g.rp4, g.deg,
+                                              g.dinv, g.flags, g.scan_sums);
+        PFN_CHECK_LAUNCH();
+    }
     if (ie > 0) {
         const int blocks = (int)std::min<int64_t>((e + 255) / 256, 2048);
         graph_fill_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.rowptr_in, g.rowptr_out, g.cur_in, g.cur_out,

@@ -70,10 +70,12 @@ struct Carver {
 // Device-side view of the adjacency built by pfn_graph_build.  "in" = CSR by destination (row i lists
 // the edges arriving at i: what the forward aggregation walks); "out" = CSR by source (what the
 // gradient w.r.t. the gathered operand walks).  eid >= e_stored marks the reversed copy of eid - e_stored.
+constexpr int GRAPH_SCAN_BLOCKS = 1024;   // blocks of the degree scan (= its block size: one total per thread)
 struct GraphView {
     int n;          // nodes
     int e_stored;   // stored edges
     int* flags;     // [0] directed, [1] effective edge count, [2] index error, [3] reverse-found scratch
+    int* scan_sums; // [3][GRAPH_SCAN_BLOCKS] per-block totals of the degree scan (graph.hip pass 2)
     int* rowptr_in;   // [n+1]
     int* rowptr_out;  // [n+1]
     int* in_src;      // [2*e_stored]

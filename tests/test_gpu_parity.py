@@ -54,6 +54,27 @@ def test_scatter_add_matches_index_add_bitwise():
     assert torch.equal(out.cpu(), want)
 
 
+@pytest.mark.parametrize("n,e", [(1, 0), (1025, 3000), (1_200_000, 1_500_000)])
+def test_graph_build_degree_scan_over_many_blocks(n, e):
+    """pfn_graph_build's row pointers come from a two-launch scan (per-block totals, then per-block scans; above 2^20 nodes a
+    block walks several 1024-row chunks): the exported adjacency, in CSR order, must be the stable by-destination sort of
+    the effective edge list, and a scatter-add over it must equal torch's index_add_ bit for bit."""
+    import ctypes as C
+    from poweflownet_amd import _lib as L
+    gen = torch.Generator().manual_seed(n)
+    ei = torch.randint(0, n, (2, e), generator=gen)
+    g = GraphCSR(ei.to(DEV), n, mode=1)                      # directed: every stored edge also runs backwards
+    eff = g.export_edges().cpu()
+    want_src = torch.cat([ei[0], ei[1]])
+    want_dst = torch.cat([ei[1], ei[0]])
+    assert torch.equal(eff[0], want_src) and torch.equal(eff[1], want_dst)
+    x = torch.randn(n, 4, device=DEV)
+    out = torch.empty_like(x)
+    L.check(L.load().pfn_scatter_add(g.ws.data_ptr(), n, e, x.data_ptr(), out.data_ptr(), 4, L.stream_ptr()), "sa")
+    want = torch.zeros(n, 4).index_add_(0, want_dst, x.cpu()[want_src])
+    assert torch.equal(out.cpu(), want)
+
+
 # ------------------------------------------------------------------------------------------- single layers
 @pytest.mark.parametrize("tag", ["4_8_8", "8_8_4", "129_129_129", "129_129_4"])
 def test_g2_edge_aggregation_layer(tag):
