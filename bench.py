@@ -343,7 +343,9 @@ def main():
         def cold():
             data.edge_index = ei_saved.clone()      # a tensor the cache has never seen
             fwd_bwd()
-        extras["cold_topology_fwd_bwd_ms"] = round(timed(cold, 5), 4)
+        reps = [timed(cold, 1) for _ in range(5)]
+        extras["cold_topology_fwd_bwd_ms"] = round(sorted(reps)[len(reps) // 2], 4)       # median of 5
+        extras["cold_topology_reps_ms"] = [round(r, 3) for r in reps]
         data.edge_index = ei_saved
 
     # ---- the scatter-add in isolation (north_star's 40 % figure): pfn_scatter_add over this batch's adjacency, F = hidden_dim,

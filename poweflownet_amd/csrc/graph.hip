@@ -3,7 +3,7 @@
 // Replaces, per forward call: MaskEmbdMultiMPN.is_directed / undirect_graph (networks/MPN.py:498-523),
 // the index_select lifting and degree scatter PyG performs under propagate()/gcn_norm, and the dead
 // degree computation of EdgeAggregation.forward (networks/MPN.py:43-47, not reproduced: it does not
-// reach the output).  One histogram pass, one scan, one fill, one per-row ordering pass; no host sync:
+// reach the output).  One histogram pass, a two-launch scan, one fill, one placement pass (rows in edge-id order); no host sync:
 // the "directed" decision of the reference's first-edge heuristic is taken on device and consumed by
 // the later kernels through flags[].
 #include <stdarg.h>
@@ -229,57 +229,61 @@ __global__ __launch_bounds__(1024) void graph_scan_kernel(int n, int e, int mode
     }
 }
 
-// Pass 3: place every effective edge into both adjacencies (slot order inside a row is arbitrary here).
+// Pass 3: every effective edge drops its edge id into its destination's by-destination row and its source's by-source row
+// (scratch arrays; slot order inside a row is whatever the atomics gave).
 __global__ __launch_bounds__(256) void graph_fill_kernel(const int64_t* __restrict__ ei, int e, int n,
                                                          const int* __restrict__ rowptr_in,
                                                          const int* __restrict__ rowptr_out, int* cur_in, int* cur_out,
-                                                         int* in_src, int* in_eid, int* out_dst, int* out_eid,
-                                                         const int* flags) {
+                                                         int* __restrict__ tmp_in, int* __restrict__ tmp_out, const int* flags) {
     const int directed = flags[0];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) {
         const int64_t s64 = ei[i], d64 = ei[(size_t)e + i];
         if (s64 < 0 || s64 >= n || d64 < 0 || d64 >= n) continue;
         const int s = (int)s64, d = (int)d64;
-        int p = rowptr_in[d] + atomicAdd(&cur_in[d], 1);
-        in_src[p] = s;
-        in_eid[p] = i;
-        p = rowptr_out[s] + atomicAdd(&cur_out[s], 1);
-        out_dst[p] = d;
-        out_eid[p] = i;
+        tmp_in[rowptr_in[d] + atomicAdd(&cur_in[d], 1)] = i;
+        tmp_out[rowptr_out[s] + atomicAdd(&cur_out[s], 1)] = i;
         if (directed) {   // reversed copy (d -> s), edge id e + i: "originals first, reverses second"
-            p = rowptr_in[s] + atomicAdd(&cur_in[s], 1);
-            in_src[p] = d;
-            in_eid[p] = e + i;
-            p = rowptr_out[d] + atomicAdd(&cur_out[d], 1);
-            out_dst[p] = s;
-            out_eid[p] = e + i;
+            tmp_in[rowptr_in[s] + atomicAdd(&cur_in[s], 1)] = e + i;
+            tmp_out[rowptr_out[d] + atomicAdd(&cur_out[d], 1)] = e + i;
         }
     }
 }
 
-// Pass 4: order each row by edge id -> segment sums run in the stored edge order (the order the
-// reference's sequential scatter_add visits them) and results are run-to-run deterministic.
-__global__ __launch_bounds__(256) void graph_sort_rows_kernel(int n, const int* __restrict__ rowptr_in,
-                                                              const int* __restrict__ rowptr_out, int* in_src,
-                                                              int* in_eid, int* out_dst, int* out_eid) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * n) return;
-    const bool out_side = t >= n;
-    const int row = out_side ? t - n : t;
-    const int* rp = out_side ? rowptr_out : rowptr_in;
-    int* nbr = out_side ? out_dst : in_src;
-    int* eid = out_side ? out_eid : in_eid;
-    const int beg = rp[row], end = rp[row + 1];
-    for (int i = beg + 1; i < end; ++i) {
-        const int ke = eid[i], kn = nbr[i];
-        int j = i - 1;
-        while (j >= beg && eid[j] > ke) {
-            eid[j + 1] = eid[j];
-            nbr[j + 1] = nbr[j];
-            --j;
+// Pass 4: order each row by edge id -> segment sums run in the stored edge order (the order the reference's sequential
+// scatter_add visits them) and results are run-to-run deterministic.  Edge ids are unique, so an edge's slot in a row is the
+// number of smaller ids in that row: every edge counts them itself (a row of degree d costs d reads on d threads -- a
+// per-row insertion sort was d^2 steps on ONE thread, 0.8 ms for the 170-edge hub rows of the 6470rte x 64 hub case).
+__device__ __forceinline__ int rank_in_row(const int* __restrict__ tmp, int beg, int end, int id) {
+    int r = 0;
+    for (int q = beg; q < end; ++q) r += tmp[q] < id ? 1 : 0;
+    return r;
+}
+__global__ __launch_bounds__(256) void graph_place_kernel(const int64_t* __restrict__ ei, int e, int n,
+                                                          const int* __restrict__ rowptr_in, const int* __restrict__ rowptr_out,
+                                                          const int* __restrict__ tmp_in, const int* __restrict__ tmp_out,
+                                                          int* __restrict__ in_src, int* __restrict__ in_eid,
+                                                          int* __restrict__ out_dst, int* __restrict__ out_eid, const int* flags) {
+    const int directed = flags[0];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < e; i += gridDim.x * blockDim.x) {
+        const int64_t s64 = ei[i], d64 = ei[(size_t)e + i];
+        if (s64 < 0 || s64 >= n || d64 < 0 || d64 >= n) continue;
+        const int s = (int)s64, d = (int)d64;
+        const int ib = rowptr_in[d], ie = rowptr_in[d + 1], ob = rowptr_out[s], oe = rowptr_out[s + 1];
+        int p = ib + rank_in_row(tmp_in, ib, ie, i);
+        in_src[p] = s;
+        in_eid[p] = i;
+        p = ob + rank_in_row(tmp_out, ob, oe, i);
+        out_dst[p] = d;
+        out_eid[p] = i;
+        if (directed) {
+            const int rb = rowptr_in[s], re = rowptr_in[s + 1], qb = rowptr_out[d], qe = rowptr_out[d + 1];
+            p = rb + rank_in_row(tmp_in, rb, re, e + i);
+            in_src[p] = d;
+            in_eid[p] = e + i;
+            p = qb + rank_in_row(tmp_out, qb, qe, e + i);
+            out_dst[p] = s;
+            out_eid[p] = e + i;
         }
-        eid[j + 1] = ke;
-        nbr[j + 1] = kn;
     }
 }
 
@@ -373,11 +377,12 @@ int pfn_graph_build(const int64_t* edge_index, int64_t e, int64_t n, int mode, v
     }
     if (ie > 0) {
         const int blocks = (int)std::min<int64_t>((e + 255) / 256, 2048);
+        // (scratch: the two mask-index arrays, written for good by graph_mask_index_kernel below)
         graph_fill_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.rowptr_in, g.rowptr_out, g.cur_in, g.cur_out,
-                                                 g.in_src, g.in_eid, g.out_dst, g.out_eid, g.flags);
+                                                 g.out_mbase, g.out_ml4k, g.flags);
         PFN_CHECK_LAUNCH();
-        graph_sort_rows_kernel<<<(2 * in + 255) / 256, 256, 0, s>>>(in, g.rowptr_in, g.rowptr_out, g.in_src, g.in_eid,
-                                                                   g.out_dst, g.out_eid);
+        graph_place_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.rowptr_in, g.rowptr_out, g.out_mbase, g.out_ml4k,
+                                                  g.in_src, g.in_eid, g.out_dst, g.out_eid, g.flags);
         PFN_CHECK_LAUNCH();
         const int sblocks = (int)std::min<int64_t>((2 * e + 255) / 256, 2048);
         graph_slot_of_eid_kernel<<<sblocks, 256, 0, s>>>(in, g.rowptr_in, g.in_eid, g.slot_of_eid);
