@@ -50,8 +50,9 @@ typedef struct pfn_mpn_config {
     int32_t training;       /* 1: dropout active (model.train()), 0: model.eval() */
     int32_t need_backward;  /* 1: pfn_mpn_backward will be called on this forward's workspace (autograd records the call): the
                              * forward edge walks also save their ReLU masks, which the backward walks then read instead of
-                             * recomputing the edge pre-activations.  0: inference, nothing extra is written.  pfn_mpn_backward
-                             * must be given the value the forward call had.                                            */
+                             * recomputing the edge pre-activations.  0: inference: nothing extra is written and tensors only
+                             * the backward reads (mask_embd's hidden layer) are not stored; pfn_mpn_backward then returns
+                             * PFN_EINVAL.  pfn_mpn_backward must be given the value the forward call had.                */
 } pfn_mpn_config;
 
 /* The library keeps NO process-global mutable state: no stream, event, cache or "first caller" device binding of its own

@@ -81,7 +81,7 @@ __device__ __forceinline__ void front_fwd_body(const FrontFwdArgs& a, int bid, i
                 acc.x = fmaf(rwb[i][0], v, acc.x); acc.y = fmaf(rwb[i][1], v, acc.y);
                 acc.z = fmaf(rwb[i][2], v, acc.z); acc.w = fmaf(rwb[i][3], v, acc.w);
             }
-            st4f(a.me_h + (size_t)row * ld + 4 * c, make_float4(hv[0], hv[1], hv[2], hv[3]));
+            if (a.me_h) st4f(a.me_h + (size_t)row * ld + 4 * c, make_float4(hv[0], hv[1], hv[2], hv[3]));   // (null: no backward follows)
             part[r * nchunk + c] = acc;
         }
         __syncthreads();
@@ -179,7 +179,7 @@ __device__ __forceinline__ void front_fwd_wave_body(const FrontFwdArgs& a, int b
             acc.x = fmaf(rwb[i][0], v, acc.x); acc.y = fmaf(rwb[i][1], v, acc.y);
             acc.z = fmaf(rwb[i][2], v, acc.z); acc.w = fmaf(rwb[i][3], v, acc.w);
         }
-        if (lane_on) st4f(a.me_h + (size_t)row * ld + 4 * c, make_float4(hv[0], hv[1], hv[2], hv[3]));
+        if (lane_on && a.me_h) st4f(a.me_h + (size_t)row * ld + 4 * c, make_float4(hv[0], hv[1], hv[2], hv[3]));
         const float4 s4 = wave_sum4(acc);            // fixed butterfly: every lane ends with the same, deterministic sum
         const float4 o = make_float4(xi.x + (s4.x + bb4.x), xi.y + (s4.y + bb4.y), xi.z + (s4.z + bb4.z), xi.w + (s4.w + bb4.w));
         if (lane == 0) {

@@ -490,7 +490,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         f.n = lo.n; f.h = lo.h; f.ldw1 = 2 * lo.f0 + lo.fe; f.mask_dtype = mask_dtype;
         f.x = x; f.mask = pred_mask;
         f.wa = me[0]; f.ba = me[1]; f.wb = me[2]; f.bb = me[3]; f.w1 = params[0]; f.b1 = params[1];
-        f.maskf = lo.maskf; f.me_h = lo.me_h; f.x0 = lo.x0; f.P = lo.ea[0].P; f.Q = lo.ea[0].Q;
+        f.maskf = lo.maskf; f.me_h = c.need_backward ? lo.me_h : nullptr; f.x0 = lo.x0; f.P = lo.ea[0].P; f.Q = lo.ea[0].Q;
         PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s, seg_ea ? &se : nullptr));
     } else {
         // ... the pack launch also advances the dropout stream for this forward and converts pred_mask to float32
@@ -887,6 +887,7 @@ int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_
     (void)pred_mask; (void)mask_dtype;
     PFN_TRY(check_common(c, gws, n, e, ws));
     PFN_CHECK_ARG(params && grads && (n == 0 || (x && gout)), "pfn_mpn_backward: null tensor");
+    PFN_CHECK_ARG(c->need_backward != 0, "pfn_mpn_backward: the forward ran with need_backward = 0 (inference: what only the backward reads was not saved)");
     Layout lo;
     PFN_TRY(make_layout(*c, n, e, ws, lo));
     if (ws_bytes < lo.bytes) {

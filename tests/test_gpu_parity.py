@@ -929,6 +929,23 @@ def test_config3_inference_batch2048_properties():
             assert_close(m(single), out[gidx * 118:(gidx + 1) * 118], RTOL, f"graph {gidx}")
 
 
+@pytest.mark.parametrize("batch", [4, 300])
+def test_inference_forward_equals_training_forward_bitwise(batch):
+    """A forward under torch.no_grad() announces need_backward = 0: the edge walks save no ReLU masks and the front kernel does
+    not store mask_embd's hidden layer.  The output must not change by a bit (row-per-wave front at 4 graphs, block front at
+    300 graphs = 35,400 rows)."""
+    torch.manual_seed(7)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).to(DEV).eval()
+    b = make_batch("118v2", batch, seed=3).to(DEV)
+    with torch.no_grad():
+        o_inf = m(b)
+    o_grad = m(b)
+    assert o_grad.requires_grad and not o_inf.requires_grad
+    assert torch.equal(o_inf, o_grad.detach())
+    torch.nn.MSELoss()(o_grad, b.y).backward()           # and the training forward's backward still has what it needs
+    assert all(torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in m.parameters())
+
+
 @pytest.mark.parametrize("hub", [0.0, 0.2])
 def test_config4_case6470_batch64_properties(hub):
     """configs[3]: case6470rte training batch 64 (and the high-degree 'hub' variant): graphs of the batch equal the same
