@@ -1,6 +1,7 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
-O=$GRAFT_REPO_ROOT/gpurun_out/t; mkdir -p $O
-cd /tmp; export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pr/trace -o bench -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --case 6470rte --batch 64 --steps 3 --warmup 1 > $O/prof.out 2> $O/prof.err
-find /tmp/pr/trace -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/cold_stats.csv
+O=gpurun_out/t; mkdir -p $O
+for w in 4 64; do
+PFN_SEG_EA_PER_CU=$w python bench.py --no-cpu-baseline --mode infer --batch 2048 > $O/b3_seg$w.json 2> $O/b3_seg$w.err
+PFN_SEG_EA_PER_CU=$w python bench.py --no-cpu-baseline --mode infer --batch 512 > $O/b3b_seg$w.json 2> $O/b3b_seg$w.err
+done
