@@ -34,6 +34,14 @@ __device__ __forceinline__ float4 mask4(unsigned m, float4 g) {   // g where the
 __device__ __forceinline__ float4 sel4(bool k, float4 a, float4 b) { return make_float4(k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z, k ? a.w : b.w); }
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
 
+#ifdef PFN_EXP_XCD   /* tools experiment switch (never defined in the product build): XCD k walks the k-th eighth of the rows */
+__device__ __forceinline__ int exp_block(int b, int nb) {
+    const int x = b & 7, q = nb >> 3, r = nb & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+#else
+__device__ __forceinline__ int exp_block(int b, int) { return b; }
+#endif
 // ------------------------------------------------------------------------------------------- hop
 template <bool NORM>
 __global__ __launch_bounds__(256) void hop_kernel(int n, int nchunk, const int* __restrict__ rowptr,
@@ -41,7 +49,7 @@ __global__ __launch_bounds__(256) void hop_kernel(int n, int nchunk, const int* 
                                                   const float* __restrict__ x, const float* __restrict__ add,
                                                   float* __restrict__ y, const float* __restrict__ gate,
                                                   float gate_scale, int ld) {
-    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long item = (long)exp_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const int row = (int)(item / nchunk);
     if (row >= n) return;
     const int col = (int)(item - (long)row * nchunk) * 4;
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
     extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld]
     const int fe = FE > 0 ? FE : fe_rt;
     const int ldw = 2 * fi + fe;
-    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long item = (long)exp_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const int row = (int)(item / nchunk);
     const int col = (int)(item - (long)row * nchunk) * 4;
     EdgeRowHead hd;
