@@ -642,6 +642,31 @@ def test_edge_cases_empty_edges_and_isolated_nodes():
         assert_close(m(d.to(DEV)), ref(d), RTOL, f"E={ei.shape[1]}")
 
 
+def test_ragged_batch_of_different_grids_vs_oracle():
+    """A PyG batch may mix graphs of different sizes (14- and 118-bus grids here: the "graphs of n / B nodes" guess of the
+    graph-resident kernels does not hold and the on-device segment check must send the batch down the generic path):
+    forward and every parameter gradient against the oracle."""
+    from poweflownet_amd.data import Batch
+    from poweflownet_amd.synth import make_graph
+    torch.manual_seed(11)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    d = Batch.from_data_list([make_graph(14, 20, seed=1), make_graph(118, 186, seed=2), make_graph(14, 20, seed=3, topo_seed=4),
+                              make_graph(118, 186, seed=5, topo_seed=6)])
+    assert d.x.shape[0] == 264            # 4 graphs: the guess is 66 nodes per graph, and the 118-bus grids straddle its multiples
+    out_ref = ref(d)
+    torch.nn.MSELoss()(out_ref, d.y).backward()
+    dd = d.to(DEV)
+    out = m(dd)
+    assert m._graphs._graph.seg_nodes == 0
+    assert_close(out, out_ref, RTOL, "out")
+    torch.nn.MSELoss()(out, dd.y).backward()
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(p.grad, q.grad, RTOL, f"grad.{k}")
+
+
 def test_float_mask_and_nonsymmetric_input():
     """explain_epoch-style input: already-bidirectional, asymmetric edge list + float mask."""
     torch.manual_seed(5)
