@@ -120,8 +120,8 @@ constexpr int FH_LDS_BYTES = 156 * 1024;
 
 bool fused_hops_fit(int seg, int ld, int n) {
     // A hop acts on every column independently, so a block may take a COLUMN SLICE of its graph(s): small batches still
-    // fill the chip (case118 x 128: 128 graphs x 3 slices of 11 float4 columns = 384 blocks, 41 KB of LDS each, three per
-    // CU) and the K hops cost one launch instead of K (measured 47 -> ~10 us per TAGConv at 128 graphs).  Needs two
+    // fill the chip (case118 x 128: 128 graphs x 7 slices of 5 float4 columns = 896 blocks, 21 KB of LDS each) and the K
+    // hops cost one launch instead of K (measured 47 -> ~11 us per TAGConv at 128 graphs).  Needs two
     // tiles of at least one float4 column of a whole graph in LDS.  PFN_FUSED_HOPS=0/1 forces the choice (experiments).
     static const char* force = getenv("PFN_FUSED_HOPS");
     (void)ld;
@@ -253,9 +253,11 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
         set_error("fused hops: a %d-row graph does not fit in LDS", a.seg);
         return PFN_EINVAL;
     }
-    static const int want = getenv("PFN_FH_BLOCKS") ? atoi(getenv("PFN_FH_BLOCKS")) : 512;   // tuning aid
+    // (1024: case118 x 128 = 7 slices of 5 float4 columns, 896 blocks, 11.0-11.6 us per launch; 512 blocks of 9 columns: 12.1-12.8 us;
+    //  11 slices of 3 columns: 13.4 us -- 48-byte row segments waste most of every cache line, hence the floor of 4 columns)
+    static const int want = getenv("PFN_FH_BLOCKS") ? atoi(getenv("PFN_FH_BLOCKS")) : 1024;   // tuning aid
     int cs = std::max(1, std::min(nchunk, (want + ngraphs - 1) / std::max(1, ngraphs)));   // slices wanted
-    int cw = (nchunk + cs - 1) / cs;
+    int cw = std::max((nchunk + cs - 1) / cs, std::min(nchunk, 4));
     cw = std::min(cw, max_cw);
     cs = (nchunk + cw - 1) / cw;
     // Big batches (several rounds of workgroups anyway): a block's tiles stay under HALF of the LDS, so that two workgroups
