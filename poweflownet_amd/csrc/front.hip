@@ -21,6 +21,23 @@
 
 namespace pfn {
 
+// 256-thread blocks per CU of the row-per-wave kernels (which: 0 forward, 1 backward, 2 lin_out4).  Every wave first loads its
+// lanes' slices of the weights (72 values per lane in the forward), so FEWER, longer-lived waves win as long as the CU still
+// has enough of them to hide a row's load chain: case118 x 128 (15 k rows) with 8 / 4 / 3 / 2 / 1 blocks per CU: forward
+// 22.5 / 18.1 / 17.1 / 17.0 / 22.4 us, backward 11.9 / 9.7 / 9.8 / 10.5 / - us, lin_out4 7.3 / 7.6 / 6.5 / 8.1 / - us.
+// Tuning aid: PFN_WAVE_BPC="f,b,l"
+static int wave_blocks_per_cu(int which) {
+    static int v[3] = {0, 0, 0};
+    if (v[0] == 0) {
+        int a = 3, b = 3, c = 3;
+        if (const char* e = getenv("PFN_WAVE_BPC")) sscanf(e, "%d,%d,%d", &a, &b, &c);
+        v[1] = std::max(1, b);
+        v[2] = std::max(1, c);
+        v[0] = std::max(1, a);
+    }
+    return v[which];
+}
+
 __device__ __forceinline__ float4 ld4f(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4f(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
@@ -394,7 +411,7 @@ int launch_lin_out4(int n, int h, int fo, const float* S, const float* w2, const
     if (n == 0) return PFN_OK;
     const int ld = ld_of(h);
     ProfScope ps("lin_out4", 0.0, 0.0, s);
-    lin_out4_wave_kernel<<<std::min((n + 3) / 4, 8 * device_cus()), 256, 0, s>>>(n, h, ld, ld / 4, fo, S, w2, b2, deg, out);
+    lin_out4_wave_kernel<<<std::min((n + 3) / 4, wave_blocks_per_cu(2) * device_cus()), 256, 0, s>>>(n, h, ld, ld / 4, fo, S, w2, b2, deg, out);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
@@ -446,7 +463,7 @@ int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs,
         rows_pb = 0;
         lds = 0;
     }
-    const int nb_front = f.n > 0 ? std::min((f.n + (per_wave ? 4 : rows_pb) - 1) / (per_wave ? 4 : rows_pb), 8 * device_cus()) : 0;
+    const int nb_front = f.n > 0 ? std::min((f.n + (per_wave ? 4 : rows_pb) - 1) / (per_wave ? 4 : rows_pb), (per_wave ? wave_blocks_per_cu(0) : 8) * device_cus()) : 0;
     const int nblocks = nb_front + pack_bx * pa.njobs;
     if (nblocks > 0 || rng_advance) {
         ProfScope ps("front_fwd+pack", 0.0, 0.0, s);
@@ -465,7 +482,7 @@ int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, c
     front_shape(h, ld, nchunk, rows_pb, lds);
     ProfScope ps("front_bwd", 0.0, 0.0, s);
     if (front_row_per_wave(nchunk, n)) {
-        front_bwd_wave_kernel<<<std::min((n + 3) / 4, 8 * device_cus()), 256, 0, s>>>(n, h, ld, nchunk, ldw1, dP, dQ, me_h, w1, wb, g0, dh);
+        front_bwd_wave_kernel<<<std::min((n + 3) / 4, wave_blocks_per_cu(1) * device_cus()), 256, 0, s>>>(n, h, ld, nchunk, ldw1, dP, dQ, me_h, w1, wb, g0, dh);
         PFN_CHECK_LAUNCH();
         return PFN_OK;
     }
