@@ -21,6 +21,10 @@
 
 namespace pfn {
 
+static int wave_max_rows() {   // the row-per-wave kernels serve batches up to this many rows (tuning aid: PFN_WAVE_MAX_ROWS)
+    static const int v = getenv("PFN_WAVE_MAX_ROWS") ? atoi(getenv("PFN_WAVE_MAX_ROWS")) : 32768;
+    return v;
+}
 // 256-thread blocks per CU of the row-per-wave kernels (which: 0 forward, 1 backward, 2 lin_out4).  Every wave first loads its
 // lanes' slices of the weights (72 values per lane in the forward), so FEWER, longer-lived waves win as long as the CU still
 // has enough of them to hide a row's load chain: case118 x 128 (15 k rows) with 8 / 4 / 3 / 2 / 1 blocks per CU: forward
@@ -404,7 +408,7 @@ __global__ __launch_bounds__(256) void lin_out4_wave_kernel(int n, int h, int ld
 }
 bool lin_out4_ok(int h, int fo, int ldo, int n) {
     static const bool off = getenv("PFN_NO_FUSED_BACK") != nullptr;   // (the last layer's special kernels share one A/B switch)
-    return !off && fo >= 1 && fo <= 4 && ldo == 4 && ld_of(h) / 4 <= 64 && n <= 32768;
+    return !off && fo >= 1 && fo <= 4 && ldo == 4 && ld_of(h) / 4 <= 64 && n <= wave_max_rows();
 }
 int launch_lin_out4(int n, int h, int fo, const float* S, const float* w2, const float* b2, const float* deg, float* out,
                     hipStream_t s) {
@@ -426,7 +430,7 @@ bool front_fused_ok(int f0, int h) {
 // (6470rte x 64: backward 182 -> 247 us, measured), which stays for those sizes.
 static bool front_row_per_wave(int nchunk, int n) {
     static const bool off = getenv("PFN_FRONT_BLOCK_ROWS") != nullptr;   // A/B switch: the block-per-row-group kernels
-    return !off && nchunk <= 64 && n <= 32768;
+    return !off && nchunk <= 64 && n <= wave_max_rows();
 }
 static void front_shape(int h, int& ld, int& nchunk, int& rows_pb, size_t& lds) {
     ld = ld_of(h);

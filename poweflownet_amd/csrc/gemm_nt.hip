@@ -735,7 +735,8 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     const size_t lds_budget = (size_t)NT_LDS_BYTES - bias_bytes;
     int tps = 0;
     if (nq > 0) {
-        const int start = nq >= 3 ? 4 : nq;
+        static const int tps_cap = getenv("PFN_NT_TPS") ? atoi(getenv("PFN_NT_TPS")) : 4;   // tuning aid: 1, 2 or 4 quarters per slice at most
+        const int start = std::min(nq >= 3 ? 4 : nq, std::max(1, tps_cap));
         for (tps = start; tps >= 1; tps >>= 1) {
             size_t tot = 0;
             for (const NtPiece& pc : pieces) tot += piece_bytes(pc, tps);
