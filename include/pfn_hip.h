@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 3
+#define PFN_ABI_VERSION 4
 
 enum {
     PFN_OK = 0,
@@ -114,6 +114,19 @@ int pfn_mpn_backward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_
                      const float* const* params, float* const* grads, const float* x,
                      const void* pred_mask, int mask_dtype, const float* edge_attr, const float* grad_out,
                      float* grad_x, float* grad_edge_attr, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream);
+
+/* Verification aid for the autograd above (what loss.backward() differentiates, utils/training.py:74; the ReLUs are
+ * networks/MPN.py:19 (edge MLP), :547 (layer outputs) and :493 (mask_embd)): the ReLU gate decisions of the forward pass that
+ * filled `ws`, as bytes (1 = the unit passed), so that a float64 run of the CPU oracle can be held to the same piecewise-linear
+ * branch and every gradient compared at 1e-5.  Call after pfn_mpn_forward (need_backward = 1), before `ws` is reused.
+ *   kind 0: edge stage of EdgeAggregation layer `layer` (index into `layers`): out [E_effective][H] in edge-id order
+ *           (originals first, reversed copies second -- the order undirect_graph produces, networks/MPN.py:506-523);
+ *           out must hold 2 * e_stored * H bytes;
+ *   kind 1: output of hidden layer `layer` after dropout -> ReLU (:546-547): out [N][H];
+ *   kind 2: mask_embd's hidden layer (:493): out [N][H].                                                              */
+int pfn_mpn_export_gates(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
+                         const float* const* params, const float* edge_attr, void* ws, size_t ws_bytes, int32_t kind,
+                         int32_t layer, uint8_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------- single layers
  * EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, output_dim).forward (networks/MPN.py:30-56):

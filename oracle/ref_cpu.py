@@ -51,13 +51,22 @@ def in_degree(edge_index: torch.Tensor, num_nodes: int, dtype=torch.float32) -> 
 
 
 # --------------------------------------------------------------------------- the two layers
-def edge_aggregation(x, edge_index, edge_attr, w1, b1, w2, b2):
+def gated_relu(z, gate=None, record=None):
+    """relu(z) -- or, test hook, z * gate with the {0,1} decisions supplied from outside (the HIP path exports the ones its
+    forward took, pfn_mpn_export_gates): the same function on the branch those decisions select, so that a float64 run and an
+    fp32 run are differentiated on the SAME piecewise-linear piece.  `record`: list that receives this call's own z > 0."""
+    if record is not None:
+        record.append((z > 0).detach())
+    return F.relu(z) if gate is None else z * gate.to(z.dtype)
+
+
+def edge_aggregation(x, edge_index, edge_attr, w1, b1, w2, b2, gate=None, record=None):
     """EdgeAggregation.forward / .message (networks/MPN.py:23-56) under PyG propagate(aggr='add'):
     out[i] = sum_{e: dst(e)=i} ( W2 relu(W1 [x_i ; x_src(e) ; a_e] + b1) + b2 ).
     Concat order target, source, attr (:28).  The degree `norm` computed at :43-47 is dead."""
     src, dst = edge_index[0], edge_index[1]
     z = torch.cat([x.index_select(0, dst), x.index_select(0, src), edge_attr], dim=-1)
-    msg = F.linear(F.relu(F.linear(z, w1, b1)), w2, b2)
+    msg = F.linear(gated_relu(F.linear(z, w1, b1), gate, record), w2, b2)
     out = torch.zeros(x.shape[0], msg.shape[1], dtype=msg.dtype, device=msg.device)
     return out.index_add(0, dst, msg)
 
@@ -90,9 +99,9 @@ class EdgeAggregation(nn.Module):
         self.edge_aggr = nn.Sequential(nn.Linear(2 * nfeature_dim + efeature_dim, hidden_dim), nn.ReLU(),
                                        nn.Linear(hidden_dim, output_dim))
 
-    def forward(self, x, edge_index, edge_attr):
+    def forward(self, x, edge_index, edge_attr, gate=None, record=None):
         l1, l2 = self.edge_aggr[0], self.edge_aggr[2]
-        return edge_aggregation(x, edge_index, edge_attr, l1.weight, l1.bias, l2.weight, l2.bias)
+        return edge_aggregation(x, edge_index, edge_attr, l1.weight, l1.bias, l2.weight, l2.bias, gate, record)
 
 
 class TAGConv(nn.Module):
@@ -127,6 +136,10 @@ class MaskEmbdMultiMPN(nn.Module):
         # test hook: per hidden layer a {0,1} keep mask (N, H).  When set, dropout(x) is x * keep / (1 - p) -- nn.Dropout's
         # definition with the Bernoulli draw supplied from outside (the HIP path exports its masks: pfn_dropout_mask)
         self.dropout_masks = None
+        # test hook: externally supplied ReLU decisions {"edge": {layer: (E, H)}, "out": {layer: (N, H)}, "mask_embd": (N, H)}
+        # (what MaskEmbdMultiMPN.export_gates of the HIP mirror returns); every relu(z) becomes z * gate (see gated_relu)
+        self.gates = None
+        self.recorded_gates = None     # set to {} before a forward: receives this run's own decisions in the same layout
 
     is_directed = staticmethod(is_directed)
     undirect_graph = staticmethod(undirect_graph)
@@ -134,17 +147,46 @@ class MaskEmbdMultiMPN(nn.Module):
     def forward(self, data, return_intermediates: bool = False):
         assert data.x.shape[-1] == 4                                       # :528
         # `.float()` in the reference (:533); cast to x's dtype so the same oracle also runs in float64 as a yardstick
-        x = self.mask_embd(data.pred_mask.to(data.x.dtype)) + data.x      # :533,:537
+        gt, rec = self.gates, self.recorded_gates
+        if rec is not None:
+            rec.update({"edge": {}, "out": {}})
+
+        def hook(kind, li):
+            """(gate, record list) of one ReLU site; the record list's single entry is moved into `rec` by `keep`."""
+            g = None if gt is None else (gt[kind] if li is None else gt[kind][li])
+            return g, ([] if rec is not None else None)
+
+        def keep(kind, li, lst):
+            if rec is not None:
+                if li is None:
+                    rec[kind] = lst[0]
+                else:
+                    rec[kind][li] = lst[0]
+        g, r = hook("mask_embd", None)
+        a, b = self.mask_embd[0], self.mask_embd[2]
+        x = b(gated_relu(a(data.pred_mask.to(data.x.dtype)), g, r)) + data.x   # :533,:537 (mask_embd = Linear, ReLU, Linear :491-495)
+        keep("mask_embd", None, r)
         edge_index, edge_attr = undirect_graph(data.edge_index, data.edge_attr)   # :539
         inter = [x]
+
+        def run_layer(li, layer, x):
+            if not isinstance(layer, EdgeAggregation):
+                return layer(x, edge_index)
+            g, r = hook("edge", li)
+            y = layer(x, edge_index, edge_attr, g, r)
+            keep("edge", li, r)
+            return y
         for li, layer in enumerate(self.layers[:-1]):                      # :541-547
-            x = layer(x, edge_index, edge_attr) if isinstance(layer, EdgeAggregation) else layer(x, edge_index)
+            x = run_layer(li, layer, x)
             inter.append(x)                                                # pre-activation layer output
             if self.dropout_masks is not None:
-                x = F.relu(x * self.dropout_masks[li].to(x.dtype) / (1.0 - self.dropout_rate))
+                x = x * self.dropout_masks[li].to(x.dtype) / (1.0 - self.dropout_rate)
             else:
-                x = F.relu(self.dropout(x))
-        x = self.layers[-1](x, edge_index, edge_attr)                      # :554-555
+                x = self.dropout(x)
+            g, r = hook("out", li)
+            x = gated_relu(x, g, r)
+            keep("out", li, r)
+        x = run_layer(len(self.layers) - 1, self.layers[-1], x)            # :554-555
         inter.append(x)
         return (x, inter) if return_intermediates else x
 

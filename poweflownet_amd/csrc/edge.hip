@@ -761,7 +761,7 @@ __device__ __forceinline__ void edge_bwd_dst_body_mask(int bid, int nblk, int n,
 template <bool DSG>
 __device__ __forceinline__ void edge_bwd_src_body_mask(int bid, int n, int nchunk, const int* __restrict__ rowptr,
                                                        const int* __restrict__ nbr, const int* __restrict__ out_mbase,
-                                                       const int* __restrict__ out_ml4k, const float* __restrict__ dS,
+                                                       const int2* __restrict__ out_ml4k, const float* __restrict__ dS,
                                                        const unsigned* __restrict__ mask,
                                                        float* __restrict__ dQ, int ld, int h, const float* __restrict__ w2,
                                                        int fo) {
@@ -784,8 +784,8 @@ __device__ __forceinline__ void edge_bwd_src_body_mask(int bid, int n, int nchun
         for (int u = 0; u < 4; ++u) {
             const int q = min(p + u, last);
             d_[u] = nbr[q];
-            const int l4k = out_ml4k[q];                             // (ceil(deg_dst / 4) << 16) | position among dst's incoming edges
-            const size_t at = ((size_t)out_mbase[q] * nchunk + (size_t)c * (l4k >> 16)) * 4 + (l4k & 0xffff);
+            const int2 l4k = out_ml4k[q];                            // {ceil(deg_dst / 4), position among dst's incoming edges}
+            const size_t at = ((size_t)out_mbase[q] * nchunk + (size_t)c * l4k.x) * 4 + l4k.y;
             m_[u] = p + u < end ? mbytes[at] : 0u;
         }
         float4 g_[4];
@@ -801,7 +801,7 @@ template <bool DSG>
 __global__ __launch_bounds__(256) void edge_bwd_mask_kernel(int nb_dst, int n, int nchunk, int bdx, int bdy, int e_stored,
                                                             const int* __restrict__ rp_in, const int* __restrict__ in_eid,
                                                             const int* __restrict__ rp_out, const int* __restrict__ out_dst,
-                                                            const int* __restrict__ out_mbase, const int* __restrict__ out_ml4k,
+                                                            const int* __restrict__ out_mbase, const int2* __restrict__ out_ml4k,
                                                             const int* __restrict__ rp4, const float* __restrict__ dS,
                                                             const float* __restrict__ ea, const unsigned* __restrict__ mask,
                                                             float* __restrict__ dP, float* __restrict__ dQ,

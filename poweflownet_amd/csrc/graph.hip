@@ -63,7 +63,7 @@ GraphView graph_view(void* ws, int64_t n, int64_t e) {
     g.out_eid = c.take<int>(2 * e + 1);
     g.rp4 = c.take<int>(n + 1);
     g.out_mbase = c.take<int>(2 * e + 1);
-    g.out_ml4k = c.take<int>(2 * e + 1);
+    g.out_ml4k = c.take<int2>(2 * e + 1);
     g.slot_of_eid = c.take<int>(2 * e + 1);
     g.cur_in = c.take<int>(n + 1);
     g.cur_out = c.take<int>(n + 1);
@@ -334,13 +334,13 @@ __global__ __launch_bounds__(256) void graph_mask_index_kernel(int n, const int*
                                                                const int* __restrict__ rowptr_out, const int* __restrict__ out_dst,
                                                                const int* __restrict__ out_eid, const int* __restrict__ slot_of_eid,
                                                                const int* __restrict__ rp4, int* __restrict__ out_mbase,
-                                                               int* __restrict__ out_ml4k) {
+                                                               int2* __restrict__ out_ml4k) {
     const int nslot = rowptr_out[n];
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < nslot; p += gridDim.x * blockDim.x) {
         const int d = out_dst[p];
         const int k = slot_of_eid[out_eid[p]] - rowptr_in[d];       // position of the edge among d's incoming edges
         out_mbase[p] = rp4[d];
-        out_ml4k[p] = ((rp4[d + 1] - rp4[d]) << 16) | (k & 0xffff);
+        out_ml4k[p] = make_int2(rp4[d + 1] - rp4[d], k);   // (two full ints: any in-degree)
     }
 }
 
@@ -379,9 +379,9 @@ int pfn_graph_build(const int64_t* edge_index, int64_t e, int64_t n, int mode, v
         const int blocks = (int)std::min<int64_t>((e + 255) / 256, 2048);
         // (scratch: the two mask-index arrays, written for good by graph_mask_index_kernel below)
         graph_fill_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.rowptr_in, g.rowptr_out, g.cur_in, g.cur_out,
-                                                 g.out_mbase, g.out_ml4k, g.flags);
+                                                 g.out_mbase, reinterpret_cast<int*>(g.out_ml4k), g.flags);
         PFN_CHECK_LAUNCH();
-        graph_place_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.rowptr_in, g.rowptr_out, g.out_mbase, g.out_ml4k,
+        graph_place_kernel<<<blocks, 256, 0, s>>>(edge_index, ie, in, g.rowptr_in, g.rowptr_out, g.out_mbase, reinterpret_cast<int*>(g.out_ml4k),
                                                   g.in_src, g.in_eid, g.out_dst, g.out_eid, g.flags);
         PFN_CHECK_LAUNCH();
         const int sblocks = (int)std::min<int64_t>((2 * e + 255) / 256, 2048);

@@ -430,6 +430,13 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     lo.dQ.assign(lo.nlayers, nullptr);
     lo.dWe.assign(lo.nlayers, nullptr);
     lo.relu_mask.assign(lo.nlayers, nullptr);
+    lo.dh = nullptr;
+    lo.eas = EaScratch{nullptr, nullptr, nullptr, nullptr, ReduceWs{nullptr, 0}};
+    lo.tags = TagScratch{nullptr, nullptr, nullptr, ReduceWs{nullptr, 0}};
+    if (!c.need_backward) {   // inference: none of the backward pass's buffers exist (they were ~2/3 of the footprint)
+        lo.bytes = cv.off;
+        return PFN_OK;
+    }
     for (int i = 0; i < lo.nlayers; ++i) {
         lo.gin[i] = cv.take<float>(i == 0 ? (size_t)n * lo.ld0 : nld);
         if (is_ea(i)) {
@@ -727,7 +734,12 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ o, c
         // hand-off to the last arriver without __threadfence() (an L2 write-back + L1 invalidate, ~3.5 us each on this
         // multi-XCD part, and the kernel had two): the partial is stored WRITE-THROUGH (agent-scope atomic store = sc1), the
         // store is drained, then the ticket is taken; the last arriver reads the partials with agent-scope atomic loads (sc1:
-        // served by L2 / memory, never by its L1)
+        // served by L2 / memory, never by its L1).  This is the "sc1 payload -> asm vmcnt(0) -> flag, sc1 loads on the consumer"
+        // form MI355X_MICROARCH.md lists as valid ON gfx950 (vmcnt covers stores there; the language memory model does not
+        // promise it) -- hence the target guard below, and tests/test_gpu_parity.py::test_mse_loss_handoff_stress.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "mse_kernel's last-arriver hand-off relies on gfx950 semantics (sc1 write-through stores drained by s_waitcnt vmcnt(0))"
+#endif
         __hip_atomic_store(partial + blockIdx.x, red[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -836,6 +848,39 @@ __global__ __launch_bounds__(256) void dropout_mask_kernel(const uint64_t* __res
     }
 }
 
+// ---- ReLU gate export (verification aid, pfn_mpn_export_gates): the decisions of the three kinds of ReLU a forward pass
+// took, as bytes, so that a float64 run of the oracle can be held to the SAME piecewise-linear branch and the gradients compared
+// at north_star's tolerance (a pre-activation within the fp32 forward error of zero otherwise flips its gate in one of the two
+// runs and moves a weight gradient by 1e-5..2e-4 of its largest entry).
+// Edge stage of an EdgeAggregation layer: out[eid][k] = (P[dst][k] + Q[src][k] + sum_f a_e[f] We[k][f] > 0) with EXACTLY the
+// expression the walks evaluate (edge.hip edge_sum_chunk / edge_bwd_*_body, ea_seg.hip: add, then one fmaf per attribute, in
+// attribute order) on the P | Q the forward saved -- which is also what the saved mask bytes hold where the forward saved them.
+__global__ __launch_bounds__(256) void export_edge_gates_kernel(int n, int e_stored, const int* __restrict__ rowptr,
+                                                                const int* __restrict__ nbr, const int* __restrict__ eid,
+                                                                const float* __restrict__ P, const float* __restrict__ Q,
+                                                                const float* __restrict__ ea, const float* __restrict__ w1,
+                                                                int ld, int h, int fi, int fe, uint8_t* __restrict__ out) {
+    const int ldw = 2 * fi + fe;
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < (int64_t)n * h; it += (int64_t)gridDim.x * blockDim.x) {
+        const int row = (int)(it / h), k = (int)(it - (int64_t)row * h);
+        const float p = P[(size_t)row * ld + k];
+        for (int q = rowptr[row]; q < rowptr[row + 1]; ++q) {
+            const int id = eid[q], idm = id >= e_stored ? id - e_stored : id;
+            float v = p + Q[(size_t)nbr[q] * ld + k];
+            for (int f = 0; f < fe; ++f) v = fmaf(ea[(size_t)idm * fe + f], w1[(size_t)k * ldw + 2 * fi + f], v);
+            out[(size_t)id * h + k] = v > 0.f ? 1 : 0;
+        }
+    }
+}
+// Layer outputs (and mask_embd's hidden layer): out[row][k] = y[row][k] > 0, the test the backward pass applies (GemmArgs::gate).
+__global__ __launch_bounds__(256) void export_row_gates_kernel(int64_t n, int h, int ld, const float* __restrict__ y,
+                                                               uint8_t* __restrict__ out) {
+    for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n * h; it += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t row = it / h;
+        out[it] = y[row * ld + (it - row * h)] > 0.f ? 1 : 0;
+    }
+}
+
 }  // namespace pfn
 
 using namespace pfn;
@@ -897,6 +942,44 @@ int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
     PFN_CHECK_ARG(seg_nodes >= 0 && (seg_nodes == 0 || n % seg_nodes == 0), "seg_nodes must be 0 or divide n_nodes");
     return model_backward(*c, g, lo, params, grads, x, edge_attr, gout, gx, gea, (int)seg_nodes, static_cast<hipStream_t>(stream));
+}
+
+int pfn_mpn_export_gates(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
+                         const float* edge_attr, void* ws, size_t ws_bytes, int32_t kind, int32_t layer, uint8_t* out,
+                         void* stream) {
+    PFN_TRY(check_common(c, gws, n, e, ws));
+    PFN_CHECK_ARG(params && out, "pfn_mpn_export_gates: null pointer");
+    PFN_CHECK_ARG(c->need_backward != 0, "pfn_mpn_export_gates: the forward ran with need_backward = 0 (mask_embd's hidden layer was not saved)");
+    Layout lo;
+    PFN_TRY(make_layout(*c, n, e, ws, lo));
+    if (ws_bytes < lo.bytes) {
+        set_error("pfn_mpn_export_gates: workspace %zu < %zu bytes", ws_bytes, lo.bytes);
+        return PFN_ENOSPACE;
+    }
+    if (n == 0) return PFN_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int64_t items = n * lo.h;
+    const int blocks = (int)std::min<int64_t>((items + 255) / 256, 16384);
+    if (kind == 0) {
+        PFN_CHECK_ARG(layer >= 0 && layer < lo.nlayers && is_ea(layer), "pfn_mpn_export_gates: kind 0 needs an EdgeAggregation layer index");
+        PFN_CHECK_ARG(e == 0 || edge_attr, "pfn_mpn_export_gates: null edge_attr");
+        GraphView g = graph_view(const_cast<void*>(gws), n, e);
+        int pi = 0;
+        for (int i = 0; i < layer; ++i) pi += is_ea(i) ? 4 : lo.K + 2;
+        const int fi = layer == 0 ? lo.f0 : lo.h;
+        export_edge_gates_kernel<<<blocks, 256, 0, s>>>(g.n, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, lo.ea[layer].P, lo.ea[layer].Q,
+                                                       edge_attr, params[pi], lo.ld, lo.h, fi, lo.fe, out);
+    } else if (kind == 1) {
+        PFN_CHECK_ARG(layer >= 0 && layer + 1 < lo.nlayers, "pfn_mpn_export_gates: kind 1 needs a hidden layer index");
+        export_row_gates_kernel<<<blocks, 256, 0, s>>>(n, lo.h, lo.ld, lo.y[layer], out);
+    } else if (kind == 2) {
+        export_row_gates_kernel<<<blocks, 256, 0, s>>>(n, lo.h, lo.ld, lo.me_h, out);
+    } else {
+        set_error("pfn_mpn_export_gates: kind must be 0 (edge stage), 1 (layer output) or 2 (mask_embd hidden)");
+        return PFN_EINVAL;
+    }
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
 }
 
 // ------------------------------------------------------------------------------------- single layers

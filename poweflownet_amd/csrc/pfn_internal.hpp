@@ -83,8 +83,8 @@ struct GraphView {
     int* out_dst;
     int* out_eid;
     int* rp4;         // [n+1] prefix sum of ceil(in-degree / 4): row offsets of the edge stage's ReLU masks (EdgeFwdArgs::mask)
-    int* out_mbase;   // [2*e_stored] per by-source slot: rp4[dst], and (ceil(deg_dst / 4) << 16) | position of the edge among dst's
-    int* out_ml4k;    //              incoming edges -- where the by-source half of the backward walk finds the edge's mask byte
+    int* out_mbase;   // [2*e_stored] per by-source slot: rp4[dst], and {ceil(deg_dst / 4), position of the edge among dst's incoming
+    int2* out_ml4k;   //              edges} -- where the by-source half of the backward walk finds the edge's mask byte
     int* slot_of_eid; // [2*e_stored] build scratch: by-destination slot of edge id
     int* cur_in;      // [n] scratch: histogram, then fill cursor
     int* cur_out;     // [n]

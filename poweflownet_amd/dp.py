@@ -83,9 +83,14 @@ def allreduce_gradients(model: torch.nn.Module, ordered_params=None) -> None:
     flat = model.flat_grad() if hasattr(model, "flat_grad") else None
     params = ordered_params if ordered_params is not None else (
         model._ordered_params() if hasattr(model, "_ordered_params") else list(model.parameters()))
-    # (the check walks every parameter; under hipGraph replay the flat buffer is the same tensor every step: remember the verdict)
+    # (the check walks every parameter; under hipGraph replay the flat buffer is the same tensor every step: remember the verdict.
+    #  The caching allocator hands the same address to a NEW flat buffer whose .grads may no longer be views -- a hook cloned
+    #  them, a parameter was frozen -- so the remembered verdict is re-confirmed on the first and the last parameter per call.)
     key = None if flat is None else (flat.data_ptr(), flat.numel())
-    if key is not None and getattr(model, "_dp_inplace_key", None) == key:
+    if key is not None and getattr(model, "_dp_inplace_key", None) == key and params and \
+            params[0].grad is not None and params[0].grad.data_ptr() == flat.data_ptr() and \
+            params[-1].grad is not None and \
+            params[-1].grad.data_ptr() + 4 * params[-1].numel() == flat.data_ptr() + 4 * flat.numel():
         in_place = True
     else:
         in_place = flat is not None and _grads_are_views_of(flat, params)
@@ -106,3 +111,58 @@ def allreduce_gradients(model: torch.nn.Module, ordered_params=None) -> None:
         for g in grads:
             g.copy_(flat[off:off + g.numel()].view_as(g))
             off += g.numel()
+
+
+class GraphedStep:
+    """`fwd_bwd()` -> gradient all-reduce -> `opt_step()` replayed from hipGraphs.
+
+    Without a process group: ONE graph.  With RCCL (`backend == "nccl"`): still ONE graph -- `ncclAllReduce` is captured
+    between the backward pass and the optimizer kernel like any other node (RCCL supports stream capture; the process group's
+    watchdog thread queries events, hence thread-local capture mode), so a data-parallel step costs one graph launch and the
+    collective starts the moment the last gradient kernel retires.  With any other backend (gloo in the one-GPU plumbing
+    tests: its all-reduce goes through the host and cannot be captured), or when the one-graph capture fails: graph(fwd+bwd),
+    an eager all-reduce, graph(optimizer).  `mode` says which of the three was built.
+
+    `fwd_bwd` must write its loss into tensors it returns (kept as `self.out`); capture happens on the current stream after the
+    caller's own warm-up (the process group's communicator must already exist: run at least one eager all-reduce first)."""
+
+    def __init__(self, fwd_bwd, opt_step, model=None, allreduce: Optional[bool] = None):
+        self.fwd_bwd, self.opt_step, self.model = fwd_bwd, opt_step, model
+        self.allreduce = active() if allreduce is None else (allreduce and active())
+        self.graphs, self.mode, self.out = [], None, None
+
+    def _reduce(self):
+        allreduce_gradients(self.model)
+
+    def capture(self):
+        kw = {"capture_error_mode": "thread_local"} if self.allreduce else {}
+        if not self.allreduce or dist.get_backend() == "nccl":
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, **kw):
+                    self.out = self.fwd_bwd()
+                    if self.allreduce:
+                        self._reduce()
+                    self.opt_step()
+                self.graphs, self.mode = [g], ("one graph incl. RCCL all-reduce" if self.allreduce else "one graph")
+                return self
+            except Exception:                      # noqa: BLE001
+                if not self.allreduce:
+                    raise
+                torch.cuda.synchronize()           # a collective that would not capture: fall through to the split form
+        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_fb, **kw):
+            self.out = self.fwd_bwd()
+        with torch.cuda.graph(g_opt, **kw):
+            self.opt_step()
+        self.graphs, self.mode = [g_fb, g_opt], "graph(fwd+bwd) -> eager all-reduce -> graph(optimizer)"
+        return self
+
+    def replay(self):
+        if len(self.graphs) == 1:
+            self.graphs[0].replay()
+        else:
+            self.graphs[0].replay()
+            self._reduce()
+            self.graphs[1].replay()
+        return self.out

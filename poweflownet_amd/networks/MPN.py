@@ -288,6 +288,8 @@ class _MpnFn(torch.autograd.Function):
                 "pfn_mpn_forward")
         ctx.model, ctx.graph, ctx.cfg, ctx.ws, ctx.mask_dtype = model, graph, cfg, ws, mask_dtype
         ctx.save_for_backward(x, pred_mask, edge_attr, *params)
+        # (verification aid, `export_gates`: what the last recorded forward left behind -- weak, nothing is kept alive)
+        model._last_forward = (weakref.ref(ws), weakref.ref(graph), cfg, weakref.ref(edge_attr)) if cfg.need_backward else None
         return _unpad_rows(out, fo)
 
     @staticmethod
@@ -406,6 +408,37 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
         """The flat fp32 buffer the last backward wrote all parameter gradients into (views of it are the
         `.grad`s autograd handed out) -- the unit poweflownet_amd.dp all-reduces."""
         return self._last_flat_grad
+
+    def export_gates(self):
+        """Verification aid (`pfn_mpn_export_gates`): the ReLU decisions of the last forward pass that autograd recorded, while
+        its workspace is still alive (i.e. before the output / loss tensor is dropped): {"edge": {layer index: bool (E_eff, H)},
+        "out": {layer index: bool (N, H)}, "mask_embd": bool (N, H)}, edges in the order `undirect_graph` produces.  Tests feed
+        them to a float64 run of the CPU oracle so that gradients are compared on the SAME piecewise-linear branch."""
+        lf = getattr(self, "_last_forward", None)
+        ws, graph, edge_attr = (lf[0](), lf[1](), lf[3]()) if lf is not None else (None, None, None)
+        if ws is None or graph is None or edge_attr is None:
+            raise RuntimeError("export_gates: no recorded forward pass is alive (call it before dropping the output / loss)")
+        lib, cfg = L.load(), lf[2]
+        n, h, dev = graph.num_nodes, self.hidden_dim, ws.device
+        params = self._ordered_params()
+        _, e_eff = graph.info()
+        nlayers = 2 * self.n_gnn_layers - 1
+
+        def run(kind, layer, rows):
+            out = torch.empty(max(rows, 1), h, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                L.check(lib.pfn_mpn_export_gates(C.byref(cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
+                                                 edge_attr.data_ptr(), ws.data_ptr(), ws.numel(), kind, layer, out.data_ptr(),
+                                                 L.stream_ptr()), "pfn_mpn_export_gates")
+            return out
+        gates = {"edge": {}, "out": {}}
+        for i in range(nlayers):
+            if i % 2 == 0:
+                gates["edge"][i] = run(0, i, 2 * graph.e_stored)[:e_eff].bool()
+            if i + 1 < nlayers:
+                gates["out"][i] = run(1, i, n).bool()
+        gates["mask_embd"] = run(2, 0, n).bool()
+        return gates
 
     # -------------------------------------------------------------------------------------- forward
     def forward(self, data):

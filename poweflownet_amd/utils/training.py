@@ -46,15 +46,19 @@ def _backward(loss_fn, loss):
 
 class GraphedTrainStep:
     """The per-batch body of `train_epoch` (zero_grad -> forward -> loss -> backward -> step) captured ONCE into a hipGraph
-    and replayed for every following batch of the same shape and topology: the ~75 kernel launches of a step cost one
+    and replayed for every following batch of the same shape and topology: the ~34 kernel launches of a step cost one
     graph launch (what bench.py measures).  A batch is copied into the captured input tensors (4 small device copies).
+    Under data parallelism the gradient all-reduce is inside the replayed step (dp.GraphedStep).
 
     Replays only when it is safe, otherwise runs the eager body: the batch must have the captured shapes and hand in the SAME
     `edge_index` tensor (the device-resident `PowerFlowData` does: one cached tensor per batch size) -- the adjacency is baked
     into the captured launches; the learning rate is a captured kernel argument, so a scheduler step re-captures."""
 
-    def __init__(self, model, loss_fn, optimizer):
+    def __init__(self, model, loss_fn, optimizer, allreduce: Optional[bool] = None):
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
+        # data parallel (dp.py): the gradient all-reduce is part of the replayed step -- ONE hipGraph with the RCCL collective
+        # captured between backward and optimizer, or graph / eager all-reduce / graph for a backend that cannot be captured
+        self.allreduce = (dp.world_size() > 1) if allreduce is None else bool(allreduce)
         self.graph = self.static = self.loss = None
         self.key = None            # optimiser hyper-parameters baked into the captured launches
         self.disabled = False      # a failed capture, or a dataset that never hands the same edge_index twice: stay eager
@@ -70,12 +74,18 @@ class GraphedTrainStep:
         betas = tuple(float(b) for b in g.get("betas", ()))
         return (float(g["lr"]), betas, float(g.get("eps", 0.0)), float(g.get("weight_decay", 0.0)))
 
-    def _eager(self, data):
+    def _fwd_bwd(self, data):
         self.opt.zero_grad()
         loss = _dispatch_loss(self.loss_fn, self.model(data), data)
         _backward(self.loss_fn, loss)
-        self.opt.step()
         return loss.detach()
+
+    def _eager(self, data):
+        loss = self._fwd_bwd(data)
+        if self.allreduce:
+            dp.allreduce_gradients(self.model)
+        self.opt.step()
+        return loss
 
     def _snapshot(self):
         """Everything a training step mutates, so that the warm-up steps torch asks for before a capture leave no trace."""
@@ -115,9 +125,8 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(side)
         self._restore(snap)
         self.opt.zero_grad(set_to_none=True)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._eager(self.static)
+        self.graph = dp.GraphedStep(lambda: self._fwd_bwd(self.static), self.opt.step, self.model, self.allreduce).capture()
+        self.loss = self.graph.out
         self.key = self._hyper_key()
         return self.loss                                           # the capture pass does not execute: caller replays
 
@@ -127,7 +136,7 @@ class GraphedTrainStep:
                 data.edge_attr.shape == s.edge_attr.shape and data.x.device == s.x.device)
 
     def __call__(self, data):
-        if self.disabled or not data.x.is_cuda or dp.world_size() > 1:
+        if self.disabled or not data.x.is_cuda:
             return self._eager(data)
         if self.graph is not None and self.key != self._hyper_key():
             self.graph = self.static = None                        # a scheduler moved lr / betas / ...: capture again
@@ -177,9 +186,12 @@ def train_epoch(model: nn.Module, loader, loss_fn: Callable, optimizer, device, 
     if progress:
         from tqdm import tqdm
         it = tqdm(loader, total=len(loader), desc="Training")
+    if graph is not None and graph.allreduce != bool(allreduce):
+        graph.graph = graph.static = None       # the replayed step contains (or not) the collective: capture again
+        graph.allreduce = bool(allreduce)
     for data in it:
         data = data.to(device)
-        if graph is not None and not allreduce:
+        if graph is not None:
             loss = graph(data)
         else:
             optimizer.zero_grad()

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(L.SYMBOLS), (declared, L.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pfn_abi_version() == L.ABI_VERSION == 3
+    assert lib.pfn_abi_version() == L.ABI_VERSION == 4
 
 
 def test_host_only_entry_points():
@@ -39,6 +39,8 @@ def test_host_only_entry_points():
     assert lib.pfn_graph_workspace_bytes(15104, 23808) > 4 * (2 * 15104 + 8 * 23808)
     ws = lib.pfn_mpn_workspace_bytes(C.byref(cfg), 15104, 23808)
     assert ws > 15104 * 132 * 4 * 20
+    cfgb = L.MpnConfig(4, 2, 4, 129, 4, 3, 0.2, 1, 1)      # need_backward = 1: the backward pass's buffers come on top
+    assert lib.pfn_mpn_workspace_bytes(C.byref(cfgb), 15104, 23808) > 1.9 * ws
     bad = L.MpnConfig(4, 2, 4, 129, 1, 3, 0.2, 1)          # L == 1 is rejected
     assert lib.pfn_mpn_workspace_bytes(C.byref(bad), 10, 10) == 0
 

@@ -90,8 +90,9 @@ def test_two_ranks_hip_inplace_allreduce_equals_single_process(tmp_path, case, g
 
 
 def test_bench_two_ranks_on_one_gpu_gloo():
-    """bench.py's multi-process path (what the driver launches for N > 1): hipGraph(fwd+bwd) -> eager all-reduce ->
-    hipGraph(AdamW), every rank entering every collective including the ones inside rank 0's profiling pass."""
+    """bench.py's multi-process path as the driver launches it for N > 1 (torchrun).  Under gloo (the collective goes through
+    the host and cannot be captured) the step is hipGraph(fwd+bwd) -> eager all-reduce -> hipGraph(AdamW); every rank enters
+    every collective including the ones inside rank 0's profiling pass."""
     cmd, env = _torchrun(2, [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2",
                              "--profile-steps", "2", "--no-cpu-baseline", "--case", "14", "--batch", "8"],
                          {"PFN_SINGLE_DEVICE": "1", "PFN_DIST_BACKEND": "gloo"})
@@ -101,6 +102,65 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["roofline"] is not None
+    assert d["config"]["launch"] == "hipGraph replay: graph(fwd+bwd) -> eager all-reduce -> graph(optimizer)"
+
+
+def test_bench_self_launches_its_ranks():
+    """`python bench.py --gpus 2` with NO torchrun environment starts its own two ranks (torch.distributed.run on a free port) and
+    rank 0 prints the one JSON line, labelled n_gpus = 2; asking for more GPUs than the box has (without the one-device test aid)
+    is an error, not a mislabelled 1-GPU number."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", PFN_SINGLE_DEVICE="1", PFN_DIST_BACKEND="gloo", PFN_HANG_DUMP="150")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--profile-steps", "0",
+           "--no-cpu-baseline", "--case", "14", "--batch", "8"]
+    out, err = _run(cmd, env, 420)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:] + err[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["value"] > 0
+    if torch.cuda.device_count() < 2:
+        env.pop("PFN_SINGLE_DEVICE")
+        proc = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
+        assert proc.returncode != 0 and "device(s) are visible" in proc.stderr and "{" not in proc.stdout
+
+
+def test_config5_workload_two_ranks_one_device():
+    """BASELINE configs[4]'s per-rank workload (case6470rte x 64 per rank, data parallel) with two ranks -- sharing the one GPU
+    of this box, gradients over gloo: the step bench.py times on the 8-GPU node, at its real size (2 x 11 GB of workspaces)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY="0", PFN_SINGLE_DEVICE="1", PFN_DIST_BACKEND="gloo", PFN_HANG_DUMP="300")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--profile-steps", "0",
+           "--no-cpu-baseline", "--case", "6470rte", "--batch", "64"]
+    out, err = _run(cmd, env, 600)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:] + err[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 128 and d["config"]["nodes_per_gpu"] == 64 * 6470
+    assert d["value"] > 0 and d["final_loss"] == d["final_loss"]            # finite loss
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_graphed_train_step_under_dp_equals_eager_dp(tmp_path, world):
+    """train_epoch + GraphedTrainStep under data parallelism: the replayed step contains the all-reduce.  World 1 runs it over a
+    real RCCL process group (PFN_FORCE_DIST=1): ONE hipGraph with ncclAllReduce captured between backward and AdamW.  World 2
+    (two ranks on the one GPU, gloo): graph / eager all-reduce / graph.  Either way two epochs end on the parameters of the
+    eager data-parallel loop, bit for bit, and the replicas agree."""
+    out_path = str(tmp_path / "dp_train.json")
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_raw_dataset.py"), "--root", str(tmp_path), "--case", "14",
+                    "--samples", "60"], check=True, capture_output=True)        # train split: 30 samples = 5 global batches of 6
+    script = [os.path.join(ROOT, "tests", "dp_train_worker.py"), out_path, str(tmp_path), "14", "6"]
+    if world == 1:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PFN_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), PFN_HANG_DUMP="150")
+        cmd = [sys.executable] + script
+    else:
+        cmd, env = _torchrun(2, script, {"PFN_SINGLE_DEVICE": "1", "PFN_DIST_BACKEND": "gloo"})
+    _run(cmd, env, 420)
+    got = json.load(open(out_path))
+    want_mode = "one graph incl. RCCL all-reduce" if world == 1 else "graph(fwd+bwd) -> eager all-reduce -> graph(optimizer)"
+    assert got["mode"] == want_mode and got["world"] == world, got
+    assert got["max_abs_diff"] == 0.0, got
+    assert got["losses_graph"] == got["losses_eager"], got
 
 
 def test_bench_rccl_collective_path_world1():
@@ -115,4 +175,5 @@ def test_bench_rccl_collective_path_world1():
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out[-2000:] + err[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["launch"] == "hipGraph replay", d["config"]
+    # the collective is INSIDE the replayed graph (dp.GraphedStep): one hipGraph per data-parallel step
+    assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["launch"] == "hipGraph replay: one graph incl. RCCL all-reduce", d["config"]
