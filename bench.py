@@ -209,15 +209,16 @@ def dp_overhead(fb, opt, model, dev, steps, base_ms):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     try:
-        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):             # creates the communicator outside any capture
-            fb()
-            dp.allreduce_gradients(model)
-            opt.step()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
+        with dp.stdout_to_stderr():               # (RCCL's version banner must not land on the JSON line's stdout)
+            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):         # creates the communicator outside any capture
+                fb()
+                dp.allreduce_gradients(model)
+                opt.step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
         opt.zero_grad(set_to_none=True)
         gs = dp.GraphedStep(fb, opt.step, model, allreduce=True).capture()
         for _ in range(5):

@@ -44,6 +44,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int T3_THREADS = 512;            // 8 waves = two per SIMD
 constexpr int T3_WAVES = 8;
 constexpr int T3_R = 8;                    // ring depth: steps (row pairs) in flight per wave
+constexpr int T3_FLUSH = 64;                // narrow shapes: ring turns (of T3_R steps = 16 rows) between two-level flushes
 constexpr int T3_ROWS = 8;                 // row ranges of blocks are multiples of T3_ROWS x T3_WAVES rows
 constexpr int T3_MAX_PAIRS = 28;            // standard.json needs 26 (kernel arguments: 28 x 72 + 56 x 24 bytes < 4 KB)
 constexpr int T3_MAX_TASKS = 56;
@@ -162,6 +163,40 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[ta][tb][q] = 0.f;
     float xc[4] = {0.f, 0.f, 0.f, 0.f}, bs[4] = {0.f, 0.f, 0.f, 0.f}, xr[4] = {0.f, 0.f, 0.f, 0.f}, cn = 0.f, cb = 0.f;
+    // Two-level summation for the NARROW shapes (a 4-wide operand: few accumulators, and -- being cheap -- few row splits, so an
+    // accumulator would be ONE fp32 FMA chain over tens of thousands of rows at 414 k nodes: 2e-5 of the largest entry of dW2 on
+    // a high-degree grid): every T3_FLUSH ring turns (1,024 rows of the wave) the accumulators are added into a second set and
+    // cleared.  The wide shape has no registers for that and gets ~3x the row splits anyway.
+    constexpr bool TWO_LEVEL = TA * TB < 8;
+    constexpr int OA = TWO_LEVEL ? TA : 1, OB = TWO_LEVEL ? TB : 1;
+    f32x16 outer[OA][OB];
+    float oxc[4] = {0.f, 0.f, 0.f, 0.f}, obs[4] = {0.f, 0.f, 0.f, 0.f}, oxr[4] = {0.f, 0.f, 0.f, 0.f}, ocn = 0.f, ocb = 0.f;
+#pragma unroll
+    for (int ta = 0; ta < OA; ++ta)
+#pragma unroll
+        for (int tb = 0; tb < OB; ++tb)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) outer[ta][tb][q] = 0.f;
+    auto flush = [&]() {
+        if (!TWO_LEVEL) return;
+#pragma unroll
+        for (int ta = 0; ta < OA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < OB; ++tb)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    outer[ta][tb][q] += acc[ta][tb][q];
+                    acc[ta][tb][q] = 0.f;
+                }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            oxc[e] += xc[e]; xc[e] = 0.f;
+            obs[e] += bs[e]; bs[e] = 0.f;
+            oxr[e] += xr[e]; xr[e] = 0.f;
+        }
+        ocn += cn; cn = 0.f;
+        ocb += cb; cb = 0.f;
+    };
 
     // ---- the streaming loop: a RING of T3_R steps (2 rows each) per wave, hand-managed like gemm_nt's A fragment.
     // Every vector-memory instruction is inline asm and every wait a hand-counted `s_waitcnt vmcnt(N)` tied to the
@@ -239,6 +274,7 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
                 issue(ring[r], t0 + r + T3_R);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (TWO_LEVEL && ((t0 / T3_R) & (T3_FLUSH - 1)) == T3_FLUSH - 1) flush();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-fetched slots: nothing of the ring is in flight past here
     }
@@ -259,6 +295,18 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
         }
         // (with has_rs false the bias column is the constant 1: the upper half must not add its 1 * a -- a is zeroed above)
         compute(t);
+    }
+    if (TWO_LEVEL) {   // total = second level + what the first level holds
+        flush();
+#pragma unroll
+        for (int ta = 0; ta < OA; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < OB; ++tb) acc[ta][tb] = outer[ta][tb];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            xc[e] = oxc[e]; bs[e] = obs[e]; xr[e] = oxr[e];
+        }
+        cn = ocn; cb = ocb;
     }
     // the two k halves of the VALU extras
 #pragma unroll

@@ -9,7 +9,10 @@ per graph the averaged gradient equals the single-device gradient on the global 
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes
 import os
+import sys
 from typing import Iterable, Optional
 
 import torch
@@ -38,8 +41,29 @@ def init_from_env(backend: Optional[str] = None):
         kwargs = {}
         if backend == "nccl":
             kwargs["device_id"] = torch.device("cuda", local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
+        with stdout_to_stderr():
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kwargs)
     return rank, local_rank, world
+
+
+@contextlib.contextmanager
+def stdout_to_stderr():
+    """RCCL prints a version banner on the C-level stdout when a communicator is created.  A caller whose stdout is a protocol
+    (bench.py: ONE JSON line) wraps the process-group / communicator creation in this: file descriptor 1 points at stderr for
+    the duration, and the C stdio buffer is flushed before it is restored."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                          # noqa: BLE001
+            pass
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def world_size() -> int:
@@ -73,13 +97,21 @@ def _grads_are_views_of(flat: torch.Tensor, params: Iterable[torch.nn.Parameter]
     return off == flat.numel()
 
 
+def allreduce_flat(flat: torch.Tensor) -> None:
+    """Average one flat buffer across ranks in place (RCCL: ncclAvg; gloo: sum, then scale)."""
+    if dist.get_backend() == "nccl":
+        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+    else:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.mul_(1.0 / world_size())
+
+
 def allreduce_gradients(model: torch.nn.Module, ordered_params=None) -> None:
     """Average gradients across ranks with ONE collective.  Fast path: the `.grad`s are views of the flat buffer
     the HIP backward produced (model.flat_grad()) -> all-reduce it in place, nothing is copied.  Generic path
     (any nn.Module, used by the gloo CPU tests): flatten -> all-reduce -> scatter back."""
     if not active():
         return
-    w = world_size()
     flat = model.flat_grad() if hasattr(model, "flat_grad") else None
     params = ordered_params if ordered_params is not None else (
         model._ordered_params() if hasattr(model, "_ordered_params") else list(model.parameters()))
@@ -101,11 +133,7 @@ def allreduce_gradients(model: torch.nn.Module, ordered_params=None) -> None:
     if not in_place:
         grads = [p.grad for p in params if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])
-    if dist.get_backend() == "nccl":
-        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
-    else:
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.mul_(1.0 / w)
+    allreduce_flat(flat)
     if not in_place:
         off = 0
         for g in grads:
@@ -130,9 +158,33 @@ class GraphedStep:
         self.fwd_bwd, self.opt_step, self.model = fwd_bwd, opt_step, model
         self.allreduce = active() if allreduce is None else (allreduce and active())
         self.graphs, self.mode, self.out = [], None, None
+        self._flat, self._grads = None, None       # split form: the gradient tensors the CAPTURED backward writes
 
     def _reduce(self):
         allreduce_gradients(self.model)
+
+    def _remember_captured_grads(self):
+        """Split form only: the eager all-reduce between the two graphs must reduce the buffers the captured backward writes and
+        the captured optimizer reads -- NOT whatever `model.flat_grad()` / `.grad` point at by then (an eager step in between,
+        e.g. the short last batch of an epoch, re-points both at fresh tensors)."""
+        m = self.model
+        params = m._ordered_params() if hasattr(m, "_ordered_params") else list(m.parameters())
+        flat = m.flat_grad() if hasattr(m, "flat_grad") else None
+        if flat is not None and _grads_are_views_of(flat, params):
+            self._flat = flat
+        else:
+            self._grads = [p.grad for p in params if p.grad is not None]
+
+    def _reduce_captured(self):
+        if self._flat is not None:
+            allreduce_flat(self._flat)
+            return
+        flat = torch.cat([g.reshape(-1) for g in self._grads])
+        allreduce_flat(flat)
+        off = 0
+        for g in self._grads:
+            g.copy_(flat[off:off + g.numel()].view_as(g))
+            off += g.numel()
 
     def capture(self):
         kw = {"capture_error_mode": "thread_local"} if self.allreduce else {}
@@ -153,6 +205,7 @@ class GraphedStep:
         g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(g_fb, **kw):
             self.out = self.fwd_bwd()
+        self._remember_captured_grads()
         with torch.cuda.graph(g_opt, **kw):
             self.opt_step()
         self.graphs, self.mode = [g_fb, g_opt], "graph(fwd+bwd) -> eager all-reduce -> graph(optimizer)"
@@ -163,6 +216,6 @@ class GraphedStep:
             self.graphs[0].replay()
         else:
             self.graphs[0].replay()
-            self._reduce()
+            self._reduce_captured()
             self.graphs[1].replay()
         return self.out

@@ -1099,7 +1099,27 @@ def test_in_degree_above_65535_saved_masks():
     dd = data.to(DEV)
     out = m(dd)
     assert m._graphs._graph.info() == (True, 2 * (n - 1))
-    with torch.no_grad():
-        assert_close(out, ref(data), RTOL, "star: out vs fp32 oracle")
     torch.nn.MSELoss()(out, dd.y).backward()
-    _assert_grads_on_hip_gates(m, ref, data, "star graph, in-degree 70,000", out)
+    # The hub row is a SEQUENTIAL fp32 sum of 70,000 messages in edge order -- here as in torch's scatter_add -- whose rounding
+    # error (~sqrt(d) eps .. d eps) is far above 1e-5 for ANY fp32 implementation, and the hub dominates every gradient.  So the
+    # yardstick is the float64 oracle on the HIP path's ReLU decisions, and the bound is 4x the error the fp32 ORACLE itself makes
+    # against it on the same decisions (or 1e-5).  A wrong mask byte is not subtle: it moves dQ, hence every gradient, by O(1).
+    gates = _cpu_gates(m)
+    torch.set_num_threads(8)
+    ref64 = copy.deepcopy(ref).double()
+    ref32 = copy.deepcopy(ref)
+    ref64.gates = ref32.gates = gates
+    d64 = _to64(data)
+    o64 = ref64(d64)
+    torch.nn.MSELoss()(o64, d64.y).backward()
+    o32 = ref32(data)
+    torch.nn.MSELoss()(o32, data.y).backward()
+
+    def check(what, ours, fp32, truth):
+        e_ours, scale = rel_err(ours, truth)
+        e_ref, _ = rel_err(fp32, truth)
+        record(f"star graph: {what} vs fp64 oracle on the HIP gates (fp32 oracle: {e_ref / max(scale, 1e-300):.2e})", e_ours, scale, None)
+        assert e_ours <= max(RTOL * scale, 4 * e_ref), (what, e_ours, e_ref, scale)
+    check("out", out, o32, o64)
+    for (k, p), q, t in zip(m.named_parameters(), ref32.parameters(), ref64.parameters()):
+        check(f"grad.{k}", p.grad, q.grad, t.grad)
