@@ -312,7 +312,12 @@ __device__ unsigned long long nt_ts[4096 * 4];
 #define NT_TS_END
 #endif
 
-template <int CT>
+// VAR = the multiply variant of the launch (all pieces of a launch share it; chosen on the host, so that a kernel holds at most
+// TWO instantiations of the round loop -- with / without the trailing VALU column, a per-wave property; with more of them in one
+// kernel the CT = 2 build had no registers left for the one-step tail):
+//   0: 17 chunks, the last chunk is ONE MFMA step (K = 129)     1: 17 chunks, last chunk 4 steps
+//   2: 16 chunks (K = 128), no trailing column                  3: generic (per-chunk guards, 4 trailing columns; CT < 2 only)
+template <int CT, int VAR>
 __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     NT_TS_DECL;
@@ -648,35 +653,36 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     using I0 = integral_constant<int, 0>;
     using I1 = integral_constant<int, 1>;
     using I4 = integral_constant<int, 4>;
-    // (the one-step tail is instantiated for CT < 2 only: in the CT = 2 kernel the extra variants cost registers -> spills)
-    bool done = false;
-    if constexpr (CT < 2) {
-        if (a.kuni == KP && a.klast == 1 && nr <= 1) {
-            if (nr == 0) rounds(integral_constant<int, NCH>{}, I0{}, I1{});
-            else rounds(integral_constant<int, NCH>{}, I1{}, I1{});
-            done = true;
-        }
+    if constexpr (VAR == 0) {
+        if (nr == 0) rounds(integral_constant<int, NCH>{}, I0{}, I1{});
+        else rounds(integral_constant<int, NCH>{}, I1{}, I1{});
+    } else if constexpr (VAR == 1) {
+        if (nr == 0) rounds(integral_constant<int, NCH>{}, I0{}, I4{});
+        else rounds(integral_constant<int, NCH>{}, I1{}, I4{});
+    } else if constexpr (VAR == 2) {
+        rounds(integral_constant<int, NCH - 1>{}, I0{}, I4{});
+    } else {
+        rounds(I0{}, I4{}, I4{});
     }
-    if (done) {
-        NT_TS_END;
-        return;
-    }
-    if (a.kuni == KP && nr == 0) rounds(integral_constant<int, NCH>{}, I0{}, I4{});
-    else if (a.kuni == KP && nr == 1) rounds(integral_constant<int, NCH>{}, I1{}, I4{});
-    else if (a.kuni == KP - 8 && nr == 0) rounds(integral_constant<int, NCH - 1>{}, I0{}, I4{});
-    else if constexpr (CT < 2) rounds(I0{}, I4{}, I4{});
     NT_TS_END;
     // CT == 2 exists only for the straight-line variants (the launcher never pairs it with the generic one: two tiles plus
     // four trailing columns plus per-chunk guards do not fit the register file without spills)
 }
 
-template <int CT>
+template <int CT, int VAR>
 static int launch_variant(const NtArgs& k, dim3 grid, size_t lds_bytes, hipStream_t s) {
     static std::atomic<uint64_t> lds_raised{0};
-    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<CT>), NT_LDS_BYTES, lds_raised));
-    gemm_nt_kernel<CT><<<grid, NT_THREADS, lds_bytes, s>>>(k);
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<CT, VAR>), NT_LDS_BYTES, lds_raised));
+    gemm_nt_kernel<CT, VAR><<<grid, NT_THREADS, lds_bytes, s>>>(k);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
+}
+// the multiply variant of one launch (see gemm_nt_kernel); -1: not expressible with this CT
+static int pick_variant(const NtArgs& k, int CT) {
+    const int nr = k.remv > 0 ? (k.nrem > 1 ? 4 : 1) : 0;   // trailing columns the launch's last column group owns
+    if (k.kuni == KP && nr <= 1) return k.klast == 1 ? 0 : 1;
+    if (k.kuni == KP - 8 && nr == 0) return 2;
+    return CT < 2 ? 3 : -1;
 }
 
 int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
@@ -807,10 +813,17 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
             k.gflags[g] = (seen[g] ? 1 : 0) | (later ? 2 : 0);
             seen[g] |= here[g];
         }
-        int rc;
-        if (CT == 0) rc = launch_variant<0>(k, grid, used + bias_bytes, s);
-        else if (CT == 1) rc = launch_variant<1>(k, grid, used + bias_bytes, s);
-        else rc = launch_variant<2>(k, grid, used + bias_bytes, s);
+        int rc = PFN_EINVAL;
+        static const bool ls4 = getenv("PFN_NT_LS4") != nullptr;   // A/B switch: four MFMA steps in the last chunk although K = 129
+        if (ls4) k.klast = 4;
+        const int var = pick_variant(k, CT);
+        const size_t lb = used + bias_bytes;
+#define PFN_NT_CASE(CT_, V_) if (CT == CT_ && var == V_) rc = launch_variant<CT_, V_>(k, grid, lb, s)
+        PFN_NT_CASE(0, 0); PFN_NT_CASE(0, 1); PFN_NT_CASE(0, 2); PFN_NT_CASE(0, 3);
+        PFN_NT_CASE(1, 0); PFN_NT_CASE(1, 1); PFN_NT_CASE(1, 2); PFN_NT_CASE(1, 3);
+        PFN_NT_CASE(2, 0); PFN_NT_CASE(2, 1); PFN_NT_CASE(2, 2);
+#undef PFN_NT_CASE
+        if (var < 0) set_error("gemm_nt: no CT = %d kernel for this launch (kuni %d, nrem %d)", CT, k.kuni, k.nrem);
         if (rc != PFN_OK) return rc;
         i0 = i1;
     }
