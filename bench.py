@@ -501,6 +501,25 @@ def main():
         data.edge_index = ei_saved
         if use_graph and not dist_on and not args.no_dp_overhead:
             extras.update(dp_overhead(fb, opt, model, dev, args.steps, ms_per_step))
+        if use_graph and not dist_on:
+            # a topology that changes per batch (the reference's `perturbed` datasets): the adjacency build -- is_directed,
+            # undirect, both CSRs, degrees, the segment check -- is INSIDE the replayed graph, nothing syncs with the host
+            try:
+                model.dynamic_topology = True
+                side2 = torch.cuda.Stream()
+                side2.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side2):
+                    step_eager()
+                torch.cuda.current_stream().wait_stream(side2)
+                torch.cuda.synchronize()
+                opt.zero_grad(set_to_none=True)
+                gdyn = dp.GraphedStep(fb, opt.step, model, allreduce=False).capture()
+                extras["dynamic_topology_ms_per_step"] = round(timed(gdyn.replay, max(10, args.steps)), 4)
+                del gdyn
+            except Exception as exc:              # noqa: BLE001
+                extras["dynamic_topology_error"] = f"{type(exc).__name__}: {exc}"[:300]
+            finally:
+                model.dynamic_topology = False
 
     # ---- the scatter-add in isolation (north_star's 40 % figure): pfn_scatter_add over this batch's adjacency, F = hidden_dim,
     # against B_sa(F) = 4 [E F + E + N F + (N+1)]; HIP events on the launch stream around 20 back-to-back launches

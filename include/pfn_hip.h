@@ -82,6 +82,14 @@ int pfn_graph_info(const void* graph_ws, int64_t n_nodes, int64_t e_stored, int3
  * reference case is).  A caller that got ok may pass seg_nodes to the model / TAGConv entry points, which then keep the K
  * propagation hops of a TAGConv resident in LDS per graph instead of running K gather kernels over HBM/L2.            */
 int pfn_graph_segments(void* graph_ws, int64_t n_nodes, int64_t e_stored, int64_t seg_nodes, int32_t* ok, void* stream);
+/* The same check WITHOUT the read-back, for callers that cannot synchronise (a topology that changes per batch inside a captured
+ * hipGraph -- the reference's `perturbed` datasets, dataset_generator.py:250-253, utils/data_utils.py:12-59): the verdict stays in
+ * the workspace.  The caller passes seg_nodes to the model on trust and ends its forward pass with pfn_graph_poison_if_bad, which
+ * overwrites `out` (count floats) with NaN when the workspace records a node id outside [0, n_nodes) or an edge that crosses a
+ * segment boundary -- so a bad batch surfaces as a NaN loss instead of a silently wrong one (pfn_graph_info still reports the
+ * id error, with a sync, whenever the caller can afford one).  Both calls are hipGraph-capturable.                       */
+int pfn_graph_segments_async(void* graph_ws, int64_t n_nodes, int64_t e_stored, int64_t seg_nodes, void* stream);
+int pfn_graph_poison_if_bad(const void* graph_ws, int64_t n_nodes, int64_t e_stored, float* out, int64_t count, void* stream);
 /* Copies the effective (post-undirect) edge list back out as int64 [2, 2*e_stored] (tests). */
 int pfn_graph_export_edges(const void* graph_ws, int64_t n_nodes, int64_t e_stored,
                            int64_t* edge_index_out, void* stream);

@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpfn_hip.so")
 # every symbol include/pfn_hip.h declares (checked by tests/test_abi.py without a GPU)
 SYMBOLS = (
     "pfn_abi_version", "pfn_last_error", "pfn_padded_ld",
-    "pfn_graph_workspace_bytes", "pfn_graph_build", "pfn_graph_info", "pfn_graph_segments", "pfn_graph_export_edges",
+    "pfn_graph_workspace_bytes", "pfn_graph_build", "pfn_graph_info", "pfn_graph_segments", "pfn_graph_segments_async", "pfn_graph_poison_if_bad", "pfn_graph_export_edges",
     "pfn_mpn_num_params", "pfn_mpn_workspace_bytes", "pfn_mpn_forward", "pfn_mpn_backward", "pfn_mpn_export_gates",
     "pfn_edge_aggr_workspace_bytes", "pfn_edge_aggr_forward", "pfn_edge_aggr_backward",
     "pfn_tag_conv_workspace_bytes", "pfn_tag_conv_forward", "pfn_tag_conv_backward",
@@ -57,6 +57,8 @@ def load() -> C.CDLL:
         "pfn_graph_build": (C.c_int, [p, i64, i64, i32, p, sz, p]),
         "pfn_graph_info": (C.c_int, [p, i64, i64, C.POINTER(C.c_int32), C.POINTER(C.c_int64), p]),
         "pfn_graph_segments": (C.c_int, [p, i64, i64, i64, C.POINTER(C.c_int32), p]),
+        "pfn_graph_segments_async": (C.c_int, [p, i64, i64, i64, p]),
+        "pfn_graph_poison_if_bad": (C.c_int, [p, i64, i64, p, i64, p]),
         "pfn_graph_export_edges": (C.c_int, [p, i64, i64, p, p]),
         "pfn_mpn_num_params": (C.c_int, [cfgp]),
         "pfn_mpn_workspace_bytes": (sz, [cfgp, i64, i64]),

@@ -426,6 +426,34 @@ int pfn_graph_segments(void* ws, int64_t n, int64_t e, int64_t seg_nodes, int32_
     return PFN_OK;
 }
 
+// fill `out` with NaN when the adjacency's error flags are set (one block; the fill only ever runs in the error case)
+__global__ __launch_bounds__(256) void graph_poison_kernel(const int* __restrict__ flags, float* __restrict__ out, int64_t count) {
+    if ((flags[2] | flags[4]) == 0) return;
+    const float nan = __builtin_nanf("");
+    for (int64_t i = threadIdx.x; i < count; i += blockDim.x) out[i] = nan;
+}
+
+int pfn_graph_segments_async(void* ws, int64_t n, int64_t e, int64_t seg_nodes, void* stream) {
+    PFN_CHECK_ARG(ws != nullptr, "pfn_graph_segments_async: null workspace");
+    PFN_CHECK_ARG(seg_nodes > 0 && seg_nodes <= (1 << 20) && n > 0 && n % seg_nodes == 0,
+                  "pfn_graph_segments_async: seg_nodes must be positive and divide n_nodes");
+    GraphView g = graph_view(ws, n, e);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    PFN_CHECK_HIP(hipMemsetAsync(g.flags + 4, 0, sizeof(int), s));
+    graph_segcheck_kernel<<<((int)n + 255) / 256, 256, 0, s>>>((int)n, (int)seg_nodes, g.rowptr_in, g.in_src, g.flags);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+int pfn_graph_poison_if_bad(const void* ws, int64_t n, int64_t e, float* out, int64_t count, void* stream) {
+    PFN_CHECK_ARG(ws != nullptr && (count == 0 || out != nullptr), "pfn_graph_poison_if_bad: null pointer");
+    if (count == 0) return PFN_OK;
+    GraphView g = graph_view(const_cast<void*>(ws), n, e);
+    graph_poison_kernel<<<1, 256, 0, static_cast<hipStream_t>(stream)>>>(g.flags, out, count);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
 int pfn_graph_export_edges(const void* ws, int64_t n, int64_t e, int64_t* out, void* stream) {
     PFN_CHECK_ARG(ws != nullptr && out != nullptr, "pfn_graph_export_edges: null pointer");
     GraphView g = graph_view(const_cast<void*>(ws), n, e);

@@ -39,7 +39,7 @@ class GraphCSR:
     """
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, mode: int = -1, validate: bool = True,
-                 seg_hint: int = 0):
+                 seg_hint: int = 0, async_checks: bool = False):
         lib = L.load()
         L.require_device(edge_index, what="edge_index")
         if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
@@ -55,7 +55,17 @@ class GraphCSR:
                                         self.ws.data_ptr(), nbytes, L.stream_ptr()), "pfn_graph_build")
         self._keepalive = None
         self.seg_nodes = 0       # > 0: the batch is a union of index-contiguous graphs of this many nodes (checked on device)
-        if validate and not _capturing():
+        # `unverified`: the id-range and segment checks ran on the device but were NOT read back (no host sync: a topology that
+        # changes per batch, or a build inside a stream capture).  The segment hint is then taken on trust and the model ends its
+        # forward with pfn_graph_poison_if_bad: a violated check turns the output into NaN instead of going unnoticed.
+        self.unverified = bool(async_checks or _capturing())
+        if self.unverified:
+            if seg_hint > 0 and self.num_nodes > 0 and self.num_nodes % seg_hint == 0:
+                with torch.cuda.device(self.device):
+                    L.check(lib.pfn_graph_segments_async(self.ws.data_ptr(), self.num_nodes, self.e_stored, int(seg_hint),
+                                                         L.stream_ptr()), "pfn_graph_segments_async")
+                self.seg_nodes = int(seg_hint)
+        elif validate:
             self.info()          # raises on out-of-range ids (one sync per NEW topology only)
             if seg_hint > 0 and self.num_nodes % seg_hint == 0:
                 ok = C.c_int32(0)
@@ -92,11 +102,14 @@ class _GraphCache:
     def __init__(self):
         self._ref, self._key, self._graph = None, None, None
 
-    def get(self, edge_index: torch.Tensor, num_nodes: int, mode: int, seg_hint: int = 0) -> GraphCSR:
+    def get(self, edge_index: torch.Tensor, num_nodes: int, mode: int, seg_hint: int = 0, rebuild: bool = False) -> GraphCSR:
+        """`rebuild`: the caller's topology changes per batch -- build anew from `edge_index` every time, checks left on the
+        device (no host sync, hipGraph-capturable: a captured step then re-derives the adjacency from whatever the captured
+        edge_index buffer holds at replay time)."""
         key = (edge_index._version, edge_index.data_ptr(), tuple(edge_index.shape), num_nodes, mode, seg_hint)
-        if self._ref is not None and self._ref() is edge_index and self._key == key:
+        if not rebuild and self._ref is not None and self._ref() is edge_index and self._key == key:
             return self._graph
-        g = GraphCSR(edge_index, num_nodes, mode, seg_hint=seg_hint)
+        g = GraphCSR(edge_index, num_nodes, mode, seg_hint=seg_hint, async_checks=rebuild)
         self._ref, self._key, self._graph = weakref.ref(edge_index), key, g
         return g
 
@@ -286,6 +299,9 @@ class _MpnFn(torch.autograd.Function):
                                     pred_mask.data_ptr(), mask_dtype, edge_attr.data_ptr(), out.data_ptr(), ws.data_ptr(),
                                     nbytes, L.ptr(model._rng_state_on(x.device)), graph.seg_nodes, L.stream_ptr()),
                 "pfn_mpn_forward")
+        if graph.unverified:     # checks not read back (changing topology / capture): a bad batch must not pass silently
+            L.check(lib.pfn_graph_poison_if_bad(graph.ws.data_ptr(), n, graph.e_stored, out.data_ptr(), out.numel(),
+                                                L.stream_ptr()), "pfn_graph_poison_if_bad")
         ctx.model, ctx.graph, ctx.cfg, ctx.ws, ctx.mask_dtype = model, graph, cfg, ws, mask_dtype
         ctx.save_for_backward(x, pred_mask, edge_attr, *params)
         # (verification aid, `export_gates`: what the last recorded forward left behind -- weak, nothing is kept alive)
@@ -373,6 +389,10 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
         self._graphs = _GraphCache()
         self._rng_state: Optional[torch.Tensor] = None
         self._last_flat_grad: Optional[torch.Tensor] = None
+        # True: every forward rebuilds the adjacency from the batch's edge_index on the device without a host sync (datasets
+        # whose topology differs per sample: the reference's `perturbed` sets, dataset_generator.py:250-253) -- hipGraph-
+        # capturable; the id-range / segment checks then surface as a NaN output (GraphCSR.unverified)
+        self.dynamic_topology = False
 
     # ------------------------------------------------------------------------------------- plumbing
     def _config(self) -> L.MpnConfig:
@@ -468,7 +488,7 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
             ptr = getattr(data, "ptr", None)
             nseg = int(ptr.numel()) - 1 if torch.is_tensor(ptr) else 0
             seg_hint = x.shape[0] // nseg if nseg > 0 and x.shape[0] % nseg == 0 else 0
-            graph = self._graphs.get(edge_index, x.shape[0], -1, seg_hint)   # is_directed + undirect_graph (:539)
+            graph = self._graphs.get(edge_index, x.shape[0], -1, seg_hint, rebuild=self.dynamic_topology)   # is_directed + undirect_graph (:539)
             self._grad_mode_at_apply = torch.is_grad_enabled()
             return _MpnFn.apply(self, graph, x, mask, edge_features, *self._ordered_params())
 

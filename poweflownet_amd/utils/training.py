@@ -50,9 +50,12 @@ class GraphedTrainStep:
     graph launch (what bench.py measures).  A batch is copied into the captured input tensors (4 small device copies).
     Under data parallelism the gradient all-reduce is inside the replayed step (dp.GraphedStep).
 
-    Replays only when it is safe, otherwise runs the eager body: the batch must have the captured shapes and hand in the SAME
-    `edge_index` tensor (the device-resident `PowerFlowData` does: one cached tensor per batch size) -- the adjacency is baked
-    into the captured launches; the learning rate is a captured kernel argument, so a scheduler step re-captures."""
+    Replays only when it is safe, otherwise runs the eager body: the batch must have the captured shapes.  While the loader
+    hands in the SAME `edge_index` tensor (the device-resident `PowerFlowData` does: one cached tensor per batch size) the
+    adjacency is built once, outside the graph.  The first batch that brings another `edge_index` of the same shape switches
+    the step to `dynamic` mode: re-captured with the adjacency build INSIDE the graph (pfn_graph_build from the captured
+    edge_index buffer, checks left on the device -- a bad batch gives a NaN loss, see GraphCSR.unverified), so per-batch
+    topologies replay too, with no host sync per step (the reference syncs in every forward, networks/MPN.py:498-504)."""
 
     def __init__(self, model, loss_fn, optimizer, allreduce: Optional[bool] = None):
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
@@ -61,8 +64,12 @@ class GraphedTrainStep:
         self.allreduce = (dp.world_size() > 1) if allreduce is None else bool(allreduce)
         self.graph = self.static = self.loss = None
         self.key = None            # optimiser hyper-parameters baked into the captured launches
-        self.disabled = False      # a failed capture, or a dataset that never hands the same edge_index twice: stay eager
-        self.misses = 0
+        self.disabled = False      # a failed capture: stay eager
+        # a dataset that hands in a NEW edge_index per batch (topologies that differ per sample -- the reference's `perturbed`
+        # sets; or a list-backed loader that re-collates): the step is captured once more WITH the adjacency build inside
+        # (model.dynamic_topology: pfn_graph_build + the on-device checks, no host sync), and every batch's edge_index is copied
+        # into the captured buffer like x / y / edge_attr -- still one graph launch per batch
+        self.dynamic = False
 
     def _hyper_key(self):
         """Every optimiser scalar a captured update would hold BY VALUE (as a kernel argument): lr, betas (OneCycleLR
@@ -115,7 +122,9 @@ class GraphedTrainStep:
 
     def _capture(self, data):
         self.static = data.clone()
-        self.static.edge_index = data.edge_index                   # identity matters: the model's adjacency cache keys on it
+        if not self.dynamic:
+            self.static.edge_index = data.edge_index               # identity matters: the model's adjacency cache keys on it
+        # (dynamic: the clone IS the captured edge_index buffer; model.dynamic_topology makes the captured forward rebuild from it)
         snap = self._snapshot()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -130,10 +139,17 @@ class GraphedTrainStep:
         self.key = self._hyper_key()
         return self.loss                                           # the capture pass does not execute: caller replays
 
-    def _compatible(self, data):
+    def _same_shapes(self, data):
         s = self.static
-        return (s is not None and data.edge_index is s.edge_index and data.x.shape == s.x.shape and
-                data.edge_attr.shape == s.edge_attr.shape and data.x.device == s.x.device)
+        if s is None or data.x.shape != s.x.shape or data.edge_attr.shape != s.edge_attr.shape or data.x.device != s.x.device:
+            return False
+        if data.edge_index.shape != s.edge_index.shape:
+            return False
+        ps, pd = getattr(s, "ptr", None), getattr(data, "ptr", None)
+        return (ps is None) == (pd is None) and (ps is None or ps.shape == pd.shape)
+
+    def _compatible(self, data):
+        return self._same_shapes(data) and (self.dynamic or data.edge_index is self.static.edge_index)
 
     def __call__(self, data):
         if self.disabled or not data.x.is_cuda:
@@ -153,19 +169,17 @@ class GraphedTrainStep:
                 self.disabled = True
                 return self._eager(data)
         if not self._compatible(data):
-            # e.g. the short last batch of an epoch.  A list-backed dataset collates a NEW edge_index per batch and would
-            # never replay: after a few misses in a row graphing is switched off instead of re-capturing every epoch.
-            s0 = self.static
-            if data.edge_index is not s0.edge_index and data.x.shape == s0.x.shape:
-                self.misses += 1
-                if self.misses >= 4:
-                    self.graph = self.static = None
-                    self.disabled = True
-            return self._eager(data)
-        self.misses = 0
+            if not self.dynamic and self._same_shapes(data) and hasattr(self.model, "dynamic_topology"):
+                # same shapes, another edge_index tensor: this loader changes (or re-collates) the topology per batch.  Capture
+                # once more with the adjacency build inside the graph; from here on every batch of this shape replays.
+                self.dynamic = True
+                self.model.dynamic_topology = True
+                self.graph = self.static = None
+                return self(data)
+            return self._eager(data)                               # e.g. the short last batch of an epoch
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()                                  # a scheduler moved lr / betas: 20 bytes to the device
-        for k in ("x", "y", "pred_mask", "edge_attr"):
+        for k in ("x", "y", "pred_mask", "edge_attr") + (("edge_index",) if self.dynamic else ()):
             getattr(self.static, k).copy_(getattr(data, k))
         self.graph.replay()
         return self.loss

@@ -1123,3 +1123,96 @@ def test_in_degree_above_65535_saved_masks():
     check("out", out, o32, o64)
     for (k, p), q, t in zip(m.named_parameters(), ref32.parameters(), ref64.parameters()):
         check(f"grad.{k}", p.grad, q.grad, t.grad)
+
+
+def test_graphed_train_step_with_a_new_topology_in_every_batch(tmp_path):
+    """The reference's `perturbed` datasets (dataset_generator.py:250-253, utils/data_utils.py:12-59) give every SAMPLE its own
+    line set: every batch brings a new edge_index.  GraphedTrainStep switches to its dynamic mode -- the adjacency build (device
+    is_directed / undirect / CSRs / degrees / segment check) is captured INSIDE the step's hipGraph and replays from the copied-in
+    edge_index -- and must (a) replay every full batch, (b) never synchronise with the host for the topology (pfn_graph_info /
+    pfn_graph_segments are not called once the step is captured), (c) end on the parameters of the eager loop, which rebuilds
+    and validates the adjacency per batch with a host sync like the reference (networks/MPN.py:498-504)."""
+    import numpy as np
+    from poweflownet_amd import _lib as L
+    from poweflownet_amd.data import DataLoader
+    from poweflownet_amd.datasets import PowerFlowData
+    from poweflownet_amd.loss import MSELoss
+    from poweflownet_amd.optim import FlatAdamW
+    from poweflownet_amd.synth import make_topology
+    from poweflownet_amd.utils.training import GraphedTrainStep, train_epoch
+    rng = np.random.default_rng(5)
+    S, n, e = 96, 118, 186
+    node = np.zeros((S, n, 6))
+    node[:, :, 0] = np.arange(n)
+    node[:, :, 1] = np.where(np.arange(n) == 0, 0, np.where(np.arange(n) % 3 == 0, 1, 2))
+    node[:, :, 2:] = rng.normal(size=(S, n, 4))
+    edge = np.zeros((S, e, 4))
+    for s_ in range(S):
+        edge[s_, :, :2] = make_topology(n, e, seed=100 + s_).numpy().T          # every sample: its own spanning tree + chords
+    edge[:, :, 2:] = np.abs(rng.normal(size=(S, e, 2))) * 0.1 + 0.01
+    (tmp_path / "raw").mkdir()
+    np.save(tmp_path / "raw" / "case118_edge_features.npy", edge)
+    np.save(tmp_path / "raw" / "case118_node_features.npy", node)
+    ds = PowerFlowData(root=str(tmp_path), case="118", split=[.5, .25, .25], task="train", device=DEV)      # 48 samples
+    assert not ds._blocks[0].static_topology
+
+    lib = L.load()
+    calls = {"info": 0, "segments": 0}
+    real_info, real_seg = lib.pfn_graph_info, lib.pfn_graph_segments
+
+    def run(graphed):
+        torch.manual_seed(5)
+        m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).to(DEV)
+        opt = FlatAdamW(m, lr=1e-3)
+        g = GraphedTrainStep(m, MSELoss(), opt) if graphed else None
+        losses = []
+        for epoch in range(3):
+            loader = DataLoader(ds, batch_size=16, shuffle=True, generator=torch.Generator().manual_seed(epoch))   # 3 x 16
+            if graphed and epoch == 1:          # captured by now (first batch eager-captured static, second switched to dynamic)
+                assert g.dynamic and g.graph is not None and not g.disabled
+
+                def count_info(*a):
+                    calls["info"] += 1
+                    return real_info(*a)
+
+                def count_seg(*a):
+                    calls["segments"] += 1
+                    return real_seg(*a)
+                lib.pfn_graph_info, lib.pfn_graph_segments = count_info, count_seg
+            losses.append(train_epoch(m, loader, MSELoss(), opt, DEV, graph=g))
+        lib.pfn_graph_info, lib.pfn_graph_segments = real_info, real_seg
+        return losses, opt.flat_param.detach().clone(), g
+
+    try:
+        l_g, p_g, g = run(True)
+    finally:
+        lib.pfn_graph_info, lib.pfn_graph_segments = real_info, real_seg
+    assert calls == {"info": 0, "segments": 0}, calls            # no topology read-back in two epochs of per-batch topologies
+    assert g.graph.mode == "one graph"
+    l_e, p_e, _ = run(False)
+    for a, b in zip(l_e, l_g):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (l_e, l_g)
+    assert_close(p_g, p_e, 1e-6, "parameters after 3 epochs of per-batch topologies")
+
+
+def test_dynamic_topology_bad_batches_give_nan_not_garbage():
+    """With the checks left on the device (model.dynamic_topology: no host sync) a node id outside [0, N) or a `ptr` hint the
+    edges contradict cannot raise -- the forward ends with pfn_graph_poison_if_bad, so the output (hence the loss) is NaN.  The
+    default mode raises for the same inputs (test_graph_rejects_out_of_range_ids) or rejects the hint."""
+    torch.manual_seed(2)
+    m = MaskEmbdMultiMPN(4, 2, 4, 32, 2, 2, 0.0).to(DEV).eval()
+    m.dynamic_topology = True
+    good = make_batch("14", 5).to(DEV)
+    with torch.no_grad():
+        ok = m(good)
+        assert torch.isfinite(ok).all() and m._graphs._graph.unverified and m._graphs._graph.seg_nodes == 14
+        bad = good.clone()
+        bad.edge_index = good.edge_index.clone()
+        bad.edge_index[0, 3] = 70                              # one id past the last node
+        assert torch.isnan(m(bad)).all()
+        cross = good.clone()
+        cross.edge_index = good.edge_index.clone()
+        cross.edge_index[1, 0] = 20                            # an edge from graph 0 into graph 1: the ptr hint is wrong
+        assert torch.isnan(m(cross)).all()
+        m.dynamic_topology = False
+        assert_close(m(good), ok, 1e-6, "same batch, validated build")
