@@ -165,7 +165,8 @@ struct NtArgs {
     int tps, cshift, nq, remv;   // quarters per LDS slice; log2(column groups per block); MFMA quarters; VALU columns (padded)
     int nrem, bias_group, ldr, ldg;
     int kuni, bias_lds_off;      // k length shared by every piece of the launch, or 0; float offset of the bias image in LDS
-    int klast, pad1_;            // 1: in every piece only the first MFMA step of the last chunk has real k's (K = 129); else 4
+    int klast, row0;             // 1: in every piece only the first MFMA step of the last chunk has real k's (K = 129); else 4.
+                                 // row0: global index of row 0 (dropout counter)
     NtPiece piece[NT_MAX_PIECES];
     float* C[8];
     int gflags[8];               // per group: 1 = add the C already in memory, 2 = store raw sums (no epilogue).  int, not
@@ -215,7 +216,9 @@ __device__ __forceinline__ void wait_a(f32x4& v) {   // the fragment chunk about
 // Chunk m waits for a_cur[m] with vmcnt(16): after the load that filled it, the wave issued the 16 other refills of that
 // round (plus, around a flush, a few stores / epilogue operands -- then the wait asks for slightly younger prefetches
 // than strictly needed, never for the stores).
-template <int CT, int NR, int NFAST, int LS>
+//   XW   : vector-memory ops the wave issues between the end of one piece's refills and the first chunk of the next (the
+//          streaming kernel's 9 weight DMAs): they are younger than every pending fragment chunk, so every wait count grows by XW.
+template <int CT, int NR, int NFAST, int LS, int XW = 0>
 __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], float (&racc)[4], f32x4 (&a_cur)[NCH],
                                             const float* S, int klen, int tps, int tsel, uint32_t kh4, int r32,
                                             const char* nbase, uint32_t nvoff, int nkmax) {
@@ -253,10 +256,10 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
             // (refills are issued per GROUP of four chunks, below: chunk m has 16 - (m & 3) younger loads)
 #ifndef PFN_EXP_NOWAIT   /* experiment switch */
             switch (m & 3) {
-                case 0: wait_a<NCH - 1>(a_cur[m]); break;
-                case 1: wait_a<NCH - 2>(a_cur[m]); break;
-                case 2: wait_a<NCH - 3>(a_cur[m]); break;
-                default: wait_a<NCH - 4>(a_cur[m]); break;
+                case 0: wait_a<NCH - 1 + XW>(a_cur[m]); break;
+                case 1: wait_a<NCH - 2 + XW>(a_cur[m]); break;
+                case 2: wait_a<NCH - 3 + XW>(a_cur[m]); break;
+                default: wait_a<NCH - 4 + XW>(a_cur[m]); break;
             }
 #endif
             const f32x4 av = a_cur[m];
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 float u[4];
-                                dropout_uniform4(ep.dk, (uint32_t)row_of(g), cgv, u);
+                                dropout_uniform4(ep.dk, (uint32_t)(row_of(g) + a.row0), cgv, u);
 #pragma unroll
                                 for (int e = 0; e < 4; ++e) v[g][e] = (u[e] >= ep.p_drop && v[g][e] > 0.f) ? v[g][e] * ep.keep_scale : 0.f;
                             }
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                         if (ep.act == ACT_DROPOUT_RELU) {
                             uint32_t cgv = (uint32_t)(rem_col >> 2);
                             asm volatile("" : "+v"(cgv));
-                            dropout_uniform4(ep.dk, (uint32_t)row, cgv, ud);
+                            dropout_uniform4(ep.dk, (uint32_t)(row + a.row0), cgv, ud);
                         }
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -669,6 +672,289 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     // four trailing columns plus per-chunk guards do not fit the register file without spills)
 }
 
+
+// ------------------------------------------------------------------------------------- NT, weight-STREAMING (large M)
+// The weight-stationary kernel above reads the A stream once per LDS slice: the 4 x 129 x 129 weights of a TAGConv product do not
+// fit LDS whole (287 KB), so its 64-column slices read every operand row TWICE -- 8.2 bytes per cycle and CU at the MFMA rate,
+// against ~10 the memory system delivers: at 414 k rows the kernel sat at 0.60 of the MFMA peak, 17 % of that the A stream.  When
+// M is large every wave has many row tiles, and the trade flips: here a wave owns FULL rows (all four 32-column quarters and the
+// trailing column: 64 accumulator registers) of one 32-row tile per round, reads its A rows ONCE, and the WEIGHTS stream through
+// LDS instead -- one 129 x 132 term image (72 KB) at a time, double-buffered: while the block multiplies piece s out of buffer
+// s & 1, the DMA of piece s + 1 lands in the other one (the whole 287 KB weight set is L2-resident: every block streams the same
+// bytes).  One barrier per piece: it publishes the DMA'd image and retires the buffer the previous piece was read from.  Per
+// chunk a wave now issues 16 MFMAs per fragment wait, refill group and LDS address update instead of 8.
+// vmcnt bookkeeping (VMEM returns in order): per piece a wave issues 9 DMAs (right behind the barrier) and 17 fragment refills
+// (inside the multiply), so at chunk m the ops younger than the fragment chunk it needs are 16 - (m & 3) refills + 9 DMAs
+// (nt_multiply's XW), and the DMAs of the NEXT piece are complete once at most the 17 refills issued after them are outstanding.
+// Only for launches of the shape the large graphs produce: every piece K = 129 (one 136-k piece, one-step tail), 129 output
+// columns (4 quarters + 1 trailing column).
+constexpr int WS_IMG = KP * (32 * 4) + 768;                  // floats per LDS buffer: 4 quarter images + 3 KiB for the 2,176-byte
+                                                             // trailing-column image (copied as three 1 KiB DMAs)
+constexpr int WS_DMAS = 9;                                   // DMAs per wave and piece: 4 x 17 + 3 = 71 -> 72 slots over 8 waves
+__global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int CT = 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, kh = lane >> 5;
+    const int nrt = (a.M + 31) >> 5;
+    const int rt_step = gridDim.x * NT_WAVES;
+    const int nround = (nrt + rt_step - 1) / rt_step;       // every wave of every block runs the same number of pieces (barriers)
+    const int total = nround * a.npiece;
+    int rt = blockIdx.x * NT_WAVES + wave;
+    const int rem_col = 128;
+    const int bias_off = 2 * WS_IMG;
+
+    auto a_base = [&](int rt2, int p2) -> const char* {
+        const int rc = rt2 < nrt ? rt2 : nrt - 1;           // a wave past the last row tile keeps pace on the last tile; it stores nothing
+        return reinterpret_cast<const char*>(a.piece[p2].A + (size_t)rc * 32 * a.piece[p2].lda);
+    };
+    auto a_voff = [&](int rt2, int p2) -> uint32_t {
+        const int rc = rt2 < nrt ? rt2 : nrt - 1;
+        const int lrow = min(r32, a.M - 1 - rc * 32);
+        return (uint32_t)(lrow * a.piece[p2].lda) * 4u;
+    };
+    // the 72 one-KiB DMA slots of one piece image, dealt round-robin: slot = wave + 8 j; slots 0..67 = quarter (slot / 17), KiB
+    // (slot % 17); 68..70 = the trailing-column image's three KiB (it is 2,176 bytes: the over-read stays inside the packed-weight
+    // buffer / workspace and lands in the 3 KiB the LDS buffer reserves); slot 71 repeats slot 68 so that every wave issues 9
+    auto issue_dma = [&](int p2, int buf) {
+        float* dst0 = lds + buf * WS_IMG;
+        const char* bq = reinterpret_cast<const char*>(a.piece[p2].Bq) + lane * 16;
+        const char* br = reinterpret_cast<const char*>(a.piece[p2].Brem) + lane * 16;
+        const size_t qbytes = (size_t)a.piece[p2].qstride * 4;
+#pragma unroll
+        for (int j = 0; j < WS_DMAS; ++j) {
+            const int slot = wave + NT_WAVES * j;
+            if (slot < 68) {
+                const int q = slot / 17, c = slot - 17 * q;
+                dma_1k(bq + q * qbytes + ((size_t)c << 10), dst0 + q * (KP * 32) + (c << 8));
+            } else {
+                const int c = slot == 71 ? 0 : slot - 68;
+                dma_1k(br + ((size_t)c << 10), dst0 + 4 * (KP * 32) + (c << 8));
+            }
+        }
+    };
+
+    // ---- first A fragment, first weight image, bias image
+    f32x4 a_cur[NCH];
+    {
+        const char* b0 = a_base(rt, 0);
+        const uint32_t v0 = a_voff(rt, 0);
+        const int kmax0 = a.piece[0].kmax;
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) {
+            const uint32_t kk = min((uint32_t)(8 * m + 4 * kh), (uint32_t)kmax0);
+            a_cur[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+            vload_x4(a_cur[m], b0, v0 + 4u * kk);
+        }
+    }
+    issue_dma(0, 0);
+    {
+        const float* bsrc = a.rowscale ? a.rowbias : a.bias;
+        for (int i = tid; i < a.ldc; i += NT_THREADS) lds[bias_off + i] = (bsrc && i < a.ncols) ? bsrc[i] : 0.f;
+    }
+
+    EpiCfg ep;
+    ep.ncols = a.ncols;
+    ep.act = a.act;
+    ep.has_rowscale = a.rowscale != nullptr;
+    ep.has_resid = a.resid != nullptr;
+    ep.has_gate = a.gate != nullptr;
+    ep.p_drop = a.p_drop;
+    ep.gate_scale = a.gate_scale;
+    ep.dk = DropKey{0u, 0u, 0u, 0u};
+    ep.keep_scale = 1.f;
+    if (a.act == ACT_DROPOUT_RELU) {
+        ep.dk = drop_key(a.rng[0], a.rng[1], a.rng_stream);
+        ep.keep_scale = 1.0f / (1.0f - a.p_drop);
+    }
+    f32x16 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
+    float racc[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* extra = a.gate ? a.gate : a.resid;         // at most one of rowscale / gate / resid per GEMM
+    const int ldx = a.gate ? a.ldg : a.ldr;
+    uint32_t kh4 = 4u * kh;
+
+    int p = 0;
+    for (int s = 0; s < total; ++s) {
+        asm volatile("" : "+v"(kh4));   // opaque per round: keeps the 17 refill offsets from being hoisted into 17 VGPRs
+        int np = p + 1, nrt_ = rt;
+        if (np == a.npiece) {
+            np = 0;
+            nrt_ = rt + rt_step;
+        }
+        const bool last = s + 1 == total;
+        const int group = a.piece[p].group;
+        const bool flush_after = last || np == 0 || a.piece[np].group != group;
+        // ---- piece s has landed in buffer s & 1 (this wave's share: the first piece is the youngest thing in flight; later the
+        // 17 refills of the previous multiply are younger), every wave is done reading the other buffer: one barrier says both
+        if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+#ifndef PFN_EXP_WS_NOBARRIER   /* tools/ubench experiment switches: never defined in the product build */
+        asm volatile("s_barrier" ::: "memory");
+#endif
+#ifndef PFN_EXP_WS_NODMA
+        issue_dma(last ? p : np, (s + 1) & 1);              // (nothing follows the last piece: a harmless copy keeps the counts)
+#endif
+        // ---- multiply out of buffer s & 1, refilling the fragment for the next piece / row tile
+        {
+            const int pi = last ? p : np, rti = last ? rt : nrt_;
+            nt_multiply<CT, 1, NCH, 1, WS_DMAS>(acc, racc, a_cur, lds + (s & 1) * WS_IMG, KP, 4, 0, kh4, r32, a_base(rti, pi),
+                                                 a_voff(rti, pi), a.piece[pi].kmax);
+        }
+        if (flush_after) {
+            // the accumulators are still being written by the last MFMAs (see the stationary kernel's flush)
+            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
+            const int rbase = rt * 32;
+            const bool live = rt < nrt;
+            float* C = a.C[group];
+            const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
+            const bool has_aux = a.rowscale || extra;
+            // per-row epilogue operands, all requested at once (the B operand registers of the multiply are dead here), one wait
+            f32x4 aux[CT][4], raux;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) aux[ct][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            raux = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (has_aux) {
+                if (a.rowscale) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
+                        aux[0][g][0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
+                    }
+                    const int row = rbase + r32;
+                    raux[0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
+                } else {
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const int col0 = 32 * ct + (r32 & ~3);
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
+                            aux[ct][g] = vload_x4_addr(extra + (size_t)(row < a.M ? row : a.M - 1) * ldx + col0);
+                        }
+                    }
+                    const int row = rbase + r32;
+                    raux = vload_x4_addr(extra + (size_t)(row < a.M ? row : a.M - 1) * ldx + rem_col);
+                }
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(aux[0][0]), "+v"(aux[0][1]), "+v"(aux[0][2]), "+v"(aux[0][3]), "+v"(aux[1][0]), "+v"(aux[1][1]),
+                               "+v"(aux[1][2]), "+v"(aux[1][3]), "+v"(aux[2][0]), "+v"(aux[2][1]), "+v"(aux[2][2]), "+v"(aux[2][3]),
+                               "+v"(aux[3][0]), "+v"(aux[3][1]), "+v"(aux[3][2]), "+v"(aux[3][3]), "+v"(raux));
+                if (a.rowscale) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float rs = aux[0][g][0];
+#pragma unroll
+                        for (int ct = 0; ct < CT; ++ct) aux[ct][g] = f32x4{rs, rs, rs, rs};
+                    }
+                    raux = f32x4{raux[0], raux[0], raux[0], raux[0]};
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col0 = 32 * ct + (r32 & ~3);
+                float v[4][4];
+                const int row_base = rbase + (r32 & 3) + 4 * kh;
+                auto row_of = [&](int g) { return row_base + 8 * g; };
+                auto dst_of = [&](int g) {
+                    const int rw_ = row_of(g);
+                    return C + (size_t)(rw_ < a.M ? rw_ : a.M - 1) * a.ldc + col0;
+                };
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float t[4] = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
+                    quad_transpose(t, lane);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[g][e] = t[e];
+                }
+                const f32x4 cb4 = *reinterpret_cast<const f32x4*>(lds + bias_off + col0);
+                if (use_bias && !ep.has_rowscale) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] += cb4[e];
+                }
+                if (ep.has_rowscale) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = fmaf(aux[ct][g][e], cb4[e], v[g][e]);
+                }
+                if (ep.has_resid) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] += aux[ct][g][e];
+                }
+                if (ep.act == ACT_RELU) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
+                } else if (ep.act == ACT_DROPOUT_RELU) {
+                    uint32_t cgv = (uint32_t)(col0 >> 2);
+                    asm volatile("" : "+v"(cgv));
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        float u[4];
+                        dropout_uniform4(ep.dk, (uint32_t)(row_of(g) + a.row0), cgv, u);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = (u[e] >= ep.p_drop && v[g][e] > 0.f) ? v[g][e] * ep.keep_scale : 0.f;
+                    }
+                }
+                if (ep.has_gate) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[g][e] = aux[ct][g][e] > 0.f ? v[g][e] * ep.gate_scale : 0.f;
+                }
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#ifndef PFN_EXP_NOSTORE   /* experiment switch */
+                    if (live && row_of(g) < a.M) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+#else
+                    if (live && row_of(g) < 0) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+#endif
+            }
+            {   // the trailing column (129th): the two k halves, lane half 0 stores
+                float v0 = racc[0] + __shfl_xor(racc[0], 32);
+                const int row = rbase + r32;
+                if (kh == 0 && live && row < a.M) {
+                    const f32x4 rcb = *reinterpret_cast<const f32x4*>(lds + bias_off + rem_col);
+                    float x = v0 + ((use_bias && !ep.has_rowscale) ? rcb[0] : 0.f);
+                    if (ep.has_rowscale) x = fmaf(raux[0], rcb[0], x);
+                    if (ep.has_resid) x += raux[0];
+                    if (ep.act == ACT_RELU) {
+                        x = fmaxf(x, 0.f);
+                    } else if (ep.act == ACT_DROPOUT_RELU) {
+                        float ud[4];
+                        uint32_t cgv = (uint32_t)(rem_col >> 2);
+                        asm volatile("" : "+v"(cgv));
+                        dropout_uniform4(ep.dk, (uint32_t)(row + a.row0), cgv, ud);
+                        x = (ud[0] >= ep.p_drop && x > 0.f) ? x * ep.keep_scale : 0.f;
+                    }
+                    if (ep.has_gate) x = raux[0] > 0.f ? x * ep.gate_scale : 0.f;
+                    vstore_x4(C + (size_t)row * a.ldc + rem_col, f32x4{x, 0.f, 0.f, 0.f});
+                }
+            }
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
+            racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
+        }
+        p = np;
+        rt = nrt_;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last DMA / refills: nothing of this block is in flight past here
+}
+
 template <int CT, int VAR>
 static int launch_variant(const NtArgs& k, dim3 grid, size_t lds_bytes, hipStream_t s) {
     static std::atomic<uint64_t> lds_raised{0};
@@ -685,7 +971,11 @@ static int pick_variant(const NtArgs& k, int CT) {
     return CT < 2 ? 3 : -1;
 }
 
-int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
+static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top);
+int launch_gemm_nt(const GemmArgs& a, hipStream_t s) { return launch_gemm_nt_rows(a, s, true); }
+// top: the caller's whole product (profiled as ONE gemm_nt; may be cut into a streaming launch over whole rounds of row tiles and
+// a stationary launch over the rest).  !top: the tail launch of such a cut -- stationary kernel, no profile bracket of its own.
+static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     if (a.M == 0) return PFN_OK;
     int remv, nq;
     col_plan(a.ldc, remv, nq);
@@ -780,9 +1070,52 @@ int launch_gemm_nt(const GemmArgs& a, hipStream_t s) {
     for (int g = 0; g < 8; ++g) k.C[g] = a.C[g];
     k.bias = a.bias; k.rowscale = a.rowscale; k.rowbias = a.rowbias; k.resid = a.resid; k.gate = a.gate;
     k.rng = a.rng; k.rng_stream = a.rng_stream; k.act = a.act; k.p_drop = a.p_drop; k.gate_scale = a.gate_scale;
+    k.row0 = a.row0;
 
+    ProfScope ps(top ? "gemm_nt" : nullptr, bytes, flops, s);
+    // ---- large M, the shape of the big-graph launches (every piece K = 129, 129 output columns): full rows per wave, weights
+    // streamed through LDS (gemm_nt_ws_kernel) over the largest row range that is WHOLE rounds of the chip (8 row tiles per CU
+    // and round; a wave task there is a full 32 x 129 tile, and 6.3 rounds' worth of tiles would cost 7); the remaining rows go
+    // to the stationary kernel below, whose tasks are a quarter of that size
+    if (top) {
+        static const int ws_min = getenv("PFN_NT_WS_MIN_TILES") ? atoi(getenv("PFN_NT_WS_MIN_TILES")) : 2;   // A/B aid; 0 = never
+        const long per_round = (long)ncu * NT_WAVES;
+        // Used when the stationary kernel would need MORE THAN TWO LDS slices, i.e. from five 129 x 129 terms (wide.json's K = 6
+        // TAGConv: 7 terms -> 32-column slices, every A row read four times): measured at 6470rte x 64 `wide` 36.6 -> 34.6 ms per
+        // step.  With <= 4 terms (two slices) the two kernels tie in isolation (4 terms at 414 k rows: 568 vs 582 us) and the
+        // streaming one LOSES inside the step (14.2 vs 13.9 ms): its per-piece barrier keeps the 8 waves of a block in lockstep,
+        // so all of them run the epilogue (dropout's Philox rounds, the gate loads) at the same time with the matrix pipe idle,
+        // where the free-running waves of the stationary kernel overlap one wave's flush with its SIMD partner's MFMAs
+        // (profiles/r03_gemm_nt_streaming.txt).
+        bool ws_ok = ws_min > 0 && nq == 4 && remv == 4 && nrem == 1 && nslices > 2 && pieces.size() <= (size_t)NT_MAX_PIECES &&
+                     (long)nrt >= (long)ws_min * per_round;
+        for (size_t i = 0; i < pieces.size(); ++i) ws_ok = ws_ok && pieces[i].klen == KP && last_steps[i] == 1;
+        if (ws_ok) {
+            const long nround = nrt / per_round;
+            const long rows_ws = std::min<long>(a.M, nround * per_round * 32);
+            k.npiece = (int)pieces.size();
+            for (size_t i = 0; i < pieces.size(); ++i) k.piece[i] = pieces[i];
+            k.kuni = KP;
+            k.klast = 1;
+            k.M = (int)rows_ws;
+            const size_t lb = ((size_t)2 * WS_IMG + (size_t)a.ldc) * sizeof(float);
+            static std::atomic<uint64_t> lds_raised{0};
+            PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_ws_kernel), NT_LDS_BYTES, lds_raised));
+            gemm_nt_ws_kernel<<<ncu, NT_THREADS, lb, s>>>(k);
+            PFN_CHECK_LAUNCH();
+            if (rows_ws == a.M) return PFN_OK;
+            GemmArgs t = a;                       // the rest of the rows: the same product on offset operands
+            t.M = (int)(a.M - rows_ws);
+            t.row0 = a.row0 + (int)rows_ws;
+            for (int i = 0; i < a.nterm; ++i) t.term[i].A = a.term[i].A + (size_t)rows_ws * a.term[i].lda;
+            for (int g = 0; g < 8; ++g) t.C[g] = a.C[g] ? a.C[g] + (size_t)rows_ws * a.ldc : nullptr;
+            if (a.rowscale) t.rowscale = a.rowscale + rows_ws;
+            if (a.resid) t.resid = a.resid + (size_t)rows_ws * a.ldr;
+            if (a.gate) t.gate = a.gate + (size_t)rows_ws * a.ldg;
+            return launch_gemm_nt_rows(t, s, false);
+        }
+    }
     bool seen[8] = {false, false, false, false, false, false, false, false};
-    ProfScope ps("gemm_nt", bytes, flops, s);
     for (size_t i0 = 0; i0 < pieces.size();) {
         size_t i1 = i0, used = 0;
         while (i1 < pieces.size() && i1 - i0 < (size_t)NT_MAX_PIECES && used + piece_bytes(pieces[i1], tps) <= lds_budget) {

@@ -199,6 +199,8 @@ struct GemmArgs {
     const float* gate;      // [M x ldg] or null : out *= gate > 0 ? gate_scale : 0
     int ldg;
     float gate_scale;
+    int row0;               // global index of this call's first row (the dropout stream is keyed by the GLOBAL row): a launch over
+                            // a row range of a larger product passes its offset here; 0 otherwise
 };
 int launch_gemm_nt(const GemmArgs& a, hipStream_t s);
 

@@ -48,7 +48,7 @@ static double measure_pair_overhead() {
 }
 
 ProfScope::ProfScope(const char* name, double bytes, double flops, hipStream_t s) : idx_(-1), s_(s) {
-    if (!g_on) return;
+    if (!g_on || !name) return;   // (a null name: the caller is part of a bracket that is already open)
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) return;
     std::lock_guard<std::mutex> lk(g_mu);

@@ -745,7 +745,10 @@ def test_dropout_mask_statistics_config2():
 
 
 @pytest.mark.parametrize("case,B,cfg", [("14", 4, (129, 4, 3)), ("118v2", 8, (129, 4, 3)), ("118v2", 128, (129, 4, 3)),
-                                        ("118v2", 4, (129, 6, 6))])
+                                        ("118v2", 4, (129, 6, 6)),
+                                        # 241,664 rows: the weight-streaming gemm_nt over whole rounds + the stationary kernel on
+                                        # the remaining rows (its dropout counter continues at the global row)
+                                        ("118v2", 2048, (129, 4, 3))])
 def test_train_mode_matches_oracle_fed_the_exported_masks(case, B, cfg):
     """Row a10 end to end: a TRAIN-mode pass (dropout 0.2) against the CPU oracle whose nn.Dropout is replaced by
     multiplication with the masks the HIP path exports (pfn_dropout_mask) and 1/(1-p).  Checks the three things SURVEY H4
@@ -765,7 +768,7 @@ def test_train_mode_matches_oracle_fed_the_exported_masks(case, B, cfg):
     out = m(dd)
     torch.nn.MSELoss()(out, dd.y).backward()
     ref.dropout_masks = [k.cpu() for k in _exported_masks(m, dd.x.shape[0])]
-    torch.set_num_threads(8)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
     out_ref = ref(data)
     torch.nn.MSELoss()(out_ref, data.y).backward()
     out64, _ = _fp64_truth(ref, data)                            # deepcopy carries the masks along
