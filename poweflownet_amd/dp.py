@@ -119,17 +119,19 @@ def allreduce_gradients(model: torch.nn.Module, ordered_params=None) -> None:
     #  The caching allocator hands the same address to a NEW flat buffer whose .grads may no longer be views -- a hook cloned
     #  them, a parameter was frozen -- so the remembered verdict is re-confirmed on the first and the last parameter per call.)
     key = None if flat is None else (flat.data_ptr(), flat.numel())
-    if key is not None and getattr(model, "_dp_inplace_key", None) == key and params and \
+    seen = model.__dict__.setdefault("_dp_inplace_keys", set()) if key is not None else None
+    if key is not None and key in seen and params and \
             params[0].grad is not None and params[0].grad.data_ptr() == flat.data_ptr() and \
             params[-1].grad is not None and \
             params[-1].grad.data_ptr() + 4 * params[-1].numel() == flat.data_ptr() + 4 * flat.numel():
         in_place = True
     else:
         in_place = flat is not None and _grads_are_views_of(flat, params)
-        try:
-            model._dp_inplace_key = key if in_place else None
-        except Exception:
-            pass
+        if seen is not None:
+            if in_place and len(seen) < 8:
+                seen.add(key)
+            elif not in_place:
+                seen.discard(key)
     if not in_place:
         grads = [p.grad for p in params if p.grad is not None]
         flat = torch.cat([g.reshape(-1) for g in grads])

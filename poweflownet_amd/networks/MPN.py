@@ -316,10 +316,8 @@ class _MpnFn(torch.autograd.Function):
         gp = _pad_rows(L.f32c(gout, "grad_out"), model.output_dim)
         sizes = [p.numel() for p in params]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=x.device)
-        grads, off = [], 0
-        for p, sz in zip(params, sizes):
-            grads.append(flat[off:off + sz].view(p.shape))
-            off += sz
+        # (one split call + a view per 2-D weight: slicing the flat buffer tensor by tensor was ~100 us of host time per step)
+        grads = [g if p.dim() == 1 else g.view(p.shape) for g, p in zip(flat.split_with_sizes(sizes), params)]
         gx = torch.empty_like(x) if ctx.needs_input_grad[2] else None
         gea = torch.empty_like(edge_attr) if ctx.needs_input_grad[4] else None
         L.check(lib.pfn_mpn_backward(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
@@ -400,7 +398,19 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
                            self.K, float(self.dropout_rate), 1 if self.training else 0, 0)
 
     def _ordered_params(self):
-        """The C ABI's parameter table order (include/pfn_hip.h)."""
+        """The C ABI's parameter table order (include/pfn_hip.h).  The list is built once (walking the module tree costs ~60 us,
+        several times per eager step) and rebuilt when a parameter OBJECT of the model was replaced; in-place updates,
+        load_state_dict, .to() and FlatAdamW's re-pointing of `.data` keep the objects."""
+        cached = self.__dict__.get("_param_list")
+        if cached is not None:
+            l0, ll = self.layers[0].edge_aggr[0], self.mask_embd[2]
+            if cached[0] is l0.weight and cached[-1] is ll.bias and self.__dict__.get("_param_list_n") == len(self.layers):
+                return cached
+        out = self._walk_params()
+        self.__dict__["_param_list"], self.__dict__["_param_list_n"] = out, len(self.layers)
+        return out
+
+    def _walk_params(self):
         out = []
         for layer in self.layers:
             if isinstance(layer, EdgeAggregation):
@@ -473,7 +483,8 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
         if self.nfeature_dim != 4:
             raise RuntimeError("MaskEmbdMultiMPN.forward asserts 4 node features (networks/MPN.py:528); "
                                f"this model was built with nfeature_dim={self.nfeature_dim}")
-        L.require_device(x, mask, edge_index, edge_features, *self.parameters(), what="MaskEmbdMultiMPN input")
+        params = self._ordered_params()
+        L.require_device(x, mask, edge_index, edge_features, params[0], params[-1], what="MaskEmbdMultiMPN input")
         x, edge_features = L.f32c(x, "data.x"), L.f32c(edge_features, "data.edge_attr")
         if mask.dtype != torch.int64:
             mask = mask.float()                            # `.float()` of the reference (:533)
@@ -490,7 +501,7 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
             seg_hint = x.shape[0] // nseg if nseg > 0 and x.shape[0] % nseg == 0 else 0
             graph = self._graphs.get(edge_index, x.shape[0], -1, seg_hint, rebuild=self.dynamic_topology)   # is_directed + undirect_graph (:539)
             self._grad_mode_at_apply = torch.is_grad_enabled()
-            return _MpnFn.apply(self, graph, x, mask, edge_features, *self._ordered_params())
+            return _MpnFn.apply(self, graph, x, mask, edge_features, *params)
 
 
 # ============================================================================================ MPN_simplenet
