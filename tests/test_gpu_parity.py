@@ -748,7 +748,10 @@ def test_dropout_mask_statistics_config2():
                                         ("118v2", 4, (129, 6, 6)),
                                         # 241,664 rows: the weight-streaming gemm_nt over whole rounds + the stationary kernel on
                                         # the remaining rows (its dropout counter continues at the global row)
-                                        ("118v2", 2048, (129, 4, 3))])
+                                        ("118v2", 2048, (129, 4, 3)),
+                                        # K = 6 at 135,936 rows: the 7-term TAGConv products take the weight-STREAMING gemm_nt
+                                        # (gemm_nt_ws_kernel) over whole rounds of row tiles + the stationary kernel on the tail
+                                        ("118v2", 1152, (129, 2, 6))])
 def test_train_mode_matches_oracle_fed_the_exported_masks(case, B, cfg):
     """Row a10 end to end: a TRAIN-mode pass (dropout 0.2) against the CPU oracle whose nn.Dropout is replaced by
     multiplication with the masks the HIP path exports (pfn_dropout_mask) and 1/(1-p).  Checks the three things SURVEY H4
@@ -972,6 +975,18 @@ def test_config3_size_training_step_vs_oracle():
     m = m.to(DEV).eval()
     _check_full_size(m, ref, make_batch("118v2", 2048, seed=5), "config 3 size, training")
     assert m._graphs._graph.seg_nodes == 118
+
+
+def test_wide_k6_large_batch_streaming_gemm_vs_oracle():
+    """wide.json's K = 6 (what the reference's runs.sh pairs with 6470rte) at 135,936 rows: the 7-term TAGConv products (forward
+    and input gradient) run on gemm_nt_ws_kernel -- full rows per wave, weights streamed through LDS -- with the rows beyond the
+    last whole round on the stationary kernel.  Forward and all gradients against the oracle (see _check_full_size)."""
+    torch.manual_seed(77)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 3, 6, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 6, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    _check_full_size(m, ref, make_batch("118v2", 1152, seed=9), "K = 6, 1152 graphs")
 
 
 def test_config3_inference_batch2048_properties():

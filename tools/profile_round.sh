@@ -3,12 +3,12 @@
 # two separate PMC passes (FETCH_SIZE / WRITE_SIZE) on a short eager run.  Summaries land in gpurun_out/prof_round/.
 #   tools/profile_round.sh [tag]     (BENCH_ARGS="--case ... --batch ..." selects another workload)
 cd /tmp && export TMPDIR=/tmp
-TAG=${1:-r02_case118_b128_train}
+TAG=${1:-r03_case118_b128_train}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; rm -rf /tmp/pr; mkdir -p $O /tmp/pr
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pr/trace -o bench -- python $R/bench.py --no-cpu-baseline $BENCH_ARGS > $O/${TAG}_bench_under_rocprof.json 2> /tmp/pr/trace.err
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pr/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-live-traffic --no-dp-overhead $BENCH_ARGS > $O/${TAG}_bench_under_rocprof.json 2> /tmp/pr/trace.err
 find /tmp/pr/trace -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats.csv \;
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --kernel-trace -f csv -d /tmp/pr/$c -o pmc -- python $R/bench.py --no-cpu-baseline --no-graph --steps 3 --warmup 1 --profile-steps 0 $BENCH_ARGS > /tmp/pr/$c.out 2> /tmp/pr/$c.err
+  timeout 600 rocprofv3 --pmc $c --kernel-trace -f csv -d /tmp/pr/$c -o pmc -- python $R/bench.py --child --no-cpu-baseline --no-live-traffic --no-dp-overhead --no-graph --steps 3 --warmup 1 --profile-steps 0 $BENCH_ARGS > /tmp/pr/$c.out 2> /tmp/pr/$c.err
   F=$(find /tmp/pr/$c -name "*counter_collection.csv" | head -1)
   python - "$F" "$c" > $O/${TAG}_pmc_$c.txt <<'PY'
 import csv, sys, collections
@@ -26,7 +26,7 @@ PY
 done
 # MFMA pipe occupancy of the GEMM kernels: SQ_VALU_MFMA_BUSY_CYCLES (per-SIMD busy cycles, summed over the chip) against the
 # kernel's duration from the same pass: util = busy / (duration x 2.4 GHz x 1024 SIMDs)
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -f csv -d /tmp/pr/MFMA -o pmc -- python $R/bench.py --no-cpu-baseline --no-graph --steps 3 --warmup 1 --profile-steps 0 $BENCH_ARGS > /tmp/pr/MFMA.out 2> /tmp/pr/MFMA.err
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -f csv -d /tmp/pr/MFMA -o pmc -- python $R/bench.py --child --no-cpu-baseline --no-live-traffic --no-dp-overhead --no-graph --steps 3 --warmup 1 --profile-steps 0 $BENCH_ARGS > /tmp/pr/MFMA.out 2> /tmp/pr/MFMA.err
 python - /tmp/pr/MFMA > $O/${TAG}_pmc_mfma.txt <<'PY'
 import csv, sys, glob, collections
 d = sys.argv[1]
