@@ -219,6 +219,28 @@ int pfn_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_a
 int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                        const float* hyper, int64_t* step, void* stream);
 
+/* ----------------------------------------------------------------------- Diagnostic environment switches
+ * The library reads these environment variables (each ONCE per process, through one function, pfn::diag_env).  They select
+ * between kernels that compute the SAME result -- the parity tests use them to hold a fused kernel against the generic one it
+ * replaces, the tuning scripts under tools/ to sweep a launch parameter -- and none of them is needed in production: unset, the
+ * library behaves as DESIGN.md describes.  There is no switch that routes work off the GPU or through another backend.
+ *   PFN_NO_SEG_EA=1         EdgeAggregation of small-graph batches: generic gemm_nt + edge walks instead of the graph-resident kernels
+ *   PFN_SEG_EA_PER_CU=<n>   ... use the graph-resident kernels up to n workgroups per CU (default 4)
+ *   PFN_NO_FUSED_FRONT=1    mask_embd + first P|Q as generic GEMMs instead of front.hip's one launch
+ *   PFN_NO_FUSED_BACK=1     the last layer's Linear / dS outside the edge walks (generic GEMMs)
+ *   PFN_FRONT_BLOCK_ROWS=1  front.hip: the block-per-row-group kernels instead of one row per wave
+ *   PFN_WAVE_MAX_ROWS=<n>   front.hip: largest batch (rows) that takes the row-per-wave kernels (default 32768)
+ *   PFN_WAVE_BPC=a,b,c      front.hip: workgroups per CU of the three row-per-wave kernels
+ *   PFN_FUSED_HOPS=0|1      TAGConv hops: never / always LDS-resident per graph when they fit (default: when they fit)
+ *   PFN_FH_BLOCKS=<n>       fused hops: target number of workgroups (default 1024)
+ *   PFN_FH_ONE_PER_CU=1     fused hops: whole rows per workgroup (one 125 KB workgroup per CU) instead of two half-LDS ones
+ *   PFN_TN_BLOCKS=<n>       gemm_tn: target number of workgroups (default: one per CU)
+ *   PFN_TN_NOGROUP=1        gemm_tn: do not co-schedule tasks that share an operand
+ *   PFN_NT_TPS=1|2|4        gemm_nt: at most that many 32-column quarters per LDS slice
+ *   PFN_NT_CT=1|2           gemm_nt: quarters per wave
+ *   PFN_NT_LS4=1            gemm_nt: four MFMA steps in the last k chunk although K = 129 needs one
+ *   PFN_NT_WS_MIN_TILES=<n> gemm_nt: weight-streaming kernel from n row tiles per wave (default 2; 0 = never)                     */
+
 /* --------------------------------------------------------------------------------------- profiling
  * Optional HIP-event bracket around every kernel launch (same stream), aggregated per kernel class with
  * the launch's algorithmic bytes / flops.  Inactive during hipGraph capture.

@@ -123,7 +123,7 @@ bool fused_hops_fit(int seg, int ld, int n) {
     // fill the chip (case118 x 128: 128 graphs x 7 slices of 5 float4 columns = 896 blocks, 21 KB of LDS each) and the K
     // hops cost one launch instead of K (measured 47 -> ~11 us per TAGConv at 128 graphs).  Needs two
     // tiles of at least one float4 column of a whole graph in LDS.  PFN_FUSED_HOPS=0/1 forces the choice (experiments).
-    static const char* force = getenv("PFN_FUSED_HOPS");
+    static const char* force = diag_env("PFN_FUSED_HOPS");
     (void)ld;
     (void)n;
     if (seg <= 0 || (size_t)2 * seg * 4 * sizeof(float) + (size_t)(2 * seg + 1) * sizeof(int) > (size_t)FH_LDS_BYTES / 2) return false;
@@ -255,7 +255,7 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
     }
     // (1024: case118 x 128 = 7 slices of 5 float4 columns, 896 blocks, 11.0-11.6 us per launch; 512 blocks of 9 columns: 12.1-12.8 us;
     //  11 slices of 3 columns: 13.4 us -- 48-byte row segments waste most of every cache line, hence the floor of 4 columns)
-    static const int want = getenv("PFN_FH_BLOCKS") ? atoi(getenv("PFN_FH_BLOCKS")) : 1024;   // tuning aid
+    static const int want = diag_env("PFN_FH_BLOCKS") ? atoi(diag_env("PFN_FH_BLOCKS")) : 1024;   // tuning aid
     int cs = std::max(1, std::min(nchunk, (want + ngraphs - 1) / std::max(1, ngraphs)));   // slices wanted
     int cw = std::max((nchunk + cs - 1) / cs, std::min(nchunk, 4));
     cw = std::min(cw, max_cw);
@@ -267,7 +267,7 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
     {
         const size_t half = (size_t)FH_LDS_BYTES / 2;
         const int half_cw = (int)((half - (size_t)(2 * a.seg + 1) * sizeof(int)) / per_chunk_graph);
-        static const bool off = getenv("PFN_FH_ONE_PER_CU") != nullptr;   // experiments
+        static const bool off = diag_env("PFN_FH_ONE_PER_CU") != nullptr;   // experiments
         if (!off && (long)ngraphs * cs >= 2L * device_cus() && half_cw >= 8) {
             budget = half;
             lds_cap /= 2;

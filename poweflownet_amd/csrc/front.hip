@@ -22,7 +22,7 @@
 namespace pfn {
 
 static int wave_max_rows() {   // the row-per-wave kernels serve batches up to this many rows (tuning aid: PFN_WAVE_MAX_ROWS)
-    static const int v = getenv("PFN_WAVE_MAX_ROWS") ? atoi(getenv("PFN_WAVE_MAX_ROWS")) : 32768;
+    static const int v = diag_env("PFN_WAVE_MAX_ROWS") ? atoi(diag_env("PFN_WAVE_MAX_ROWS")) : 32768;
     return v;
 }
 // 256-thread blocks per CU of the row-per-wave kernels (which: 0 forward, 1 backward, 2 lin_out4).  Every wave first loads its
@@ -34,7 +34,7 @@ static int wave_blocks_per_cu(int which) {
     static int v[3] = {0, 0, 0};
     if (v[0] == 0) {
         int a = 3, b = 3, c = 3;
-        if (const char* e = getenv("PFN_WAVE_BPC")) sscanf(e, "%d,%d,%d", &a, &b, &c);
+        if (const char* e = diag_env("PFN_WAVE_BPC")) sscanf(e, "%d,%d,%d", &a, &b, &c);
         v[1] = std::max(1, b);
         v[2] = std::max(1, c);
         v[0] = std::max(1, a);
@@ -407,7 +407,7 @@ __global__ __launch_bounds__(256) void lin_out4_wave_kernel(int n, int h, int ld
     }
 }
 bool lin_out4_ok(int h, int fo, int ldo, int n) {
-    static const bool off = getenv("PFN_NO_FUSED_BACK") != nullptr;   // (the last layer's special kernels share one A/B switch)
+    static const bool off = diag_env("PFN_NO_FUSED_BACK") != nullptr;   // (the last layer's special kernels share one A/B switch)
     return !off && fo >= 1 && fo <= 4 && ldo == 4 && ld_of(h) / 4 <= 64 && n <= wave_max_rows();
 }
 int launch_lin_out4(int n, int h, int fo, const float* S, const float* w2, const float* b2, const float* deg, float* out,
@@ -421,7 +421,7 @@ int launch_lin_out4(int n, int h, int fo, const float* S, const float* w2, const
 }
 
 bool front_fused_ok(int f0, int h) {
-    static const bool off = getenv("PFN_NO_FUSED_FRONT") != nullptr;   // experiments / tests of the generic GEMM path
+    static const bool off = diag_env("PFN_NO_FUSED_FRONT") != nullptr;   // experiments / tests of the generic GEMM path
     return !off && f0 == 4 && ld_of(h) / 4 <= 256;
 }
 
@@ -429,7 +429,7 @@ bool front_fused_ok(int f0, int h) {
 // thousands of rows the half-empty waves (33 of 64 lanes at H = 129) cost more than the barriers of the block version
 // (6470rte x 64: backward 182 -> 247 us, measured), which stays for those sizes.
 static bool front_row_per_wave(int nchunk, int n) {
-    static const bool off = getenv("PFN_FRONT_BLOCK_ROWS") != nullptr;   // A/B switch: the block-per-row-group kernels
+    static const bool off = diag_env("PFN_FRONT_BLOCK_ROWS") != nullptr;   // A/B switch: the block-per-row-group kernels
     return !off && nchunk <= 64 && n <= wave_max_rows();
 }
 static void front_shape(int h, int& ld, int& nchunk, int& rows_pb, size_t& lds) {

@@ -454,7 +454,7 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
     const size_t cap_f4 = ws.floats >= 256 ? (ws.floats - 256) / 4 : 0;
     static std::atomic<uint64_t> lds_raised{0};
     PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_tn_kernel), T3_LDS_BYTES, lds_raised));
-    static const int want_env = getenv("PFN_TN_BLOCKS") ? atoi(getenv("PFN_TN_BLOCKS")) : 0;   // tuning aid
+    static const int want_env = diag_env("PFN_TN_BLOCKS") ? atoi(diag_env("PFN_TN_BLOCKS")) : 0;   // tuning aid
     const int ncu = device_cus();
     bool ride_done = false;
     int p = 0;
@@ -506,7 +506,7 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
             int gsz = 1;
             const TnPair& p0 = ta.pair[ta.task[t].pair];
             const bool single = t + 1 >= ta.ntasks || ta.task[t + 1].pair != ta.task[t].pair;
-            static const bool no_group = getenv("PFN_TN_NOGROUP") != nullptr;   // experiments
+            static const bool no_group = diag_env("PFN_TN_NOGROUP") != nullptr;   // experiments
             while (!no_group && single && t + gsz < ta.ntasks && gsz < 8) {
                 const T3Task& nx = ta.task[t + gsz];
                 const TnPair& pn = ta.pair[nx.pair];

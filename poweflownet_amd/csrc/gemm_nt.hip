@@ -1031,7 +1031,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     const size_t lds_budget = (size_t)NT_LDS_BYTES - bias_bytes;
     int tps = 0;
     if (nq > 0) {
-        static const int tps_cap = getenv("PFN_NT_TPS") ? atoi(getenv("PFN_NT_TPS")) : 4;   // tuning aid: 1, 2 or 4 quarters per slice at most
+        static const int tps_cap = diag_env("PFN_NT_TPS") ? atoi(diag_env("PFN_NT_TPS")) : 4;   // tuning aid: 1, 2 or 4 quarters per slice at most
         const int start = std::min(nq >= 3 ? 4 : nq, std::max(1, tps_cap));
         for (tps = start; tps >= 1; tps >>= 1) {
             size_t tot = 0;
@@ -1054,7 +1054,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     const int nrem = std::max(0, std::min(remv, a.ncols - 32 * nq));
     fast = fast && ((pieces[0].klen == KP && nrem <= 1) || (pieces[0].klen == KP - 8 && remv == 0));
     if (fast && tps >= 2 && (long)nrt * nslices * (tps / 2) >= 2L * ncu * NT_WAVES) CT = 2;
-    static const int force_ct = getenv("PFN_NT_CT") ? atoi(getenv("PFN_NT_CT")) : 0;   // tuning aid: 1 or 2
+    static const int force_ct = diag_env("PFN_NT_CT") ? atoi(diag_env("PFN_NT_CT")) : 0;   // tuning aid: 1 or 2
     if (force_ct > 0 && CT > 0) CT = std::min(force_ct, (fast && tps >= 2) ? 2 : 1);
     int cshift = 0;
     while (CT > 0 && (CT << cshift) < tps) ++cshift;
@@ -1078,7 +1078,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     // and round; a wave task there is a full 32 x 129 tile, and 6.3 rounds' worth of tiles would cost 7); the remaining rows go
     // to the stationary kernel below, whose tasks are a quarter of that size
     if (top) {
-        static const int ws_min = getenv("PFN_NT_WS_MIN_TILES") ? atoi(getenv("PFN_NT_WS_MIN_TILES")) : 2;   // A/B aid; 0 = never
+        static const int ws_min = diag_env("PFN_NT_WS_MIN_TILES") ? atoi(diag_env("PFN_NT_WS_MIN_TILES")) : 2;   // A/B aid; 0 = never
         const long per_round = (long)ncu * NT_WAVES;
         // Used when the stationary kernel would need MORE THAN TWO LDS slices, i.e. from five 129 x 129 terms (wide.json's K = 6
         // TAGConv: 7 terms -> 32-column slices, every A row read four times): measured at 6470rte x 64 `wide` 36.6 -> 34.6 ms per
@@ -1147,7 +1147,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
             seen[g] |= here[g];
         }
         int rc = PFN_EINVAL;
-        static const bool ls4 = getenv("PFN_NT_LS4") != nullptr;   // A/B switch: four MFMA steps in the last chunk although K = 129
+        static const bool ls4 = diag_env("PFN_NT_LS4") != nullptr;   // A/B switch: four MFMA steps in the last chunk although K = 129
         if (ls4) k.klast = 4;
         const int var = pick_variant(k, CT);
         const size_t lb = used + bias_bytes;

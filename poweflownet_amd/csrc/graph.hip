@@ -8,6 +8,7 @@
 // the later kernels through flags[].
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -23,6 +24,8 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 const char* last_error() { return g_err; }
+
+const char* diag_env(const char* name) { return getenv(name); }
 
 int device_cus() {
     static std::atomic<int> cus[64];          // zero-initialised; 0 = not asked yet

@@ -104,7 +104,7 @@ static EaPack ea_pack(Packer& pk, int fi, int fe, int h, int fo, const float* w1
 }
 
 static bool back_fused_ok() {
-    static const bool off = getenv("PFN_NO_FUSED_BACK") != nullptr;   // A/B switch: the last layer's fused kernels
+    static const bool off = diag_env("PFN_NO_FUSED_BACK") != nullptr;   // A/B switch: the last layer's fused kernels
     return !off;
 }
 

@@ -48,6 +48,10 @@ struct ProfScope {
 // per device (hipFuncSetAttribute applies to the current device only; repeating it is harmless, so no lock is needed --
 // `done` is a bit mask over device ordinals).
 int device_cus();
+// The ONE place the library reads the environment: the diagnostic switches listed under "Diagnostic environment switches" in
+// include/pfn_hip.h (A/B aids for tests and tuning; unset = the product's behaviour).  Call sites keep the value in a
+// function-local static, i.e. a switch is read once per process.
+const char* diag_env(const char* name);
 int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done);
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }

@@ -112,3 +112,19 @@ def test_graft_entry_build_runs():
     against the Python mirror's."""
     import __graft_entry__
     __graft_entry__.build()
+
+
+def test_every_environment_switch_of_the_library_is_documented():
+    """The library's only getenv is pfn::diag_env (csrc/graph.hip); every name passed to it appears in include/pfn_hip.h's
+    "Diagnostic environment switches" list, and the list names nothing that does not exist."""
+    import glob
+    used = set()
+    for f in glob.glob(os.path.join(ROOT, "poweflownet_amd", "csrc", "*.h*")):
+        text = open(f).read()
+        used |= set(re.findall(r'diag_env\("([A-Z0-9_]+)"\)', text))
+        if not f.endswith("graph.hip"):
+            assert "getenv(" not in text, f
+    assert open(os.path.join(ROOT, "poweflownet_amd", "csrc", "graph.hip")).read().count("getenv(") == 1
+    header = open(os.path.join(ROOT, "include", "pfn_hip.h")).read()
+    documented = set(re.findall(r"^ \*   (PFN_[A-Z0-9_]+)", header, flags=re.M))
+    assert used == documented, (sorted(used - documented), sorted(documented - used))
