@@ -481,6 +481,7 @@ def main():
             extras["latency_us_per_sample"] = {"hipGraph_replay": round(1e3 * median_ms, 2), "eager_launches": round(1e3 * extras["eager_ms_per_step"], 2)}
     if rank == 0 and world == 1 and train and not args.child:
         def timed(fn, reps):
+            fn()                                             # (untimed: first-use allocations of this stream's memory pool)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):

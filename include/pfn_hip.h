@@ -233,6 +233,7 @@ int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  *   PFN_WAVE_BPC=a,b,c      front.hip: workgroups per CU of the three row-per-wave kernels
  *   PFN_FUSED_HOPS=0|1      TAGConv hops: never / always LDS-resident per graph when they fit (default: when they fit)
  *   PFN_FH_BLOCKS=<n>       fused hops: target number of workgroups (default 1024)
+ *   PFN_NO_BIG_HOPS=1       TAGConv hops of large graphs (one LDS tile + registers per graph and column chunk): K generic hop launches instead
  *   PFN_FH_ONE_PER_CU=1     fused hops: whole rows per workgroup (one 125 KB workgroup per CU) instead of two half-LDS ones
  *   PFN_TN_BLOCKS=<n>       gemm_tn: target number of workgroups (default: one per CU)
  *   PFN_TN_NOGROUP=1        gemm_tn: do not co-schedule tasks that share an operand

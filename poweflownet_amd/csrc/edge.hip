@@ -299,6 +299,167 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
     return PFN_OK;
 }
 
+// ------------------------------------------------------------------------- K hops, large graphs
+// The K hops of one TAGConv direction for graphs too large for fused_hops_kernel's two ping-pong tiles (6470 buses: one float4
+// column of a whole graph is 103 KB).  ONE tile is enough: a hop reads its neighbours' values from the LDS tile and keeps its
+// rows' results in REGISTERS (a thread owns rows tid, tid + 1024, ...: <= 8 float4), a barrier, the registers go back into the
+// tile.  Block = one graph x ONE float4 column chunk, 1024 threads; the graph's adjacency is staged once as 16-bit local ids and
+// offsets (6470 nodes / 18,010 directed edges: 36 + 13 KB beside the 103 KB tile).  The tile holds z = D^-1/2 x, so a hop is
+// y_i = d_i sum_j z_j and the next tile is d_i y_i: no per-edge weight, no D^-1/2 table in LDS.  Global traffic per direction: x
+// read once, K outputs written, the adjacency once per block (L2) -- instead of K full gather passes (3 x 852 MB at 6470rte x 64).
+// The 16-byte-per-row accesses of a chunk only make sense because the 33 chunk-blocks of a graph run TOGETHER on ONE XCD (block
+// b -> XCD b mod 8; graph = (b / (8 nchunk)) * 8 + b mod 8, chunk = (b / 8) mod nchunk): a row's cache line is fetched from HBM
+// once and serves the other chunks out of that XCD's L2, and their partial-line stores merge there.
+constexpr int BH_THREADS = 1024;
+constexpr int BH_RPT = 8;                       // rows per thread at most: graphs up to 8,192 nodes
+constexpr int BH_NBPT = 20;                     // staged neighbour ids per thread at most: 20,480 directed edges per graph
+__global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int nchunk, int ngraphs, int nb_cap,
+                                                                    const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                                    const float* __restrict__ dinv, const float* __restrict__ x0,
+                                                                    float* __restrict__ xk, size_t stride, int ld, int K, int n_total) {
+    extern __shared__ __attribute__((aligned(16))) float4 bh_tile[];          // [seg] | rp u16 [seg + 2] | nb u16 [nb_cap]
+    unsigned short* s_rp = reinterpret_cast<unsigned short*>(bh_tile + seg);
+    unsigned short* s_nb = s_rp + ((seg + 2 + 7) & ~7);
+    const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
+    const int c = j % nchunk, gi = (j / nchunk) * 8 + xcd;
+    if (gi >= ngraphs) return;
+    const int r0 = gi * seg, t = threadIdx.x;
+    const int e0 = rowptr[r0], ne = rowptr[r0 + seg] - e0;
+    const bool nb_in_lds = ne <= nb_cap && ne < 65536 && ne <= BH_NBPT * BH_THREADS;
+    // EVERYTHING the prologue needs from global memory is requested before the first LDS store (two round trips in all: e0, then
+    // the rest).  As load -> LDS-store loops every iteration waited for its own load: ~25 serial L2 round trips per thread, 40 of
+    // the block's 43 us.
+    float di[BH_RPT];
+    float4 z[BH_RPT];
+    int rpv[BH_RPT + 1], nbv[BH_NBPT];
+#pragma unroll
+    for (int r = 0; r < BH_RPT; ++r) {
+        const int row = t + r * BH_THREADS;
+        di[r] = 0.f;
+        z[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        rpv[r] = 0;
+        if (row < seg) {
+            di[r] = dinv[r0 + row];
+#ifndef BH_EXP_NOLOADX
+            z[r] = ld4(x0 + (size_t)(r0 + row) * ld + 4 * c);
+#else
+            z[r] = ld4(x0 + (size_t)(r0 + (row & 63)) * 4 + 0 * c);
+#endif
+            rpv[r] = rowptr[r0 + row];
+        }
+    }
+#pragma unroll
+    for (int jn = 0; jn < BH_NBPT; ++jn) {
+        const int i = t + jn * BH_THREADS;
+#ifndef BH_EXP_NOCSR
+        nbv[jn] = (nb_in_lds && i < ne) ? nbr[e0 + i] : 0;
+#else
+        nbv[jn] = r0 + (i % seg);
+#endif
+    }
+#pragma unroll
+    for (int r = 0; r < BH_RPT; ++r) {
+        const int row = t + r * BH_THREADS;
+        if (row < seg) {
+            s_rp[row] = (unsigned short)(rpv[r] - e0);
+            bh_tile[row] = mul4(di[r], z[r]);
+        }
+    }
+    if (t == 0) s_rp[seg] = (unsigned short)ne;
+    if (nb_in_lds) {
+#pragma unroll
+        for (int jn = 0; jn < BH_NBPT; ++jn) {
+            const int i = t + jn * BH_THREADS;
+            if (i < ne) s_nb[i] = (unsigned short)(nbv[jn] - r0);
+        }
+    }
+    __syncthreads();
+    for (int k = 1; k <= K; ++k) {
+        float* outk = xk + (size_t)(k - 1) * stride;
+#pragma unroll
+        for (int r = 0; r < BH_RPT; ++r) {
+            const int row = t + r * BH_THREADS;
+            if (row >= seg) continue;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef BH_EXP_NOGATHER   /* tools/ubench experiment switches: never defined in the product build */
+            acc = bh_tile[row];
+            if (false) {
+#else
+            if (nb_in_lds) {   // four slots per trip: index -> tile row is a chain of dependent LDS reads (see hop_kernel)
+#endif
+                const int beg = s_rp[row], end = s_rp[row + 1], last = end - 1;
+                for (int p = beg; p < end; p += 4) {
+                    int s_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s_[u] = s_nb[min(p + u, last)];
+                    float4 v_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v_[u] = bh_tile[s_[u]];
+                    acc = add4(acc, v_[0]);
+                    acc = sel4(p + 1 < end, add4(acc, v_[1]), acc);
+                    acc = sel4(p + 2 < end, add4(acc, v_[2]), acc);
+                    acc = sel4(p + 3 < end, add4(acc, v_[3]), acc);
+                }
+            } else {           // a graph with more edges than the staged list holds: indices from global memory
+#ifndef BH_EXP_NOGATHER
+                for (int p = rowptr[r0 + row]; p < rowptr[r0 + row + 1]; ++p) acc = add4(acc, bh_tile[nbr[p] - r0]);
+#endif
+            }
+            const float4 y = mul4(di[r], acc);
+            // the hop outputs are written CHUNK-MAJOR ([chunk][row][float4]): this block's 6470 x 16 bytes are one contiguous
+            // run.  Row-major they were 16 bytes per 528-byte row -- 41 M partial-line writes per direction at 6470rte x 64, and
+            // the kernel was no faster than the three gather passes it replaces (422 vs 3 x 142 us).  The consumers read the
+            // layout through GemmTerm::cm_rows (gemm_nt A operand) and TnPair::b_cm_rows (gemm_tn B operand).
+#ifndef BH_EXP_NOSTORE
+            st4(outk + ((size_t)c * n_total + r0 + row) * 4, y);
+#else
+            if (y.x == 123.456f) st4(outk + ((size_t)c * n_total + r0 + row) * 4, y);
+#endif
+            z[r] = mul4(di[r], y);
+        }
+        if (k == K) break;
+        __syncthreads();                        // every read of the tile is done
+#pragma unroll
+        for (int r = 0; r < BH_RPT; ++r) {
+            const int row = t + r * BH_THREADS;
+            if (row < seg) bh_tile[row] = z[r];
+        }
+        __syncthreads();
+    }
+}
+
+// fits: graphs of <= 8,192 nodes whose one-column tile + 16-bit offsets leave room for (most of) the 16-bit neighbour list
+bool big_hops_fit(int seg, int n, int64_t e_stored) {
+    static const bool off = diag_env("PFN_NO_BIG_HOPS") != nullptr;   // A/B switch: K generic hop launches instead
+    if (off || seg <= 0 || n <= 0 || n % seg != 0 || seg > BH_RPT * BH_THREADS || seg >= 65536) return false;
+    (void)e_stored;
+    return (size_t)seg * 16 + (size_t)((seg + 2 + 7) & ~7) * 2 + 1024 <= (size_t)160 * 1024;
+}
+
+int launch_big_graph_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s) {
+    if (g.n == 0 || a.K == 0) return PFN_OK;
+    if (a.transpose) {
+        set_error("big-graph hops: only the forward data flow (x -> A x -> A^2 x ...) is built");
+        return PFN_EINVAL;
+    }
+    const int nchunk = a.ld / 4, ngraphs = g.n / a.seg;
+    const size_t fixed = (size_t)a.seg * 16 + (size_t)((a.seg + 2 + 7) & ~7) * 2;
+    // neighbour list: an equal share of the (undirected) edges per graph, with slack; the kernel reads indices from global memory
+    // for a graph that has more
+    const size_t want_nb = (size_t)(2 * (int64_t)g.e_stored / std::max(1, ngraphs) + 64) * 2;
+    const size_t lds_total = std::min((size_t)160 * 1024, fixed + want_nb);
+    const int nb_cap = (int)((lds_total - fixed) / 2);
+    static std::atomic<uint64_t> lds_raised{0};
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(big_graph_hops_kernel), 160 * 1024, lds_raised));
+    const bool adjt = a.adjt < 0 ? false : a.adjt != 0;
+    ProfScope ps(adjt ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
+    const int blocks = ((ngraphs + 7) / 8) * 8 * nchunk;
+    big_graph_hops_kernel<<<blocks, BH_THREADS, lds_total, s>>>(a.seg, nchunk, ngraphs, nb_cap, adjt ? g.rowptr_out : g.rowptr_in,
+                                                               adjt ? g.out_dst : g.in_src, g.dinv, a.x0, a.xk, a.stride, a.ld, a.K, g.n);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
 // ------------------------------------------------------------------------------ EdgeAggregation fwd
 // The per-edge Linear(2Fi+Fe -> H) splits into per-node terms P = x W1[:, :Fi]^T + b1, Q = x W1[:, Fi:2Fi]^T
 // (node GEMMs) and a per-edge residue sum_f a_e[f] W1[:, 2Fi+f]; the second Linear commutes with the

@@ -149,9 +149,14 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     // never stored
     const int acol = TA == 4 ? min(128 * tk.ti + 4 * c, pr.lda - 4) : min(c, pr.lda - 1);
     const int bcol = TB == 2 ? min(128 * tk.tj + 64 * half + 2 * c, pr.ldb - 2) : min(c, pr.ldb - 1);
+    // B may be CHUNK-MAJOR ([ldb / 4 planes][rows][float4], what the big-graph hop kernel writes): element (row, col) then sits
+    // at float offset ((col >> 2) * rows + row) * 4 + (col & 3) -- a row step is 4 floats, a lane's two adjacent columns still
+    // share one float4
+    const int rowB = pr.b_cm_rows > 0 ? 4 : pr.ldb;
+    auto colB = [&](int col) { return pr.b_cm_rows > 0 ? (col >> 2) * pr.b_cm_rows * 4 + (col & 3) : col; };
     const float* Ap = pr.A + acol;
-    const float* Bp = pr.B + bcol;
-    const float* Xc = pr.B + (pr.nb - 1);     // the odd column of B (TNF_XCOL)
+    const float* Bp = pr.B + colB(bcol);
+    const float* Xc = pr.B + colB(pr.nb - 1);     // the odd column of B (TNF_XCOL)
     const float* Yr = pr.A + (pr.na - 1);     // the odd column of A = odd row of dW (TNF_XROW)
     const float* Rs = pr.bias_rowscale;
 
@@ -236,8 +241,8 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     const int nstep = (R1 - R0) >> 1;
     const int count = nstep > wr ? (nstep - wr + NR - 1) / NR : 0;
     if (count > 0) {
-        const uint32_t voA = (uint32_t)(kh * pr.lda + acol) * 4u, voB = (uint32_t)(kh * pr.ldb + bcol) * 4u;
-        const uint32_t voX = (uint32_t)(kh * pr.ldb + pr.nb - 1) * 4u, voY = (uint32_t)(kh * pr.lda + pr.na - 1) * 4u;
+        const uint32_t voA = (uint32_t)(kh * pr.lda + acol) * 4u, voB = (uint32_t)(kh * rowB + colB(bcol)) * 4u;
+        const uint32_t voX = (uint32_t)(kh * rowB + colB(pr.nb - 1)) * 4u, voY = (uint32_t)(kh * pr.lda + pr.na - 1) * 4u;
         const uint32_t voR = (uint32_t)(kh * rs_stride) * 4u;
         const char* baseA = reinterpret_cast<const char*>(pr.A);
         const char* baseB = reinterpret_cast<const char*>(pr.B);
@@ -245,7 +250,7 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
         auto issue = [&](Slot& t, int step) {   // refill IN PLACE; a step past the wave's last one re-reads the last one
             const int64_t row = R0 + 2 * (int64_t)(wr + NR * min(step, count - 1));
             const char* pa = baseA + row * pr.lda * 4;
-            const char* pb = baseB + row * pr.ldb * 4;
+            const char* pb = baseB + row * rowB * 4;
             const char* prs = baseR + row * rs_stride * 4;
             if (TA == 4) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(t.a) : "v"(voA), "s"(pa) : "memory");
             else asm volatile("global_load_dword %0, %1, %2" : "+v"(t.a) : "v"(voA), "s"(pa) : "memory");
@@ -284,8 +289,8 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
         const int row = R1 - 1;
         Slot t;
         t.a = *reinterpret_cast<const FA*>(Ap + (size_t)row * pr.lda);
-        t.b = *reinterpret_cast<const FB*>(Bp + (size_t)row * pr.ldb);
-        t.xv = Xc[(size_t)row * pr.ldb];
+        t.b = *reinterpret_cast<const FB*>(Bp + (size_t)row * rowB);
+        t.xv = Xc[(size_t)row * rowB];
         t.yv = Yr[(size_t)row * pr.lda];
         t.rs = Rs2[(size_t)row * rs_stride];
         if (kh != 0) {

@@ -153,7 +153,9 @@ struct NtPiece {
     const float* A;      // operand rows, advanced to this piece's first k
     const float* Bq;     // image of quarter 0 at this piece's first k group; quarter q lies q * qstride floats further
     const float* Brem;   // trailing-column image at this piece's first k group
-    int lda;             // row stride of A (floats)
+    int lda;             // floats between consecutive rows of A: its row stride -- or 4 when the operand is CHUNK-MAJOR
+                         // ([ld / 4 planes][rows][float4]: what the big-graph hop kernel writes, edge.hip)
+    int kscale;          // bytes between consecutive k's of one row: 4 -- or 4 * rows for a chunk-major operand (k a multiple of 4)
     int kmax;            // last legal 16-byte read position inside a row, relative to A
     int klen;            // k's of the piece: a multiple of 8, <= KP (the image is zero beyond the real K)
     int qstride;         // floats between quarters of the image
@@ -221,7 +223,7 @@ __device__ __forceinline__ void wait_a(f32x4& v) {   // the fragment chunk about
 template <int CT, int NR, int NFAST, int LS, int XW = 0>
 __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], float (&racc)[4], f32x4 (&a_cur)[NCH],
                                             const float* S, int klen, int tps, int tsel, uint32_t kh4, int r32,
-                                            const char* nbase, uint32_t nvoff, int nkmax) {
+                                            const char* nbase, uint32_t nvoff, int nkmax, uint32_t nkscale) {
     constexpr bool FAST = NFAST != 0;
     constexpr int CTE = CT > 0 ? CT : 1, NRE = NR > 0 ? NR : 1;
     const int tile_floats = FAST ? NFAST * 8 * 32 : klen * 32;
@@ -282,7 +284,7 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
             for (int mm = m & ~3; mm <= m; ++mm) {
                 const uint32_t kk = min(kh4 + 8u * mm, (uint32_t)nkmax);
 #ifndef PFN_EXP_NOREFILL   /* experiment switch: every refill re-reads ONE cache line (the wave's first row) */
-                vload_x4(a_cur[mm], nbase, nvoff + 4u * kk);
+                vload_x4(a_cur[mm], nbase, nvoff + nkscale * kk);
 #else
                 vload_x4(a_cur[mm], nbase, 0u * (nvoff + kk));
 #endif
@@ -357,11 +359,12 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         const char* b0 = a_base(rt0, 0);
         const uint32_t v0 = a_voff(rt0, 0);
         const int kmax0 = a.piece[0].kmax;
+        const uint32_t ks0 = (uint32_t)a.piece[0].kscale;
 #pragma unroll
         for (int m = 0; m < NCH; ++m) {
             const uint32_t kk = min((uint32_t)(8 * m + 4 * kh), (uint32_t)kmax0);
             a_cur[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            vload_x4(a_cur[m], b0, v0 + 4u * kk);
+            vload_x4(a_cur[m], b0, v0 + ks0 * kk);
         }
     }
     // ---- weights of every piece -> LDS, once: 1 KiB DMA pieces dealt round-robin to the 8 waves
@@ -483,7 +486,8 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         {
             const float* S = lds + a.piece[p].lds_off;
             const int klen = a.piece[p].klen, tsel = cg * CT;
-            nt_multiply<CT, NR, NFAST, LS>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax);
+            nt_multiply<CT, NR, NFAST, LS>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax,
+                                           (uint32_t)a.piece[pi].kscale);
         }
         if (flush_after) {
             NT_TS2;
@@ -741,11 +745,12 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
         const char* b0 = a_base(rt, 0);
         const uint32_t v0 = a_voff(rt, 0);
         const int kmax0 = a.piece[0].kmax;
+        const uint32_t ks0 = (uint32_t)a.piece[0].kscale;
 #pragma unroll
         for (int m = 0; m < NCH; ++m) {
             const uint32_t kk = min((uint32_t)(8 * m + 4 * kh), (uint32_t)kmax0);
             a_cur[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            vload_x4(a_cur[m], b0, v0 + 4u * kk);
+            vload_x4(a_cur[m], b0, v0 + ks0 * kk);
         }
     }
     issue_dma(0, 0);
@@ -803,7 +808,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
         {
             const int pi = last ? p : np, rti = last ? rt : nrt_;
             nt_multiply<CT, 1, NCH, 1, WS_DMAS>(acc, racc, a_cur, lds + (s & 1) * WS_IMG, KP, 4, 0, kh4, r32, a_base(rti, pi),
-                                                 a_voff(rti, pi), a.piece[pi].kmax);
+                                                 a_voff(rti, pi), a.piece[pi].kmax, (uint32_t)a.piece[pi].kscale);
         }
         if (flush_after) {
             // the accumulators are still being written by the last MFMAs (see the stationary kernel's flush)
@@ -1009,10 +1014,11 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
         const int K8 = (tm.K + 7) & ~7, qstride = (K8 >> 2) * 128;
         for (int k0 = 0; k0 < K8; k0 += KP) {
             NtPiece pc;
-            pc.A = tm.A + k0;
+            pc.A = tm.cm_rows > 0 ? tm.A + (size_t)(k0 >> 2) * tm.cm_rows * 4 : tm.A + k0;
             pc.Bq = tm.Bp + (size_t)(k0 >> 2) * 128;
             pc.Brem = tm.Bp + (size_t)nq * qstride + (size_t)(k0 >> 2) * 16;
-            pc.lda = tm.lda;
+            pc.lda = tm.cm_rows > 0 ? 4 : tm.lda;
+            pc.kscale = tm.cm_rows > 0 ? tm.cm_rows * 4 : 4;
             pc.kmax = tm.lda - 4 - k0;
             pc.klen = std::min(KP, K8 - k0);
             pc.qstride = qstride;
@@ -1107,7 +1113,8 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
             GemmArgs t = a;                       // the rest of the rows: the same product on offset operands
             t.M = (int)(a.M - rows_ws);
             t.row0 = a.row0 + (int)rows_ws;
-            for (int i = 0; i < a.nterm; ++i) t.term[i].A = a.term[i].A + (size_t)rows_ws * a.term[i].lda;
+            for (int i = 0; i < a.nterm; ++i)   // (chunk-major operand: 4 floats per row inside a plane, the plane stride stays)
+                t.term[i].A = a.term[i].A + (size_t)rows_ws * (a.term[i].cm_rows > 0 ? 4 : a.term[i].lda);
             for (int g = 0; g < 8; ++g) t.C[g] = a.C[g] ? a.C[g] + (size_t)rows_ws * a.ldc : nullptr;
             if (a.rowscale) t.rowscale = a.rowscale + rows_ws;
             if (a.resid) t.resid = a.resid + (size_t)rows_ws * a.ldr;

@@ -28,14 +28,14 @@ static GemmArgs gemm_defaults(int M, int ncols, int ldc) {
 }
 static GemmTerm term(const float* A, int lda, int K, const float* Bp, int group) {
     GemmTerm t;
-    t.A = A; t.Bp = Bp; t.lda = lda; t.K = K; t.group = group; t.pad_ = 0;
+    t.A = A; t.Bp = Bp; t.lda = lda; t.K = K; t.group = group; t.cm_rows = 0;
     return t;
 }
 static TnPair tn_pair(const float* A, int lda, int na, const float* B, int ldb, int nb, float* G, int ldg, int gk0,
                       float* bias_out, const float* bias_rowscale) {
     TnPair p;
     p.A = A; p.B = B; p.G = G; p.bias_out = bias_out; p.bias_rowscale = bias_rowscale;
-    p.lda = lda; p.ldb = ldb; p.na = na; p.nb = nb; p.ldg = ldg; p.gn0 = 0; p.gk0 = gk0; p.pad_ = 0;
+    p.lda = lda; p.ldb = ldb; p.na = na; p.nb = nb; p.ldg = ldg; p.gn0 = 0; p.gk0 = gk0; p.b_cm_rows = 0;
     return p;
 }
 
@@ -235,9 +235,14 @@ static int tag_forward(const GraphView& g, int cin, int cout, int K, const float
                        const float* bias, float* out, int ldo, const Act& act, float* xk, hipStream_t s, int seg = 0) {
     // xk: K buffers of n * ldx floats holding A_hat^k x, k = 1..K
     const size_t stride = (size_t)g.n * ldx;
+    int xk_cm = 0;   // > 0: the hop outputs are chunk-major with that many rows per plane (big-graph hops)
     if (K > 0 && fused_hops_fit(seg, ldx, g.n)) {
         FusedHopsArgs fh{x, xk, nullptr, nullptr, nullptr, 1.f, stride, ldx, K, 0, seg};
         PFN_TRY(launch_fused_hops(g, fh, s));
+    } else if (K > 0 && big_hops_fit(seg, g.n, g.e_stored)) {
+        FusedHopsArgs fh{x, xk, nullptr, nullptr, nullptr, 1.f, stride, ldx, K, 0, seg};
+        PFN_TRY(launch_big_graph_hops(g, fh, s));   // (writes the hop outputs chunk-major)
+        xk_cm = g.n;
     } else {
         const float* prev = x;
         for (int k = 1; k <= K; ++k) {
@@ -249,7 +254,10 @@ static int tag_forward(const GraphView& g, int cin, int cout, int K, const float
     GemmArgs a = gemm_defaults(g.n, cout, ldo);
     a.C[0] = out;
     a.nterm = K + 1;
-    for (int k = 0; k <= K; ++k) a.term[k] = term(k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, pw.wt[k], 0);
+    for (int k = 0; k <= K; ++k) {
+        a.term[k] = term(k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, pw.wt[k], 0);
+        if (k > 0) a.term[k].cm_rows = xk_cm;
+    }
     a.bias = bias;
     a.act = act.act;
     a.p_drop = act.p;
@@ -275,9 +283,14 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             // transposed adjacency, LDS-resident when the graphs fit), then ONE multi-term GEMM with the gate in its epilogue --
             // one output instead of K + 1 (measured 607 vs 754 us for the GEMM at 414 k nodes) and no Horner pass.
             const size_t gstride = (size_t)g.n * ldgo;
+            int hk_cm = 0;
             if (fused_hops_fit(seg, ldgo, g.n)) {
                 FusedHopsArgs fh{gout, hk, nullptr, nullptr, nullptr, 1.f, gstride, ldgo, K, 0, seg, 1};
                 PFN_TRY(launch_fused_hops(g, fh, s));
+            } else if (big_hops_fit(seg, g.n, g.e_stored)) {
+                FusedHopsArgs fh{gout, hk, nullptr, nullptr, nullptr, 1.f, gstride, ldgo, K, 0, seg, 1};
+                PFN_TRY(launch_big_graph_hops(g, fh, s));
+                hk_cm = g.n;
             } else {
                 const float* prev = gout;
                 for (int k = 1; k <= K; ++k) {
@@ -289,8 +302,10 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             GemmArgs a = gemm_defaults(g.n, cin, ldx);
             a.C[0] = gx;
             a.nterm = K + 1;
-            for (int k = 0; k <= K; ++k)
+            for (int k = 0; k <= K; ++k) {
                 a.term[k] = term(k == 0 ? gout : hk + (size_t)(k - 1) * gstride, ldgo, cout, pw.wd[k], 0);
+                if (k > 0) a.term[k].cm_rows = hk_cm;
+            }
             a.gate = gate.y;
             a.ldg = gate.ld;
             a.gate_scale = gate.scale;
@@ -327,9 +342,13 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
     // weight gradients need only gout and the saved hops
     std::vector<TnPair> local;
     std::vector<TnPair>& pairs = defer ? defer->pairs : local;
-    for (int k = 0; k <= K; ++k)
+    // (the forward's hop outputs are chunk-major when it took the big-graph hop kernel: the same predicate as tag_forward)
+    const int xk_cm = (K > 0 && !fused_hops_fit(seg, ldx, g.n) && big_hops_fit(seg, g.n, g.e_stored)) ? g.n : 0;
+    for (int k = 0; k <= K; ++k) {
         pairs.push_back(tn_pair(gout, ldgo, cout, k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, gw[k], cin, 0,
                                 k == 0 ? gbias : nullptr, nullptr));
+        if (k > 0) pairs.back().b_cm_rows = xk_cm;
+    }
     if (defer) return PFN_OK;
     return launch_weight_grads(local.data(), (int)local.size(), g.n, sc.red, s);
 }

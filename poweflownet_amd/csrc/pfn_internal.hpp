@@ -183,7 +183,9 @@ int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream
 struct GemmTerm {
     const float* A;
     const float* Bp;
-    int lda, K, group, pad_;
+    int lda, K, group;
+    int cm_rows;   // 0: A is row-major [M][lda].  > 0: A is CHUNK-MAJOR, [lda / 4 planes][cm_rows rows][float4] (element (r, k) at
+                   // ((k / 4) * cm_rows + r) * 4 + k % 4): what the big-graph hop kernel writes; cm_rows = rows of the whole buffer
 };
 enum { ACT_NONE = 0, ACT_RELU = 1, ACT_DROPOUT_RELU = 2 };
 struct GemmArgs {
@@ -217,7 +219,8 @@ struct TnPair {
     float* G;
     float* bias_out;
     const float* bias_rowscale;
-    int lda, ldb, na, nb, ldg, gn0, gk0, pad_;
+    int lda, ldb, na, nb, ldg, gn0, gk0;
+    int b_cm_rows;   // 0: B is row-major [M][ldb].  > 0: B is chunk-major (see GemmTerm::cm_rows), that many rows per plane
 };
 struct ReduceWs {
     float* partial;   // scratch for split partials
@@ -258,6 +261,10 @@ struct FusedHopsArgs {
 };
 bool fused_hops_fit(int seg, int ld, int n);
 int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s);
+// the same K hops (forward data flow only) for graphs too large for two LDS tiles: one float4 column of one graph per block,
+// one tile + registers (edge.hip big_graph_hops_kernel)
+bool big_hops_fit(int seg, int n, int64_t e_stored);
+int launch_big_graph_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s);
 
 // S[i] = sum_{e -> i} relu(P[i] + Q[src(e)] + sum_f a_e[f] * W1[:, 2Fi + f])
 // Sum of a row's nchunk float4 partials in a FIXED order, in two levels (a single thread walking all 33 was a chain of 33

@@ -1234,3 +1234,27 @@ def test_dynamic_topology_bad_batches_give_nan_not_garbage():
         assert torch.isnan(m(cross)).all()
         m.dynamic_topology = False
         assert_close(m(good), ok, 1e-6, "same batch, validated build")
+
+
+def test_big_graph_hops_with_unequal_edge_counts():
+    """Graphs too large for the two-tile LDS hop kernel (2,500 nodes) take big_graph_hops_kernel (one LDS tile + registers per graph
+    and column chunk, hop outputs chunk-major, read back by gemm_nt / gemm_tn through GemmTerm::cm_rows / TnPair::b_cm_rows).  The
+    staged 16-bit neighbour list is sized for an EQUAL share of the edges per graph; here the first graph has three times the edges
+    of the others, so its blocks read their indices from global memory instead.  Forward and all gradients against the oracle."""
+    from poweflownet_amd.data import Batch
+    from poweflownet_amd.synth import make_graph, make_topology
+    torch.manual_seed(8)
+    n = 2500
+    graphs = [make_graph(n, e, seed=40 + i, edge_index=make_topology(n, e, seed=7 + i)) for i, e in enumerate((9000, 3000, 3000))]
+    data = Batch.from_data_list(graphs)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 16, 3, 3, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 16, 3, 3, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    dd = data.to(DEV)
+    out = m(dd)
+    assert m._graphs._graph.seg_nodes == n
+    torch.nn.MSELoss()(out, dd.y).backward()
+    with torch.no_grad():
+        assert_close(out, ref(data), RTOL, "big-graph hops: out vs fp32 oracle")
+    _assert_grads_on_hip_gates(m, ref, data, "big-graph hops, unequal edge counts", out)
