@@ -1258,3 +1258,35 @@ def test_big_graph_hops_with_unequal_edge_counts():
     with torch.no_grad():
         assert_close(out, ref(data), RTOL, "big-graph hops: out vs fp32 oracle")
     _assert_grads_on_hip_gates(m, ref, data, "big-graph hops, unequal edge counts", out)
+
+
+def test_k6_big_graphs_streaming_gemm_reads_chunk_major_hops():
+    """K = 6 on 56 graphs of 2,500 nodes (140,000 rows): the hops run in big_graph_hops_kernel and come out CHUNK-major; the
+    7-term TAGConv products then take gemm_nt_ws_kernel (weight streaming, whole rounds) plus the stationary kernel on the tail rows,
+    both reading six of their seven A operands through GemmTerm::cm_rows, and gemm_tn reads them as B operands through
+    TnPair::b_cm_rows.  Forward and all gradients against the oracle, eval mode and train mode (dropout masks exported)."""
+    from poweflownet_amd.data import Batch
+    from poweflownet_amd.synth import make_graph, make_topology
+    torch.manual_seed(12)
+    n, e, B = 2500, 3400, 56
+    topo = make_topology(n, e, seed=3)
+    data = Batch.from_data_list([make_graph(n, e, seed=500 + i, edge_index=topo) for i in range(B)])
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 2, 6, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 2, 6, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    _check_full_size(m, ref, data, "K = 6, 56 graphs of 2,500 nodes")
+    assert m._graphs._graph.seg_nodes == n
+    # train mode: the tail launch's dropout counter continues at the global row
+    p = 0.2
+    ref2 = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 2, 6, p).train()
+    ref2.load_state_dict(ref.state_dict())
+    m2 = MaskEmbdMultiMPN(4, 2, 4, 129, 2, 6, p)
+    m2.load_state_dict(ref.state_dict())
+    m2 = m2.to(DEV).train()
+    m2.seed_dropout(99)
+    dd = data.to(DEV)
+    out = m2(dd)
+    torch.nn.MSELoss()(out, dd.y).backward()
+    ref2.dropout_masks = [k.cpu() for k in _exported_masks(m2, dd.x.shape[0])]
+    _assert_grads_on_hip_gates(m2, ref2, data, "K = 6 big graphs, train mode", out)
