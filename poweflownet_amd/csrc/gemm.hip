@@ -130,7 +130,9 @@ __device__ __forceinline__ void t3_emit(const TnPair& pr, const T3Task& tk, int 
     }
 }
 
-template <int TA, int TB>
+// RUNS: the launch has a chunk-major operand -> steps are dealt to the row groups in runs of four and refilled per run (see below);
+// otherwise step by step with immediate refills (a prefetch distance of the full ring: what small batches need)
+template <int TA, int TB, bool RUNS>
 __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int bx, float4* lds) {
     constexpr int NQ = t3_quads(TA, TB);
     constexpr int NH = TB == 2 ? 2 : 1;                 // column halves of the block
@@ -236,10 +238,18 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
         cn = fmaf(t.yv, t.xv, cn);
         cb = fmaf(t.yv, rsv, cb);
     };
-    // rows of the block's range in steps of 2: row group wr takes steps wr, wr + NR, ... (8 consecutive rows = one step of
-    // each of 4 row groups: one DRAM stream per operand).  `count` = this wave's full steps (both rows inside the range).
+    // rows of the block's range in steps of 2, dealt to the row groups in RUNS OF FOUR steps (8 consecutive rows): row group wr
+    // takes the runs wr, wr + NR, ...  A chunk-major operand keeps 8 rows of a float4 plane in one 128-byte line, and the four
+    // loads that share it are issued back to back (the refills go out per run, below) so they meet in L1; dealt step by step
+    // (round 2) the line was touched by four different waves at four different times -- with 8 waves x 32 planes in flight it
+    // was evicted in between (gemm_tn 2.72 -> 3.09 ms at 6470rte x 64 once its B operands became chunk-major).
+    // `count` = this wave's full steps (both rows inside the range); the < 4 steps of a ragged last run go to that run's owner.
     const int nstep = (R1 - R0) >> 1;
-    const int count = nstep > wr ? (nstep - wr + NR - 1) / NR : 0;
+    const int nrun = nstep >> 2, tail_steps = nstep & 3;
+    const int count = RUNS ? 4 * (nrun > wr ? (nrun - wr + NR - 1) / NR : 0) + ((nrun % NR) == wr ? tail_steps : 0)
+                           : (nstep > wr ? (nstep - wr + NR - 1) / NR : 0);
+    // the wave's q-th step -> step of the block's range
+    auto gstep = [&](int q) { return RUNS ? 4 * (NR * (q >> 2) + wr) + (q & 3) : wr + NR * q; };
     if (count > 0) {
         const uint32_t voA = (uint32_t)(kh * pr.lda + acol) * 4u, voB = (uint32_t)(kh * rowB + colB(bcol)) * 4u;
         const uint32_t voX = (uint32_t)(kh * rowB + colB(pr.nb - 1)) * 4u, voY = (uint32_t)(kh * pr.lda + pr.na - 1) * 4u;
@@ -248,7 +258,7 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
         const char* baseB = reinterpret_cast<const char*>(pr.B);
         const char* baseR = reinterpret_cast<const char*>(Rs2);
         auto issue = [&](Slot& t, int step) {   // refill IN PLACE; a step past the wave's last one re-reads the last one
-            const int64_t row = R0 + 2 * (int64_t)(wr + NR * min(step, count - 1));
+            const int64_t row = R0 + 2 * (int64_t)gstep(min(step, count - 1));
             const char* pa = baseA + row * pr.lda * 4;
             const char* pb = baseB + row * rowB * 4;
             const char* prs = baseR + row * rs_stride * 4;
@@ -272,11 +282,18 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
 #pragma unroll
             for (int r = 0; r < T3_R; ++r) {
                 // the slot about to be consumed has landed: exactly the 5 loads of each of the T3_R - 1 younger slots may still fly
+                // (refills go out per run of four slots: slot r has the 5 loads of each of the 3 - (r & 3) later slots of its run
+                //  and of the whole other run younger than its own)
                 asm volatile("s_waitcnt vmcnt(%5)"
                              : "+v"(ring[r].a), "+v"(ring[r].b), "+v"(ring[r].xv), "+v"(ring[r].yv), "+v"(ring[r].rs)
-                             : "n"(5 * (T3_R - 1)));
+                             : "n"(RUNS ? 5 * (T3_R - 1 - (r & 3)) : 5 * (T3_R - 1)));
                 if (t0 + r < count) compute(ring[r]);
-                issue(ring[r], t0 + r + T3_R);
+                if (!RUNS) {
+                    issue(ring[r], t0 + r + T3_R);
+                } else if ((r & 3) == 3) {
+#pragma unroll
+                    for (int rr = r - 3; rr <= r; ++rr) issue(ring[rr], t0 + rr + T3_R);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (TWO_LEVEL && ((t0 / T3_R) & (T3_FLUSH - 1)) == T3_FLUSH - 1) flush();
@@ -285,7 +302,7 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     }
     // ragged tail: an odd row count leaves ONE row (kh = 0 only) for the row group whose turn it is -- compiler-visible
     // loads, the upper lane half contributes zeros
-    if (((R1 - R0) & 1) && wr == nstep % NR) {
+    if (((R1 - R0) & 1) && wr == (RUNS ? nrun : nstep) % NR) {
         const int row = R1 - 1;
         Slot t;
         t.a = *reinterpret_cast<const FA*>(Ap + (size_t)row * pr.lda);
@@ -365,6 +382,7 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     for (int Q = 0; Q < NQ; ++Q) mine[Q * 64 + lane] = v[Q];
 }
 
+template <bool RUNS>
 __global__ __launch_bounds__(T3_THREADS, 1) void gemm_tn_kernel(const T3Args a, const DweRide ride) {
     extern __shared__ __attribute__((aligned(16))) float4 t3_lds[];
     if ((int)blockIdx.x >= a.nblocks) {   // riders: the dWe partial reductions of the same backward pass (edge.hip), 17 blocks per layer
@@ -399,10 +417,10 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm_tn_kernel(const T3Args a, 
         bx = 8 * nfull + (l2 - member * tail);
     }
     const T3Task tk = a.task[t + member];
-    if (tk.wa && tk.wb) t3_body<4, 2>(a, tk, bx, t3_lds);
-    else if (tk.wa) t3_body<4, 1>(a, tk, bx, t3_lds);
-    else if (tk.wb) t3_body<1, 2>(a, tk, bx, t3_lds);
-    else t3_body<1, 1>(a, tk, bx, t3_lds);
+    if (tk.wa && tk.wb) t3_body<4, 2, RUNS>(a, tk, bx, t3_lds);
+    else if (tk.wa) t3_body<4, 1, RUNS>(a, tk, bx, t3_lds);
+    else if (tk.wb) t3_body<1, 2, RUNS>(a, tk, bx, t3_lds);
+    else t3_body<1, 1, RUNS>(a, tk, bx, t3_lds);
 }
 
 // Second stage (tasks split over several blocks): thread = one (half, quad, lane) of one task; sums the task's partials in
@@ -457,8 +475,9 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
         return PFN_OK;
     }
     const size_t cap_f4 = ws.floats >= 256 ? (ws.floats - 256) / 4 : 0;
-    static std::atomic<uint64_t> lds_raised{0};
-    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_tn_kernel), T3_LDS_BYTES, lds_raised));
+    static std::atomic<uint64_t> lds_raised{0}, lds_raised_runs{0};
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_tn_kernel<false>), T3_LDS_BYTES, lds_raised));
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_tn_kernel<true>), T3_LDS_BYTES, lds_raised_runs));
     static const int want_env = diag_env("PFN_TN_BLOCKS") ? atoi(diag_env("PFN_TN_BLOCKS")) : 0;   // tuning aid
     const int ncu = device_cus();
     bool ride_done = false;
@@ -567,7 +586,10 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
                 extra = ride->njobs * ((ride->fe * ride->h + 15) / 16);
                 ride_done = true;
             }
-            gemm_tn_kernel<<<nblocks + extra, T3_THREADS, T3_LDS_BYTES, s>>>(ta, rd);
+            bool any_cm = false;   // a chunk-major operand anywhere in the launch: runs of four steps per row group
+            for (int q = 0; q < np_here; ++q) any_cm |= ta.pair[q].b_cm_rows > 0;
+            if (any_cm) gemm_tn_kernel<true><<<nblocks + extra, T3_THREADS, T3_LDS_BYTES, s>>>(ta, rd);
+            else gemm_tn_kernel<false><<<nblocks + extra, T3_THREADS, T3_LDS_BYTES, s>>>(ta, rd);
             PFN_CHECK_LAUNCH();
         }
         bool any_split = false;

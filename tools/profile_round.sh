@@ -69,7 +69,7 @@ def read(c):
     return d
 f, w = read("FETCH_SIZE"), read("WRITE_SIZE")
 cls = {"gemm_nt": "gemm_nt_kernel", "gemm_tn": "gemm_tn_kernel", "hop_norm": "hop_kernel<true>", "edge_fwd": "edge_fwd_kernel",
-       "edge_bwd": "edge_bwd_kernel", "fused_hops_fwd": "fused_hops_kernel", "fused_hops_bwd": "fused_hops_kernel",
+       "edge_bwd": "edge_bwd_kernel", "fused_hops_fwd": "_hops_kernel", "fused_hops_bwd": "_hops_kernel",
        "ea_seg_fwd": "ea_seg_fwd_kernel", "ea_seg_bwd": "ea_seg_bwd_kernel"}
 case = re.search(r"--case (\S+)", bargs); batch = re.search(r"--batch (\d+)", bargs); mode = re.search(r"--mode (\S+)", bargs)
 cfg = re.search(r"--config (\S+)", bargs); hub = re.search(r"--hub-frac (\S+)", bargs)
