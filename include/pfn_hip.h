@@ -133,8 +133,9 @@ int pfn_mpn_backward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_
  *   kind 1: output of hidden layer `layer` after dropout -> ReLU (:546-547): out [N][H];
  *   kind 2: mask_embd's hidden layer (:493): out [N][H].                                                              */
 int pfn_mpn_export_gates(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
-                         const float* const* params, const float* edge_attr, void* ws, size_t ws_bytes, int32_t kind,
-                         int32_t layer, uint8_t* out, void* stream);
+                         const float* const* params, const float* edge_attr, void* ws, size_t ws_bytes,
+                         int64_t seg_nodes /* the value the forward call had: it decides the layout of saved tensors */,
+                         int32_t kind, int32_t layer, uint8_t* out, void* stream);
 
 /* ------------------------------------------------------------------------------------- single layers
  * EdgeAggregation(nfeature_dim, efeature_dim, hidden_dim, output_dim).forward (networks/MPN.py:30-56):
@@ -234,6 +235,7 @@ int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  *   PFN_FUSED_HOPS=0|1      TAGConv hops: never / always LDS-resident per graph when they fit (default: when they fit)
  *   PFN_FH_BLOCKS=<n>       fused hops: target number of workgroups (default 1024)
  *   PFN_NO_BIG_HOPS=1       TAGConv hops of large graphs (one LDS tile + registers per graph and column chunk): K generic hop launches instead
+ *   PFN_NO_CM_INPUT=1       ... and the layer in front of such a TAGConv writes its output row-major instead of chunk-major
  *   PFN_FH_ONE_PER_CU=1     fused hops: whole rows per workgroup (one 125 KB workgroup per CU) instead of two half-LDS ones
  *   PFN_TN_BLOCKS=<n>       gemm_tn: target number of workgroups (default: one per CU)
  *   PFN_TN_NOGROUP=1        gemm_tn: do not co-schedule tasks that share an operand

@@ -64,7 +64,7 @@ def load() -> C.CDLL:
         "pfn_mpn_workspace_bytes": (sz, [cfgp, i64, i64]),
         "pfn_mpn_forward": (C.c_int, [cfgp, p, i64, i64, p, p, p, i32, p, p, p, sz, p, i64, p]),
         "pfn_mpn_backward": (C.c_int, [cfgp, p, i64, i64, p, p, p, p, i32, p, p, p, p, p, sz, i64, p]),
-        "pfn_mpn_export_gates": (C.c_int, [cfgp, p, i64, i64, p, p, p, sz, C.c_int32, C.c_int32, p, p]),
+        "pfn_mpn_export_gates": (C.c_int, [cfgp, p, i64, i64, p, p, p, sz, i64, C.c_int32, C.c_int32, p, p]),
         "pfn_edge_aggr_workspace_bytes": (sz, [i64, i64, i32, i32, i32, i32]),
         "pfn_edge_aggr_forward": (C.c_int, [p, i64, i64, i32, i32, i32, i32, p, i64, p, p, p, p, p, p, i64, p, sz, p]),
         "pfn_edge_aggr_backward": (C.c_int, [p, i64, i64, i32, i32, i32, i32, p, i64, p, p, p, p, p, p, i64, p, i64, p,

@@ -316,7 +316,8 @@ constexpr int BH_NBPT = 20;                     // staged neighbour ids per thre
 __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int nchunk, int ngraphs, int nb_cap,
                                                                     const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                                     const float* __restrict__ dinv, const float* __restrict__ x0,
-                                                                    float* __restrict__ xk, size_t stride, int ld, int K, int n_total) {
+                                                                    float* __restrict__ xk, size_t stride, int ld, int K, int n_total,
+                                                                    int x0_cm) {
     extern __shared__ __attribute__((aligned(16))) float4 bh_tile[];          // [seg] | rp u16 [seg + 2] | nb u16 [nb_cap]
     unsigned short* s_rp = reinterpret_cast<unsigned short*>(bh_tile + seg);
     unsigned short* s_nb = s_rp + ((seg + 2 + 7) & ~7);
@@ -341,7 +342,9 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
         if (row < seg) {
             di[r] = dinv[r0 + row];
 #ifndef BH_EXP_NOLOADX
-            z[r] = ld4(x0 + (size_t)(r0 + row) * ld + 4 * c);
+            // (the producing GEMM writes the layer input chunk-major when this kernel will read it: one contiguous run instead
+            //  of 16 bytes per 528-byte row -- 100 of the kernel's 330 us)
+            z[r] = x0_cm ? ld4(x0 + ((size_t)c * n_total + r0 + row) * 4) : ld4(x0 + (size_t)(r0 + row) * ld + 4 * c);
 #else
             z[r] = ld4(x0 + (size_t)(r0 + (row & 63)) * 4 + 0 * c);
 #endif
@@ -436,6 +439,14 @@ bool big_hops_fit(int seg, int n, int64_t e_stored) {
     return (size_t)seg * 16 + (size_t)((seg + 2 + 7) & ~7) * 2 + 1024 <= (size_t)160 * 1024;
 }
 
+bool tag_uses_big_hops(int seg, int ld, int n, int64_t e_stored, int K) {
+    return K > 0 && !fused_hops_fit(seg, ld, n) && big_hops_fit(seg, n, e_stored);
+}
+bool tag_input_cm(int seg, int ld, int n, int64_t e_stored, int K) {
+    static const bool off = diag_env("PFN_NO_CM_INPUT") != nullptr;   // A/B switch: the TAGConv input stays row-major
+    return !off && tag_uses_big_hops(seg, ld, n, e_stored, K);
+}
+
 int launch_big_graph_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s) {
     if (g.n == 0 || a.K == 0) return PFN_OK;
     if (a.transpose) {
@@ -455,7 +466,7 @@ int launch_big_graph_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_
     ProfScope ps(adjt ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
     const int blocks = ((ngraphs + 7) / 8) * 8 * nchunk;
     big_graph_hops_kernel<<<blocks, BH_THREADS, lds_total, s>>>(a.seg, nchunk, ngraphs, nb_cap, adjt ? g.rowptr_out : g.rowptr_in,
-                                                               adjt ? g.out_dst : g.in_src, g.dinv, a.x0, a.xk, a.stride, a.ld, a.K, g.n);
+                                                               adjt ? g.out_dst : g.in_src, g.dinv, a.x0, a.xk, a.stride, a.ld, a.K, g.n, a.x0_cm);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

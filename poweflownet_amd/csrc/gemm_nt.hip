@@ -167,6 +167,7 @@ struct NtArgs {
     int tps, cshift, nq, remv;   // quarters per LDS slice; log2(column groups per block); MFMA quarters; VALU columns (padded)
     int nrem, bias_group, ldr, ldg;
     int kuni, bias_lds_off;      // k length shared by every piece of the launch, or 0; float offset of the bias image in LDS
+    int c_cm_rows, aux_cm_rows;  // > 0: C (every group) / the gate-or-residual tensor is CHUNK-major with that many rows per plane
     int klast, row0;             // 1: in every piece only the first MFMA step of the last chunk has real k's (K = 129); else 4.
                                  // row0: global index of row 0 (dropout counter)
     NtPiece piece[NT_MAX_PIECES];
@@ -204,6 +205,11 @@ __device__ __forceinline__ void vstore_x4(float* p, f32x4 v) {
     // the s_nop is the ISA's "VMEM store wider than 64 bits -> VALU overwrites its data registers" hazard (2 wait states),
     // which hipcc fills in for its own stores but cannot see inside inline asm (without it: intermittently wrong elements)
     asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+}
+// float offset of element (row, col) of an activation tensor: row-major [rows][ld] -- or chunk-major [ld / 4 planes][cm_rows][float4]
+// when cm_rows > 0 (col a multiple of 4 here: the kernels move float4s)
+__device__ __forceinline__ size_t act_off(int row, int col, int ld, int cm_rows) {
+    return cm_rows > 0 ? ((size_t)(col >> 2) * cm_rows + row) * 4 : (size_t)row * ld + col;
 }
 template <int N>
 __device__ __forceinline__ void wait_a(f32x4& v) {   // the fragment chunk about to be consumed has landed
@@ -473,12 +479,12 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
                         const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
-                        aux[ct][g] = vload_x4_addr(extra + (size_t)(row < a.M ? row : a.M - 1) * ldx + colc);
+                        aux[ct][g] = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, colc, ldx, a.aux_cm_rows));
                     }
                 }
                 if (rem_on) {
                     const int row = rbase + r32;
-                    raux = vload_x4_addr(extra + (size_t)(row < a.M ? row : a.M - 1) * ldx + rem_col);
+                    raux = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, rem_col, ldx, a.aux_cm_rows));
                 }
             }
         }
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                     auto row_of = [&](int g) { return row_base + 8 * g; };
                     auto dst_of = [&](int g) {
                         const int rw_ = row_of(g);
-                        return C + (size_t)(rw_ < a.M ? rw_ : a.M - 1) * a.ldc + col0;
+                        return C + act_off(rw_ < a.M ? rw_ : a.M - 1, col0, a.ldc, a.c_cm_rows);
                     };
 #pragma unroll
                     for (int g = 0; g < 4; ++g) {
@@ -615,7 +621,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                 for (int e = 0; e < 4; ++e) v[e] = racc[e] + __shfl_xor(racc[e], 32);   // the two k halves
                 const int row = rbase + r32;
                 if (kh == 0 && row < a.M) {
-                    float* dst = C + (size_t)row * a.ldc + rem_col;
+                    float* dst = C + act_off(row, rem_col, a.ldc, a.c_cm_rows);
                     if (gf & 1) {
                         const float4 old = *reinterpret_cast<const float4*>(dst);
                         v[0] += old.x; v[1] += old.y; v[2] += old.z; v[3] += old.w;
@@ -841,11 +847,11 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
-                            aux[ct][g] = vload_x4_addr(extra + (size_t)(row < a.M ? row : a.M - 1) * ldx + col0);
+                            aux[ct][g] = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, col0, ldx, a.aux_cm_rows));
                         }
                     }
                     const int row = rbase + r32;
-                    raux = vload_x4_addr(extra + (size_t)(row < a.M ? row : a.M - 1) * ldx + rem_col);
+                    raux = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, rem_col, ldx, a.aux_cm_rows));
                 }
                 asm volatile("s_waitcnt vmcnt(0)"
                              : "+v"(aux[0][0]), "+v"(aux[0][1]), "+v"(aux[0][2]), "+v"(aux[0][3]), "+v"(aux[1][0]), "+v"(aux[1][1]),
@@ -869,7 +875,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
                 auto row_of = [&](int g) { return row_base + 8 * g; };
                 auto dst_of = [&](int g) {
                     const int rw_ = row_of(g);
-                    return C + (size_t)(rw_ < a.M ? rw_ : a.M - 1) * a.ldc + col0;
+                    return C + act_off(rw_ < a.M ? rw_ : a.M - 1, col0, a.ldc, a.c_cm_rows);
                 };
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -945,7 +951,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
                         x = (ud[0] >= ep.p_drop && x > 0.f) ? x * ep.keep_scale : 0.f;
                     }
                     if (ep.has_gate) x = raux[0] > 0.f ? x * ep.gate_scale : 0.f;
-                    vstore_x4(C + (size_t)row * a.ldc + rem_col, f32x4{x, 0.f, 0.f, 0.f});
+                    vstore_x4(C + act_off(row, rem_col, a.ldc, a.c_cm_rows), f32x4{x, 0.f, 0.f, 0.f});
                 }
             }
 #pragma unroll
@@ -1077,6 +1083,8 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     k.bias = a.bias; k.rowscale = a.rowscale; k.rowbias = a.rowbias; k.resid = a.resid; k.gate = a.gate;
     k.rng = a.rng; k.rng_stream = a.rng_stream; k.act = a.act; k.p_drop = a.p_drop; k.gate_scale = a.gate_scale;
     k.row0 = a.row0;
+    k.c_cm_rows = a.c_cm_rows;
+    k.aux_cm_rows = a.aux_cm_rows;
 
     ProfScope ps(top ? "gemm_nt" : nullptr, bytes, flops, s);
     // ---- large M, the shape of the big-graph launches (every piece K = 129, 129 output columns): full rows per wave, weights
@@ -1115,10 +1123,10 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
             t.row0 = a.row0 + (int)rows_ws;
             for (int i = 0; i < a.nterm; ++i)   // (chunk-major operand: 4 floats per row inside a plane, the plane stride stays)
                 t.term[i].A = a.term[i].A + (size_t)rows_ws * (a.term[i].cm_rows > 0 ? 4 : a.term[i].lda);
-            for (int g = 0; g < 8; ++g) t.C[g] = a.C[g] ? a.C[g] + (size_t)rows_ws * a.ldc : nullptr;
+            for (int g = 0; g < 8; ++g) t.C[g] = a.C[g] ? a.C[g] + (size_t)rows_ws * (a.c_cm_rows > 0 ? 4 : a.ldc) : nullptr;
             if (a.rowscale) t.rowscale = a.rowscale + rows_ws;
-            if (a.resid) t.resid = a.resid + (size_t)rows_ws * a.ldr;
-            if (a.gate) t.gate = a.gate + (size_t)rows_ws * a.ldg;
+            if (a.resid) t.resid = a.resid + (size_t)rows_ws * (a.aux_cm_rows > 0 ? 4 : a.ldr);
+            if (a.gate) t.gate = a.gate + (size_t)rows_ws * (a.aux_cm_rows > 0 ? 4 : a.ldg);
             return launch_gemm_nt_rows(t, s, false);
         }
     }

@@ -67,11 +67,14 @@ struct Act {
     float p = 0.f;
     const uint64_t* rng = nullptr;
     uint32_t stream = 0;
+    int out_cm = 0;             // > 0: the layer output is written CHUNK-major with that many rows per plane (its only reader chain
+                                // is a TAGConv on big_graph_hops_kernel: tag_uses_big_hops)
 };
 struct Gate {
     const float* y = nullptr;   // post-activation output of the producing layer
     int ld = 0;
     float scale = 1.f;
+    int cm = 0;                 // > 0: y is chunk-major (see Act::out_cm)
 };
 
 // ------------------------------------------------------------------------------------ deferred weight gradients
@@ -156,7 +159,11 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
         a.p_drop = act.p;
         a.rng = act.rng;
         a.rng_stream = act.stream;
+        a.c_cm_rows = act.out_cm;
         PFN_TRY(launch_gemm_nt(a, s));
+    } else if (act.out_cm) {
+        set_error("EdgeAggregation: a chunk-major output needs the S W2^T GEMM (internal)");
+        return PFN_EINVAL;
     }
     return PFN_OK;
 }
@@ -232,15 +239,22 @@ static TagPack tag_pack(Packer& pk, int cin, int cout, int K, const float* const
 }
 
 static int tag_forward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
-                       const float* bias, float* out, int ldo, const Act& act, float* xk, hipStream_t s, int seg = 0) {
-    // xk: K buffers of n * ldx floats holding A_hat^k x, k = 1..K
+                       const float* bias, float* out, int ldo, const Act& act, float* xk, hipStream_t s, int seg = 0,
+                       int x_cm = 0) {
+    // xk: K buffers of n * ldx floats holding A_hat^k x, k = 1..K.  x_cm > 0: x itself is chunk-major (the producing layer wrote
+    // it so because this TAGConv takes the big-graph hop kernel)
     const size_t stride = (size_t)g.n * ldx;
     int xk_cm = 0;   // > 0: the hop outputs are chunk-major with that many rows per plane (big-graph hops)
+    if (x_cm && !tag_uses_big_hops(seg, ldx, g.n, g.e_stored, K)) {
+        set_error("TAGConv: chunk-major input without the big-graph hop kernel (internal)");
+        return PFN_EINVAL;
+    }
     if (K > 0 && fused_hops_fit(seg, ldx, g.n)) {
         FusedHopsArgs fh{x, xk, nullptr, nullptr, nullptr, 1.f, stride, ldx, K, 0, seg};
         PFN_TRY(launch_fused_hops(g, fh, s));
     } else if (K > 0 && big_hops_fit(seg, g.n, g.e_stored)) {
         FusedHopsArgs fh{x, xk, nullptr, nullptr, nullptr, 1.f, stride, ldx, K, 0, seg};
+        fh.x0_cm = x_cm;
         PFN_TRY(launch_big_graph_hops(g, fh, s));   // (writes the hop outputs chunk-major)
         xk_cm = g.n;
     } else {
@@ -256,7 +270,7 @@ static int tag_forward(const GraphView& g, int cin, int cout, int K, const float
     a.nterm = K + 1;
     for (int k = 0; k <= K; ++k) {
         a.term[k] = term(k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, pw.wt[k], 0);
-        if (k > 0) a.term[k].cm_rows = xk_cm;
+        a.term[k].cm_rows = k > 0 ? xk_cm : x_cm;
     }
     a.bias = bias;
     a.act = act.act;
@@ -270,7 +284,8 @@ struct TagScratch { float* G; float *z0, *z1; ReduceWs red; };
 
 static int tag_backward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
                         const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx, float* const* gw,
-                        float* gbias, const float* xk, const TagScratch& sc, hipStream_t s, PairList* defer, int seg = 0) {
+                        float* gbias, const float* xk, const TagScratch& sc, hipStream_t s, PairList* defer, int seg = 0,
+                        int x_cm = 0) {
     const size_t stride = (size_t)g.n * ldx;
     float* hk = sc.G;
     if (gx) {
@@ -309,8 +324,13 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             a.gate = gate.y;
             a.ldg = gate.ld;
             a.gate_scale = gate.scale;
+            a.aux_cm_rows = gate.cm;
             PFN_TRY(launch_gemm_nt(a, s));
         } else {
+            if (gate.cm || x_cm) {
+                set_error("TAGConv backward: chunk-major tensors on the Horner path (internal)");
+                return PFN_EINVAL;
+            }
             // G_k = gout W_k ; dx = G_0 + A^T (G_1 + A^T (G_2 + ...))   (Horner over the transposed adjacency)
             GemmArgs a = gemm_defaults(g.n, cin, ldx);
             a.ngroup = K + 1;
@@ -347,7 +367,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
     for (int k = 0; k <= K; ++k) {
         pairs.push_back(tn_pair(gout, ldgo, cout, k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, gw[k], cin, 0,
                                 k == 0 ? gbias : nullptr, nullptr));
-        if (k > 0) pairs.back().b_cm_rows = xk_cm;
+        pairs.back().b_cm_rows = k > 0 ? xk_cm : x_cm;
     }
     if (defer) return PFN_OK;
     return launch_weight_grads(local.data(), (int)local.size(), g.n, sc.red, s);
@@ -554,6 +574,9 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         }
         float* y = last ? out : lo.y[i];
         const int ldy = last ? lo.ldo : lo.ld;
+        // an EdgeAggregation output that feeds a TAGConv on the big-graph hop kernel is written chunk-major (layer_out_cm)
+        const int big_cm = tag_input_cm(seg, lo.ld, lo.n, g.e_stored, lo.K) ? lo.n : 0;
+        if (is_ea(i) && !last) act.out_cm = big_cm;
         if (is_ea(i)) {
             const int fo = last ? lo.fo : lo.h;
             PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
@@ -562,7 +585,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
             pi += 4;
             fcur = fo;
         } else {
-            PFN_TRY(tag_forward(g, lo.h, lo.h, lo.K, cur, ldc, mp.tag[i], params[pi + lo.K + 1], y, ldy, act, lo.xk[i], s, seg));
+            PFN_TRY(tag_forward(g, lo.h, lo.h, lo.K, cur, ldc, mp.tag[i], params[pi + lo.K + 1], y, ldy, act, lo.xk[i], s, seg, big_cm));
             pi += lo.K + 2;
         }
         cur = y;
@@ -604,6 +627,8 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         }
         float* gnext = lo.gin[i];
         const int p0 = poff[i];
+        const int big_cm = tag_input_cm(seg, lo.ld, lo.n, g.e_stored, lo.K) ? lo.n : 0;
+        if (!is_ea(i)) gate.cm = big_cm;     // a TAGConv's input is the EdgeAggregation output before it (model_forward)
         if (is_ea(i)) {
             const int fi = i == 0 ? lo.f0 : lo.h, fo = last ? lo.fo : lo.h;
             EaScratch sc = lo.eas;
@@ -617,7 +642,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
                                 ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
-                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg));
+                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg, big_cm));
         }
         gcur = gnext;
         ldg = ldi;
@@ -893,10 +918,11 @@ __global__ __launch_bounds__(256) void export_edge_gates_kernel(int n, int e_sto
 }
 // Layer outputs (and mask_embd's hidden layer): out[row][k] = y[row][k] > 0, the test the backward pass applies (GemmArgs::gate).
 __global__ __launch_bounds__(256) void export_row_gates_kernel(int64_t n, int h, int ld, const float* __restrict__ y,
-                                                               uint8_t* __restrict__ out) {
+                                                               uint8_t* __restrict__ out, int cm) {
     for (int64_t it = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; it < n * h; it += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t row = it / h;
-        out[it] = y[row * ld + (it - row * h)] > 0.f ? 1 : 0;
+        const int64_t row = it / h, col = it - row * h;
+        const float v = cm ? y[((col >> 2) * n + row) * 4 + (col & 3)] : y[row * ld + col];   // (chunk-major: Act::out_cm)
+        out[it] = v > 0.f ? 1 : 0;
     }
 }
 
@@ -964,8 +990,8 @@ int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_
 }
 
 int pfn_mpn_export_gates(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
-                         const float* edge_attr, void* ws, size_t ws_bytes, int32_t kind, int32_t layer, uint8_t* out,
-                         void* stream) {
+                         const float* edge_attr, void* ws, size_t ws_bytes, int64_t seg_nodes, int32_t kind, int32_t layer,
+                         uint8_t* out, void* stream) {
     PFN_TRY(check_common(c, gws, n, e, ws));
     PFN_CHECK_ARG(params && out, "pfn_mpn_export_gates: null pointer");
     PFN_CHECK_ARG(c->need_backward != 0, "pfn_mpn_export_gates: the forward ran with need_backward = 0 (mask_embd's hidden layer was not saved)");
@@ -990,9 +1016,10 @@ int pfn_mpn_export_gates(const pfn_mpn_config* c, const void* gws, int64_t n, in
                                                        edge_attr, params[pi], lo.ld, lo.h, fi, lo.fe, out);
     } else if (kind == 1) {
         PFN_CHECK_ARG(layer >= 0 && layer + 1 < lo.nlayers, "pfn_mpn_export_gates: kind 1 needs a hidden layer index");
-        export_row_gates_kernel<<<blocks, 256, 0, s>>>(n, lo.h, lo.ld, lo.y[layer], out);
+        const int cm = is_ea(layer) && tag_input_cm((int)seg_nodes, lo.ld, lo.n, e, lo.K);
+        export_row_gates_kernel<<<blocks, 256, 0, s>>>(n, lo.h, lo.ld, lo.y[layer], out, cm);
     } else if (kind == 2) {
-        export_row_gates_kernel<<<blocks, 256, 0, s>>>(n, lo.h, lo.ld, lo.me_h, out);
+        export_row_gates_kernel<<<blocks, 256, 0, s>>>(n, lo.h, lo.ld, lo.me_h, out, 0);
     } else {
         set_error("pfn_mpn_export_gates: kind must be 0 (edge stage), 1 (layer output) or 2 (mask_embd hidden)");
         return PFN_EINVAL;

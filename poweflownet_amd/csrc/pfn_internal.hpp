@@ -205,6 +205,8 @@ struct GemmArgs {
     const float* gate;      // [M x ldg] or null : out *= gate > 0 ? gate_scale : 0
     int ldg;
     float gate_scale;
+    int c_cm_rows;          // > 0: every C is written CHUNK-major ([ldc / 4 planes][c_cm_rows][float4], see GemmTerm::cm_rows)
+    int aux_cm_rows;        // > 0: `gate` / `resid` is chunk-major
     int row0;               // global index of this call's first row (the dropout stream is keyed by the GLOBAL row): a launch over
                             // a row range of a larger product passes its offset here; 0 otherwise
 };
@@ -258,7 +260,12 @@ struct FusedHopsArgs {
     size_t stride;        // floats between consecutive k buffers
     int ld, K, transpose, seg;   // transpose = backward (Horner) data flow
     int adjt = -1;               // which adjacency: 1 = by-source rows (A_hat^T), 0 = by-destination; -1 = same as `transpose`
+    int x0_cm = 0;               // big-graph hops only: x0 is chunk-major ([ld / 4 planes][n][float4])
 };
+// Does a TAGConv over this batch take big_graph_hops_kernel (and hence chunk-major hop buffers)?  One predicate for the layer that
+// PRODUCES the TAGConv's input (it then writes it chunk-major), the TAGConv itself, and their backward passes.
+bool tag_uses_big_hops(int seg, int ld, int n, int64_t e_stored, int K);
+bool tag_input_cm(int seg, int ld, int n, int64_t e_stored, int K);   // ... and is that TAGConv's INPUT written chunk-major too?
 bool fused_hops_fit(int seg, int ld, int n);
 int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s);
 // the same K hops (forward data flow only) for graphs too large for two LDS tiles: one float4 column of one graph per block,

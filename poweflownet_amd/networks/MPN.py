@@ -458,8 +458,8 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
             out = torch.empty(max(rows, 1), h, dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
                 L.check(lib.pfn_mpn_export_gates(C.byref(cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
-                                                 edge_attr.data_ptr(), ws.data_ptr(), ws.numel(), kind, layer, out.data_ptr(),
-                                                 L.stream_ptr()), "pfn_mpn_export_gates")
+                                                 edge_attr.data_ptr(), ws.data_ptr(), ws.numel(), graph.seg_nodes, kind, layer,
+                                                 out.data_ptr(), L.stream_ptr()), "pfn_mpn_export_gates")
             return out
         gates = {"edge": {}, "out": {}}
         for i in range(nlayers):
