@@ -156,10 +156,12 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     // share one float4
     const int rowB = pr.b_cm_rows > 0 ? 4 : pr.ldb;
     auto colB = [&](int col) { return pr.b_cm_rows > 0 ? (col >> 2) * pr.b_cm_rows * 4 + (col & 3) : col; };
-    const float* Ap = pr.A + acol;
+    const int rowA = pr.a_cm_rows > 0 ? 4 : pr.lda;
+    auto colA = [&](int col) { return pr.a_cm_rows > 0 ? (col >> 2) * pr.a_cm_rows * 4 + (col & 3) : col; };
+    const float* Ap = pr.A + colA(acol);
     const float* Bp = pr.B + colB(bcol);
     const float* Xc = pr.B + colB(pr.nb - 1);     // the odd column of B (TNF_XCOL)
-    const float* Yr = pr.A + (pr.na - 1);     // the odd column of A = odd row of dW (TNF_XROW)
+    const float* Yr = pr.A + colA(pr.na - 1);     // the odd column of A = odd row of dW (TNF_XROW)
     const float* Rs = pr.bias_rowscale;
 
     f32x16 acc[TA][TB];
@@ -251,15 +253,15 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     // the wave's q-th step -> step of the block's range
     auto gstep = [&](int q) { return RUNS ? 4 * (NR * (q >> 2) + wr) + (q & 3) : wr + NR * q; };
     if (count > 0) {
-        const uint32_t voA = (uint32_t)(kh * pr.lda + acol) * 4u, voB = (uint32_t)(kh * rowB + colB(bcol)) * 4u;
-        const uint32_t voX = (uint32_t)(kh * rowB + colB(pr.nb - 1)) * 4u, voY = (uint32_t)(kh * pr.lda + pr.na - 1) * 4u;
+        const uint32_t voA = (uint32_t)(kh * rowA + colA(acol)) * 4u, voB = (uint32_t)(kh * rowB + colB(bcol)) * 4u;
+        const uint32_t voX = (uint32_t)(kh * rowB + colB(pr.nb - 1)) * 4u, voY = (uint32_t)(kh * rowA + colA(pr.na - 1)) * 4u;
         const uint32_t voR = (uint32_t)(kh * rs_stride) * 4u;
         const char* baseA = reinterpret_cast<const char*>(pr.A);
         const char* baseB = reinterpret_cast<const char*>(pr.B);
         const char* baseR = reinterpret_cast<const char*>(Rs2);
         auto issue = [&](Slot& t, int step) {   // refill IN PLACE; a step past the wave's last one re-reads the last one
             const int64_t row = R0 + 2 * (int64_t)gstep(min(step, count - 1));
-            const char* pa = baseA + row * pr.lda * 4;
+            const char* pa = baseA + row * rowA * 4;
             const char* pb = baseB + row * rowB * 4;
             const char* prs = baseR + row * rs_stride * 4;
             if (TA == 4) asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(t.a) : "v"(voA), "s"(pa) : "memory");
@@ -305,10 +307,10 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     if (((R1 - R0) & 1) && wr == (RUNS ? nrun : nstep) % NR) {
         const int row = R1 - 1;
         Slot t;
-        t.a = *reinterpret_cast<const FA*>(Ap + (size_t)row * pr.lda);
+        t.a = *reinterpret_cast<const FA*>(Ap + (size_t)row * rowA);
         t.b = *reinterpret_cast<const FB*>(Bp + (size_t)row * rowB);
         t.xv = Xc[(size_t)row * rowB];
-        t.yv = Yr[(size_t)row * pr.lda];
+        t.yv = Yr[(size_t)row * rowA];
         t.rs = Rs2[(size_t)row * rs_stride];
         if (kh != 0) {
             frag_zero(t.b);
@@ -587,7 +589,7 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
                 ride_done = true;
             }
             bool any_cm = false;   // a chunk-major operand anywhere in the launch: runs of four steps per row group
-            for (int q = 0; q < np_here; ++q) any_cm |= ta.pair[q].b_cm_rows > 0;
+            for (int q = 0; q < np_here; ++q) any_cm |= ta.pair[q].b_cm_rows > 0 || ta.pair[q].a_cm_rows > 0;
             if (any_cm) gemm_tn_kernel<true><<<nblocks + extra, T3_THREADS, T3_LDS_BYTES, s>>>(ta, rd);
             else gemm_tn_kernel<false><<<nblocks + extra, T3_THREADS, T3_LDS_BYTES, s>>>(ta, rd);
             PFN_CHECK_LAUNCH();

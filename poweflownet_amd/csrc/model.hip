@@ -35,7 +35,7 @@ static TnPair tn_pair(const float* A, int lda, int na, const float* B, int ldb, 
                       float* bias_out, const float* bias_rowscale) {
     TnPair p;
     p.A = A; p.B = B; p.G = G; p.bias_out = bias_out; p.bias_rowscale = bias_rowscale;
-    p.lda = lda; p.ldb = ldb; p.na = na; p.nb = nb; p.ldg = ldg; p.gn0 = 0; p.gk0 = gk0; p.b_cm_rows = 0;
+    p.lda = lda; p.ldb = ldb; p.na = na; p.nb = nb; p.ldg = ldg; p.gn0 = 0; p.gk0 = gk0; p.b_cm_rows = 0; p.a_cm_rows = 0;
     return p;
 }
 
@@ -172,7 +172,7 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
                        const float* w1, const float* w2, const EaPack& pw, const float* gout, int ldgo, const Gate& gate, float* gx,
                        int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
                        const EaScratch& sc, hipStream_t s, PairList* defer, int seg = 0, const float* ea_in = nullptr,
-                       const float* ea_out = nullptr, const unsigned* relu_mask = nullptr) {
+                       const float* ea_out = nullptr, const unsigned* relu_mask = nullptr, int gx_cm = 0) {
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
     // batches of small graphs: the dS GEMM and both backward walks in one launch, graph-resident in LDS (ea_seg.hip)
     const bool seg_walk = !gea && ea_in && ea_out && ea_seg_fit(seg, g.n, fe, ld, true) && (fo > 4 || ldgo == 4);
@@ -209,6 +209,8 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
         a.gate = gate.y;
         a.ldg = gate.ld;
         a.gate_scale = gate.scale;
+        a.aux_cm_rows = gate.cm;
+        a.c_cm_rows = gx_cm;     // (the gradient handed to a TAGConv on the big-graph hop kernel: chunk-major, like its input)
         PFN_TRY(launch_gemm_nt(a, s));
     }
     // weight gradients: dWe partials -> W1[:, 2Fi:], and three (dY, X) pairs
@@ -285,9 +287,13 @@ struct TagScratch { float* G; float *z0, *z1; ReduceWs red; };
 static int tag_backward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
                         const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx, float* const* gw,
                         float* gbias, const float* xk, const TagScratch& sc, hipStream_t s, PairList* defer, int seg = 0,
-                        int x_cm = 0) {
+                        int x_cm = 0, int gout_cm = 0) {
     const size_t stride = (size_t)g.n * ldx;
     float* hk = sc.G;
+    if (gout_cm && !(gx && K > 0 && ldgo <= ldx && tag_uses_big_hops(seg, ldgo, g.n, g.e_stored, K))) {
+        set_error("TAGConv backward: chunk-major output gradient without the big-graph hop kernel (internal)");
+        return PFN_EINVAL;
+    }
     if (gx) {
         if (ldgx != ldx) {
             set_error("TAGConv backward: grad_x stride %d != x stride %d", ldgx, ldx);
@@ -304,6 +310,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
                 PFN_TRY(launch_fused_hops(g, fh, s));
             } else if (big_hops_fit(seg, g.n, g.e_stored)) {
                 FusedHopsArgs fh{gout, hk, nullptr, nullptr, nullptr, 1.f, gstride, ldgo, K, 0, seg, 1};
+                fh.x0_cm = gout_cm;
                 PFN_TRY(launch_big_graph_hops(g, fh, s));
                 hk_cm = g.n;
             } else {
@@ -319,7 +326,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             a.nterm = K + 1;
             for (int k = 0; k <= K; ++k) {
                 a.term[k] = term(k == 0 ? gout : hk + (size_t)(k - 1) * gstride, ldgo, cout, pw.wd[k], 0);
-                if (k > 0) a.term[k].cm_rows = hk_cm;
+                a.term[k].cm_rows = k > 0 ? hk_cm : gout_cm;
             }
             a.gate = gate.y;
             a.ldg = gate.ld;
@@ -327,7 +334,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             a.aux_cm_rows = gate.cm;
             PFN_TRY(launch_gemm_nt(a, s));
         } else {
-            if (gate.cm || x_cm) {
+            if (gate.cm || x_cm || gout_cm) {
                 set_error("TAGConv backward: chunk-major tensors on the Horner path (internal)");
                 return PFN_EINVAL;
             }
@@ -368,6 +375,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
         pairs.push_back(tn_pair(gout, ldgo, cout, k == 0 ? x : xk + (size_t)(k - 1) * stride, ldx, cin, gw[k], cin, 0,
                                 k == 0 ? gbias : nullptr, nullptr));
         pairs.back().b_cm_rows = k > 0 ? xk_cm : x_cm;
+        pairs.back().a_cm_rows = gout_cm;
     }
     if (defer) return PFN_OK;
     return launch_weight_grads(local.data(), (int)local.size(), g.n, sc.red, s);
@@ -629,6 +637,9 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         const int p0 = poff[i];
         const int big_cm = tag_input_cm(seg, lo.ld, lo.n, g.e_stored, lo.K) ? lo.n : 0;
         if (!is_ea(i)) gate.cm = big_cm;     // a TAGConv's input is the EdgeAggregation output before it (model_forward)
+        // ... and the gradient an EdgeAggregation hands DOWN to a TAGConv (layers 2, 4, ...: their input is a TAGConv's output) is
+        // written chunk-major too: the TAGConv's backward hops, its GEMM and the weight-gradient pairs read it through the flags
+        const int gx_cm = (is_ea(i) && i >= 2) ? big_cm : 0, gout_cm = (!is_ea(i)) ? big_cm : 0;
         if (is_ea(i)) {
             const int fi = i == 0 ? lo.f0 : lo.h, fo = last ? lo.fo : lo.h;
             EaScratch sc = lo.eas;
@@ -639,10 +650,10 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
             PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], params[p0 + 2], mp.ea[i], gcur, ldg, gate,
                                 (fused_front && i == 0) ? nullptr : gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2],
                                 grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs, seg, lo.ea_in, lo.ea_out,
-                                ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr));
+                                ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr, gx_cm));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
-                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg, big_cm));
+                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg, big_cm, gout_cm));
         }
         gcur = gnext;
         ldg = ldi;

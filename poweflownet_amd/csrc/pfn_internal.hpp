@@ -223,6 +223,7 @@ struct TnPair {
     const float* bias_rowscale;
     int lda, ldb, na, nb, ldg, gn0, gk0;
     int b_cm_rows;   // 0: B is row-major [M][ldb].  > 0: B is chunk-major (see GemmTerm::cm_rows), that many rows per plane
+    int a_cm_rows;   // the same for A
 };
 struct ReduceWs {
     float* partial;   // scratch for split partials
