@@ -236,6 +236,7 @@ int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  *   PFN_FH_BLOCKS=<n>       fused hops: target number of workgroups (default 1024)
  *   PFN_NO_BIG_HOPS=1       TAGConv hops of large graphs (one LDS tile + registers per graph and column chunk): K generic hop launches instead
  *   PFN_NO_CM_INPUT=1       ... and the layer in front of such a TAGConv writes its output row-major instead of chunk-major
+ *   PFN_NO_ROW_HOPS=1       TAGConv hops of big batches of small graphs: the two-tile column-slice kernel instead of whole rows per block
  *   PFN_FH_ONE_PER_CU=1     fused hops: whole rows per workgroup (one 125 KB workgroup per CU) instead of two half-LDS ones
  *   PFN_TN_BLOCKS=<n>       gemm_tn: target number of workgroups (default: one per CU)
  *   PFN_TN_NOGROUP=1        gemm_tn: do not co-schedule tasks that share an operand

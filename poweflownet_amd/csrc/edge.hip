@@ -243,9 +243,130 @@ __global__ __launch_bounds__(FH_THREADS) void fused_hops_kernel(int n, int rows_
     }
 }
 
+// ---- the same one-tile-plus-registers scheme for BIG BATCHES OF SMALL graphs (case118 x 2048): with the second ping-pong tile
+// gone a block affords WHOLE ROWS (all 33 chunks) of its graph in half of the LDS -- two blocks per CU as before, but every global
+// access is a full 528-byte row (fused_hops_kernel's two 17-column slices leave cache lines partly used: 600 MB of fabric traffic
+// per launch for 503 MB of minimum traffic) and inputs / outputs stay row-major.  Item = (row, chunk), chunk fastest; <= 4 items
+// per thread.
+constexpr int RH_THREADS = 512;                  // (1024 threads x 4 items would need <= 64 VGPRs for two blocks per CU: spills)
+constexpr int RH_IPT = 8;                       // items per thread at most: rows x chunks <= 4,096 per block
+constexpr int RH_NBPT = 4;                      // staged neighbour ids per thread at most: 2,048 directed edges per block
+__global__ __launch_bounds__(RH_THREADS, 4) void row_hops_kernel(int n, int rows_pb, int nchunk, int nb_cap,
+                                                                const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                                const float* __restrict__ dinv, const float* __restrict__ x0,
+                                                                float* __restrict__ xk, size_t stride, int ld, int K) {
+    extern __shared__ __attribute__((aligned(16))) float4 rh_tile[];          // [rows_pb * nchunk] | rp u16 [rows_pb + 2] | nb u16 [nb_cap]
+    unsigned short* s_rp = reinterpret_cast<unsigned short*>(rh_tile + (size_t)rows_pb * nchunk);
+    unsigned short* s_nb = s_rp + ((rows_pb + 2 + 7) & ~7);
+    const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0), t = threadIdx.x;
+    const int items = rows * nchunk;
+    const int e0 = rowptr[r0], ne = rowptr[r0 + rows] - e0;
+    const bool nb_in_lds = ne <= nb_cap && ne < 65536 && ne <= RH_NBPT * RH_THREADS;
+    float di[RH_IPT];
+    float4 z[RH_IPT];
+    int nbv[RH_NBPT];
+#pragma unroll
+    for (int r = 0; r < RH_IPT; ++r) {          // every global load of the prologue is requested before the first LDS store
+        const int i = t + r * RH_THREADS;
+        const int row = i / nchunk, lc = i - row * nchunk;   // (recomputed per hop below: kept in registers they spilled)
+        di[r] = 0.f;
+        z[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < items) {
+            di[r] = dinv[r0 + row];
+            z[r] = ld4(x0 + (size_t)(r0 + row) * ld + 4 * lc);
+        }
+    }
+    int rpv[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) rpv[q] = t + q * RH_THREADS <= rows ? rowptr[r0 + t + q * RH_THREADS] : 0;    // (rows_pb <= 1023)
+#pragma unroll
+    for (int jn = 0; jn < RH_NBPT; ++jn) {
+        const int i = t + jn * RH_THREADS;
+        nbv[jn] = (nb_in_lds && i < ne) ? nbr[e0 + i] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        if (t + q * RH_THREADS <= rows) s_rp[t + q * RH_THREADS] = (unsigned short)(rpv[q] - e0);
+#pragma unroll
+    for (int r = 0; r < RH_IPT; ++r)
+        if (t + r * RH_THREADS < items) rh_tile[t + r * RH_THREADS] = mul4(di[r], z[r]);
+    if (nb_in_lds) {
+#pragma unroll
+        for (int jn = 0; jn < RH_NBPT; ++jn) {
+            const int i = t + jn * RH_THREADS;
+            if (i < ne) s_nb[i] = (unsigned short)(nbv[jn] - r0);
+        }
+    }
+    __syncthreads();
+    for (int k = 1; k <= K; ++k) {
+        float* outk = xk + (size_t)(k - 1) * stride;
+#pragma unroll
+        for (int r = 0; r < RH_IPT; ++r) {
+            const int i = t + r * RH_THREADS;
+            if (i >= items) continue;
+            const int row = i / nchunk, lc = i - row * nchunk;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nb_in_lds) {
+                const int beg = s_rp[row], end = s_rp[row + 1], last = end - 1;
+                for (int p = beg; p < end; p += 4) {
+                    int s_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) s_[u] = s_nb[min(p + u, last)];
+                    float4 v_[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v_[u] = rh_tile[s_[u] * nchunk + lc];
+                    acc = add4(acc, v_[0]);
+                    acc = sel4(p + 1 < end, add4(acc, v_[1]), acc);
+                    acc = sel4(p + 2 < end, add4(acc, v_[2]), acc);
+                    acc = sel4(p + 3 < end, add4(acc, v_[3]), acc);
+                }
+            } else {
+                for (int p = rowptr[r0 + row]; p < rowptr[r0 + row + 1]; ++p) acc = add4(acc, rh_tile[(nbr[p] - r0) * nchunk + lc]);
+            }
+            const float4 y = mul4(di[r], acc);
+            st4(outk + (size_t)(r0 + row) * ld + 4 * lc, y);
+            z[r] = mul4(di[r], y);
+            __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler interleaves all eight items' gathers and spills)
+        }
+        if (k == K) break;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RH_IPT; ++r)
+            if (t + r * RH_THREADS < items) rh_tile[t + r * RH_THREADS] = z[r];
+        __syncthreads();
+    }
+}
+// whole graphs per block: rows x chunks <= 4,096 items, rows <= 1,024, tile + offsets in HALF of the LDS (two blocks per CU)
+static int row_hops_graphs_per_block(int seg, int nchunk) {
+    if (seg <= 0 || seg > 1023 || (long)seg * nchunk > (long)RH_IPT * RH_THREADS) return 0;
+    int gpb = std::min((RH_IPT * RH_THREADS) / (seg * nchunk), 1023 / seg);
+    while (gpb > 0 && (size_t)gpb * seg * nchunk * 16 + (size_t)((gpb * seg + 2 + 7) & ~7) * 2 + 4096 > (size_t)78 * 1024) --gpb;
+    return gpb;
+}
+
 int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s) {
     if (g.n == 0 || a.K == 0) return PFN_OK;
     const int nchunk = a.ld / 4, ngraphs = g.n / a.seg;
+    {   // big batches of small graphs, forward data flow: whole rows per block, one LDS tile + registers (row_hops_kernel)
+        static const bool off = diag_env("PFN_NO_ROW_HOPS") != nullptr;   // A/B switch: the two-tile column-slice kernel below
+        const int gpb = row_hops_graphs_per_block(a.seg, nchunk);
+        if (!off && !a.transpose && gpb > 0 && (long)(ngraphs + gpb - 1) / gpb >= 4L * device_cus()) {
+            const int rows_pb = gpb * a.seg;
+            const size_t fixed = (size_t)rows_pb * nchunk * 16 + (size_t)((rows_pb + 2 + 7) & ~7) * 2;
+            const size_t want_nb = (size_t)(2 * (int64_t)g.e_stored / std::max(1, ngraphs) * gpb + 64) * 2;
+            const size_t lds_total = std::min((size_t)80 * 1024, fixed + want_nb);
+            const int nb_cap = (int)((lds_total - fixed) / 2);
+            static std::atomic<uint64_t> lds_raised_rh{0};
+            PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(row_hops_kernel), 160 * 1024, lds_raised_rh));
+            const bool adjt_rh = a.adjt < 0 ? false : a.adjt != 0;
+            ProfScope ps(adjt_rh ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
+            row_hops_kernel<<<(g.n + rows_pb - 1) / rows_pb, RH_THREADS, lds_total, s>>>(
+                g.n, rows_pb, nchunk, nb_cap, adjt_rh ? g.rowptr_out : g.rowptr_in, adjt_rh ? g.out_dst : g.in_src, g.dinv, a.x0, a.xk,
+                a.stride, a.ld, a.K);
+            PFN_CHECK_LAUNCH();
+            return PFN_OK;
+        }
+    }
     // column slices: aim for >= 512 blocks; a slice must leave room for two tiles of a whole graph
     const size_t per_chunk_graph = (size_t)2 * a.seg * 4 * sizeof(float);
     const int max_cw = (int)std::min<size_t>(nchunk, ((size_t)FH_LDS_BYTES - (size_t)(2 * a.seg + 1) * sizeof(int)) / per_chunk_graph);
