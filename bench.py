@@ -73,6 +73,9 @@ def alg_bytes(n, e, h, fe, K=3, train=True):
         # it as `equiv_unfused`: bytes this kernel by design never touches)
         "fused_hops_fwd": 4.0 * (n * h + K * n * h + e + (n + 1)),
         "fused_hops_bwd": 4.0 * (n * h + K * n * h + e + (n + 1)),
+        # the LDS-resident edge stage of big inference batches of small graphs: its OWN minimum traffic -- P, Q read once, S written,
+        # attributes and indices once (the per-edge gathers of the generic kernel never leave LDS here)
+        "edge_rows_fwd": 4.0 * (3 * n * h + e * fe + 2 * e + (n + 1)),
         # training: the forward walk also saves one ReLU-mask byte per (edge, float4 chunk) ...
         "edge_fwd": 4.0 * (n * h + e * h + e * fe + e + (n + 1) + n * h) + (e * ((h + 3) // 4) if train else 0),
         # ... and the backward walks (one launch: the by-destination half -> dP, dWe; the by-source half -> dQ) read the masks
@@ -134,7 +137,7 @@ def cpu_baseline(args, cfg, data_cpu, seconds):
             "host_logical_cores": ncpu, "ms_per_step": round(1e3 * dt / n, 2)}
 
 
-KERNEL_OF_CLASS = {"gemm_nt": "gemm_nt_kernel", "gemm_tn": "gemm_tn_kernel", "hop_norm": "hop_kernel<true", "edge_fwd": "edge_fwd_",
+KERNEL_OF_CLASS = {"gemm_nt": "gemm_nt_kernel", "gemm_tn": "gemm_tn_kernel", "hop_norm": "hop_kernel<true", "edge_fwd": "edge_fwd_", "edge_rows_fwd": "edge_rows_fwd_kernel",
                    "edge_bwd": "edge_bwd_", "fused_hops_fwd": "_hops_kernel", "fused_hops_bwd": "_hops_kernel",
                    "ea_seg_fwd": "ea_seg_fwd_kernel", "ea_seg_bwd": "ea_seg_bwd_kernel", "front_fwd": "front_fwd", "front_bwd": "front_bwd"}
 

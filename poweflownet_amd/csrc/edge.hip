@@ -758,10 +758,152 @@ __global__ __launch_bounds__(256) void edge_fwd_out_kernel(int n, int nchunk, in
     }
 }
 
+// ---- the edge stage of big batches of SMALL graphs (case118 x 2048, inference): block = whole graphs x all column chunks, the
+// graphs' Q rows LDS-resident (one tile, as row_hops_kernel), adjacency and edge attributes staged in slot order; P and S move as
+// full 528-byte rows.  The generic kernel gathers every Q row from L2 / HBM once per edge (691 MB of fabric traffic per launch
+// for 383 MB of P + Q + S); here Q is read once.  Same arithmetic, same edge order as edge_sum_chunk.
+constexpr int ER_THREADS = 512;
+constexpr int ER_IPT = 8;                       // (row, chunk) items per thread at most: rows x chunks <= 4,096 per block
+constexpr int ER_NBPT = 4;                      // staged edge slots per thread at most: 2,048 per block
+__global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int rows_pb, int nchunk, int nb_cap, int e_stored,
+                                                                     const int* __restrict__ rowptr, const int* __restrict__ nbr,
+                                                                     const int* __restrict__ eid, const float* __restrict__ P,
+                                                                     const float* __restrict__ Q, const float* __restrict__ ea,
+                                                                     const float* __restrict__ w1, float* __restrict__ S, int ld,
+                                                                     int h, int fi) {
+    extern __shared__ __attribute__((aligned(16))) float4 er_tile[];   // Q [rows_pb * nchunk] | we [2 * nchunk] | ea float2 [nb_cap] | rp u16 | nb u16
+    float4* s_we = er_tile + (size_t)rows_pb * nchunk;
+    float2* s_ea = reinterpret_cast<float2*>(s_we + 2 * nchunk);
+    unsigned short* s_rp = reinterpret_cast<unsigned short*>(s_ea + nb_cap);
+    unsigned short* s_nb = s_rp + ((rows_pb + 2 + 7) & ~7);
+    const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0), t = threadIdx.x;
+    const int items = rows * nchunk;
+    const int e0 = rowptr[r0], ne = rowptr[r0 + rows] - e0;
+    const bool in_lds = ne <= nb_cap && ne < 65536 && ne <= ER_NBPT * ER_THREADS;
+    const int ldw = 2 * fi + 2;
+    // every global load of the prologue is requested before the first LDS store (the attributes need their edge id first: two trips)
+    float4 q[ER_IPT];
+#pragma unroll
+    for (int r = 0; r < ER_IPT; ++r) {
+        const int i = t + r * ER_THREADS;
+        const int row = i / nchunk, lc = i - row * nchunk;
+        q[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < items) q[r] = ld4(Q + (size_t)(r0 + row) * ld + 4 * lc);
+    }
+    int rpv[2], nbv[ER_NBPT], idv[ER_NBPT];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) rpv[k2] = t + k2 * ER_THREADS <= rows ? rowptr[r0 + t + k2 * ER_THREADS] : 0;
+#pragma unroll
+    for (int jn = 0; jn < ER_NBPT; ++jn) {
+        const int i = t + jn * ER_THREADS;
+        const bool on = in_lds && i < ne;
+        nbv[jn] = on ? nbr[e0 + i] : 0;
+        idv[jn] = on ? eid[e0 + i] : 0;
+    }
+    float wv[2] = {0.f, 0.f};                    // the residue weights W1[:, 2 Fi + f], f = 0, 1, as two [ld] rows
+    if (t < 2 * 4 * nchunk) {
+        const int f = t / (4 * nchunk), k = t - f * 4 * nchunk;
+        wv[0] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
+    }
+    float2 eav[ER_NBPT];
+#pragma unroll
+    for (int jn = 0; jn < ER_NBPT; ++jn) {
+        const int id = idv[jn] >= e_stored ? idv[jn] - e_stored : idv[jn];
+        eav[jn] = (in_lds && t + jn * ER_THREADS < ne) ? *reinterpret_cast<const float2*>(ea + (size_t)id * 2) : make_float2(0.f, 0.f);
+    }
+#pragma unroll
+    for (int r = 0; r < ER_IPT; ++r)
+        if (t + r * ER_THREADS < items) er_tile[t + r * ER_THREADS] = q[r];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+        if (t + k2 * ER_THREADS <= rows) s_rp[t + k2 * ER_THREADS] = (unsigned short)(rpv[k2] - e0);
+    if (t < 2 * 4 * nchunk) reinterpret_cast<float*>(s_we)[t] = wv[0];
+    if (in_lds) {
+#pragma unroll
+        for (int jn = 0; jn < ER_NBPT; ++jn) {
+            const int i = t + jn * ER_THREADS;
+            if (i < ne) {
+                s_nb[i] = (unsigned short)(nbv[jn] - r0);
+                s_ea[i] = eav[jn];
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < ER_IPT; ++r) {
+        const int i = t + r * ER_THREADS;
+        if (i >= items) continue;
+        const int row = i / nchunk, lc = i - row * nchunk;
+        const float4 p4 = ld4(P + (size_t)(r0 + row) * ld + 4 * lc);
+        const float4 w0 = s_we[lc], w1v = s_we[nchunk + lc];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (in_lds) {
+            const int beg = s_rp[row], end = s_rp[row + 1], last = end - 1;
+            for (int p = beg; p < end; p += 4) {
+                int s_[4];
+                float2 a_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int qq = min(p + u, last);
+                    s_[u] = s_nb[qq];
+                    a_[u] = s_ea[qq];
+                }
+                float4 q_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q_[u] = er_tile[s_[u] * nchunk + lc];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float4 v = add4(p4, q_[u]);
+                    v = fma4(a_[u].x, w0, v);
+                    v = fma4(a_[u].y, w1v, v);
+                    acc = sel4(p + u < end, add4(acc, relu4(v)), acc);
+                }
+            }
+        } else {            // a block with more edges than the staged lists hold: indices and attributes from global memory
+            for (int p = rowptr[r0 + row]; p < rowptr[r0 + row + 1]; ++p) {
+                int id = eid[p];
+                id = id >= e_stored ? id - e_stored : id;
+                const float2 a2 = *reinterpret_cast<const float2*>(ea + (size_t)id * 2);
+                float4 v = add4(p4, er_tile[(nbr[p] - r0) * nchunk + lc]);
+                v = fma4(a2.x, w0, v);
+                v = fma4(a2.y, w1v, v);
+                acc = add4(acc, relu4(v));
+            }
+        }
+        st4(S + (size_t)(r0 + row) * ld + 4 * lc, acc);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+static int edge_rows_graphs_per_block(int seg, int nchunk) {
+    if (seg <= 0 || seg > 1023 || (long)seg * nchunk > (long)ER_IPT * ER_THREADS || 8 * nchunk > ER_THREADS) return 0;
+    int gpb = std::min((ER_IPT * ER_THREADS) / (seg * nchunk), 1023 / seg);
+    while (gpb > 0 && (size_t)gpb * seg * nchunk * 16 + 4096 > (size_t)66 * 1024) --gpb;   // (+ attributes, adjacency: <= 80 KB in all)
+    return gpb;
+}
+
 bool edge_fwd_out_ok(int fe, int h, int fo, int ldo) { return fe == 2 && fo >= 1 && fo <= 4 && ldo == 4 && ld_of(h) / 4 <= 256; }
 int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
     if (g.n == 0) return PFN_OK;
     const int nchunk = a.ld / 4;
+    if (a.seg > 0 && a.fe == 2 && !a.mask && !a.out && g.n % a.seg == 0) {   // inference on a big batch of small graphs
+        static const bool off = diag_env("PFN_NO_EDGE_ROWS") != nullptr;      // A/B switch: the generic gather kernel
+        const int ngraphs = g.n / a.seg, gpb = edge_rows_graphs_per_block(a.seg, nchunk);
+        if (!off && gpb > 0 && (long)(ngraphs + gpb - 1) / gpb >= 4L * device_cus()) {
+            const int rows_pb = gpb * a.seg;
+            const size_t fixed = (size_t)rows_pb * nchunk * 16 + (size_t)2 * nchunk * 16 + (size_t)((rows_pb + 2 + 7) & ~7) * 2;
+            const size_t per_slot = 8 + 2;
+            const size_t want = (size_t)(2 * (int64_t)g.e_stored / std::max(1, ngraphs) * gpb + 64);
+            const size_t lds_total = std::min((size_t)80 * 1024, fixed + want * per_slot + 16);
+            const int nb_cap = (int)((lds_total - fixed - 16) / per_slot) & ~3;
+            static std::atomic<uint64_t> lds_raised_er{0};
+            PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(edge_rows_fwd_kernel), 160 * 1024, lds_raised_er));
+            ProfScope ps("edge_rows_fwd", 0.0, 0.0, s);
+            edge_rows_fwd_kernel<<<(g.n + rows_pb - 1) / rows_pb, ER_THREADS, lds_total, s>>>(
+                g.n, rows_pb, nchunk, nb_cap, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi);
+            PFN_CHECK_LAUNCH();
+            return PFN_OK;
+        }
+    }
     const long items = (long)g.n * nchunk;
     const int blocks = (int)((items + 255) / 256);
     const size_t lds = (size_t)a.fe * a.ld * sizeof(float);

@@ -138,6 +138,7 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
     if (!seg_walk) {
         EdgeFwdArgs e{sv.P, sv.Q, ea, w1, sv.S, ld, h, fi, fe};
         e.mask = relu_mask;   // (a backward pass will follow: it reads the masks instead of recomputing the pre-activations)
+        e.seg = seg;
         if (out_in_walk) {
             e.out = out;
             e.w2 = w2;

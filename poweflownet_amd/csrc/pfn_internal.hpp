@@ -320,6 +320,8 @@ struct EdgeFwdArgs {
     const float* w2 = nullptr;
     const float* b2 = nullptr;
     int fo = 0;
+    int seg = 0;                     // > 0: the batch is a union of graphs of this many nodes (pfn_graph_segments): big batches of
+                                     // small graphs take edge_rows_fwd_kernel (the graph's Q rows LDS-resident)
 };
 bool edge_fwd_out_ok(int fe, int h, int fo, int ldo);
 int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s);
