@@ -770,10 +770,15 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
                                                                      const int* __restrict__ eid, const float* __restrict__ P,
                                                                      const float* __restrict__ Q, const float* __restrict__ ea,
                                                                      const float* __restrict__ w1, float* __restrict__ S, int ld,
-                                                                     int h, int fi) {
-    extern __shared__ __attribute__((aligned(16))) float4 er_tile[];   // Q [rows_pb * nchunk] | we [2 * nchunk] | ea float2 [nb_cap] | rp u16 | nb u16
+                                                                     int h, int fi, const float* __restrict__ w2,
+                                                                     const float* __restrict__ b2, const float* __restrict__ deg,
+                                                                     float* __restrict__ out, int fo) {
+    // `out` != null: the network's LAST layer (Fo <= 4): out[row] = S[row] W2^T + deg[row] b2 is formed here and S itself (which
+    // only a backward pass reads) is not written
+    extern __shared__ __attribute__((aligned(16))) float4 er_tile[];   // Q [rows_pb * nchunk] | we [2 * nchunk] | w2 [4 * nchunk] | ea float2 [nb_cap] | rp u16 | nb u16
     float4* s_we = er_tile + (size_t)rows_pb * nchunk;
-    float2* s_ea = reinterpret_cast<float2*>(s_we + 2 * nchunk);
+    float4* s_w2 = s_we + 2 * nchunk;
+    float2* s_ea = reinterpret_cast<float2*>(s_w2 + 4 * nchunk);
     unsigned short* s_rp = reinterpret_cast<unsigned short*>(s_ea + nb_cap);
     unsigned short* s_nb = s_rp + ((rows_pb + 2 + 7) & ~7);
     const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0), t = threadIdx.x;
@@ -818,6 +823,7 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
     for (int k2 = 0; k2 < 2; ++k2)
         if (t + k2 * ER_THREADS <= rows) s_rp[t + k2 * ER_THREADS] = (unsigned short)(rpv[k2] - e0);
     if (t < 2 * 4 * nchunk) reinterpret_cast<float*>(s_we)[t] = wv[0];
+    if (out) stage_w2(reinterpret_cast<float*>(s_w2), w2, h, fo, ld);
     if (in_lds) {
 #pragma unroll
         for (int jn = 0; jn < ER_NBPT; ++jn) {
@@ -870,8 +876,32 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
                 acc = add4(acc, relu4(v));
             }
         }
-        st4(S + (size_t)(r0 + row) * ld + 4 * lc, acc);
+        if (!out) {
+            st4(S + (size_t)(r0 + row) * ld + 4 * lc, acc);
+        } else {   // this chunk's share of the four output dot products; q[] (dead since the prologue) keeps it until the tile is free
+            q[r].x = dot4(acc, s_w2[lc]);
+            q[r].y = dot4(acc, s_w2[nchunk + lc]);
+            q[r].z = dot4(acc, s_w2[2 * nchunk + lc]);
+            q[r].w = dot4(acc, s_w2[3 * nchunk + lc]);
+        }
         __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!out) return;
+    __syncthreads();                             // every walk is done with the Q tile: it now holds the partials
+#pragma unroll
+    for (int r = 0; r < ER_IPT; ++r)
+        if (t + r * ER_THREADS < items) er_tile[t + r * ER_THREADS] = q[r];
+    __syncthreads();
+    for (int row = t; row < rows; row += ER_THREADS) {   // a row's chunks added in chunk order (fixed)
+        float4 sum = er_tile[row * nchunk];
+        for (int k2 = 1; k2 < nchunk; ++k2) sum = add4(sum, er_tile[row * nchunk + k2]);
+        const float d = deg[r0 + row];
+        float4 o;
+        o.x = fmaf(d, b2[0], sum.x);
+        o.y = fo > 1 ? fmaf(d, b2[1], sum.y) : 0.f;
+        o.z = fo > 2 ? fmaf(d, b2[2], sum.z) : 0.f;
+        o.w = fo > 3 ? fmaf(d, b2[3], sum.w) : 0.f;
+        st4(out + (size_t)(r0 + row) * 4, o);
     }
 }
 static int edge_rows_graphs_per_block(int seg, int nchunk) {
@@ -885,12 +915,12 @@ bool edge_fwd_out_ok(int fe, int h, int fo, int ldo) { return fe == 2 && fo >= 1
 int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
     if (g.n == 0) return PFN_OK;
     const int nchunk = a.ld / 4;
-    if (a.seg > 0 && a.fe == 2 && !a.mask && !a.out && g.n % a.seg == 0) {   // inference on a big batch of small graphs
+    if (a.seg > 0 && a.fe == 2 && !a.mask && g.n % a.seg == 0) {   // inference on a big batch of small graphs
         static const bool off = diag_env("PFN_NO_EDGE_ROWS") != nullptr;      // A/B switch: the generic gather kernel
         const int ngraphs = g.n / a.seg, gpb = edge_rows_graphs_per_block(a.seg, nchunk);
         if (!off && gpb > 0 && (long)(ngraphs + gpb - 1) / gpb >= 4L * device_cus()) {
             const int rows_pb = gpb * a.seg;
-            const size_t fixed = (size_t)rows_pb * nchunk * 16 + (size_t)2 * nchunk * 16 + (size_t)((rows_pb + 2 + 7) & ~7) * 2;
+            const size_t fixed = (size_t)rows_pb * nchunk * 16 + (size_t)6 * nchunk * 16 + (size_t)((rows_pb + 2 + 7) & ~7) * 2;
             const size_t per_slot = 8 + 2;
             const size_t want = (size_t)(2 * (int64_t)g.e_stored / std::max(1, ngraphs) * gpb + 64);
             const size_t lds_total = std::min((size_t)80 * 1024, fixed + want * per_slot + 16);
@@ -899,7 +929,8 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
             PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(edge_rows_fwd_kernel), 160 * 1024, lds_raised_er));
             ProfScope ps("edge_rows_fwd", 0.0, 0.0, s);
             edge_rows_fwd_kernel<<<(g.n + rows_pb - 1) / rows_pb, ER_THREADS, lds_total, s>>>(
-                g.n, rows_pb, nchunk, nb_cap, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi);
+                g.n, rows_pb, nchunk, nb_cap, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi,
+                a.w2, a.b2, g.deg, a.out, a.fo);
             PFN_CHECK_LAUNCH();
             return PFN_OK;
         }
