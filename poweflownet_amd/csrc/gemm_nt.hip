@@ -966,6 +966,98 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last DMA / refills: nothing of this block is in flight past here
 }
 
+
+// ------------------------------------------------------------------------------------- NT, small M (latency)
+// A batch of ONE graph (118 rows: the per-sample latency the reference itself measures, perfomance_evaluator.py:61-74) is four row
+// tiles: the kernels above give each wave a whole tile x all terms -- 260 dependent MFMAs = 7 us on one SIMD while 250 CUs idle --
+// behind a 135 KB weight copy.  Here the K dimension is split ACROSS WAVES: block = one (row tile, 32-column quarter), wave p =
+// term p: its A fragment and its quarter of the term's weight image straight from global memory into registers (34 float4 per lane,
+// both requested at once), 65 MFMAs, the partial tiles summed through LDS in term order, wave 0 runs the epilogue.  The trailing
+// column (129th) is a VALU dot product in the blocks of quarter 0.  Only the shapes that path produces: every piece K = 129, 129
+// output columns, bias or row-scaled bias, optional ReLU, one output.
+constexpr int TINY_MAX_PIECES = 8;
+__global__ __launch_bounds__(64 * TINY_MAX_PIECES) void gemm_nt_tiny_kernel(const NtArgs a) {
+    __shared__ __attribute__((aligned(16))) float part[TINY_MAX_PIECES][17][64];   // [term][16 accumulator values + trailing column][lane]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int p = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31, kh = lane >> 5;
+    const int rt = blockIdx.x, q = blockIdx.y;
+    const NtPiece& pc = a.piece[p];
+    const int lrow = min(r32, a.M - 1 - rt * 32);
+    const float* arow = pc.A + (size_t)(rt * 32) * pc.lda;
+    f32x4 av[NCH], bv[NCH], rv[NCH];
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+        const uint32_t kk = min((uint32_t)(8 * m + 4 * kh), (uint32_t)pc.kmax);
+        av[m] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(arow) + (size_t)lrow * pc.lda * 4 + (size_t)pc.kscale * kk);
+        bv[m] = *reinterpret_cast<const f32x4*>(pc.Bq + (size_t)q * pc.qstride + ((2 * m + kh) * 32 + r32) * 4);
+    }
+    const bool rem = q == 0;
+    if (rem) {
+#pragma unroll
+        for (int m = 0; m < NCH; ++m) rv[m] = *reinterpret_cast<const f32x4*>(pc.Brem + ((2 * m + kh) * 4 + 0) * 4);
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float racc = 0.f;
+#pragma unroll
+    for (int m = 0; m < NCH; ++m) {
+#pragma unroll
+        for (int i = 0; i < (m == NCH - 1 ? 1 : 4); ++i) {       // K = 129: the last chunk carries one real k
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[m][i], bv[m][i], acc, 0, 0, 0);
+            if (rem) racc = fmaf(av[m][i], rv[m][i], racc);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) part[p][i][lane] = acc[i];
+    part[p][16][lane] = racc;
+    __syncthreads();
+    if (p != 0) return;
+    float v16[16];
+    float rsum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v16[i] = 0.f;
+    for (int t2 = 0; t2 < a.npiece; ++t2) {                      // term order: deterministic
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v16[i] += part[t2][i][lane];
+        rsum += part[t2][16][lane];
+    }
+    // ---- epilogue (as gemm_nt_kernel's flush: quad transpose -> four consecutive columns of one row per lane)
+    const int rbase = rt * 32;
+    float* C = a.C[0];
+    const float* cvec = a.rowscale ? a.rowbias : a.bias;
+    const int col0 = 32 * q + (r32 & ~3);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float t4[4] = {v16[4 * g], v16[4 * g + 1], v16[4 * g + 2], v16[4 * g + 3]};
+        quad_transpose(t4, lane);
+        const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
+        if (row < a.M) {
+            const float rs = a.rowscale ? a.rowscale[row] : 1.f;
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int col = col0 + e;
+                float x = t4[e] + ((cvec && col < a.ncols) ? rs * cvec[col] : 0.f);
+                if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
+                o[e] = col < a.ncols ? x : 0.f;
+            }
+            *reinterpret_cast<float4*>(C + act_off(row, col0, a.ldc, a.c_cm_rows)) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    if (rem) {
+        const float tot = rsum + __shfl_xor(rsum, 32);           // the two k halves
+        const int row = rbase + r32;
+        if (kh == 0 && row < a.M) {
+            const float rs = a.rowscale ? a.rowscale[row] : 1.f;
+            float x = tot + (cvec ? rs * cvec[128] : 0.f);
+            if (a.act == ACT_RELU) x = fmaxf(x, 0.f);
+            *reinterpret_cast<float4*>(C + act_off(row, 128, a.ldc, a.c_cm_rows)) = make_float4(x, 0.f, 0.f, 0.f);
+        }
+    }
+}
+
 template <int CT, int VAR>
 static int launch_variant(const NtArgs& k, dim3 grid, size_t lds_bytes, hipStream_t s) {
     static std::atomic<uint64_t> lds_raised{0};
@@ -1091,6 +1183,19 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     // streamed through LDS (gemm_nt_ws_kernel) over the largest row range that is WHOLE rounds of the chip (8 row tiles per CU
     // and round; a wave task there is a full 32 x 129 tile, and 6.3 rounds' worth of tiles would cost 7); the remaining rows go
     // to the stationary kernel below, whose tasks are a quarter of that size
+    if (top) {   // small M: the K dimension split across the waves of a block (gemm_nt_tiny_kernel)
+        static const int tiny_max = diag_env("PFN_NT_TINY_MAX_TILES") ? atoi(diag_env("PFN_NT_TINY_MAX_TILES")) : 16;   // tuning aid; 0 = never
+        bool tiny_ok = tiny_max > 0 && nrt <= tiny_max && nq == 4 && remv == 4 && nrem == 1 && a.ngroup == 1 && !a.gate && !a.resid &&
+                       (a.act == ACT_NONE || a.act == ACT_RELU) && pieces.size() <= (size_t)TINY_MAX_PIECES && !(a.bias && a.rowscale);
+        for (size_t i = 0; i < pieces.size(); ++i) tiny_ok = tiny_ok && pieces[i].klen == KP && last_steps[i] == 1 && pieces[i].group == 0;
+        if (tiny_ok) {
+            k.npiece = (int)pieces.size();
+            for (size_t i = 0; i < pieces.size(); ++i) k.piece[i] = pieces[i];
+            gemm_nt_tiny_kernel<<<dim3(nrt, 4), 64 * k.npiece, 0, s>>>(k);
+            PFN_CHECK_LAUNCH();
+            return PFN_OK;
+        }
+    }
     if (top) {
         static const int ws_min = diag_env("PFN_NT_WS_MIN_TILES") ? atoi(diag_env("PFN_NT_WS_MIN_TILES")) : 2;   // A/B aid; 0 = never
         const long per_round = (long)ncu * NT_WAVES;
