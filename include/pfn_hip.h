@@ -244,7 +244,7 @@ int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  *   PFN_NT_TPS=1|2|4        gemm_nt: at most that many 32-column quarters per LDS slice
  *   PFN_NT_CT=1|2           gemm_nt: quarters per wave
  *   PFN_NT_LS4=1            gemm_nt: four MFMA steps in the last k chunk although K = 129 needs one
- *   PFN_NT_TINY_MAX_TILES=<n> gemm_nt: the split-K small-batch kernel up to n row tiles of 32 rows (default 16; 0 = never)
+ *   PFN_NT_TINY_MAX_TILES=<n> gemm_nt: the split-K small-batch kernel up to n row tiles of 32 rows (default 256; 0 = never)
  *   PFN_NT_WS_MIN_TILES=<n> gemm_nt: weight-streaming kernel from n row tiles per wave (default 2; 0 = never)                     */
 
 /* --------------------------------------------------------------------------------------- profiling

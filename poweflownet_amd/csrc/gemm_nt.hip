@@ -1184,7 +1184,9 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     // and round; a wave task there is a full 32 x 129 tile, and 6.3 rounds' worth of tiles would cost 7); the remaining rows go
     // to the stationary kernel below, whose tasks are a quarter of that size
     if (top) {   // small M: the K dimension split across the waves of a block (gemm_nt_tiny_kernel)
-        static const int tiny_max = diag_env("PFN_NT_TINY_MAX_TILES") ? atoi(diag_env("PFN_NT_TINY_MAX_TILES")) : 16;   // tuning aid; 0 = never
+        static const int tiny_max = diag_env("PFN_NT_TINY_MAX_TILES") ? atoi(diag_env("PFN_NT_TINY_MAX_TILES")) : 256;   // tuning aid; 0 = never
+        // (measured, 4-term + 1-term launches of an inference forward, us per launch tiny / stationary: 4 row tiles 5.6 / 15.5,
+        //  59 tiles 6.7 / 16.4, 118 tiles 9.1 / 16.8, 236 tiles 15.2 / 17.4, 472 tiles 27.9 / 19.5)
         bool tiny_ok = tiny_max > 0 && nrt <= tiny_max && nq == 4 && remv == 4 && nrem == 1 && a.ngroup == 1 && !a.gate && !a.resid &&
                        (a.act == ACT_NONE || a.act == ACT_RELU) && pieces.size() <= (size_t)TINY_MAX_PIECES && !(a.bias && a.rowscale);
         for (size_t i = 0; i < pieces.size(); ++i) tiny_ok = tiny_ok && pieces[i].klen == KP && last_steps[i] == 1 && pieces[i].group == 0;
