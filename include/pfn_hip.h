@@ -238,6 +238,7 @@ int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  *   PFN_NO_CM_INPUT=1       ... and the layer in front of such a TAGConv writes its output row-major instead of chunk-major
  *   PFN_NO_ROW_HOPS=1       TAGConv hops of big batches of small graphs: the two-tile column-slice kernel instead of whole rows per block
  *   PFN_NO_EDGE_ROWS=1      the edge stage of big inference batches of small graphs: the generic gather kernel instead of the LDS-resident one
+ *   PFN_NO_CM_GRAD=1        ... and the layer behind it hands its gradient down row-major instead of chunk-major
  *   PFN_FH_ONE_PER_CU=1     fused hops: whole rows per workgroup (one 125 KB workgroup per CU) instead of two half-LDS ones
  *   PFN_TN_BLOCKS=<n>       gemm_tn: target number of workgroups (default: one per CU)
  *   PFN_TN_NOGROUP=1        gemm_tn: do not co-schedule tasks that share an operand

@@ -640,7 +640,8 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         if (!is_ea(i)) gate.cm = big_cm;     // a TAGConv's input is the EdgeAggregation output before it (model_forward)
         // ... and the gradient an EdgeAggregation hands DOWN to a TAGConv (layers 2, 4, ...: their input is a TAGConv's output) is
         // written chunk-major too: the TAGConv's backward hops, its GEMM and the weight-gradient pairs read it through the flags
-        const int gx_cm = (is_ea(i) && i >= 2) ? big_cm : 0, gout_cm = (!is_ea(i)) ? big_cm : 0;
+        static const bool no_cm_grad = diag_env("PFN_NO_CM_GRAD") != nullptr;   // A/B switch: that gradient stays row-major
+        const int gx_cm = (is_ea(i) && i >= 2 && !no_cm_grad) ? big_cm : 0, gout_cm = (!is_ea(i) && !no_cm_grad) ? big_cm : 0;
         if (is_ea(i)) {
             const int fi = i == 0 ? lo.f0 : lo.h, fo = last ? lo.fo : lo.h;
             EaScratch sc = lo.eas;
