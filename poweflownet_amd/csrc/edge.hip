@@ -612,24 +612,49 @@ __device__ __forceinline__ float dot4(float4 a, float4 b) { return fmaf(a.w, b.w
 // What a (row, chunk) walk needs before its first edge: requested BEFORE the barrier that publishes the block's residue weights
 // (behind it these loads were one more serial round trip; a load cannot move across __syncthreads by itself)
 struct EdgeRowHead { float4 p4; int beg, end, b4, b4n; };
-template <bool MASK>
+// FLY (EdgeFwdArgs::x0): the first layer behind the 4-wide front.  `P` and `Q` are both the N x 4 array x0; the head carries the
+// row's x0 and the walk forms P[row] = b1 + W1i x0[row], Q[src] = W1j x0[src] per chunk with the fma chains of front.hip (same
+// operands, same order: the bits the front would have stored) from weights staged behind the residue weights in LDS.
+template <bool MASK, bool FLY = false>
 __device__ __forceinline__ EdgeRowHead edge_row_head(int row, int col, const int* __restrict__ rowptr, const float* __restrict__ P,
                                                      int ld, const int* __restrict__ rp4) {
     EdgeRowHead hd;
-    hd.p4 = ld4(P + (size_t)row * ld + col);
+    hd.p4 = FLY ? ld4(P + (size_t)row * 4) : ld4(P + (size_t)row * ld + col);
     hd.beg = rowptr[row];
     hd.end = rowptr[row + 1];
     hd.b4 = MASK ? rp4[row] : 0;
     hd.b4n = MASK ? rp4[row + 1] : 0;
     return hd;
 }
-template <int FE, bool MASK>   // MASK: also save the ReLU masks (EdgeFwdArgs::mask) -- a backward pass will follow
+// the front's chains (front.hip): p = b1 + sum_f W1[u][f] x[f], q = sum_f W1[u][4 + f] x[f], f ascending, one fma per term
+__device__ __forceinline__ float4 fly_chain(float4 x, float4 w0, float4 w1, float4 w2, float4 w3, float4 acc) {
+    acc = fma4(x.x, w0, acc);
+    acc = fma4(x.y, w1, acc);
+    acc = fma4(x.z, w2, acc);
+    return fma4(x.w, w3, acc);
+}
+// stages wi [4][ld] | wj [4][ld] | b1 [ld] (zero past H) for the FLY walks
+__device__ __forceinline__ void stage_fly_weights(float* wf, const float* __restrict__ w1, const float* __restrict__ b1, int ld, int h,
+                                                  int ldw) {
+    for (int i = threadIdx.x; i < 9 * ld; i += blockDim.x) {
+        const int f = i / ld, k = i - f * ld;
+        wf[i] = k < h ? (f < 8 ? w1[(size_t)k * ldw + f] : b1[k]) : 0.f;
+    }
+}
+template <int FE, bool MASK, bool FLY = false>   // MASK: also save the ReLU masks (EdgeFwdArgs::mask) -- a backward pass will follow
 __device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored, const int* __restrict__ rowptr,
                                                  const int* __restrict__ nbr, const int* __restrict__ eid,
                                                  const float* __restrict__ P, const float* __restrict__ Q,
                                                  const float* __restrict__ ea, const float* we, int ld, int fe,
                                                  unsigned* __restrict__ mask, const EdgeRowHead& hd) {
-    const float4 p4 = hd.p4;
+    float4 p4 = hd.p4;
+    float4 wj0, wj1, wj2, wj3;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (FLY) {
+        const float* wf = we + fe * ld;          // wi [4][ld] | wj [4][ld] | b1 [ld]
+        p4 = fly_chain(hd.p4, ld4(wf + col), ld4(wf + ld + col), ld4(wf + 2 * ld + col), ld4(wf + 3 * ld + col), ld4(wf + 8 * ld + col));
+        wj0 = ld4(wf + 4 * ld + col); wj1 = ld4(wf + 5 * ld + col); wj2 = ld4(wf + 6 * ld + col); wj3 = ld4(wf + 7 * ld + col);
+    }
     // this (row, chunk)'s run of mask dwords (EdgeFwdArgs::mask): one dword per trip of four slots
     unsigned* mrun = nullptr;
     if (MASK) mrun = mask + (size_t)hd.b4 * (ld >> 2) + (size_t)(col >> 2) * (hd.b4n - hd.b4);
@@ -652,8 +677,12 @@ __device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored,
             float2 a_[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                q_[u] = ld4(Q + (size_t)s_[u] * ld + col);
+                q_[u] = FLY ? ld4(Q + (size_t)s_[u] * 4) : ld4(Q + (size_t)s_[u] * ld + col);
                 a_[u] = *reinterpret_cast<const float2*>(ea + (size_t)id_[u] * 2);
+            }
+            if (FLY) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q_[u] = fly_chain(q_[u], wj0, wj1, wj2, wj3, zero4);
             }
             unsigned mword = 0u;
 #pragma unroll
@@ -680,28 +709,30 @@ __device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored,
     return acc;
 }
 
-template <int FE, bool MASK>
+template <int FE, bool MASK, bool FLY = false>
 __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_stored, const int* __restrict__ rowptr,
                                                        const int* __restrict__ nbr, const int* __restrict__ eid,
                                                        const float* __restrict__ P, const float* __restrict__ Q,
                                                        const float* __restrict__ ea, const float* __restrict__ w1,
                                                        float* __restrict__ S, int ld, int h, int fi, int fe_rt,
-                                                       unsigned* __restrict__ mask, const int* __restrict__ rp4) {
-    extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld]
+                                                       unsigned* __restrict__ mask, const int* __restrict__ rp4,
+                                                       const float* __restrict__ b1) {
+    extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld] (| FLY: wi [4][ld] | wj [4][ld] | b1 [ld])
     const int fe = FE > 0 ? FE : fe_rt;
     const int ldw = 2 * fi + fe;
     const long item = (long)exp_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
     const int row = (int)(item / nchunk);
     const int col = (int)(item - (long)row * nchunk) * 4;
     EdgeRowHead hd;
-    if (row < n) hd = edge_row_head<MASK>(row, col, rowptr, P, ld, rp4);
+    if (row < n) hd = edge_row_head<MASK, FLY>(row, col, rowptr, P, ld, rp4);
     for (int i = threadIdx.x; i < fe * ld; i += blockDim.x) {
         const int f = i / ld, k = i - f * ld;
         we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
     }
+    if (FLY) stage_fly_weights(we + fe * ld, w1, b1, ld, h, ldw);
     __syncthreads();
     if (row >= n) return;
-    st4(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, hd));
+    st4(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK, FLY>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, hd));
 }
 
 // The network's LAST EdgeAggregation layer (Fo <= 4, no activation): the second Linear rides in the same launch.  Block =
@@ -765,6 +796,7 @@ __global__ __launch_bounds__(256) void edge_fwd_out_kernel(int n, int nchunk, in
 constexpr int ER_THREADS = 512;
 constexpr int ER_IPT = 8;                       // (row, chunk) items per thread at most: rows x chunks <= 4,096 per block
 constexpr int ER_NBPT = 4;                      // staged edge slots per thread at most: 2,048 per block
+template <bool FLY>   // FLY (EdgeFwdArgs::x0): P = Q = x0 (N x 4); the tile holds the block's x0 rows, wf the front's weights
 __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int rows_pb, int nchunk, int nb_cap, int e_stored,
                                                                      const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                                      const int* __restrict__ eid, const float* __restrict__ P,
@@ -772,13 +804,14 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
                                                                      const float* __restrict__ w1, float* __restrict__ S, int ld,
                                                                      int h, int fi, const float* __restrict__ w2,
                                                                      const float* __restrict__ b2, const float* __restrict__ deg,
-                                                                     float* __restrict__ out, int fo) {
+                                                                     float* __restrict__ out, int fo, const float* __restrict__ b1) {
     // `out` != null: the network's LAST layer (Fo <= 4): out[row] = S[row] W2^T + deg[row] b2 is formed here and S itself (which
     // only a backward pass reads) is not written
     extern __shared__ __attribute__((aligned(16))) float4 er_tile[];   // Q [rows_pb * nchunk] | we [2 * nchunk] | w2 [4 * nchunk] | ea float2 [nb_cap] | rp u16 | nb u16
-    float4* s_we = er_tile + (size_t)rows_pb * nchunk;
-    float4* s_w2 = s_we + 2 * nchunk;
-    float2* s_ea = reinterpret_cast<float2*>(s_w2 + 4 * nchunk);
+    // (FLY: x0 [rows_pb] | we [2 * nchunk] | wf [9 * nchunk] | ea | rp | nb)
+    float4* s_we = er_tile + (FLY ? (size_t)rows_pb : (size_t)rows_pb * nchunk);
+    float4* s_w2 = s_we + 2 * nchunk;            // (FLY: wi [4] | wj [4] | b1, nchunk float4 each)
+    float2* s_ea = reinterpret_cast<float2*>(s_w2 + (FLY ? 9 : 4) * nchunk);
     unsigned short* s_rp = reinterpret_cast<unsigned short*>(s_ea + nb_cap);
     unsigned short* s_nb = s_rp + ((rows_pb + 2 + 7) & ~7);
     const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0), t = threadIdx.x;
@@ -788,12 +821,17 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
     const int ldw = 2 * fi + 2;
     // every global load of the prologue is requested before the first LDS store (the attributes need their edge id first: two trips)
     float4 q[ER_IPT];
+    if (!FLY) {
 #pragma unroll
-    for (int r = 0; r < ER_IPT; ++r) {
-        const int i = t + r * ER_THREADS;
-        const int row = i / nchunk, lc = i - row * nchunk;
-        q[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < items) q[r] = ld4(Q + (size_t)(r0 + row) * ld + 4 * lc);
+        for (int r = 0; r < ER_IPT; ++r) {
+            const int i = t + r * ER_THREADS;
+            const int row = i / nchunk, lc = i - row * nchunk;
+            q[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < items) q[r] = ld4(Q + (size_t)(r0 + row) * ld + 4 * lc);
+        }
+    } else {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) q[k2] = t + k2 * ER_THREADS < rows ? ld4(Q + (size_t)(r0 + t + k2 * ER_THREADS) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     int rpv[2], nbv[ER_NBPT], idv[ER_NBPT];
 #pragma unroll
@@ -816,14 +854,21 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
         const int id = idv[jn] >= e_stored ? idv[jn] - e_stored : idv[jn];
         eav[jn] = (in_lds && t + jn * ER_THREADS < ne) ? *reinterpret_cast<const float2*>(ea + (size_t)id * 2) : make_float2(0.f, 0.f);
     }
+    if (!FLY) {
 #pragma unroll
-    for (int r = 0; r < ER_IPT; ++r)
-        if (t + r * ER_THREADS < items) er_tile[t + r * ER_THREADS] = q[r];
+        for (int r = 0; r < ER_IPT; ++r)
+            if (t + r * ER_THREADS < items) er_tile[t + r * ER_THREADS] = q[r];
+    } else {
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+            if (t + k2 * ER_THREADS < rows) er_tile[t + k2 * ER_THREADS] = q[k2];
+        stage_fly_weights(reinterpret_cast<float*>(s_w2), w1, b1, ld, h, ldw);
+    }
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2)
         if (t + k2 * ER_THREADS <= rows) s_rp[t + k2 * ER_THREADS] = (unsigned short)(rpv[k2] - e0);
     if (t < 2 * 4 * nchunk) reinterpret_cast<float*>(s_we)[t] = wv[0];
-    if (out) stage_w2(reinterpret_cast<float*>(s_w2), w2, h, fo, ld);
+    if (!FLY && out) stage_w2(reinterpret_cast<float*>(s_w2), w2, h, fo, ld);
     if (in_lds) {
 #pragma unroll
         for (int jn = 0; jn < ER_NBPT; ++jn) {
@@ -840,7 +885,15 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
         const int i = t + r * ER_THREADS;
         if (i >= items) continue;
         const int row = i / nchunk, lc = i - row * nchunk;
-        const float4 p4 = ld4(P + (size_t)(r0 + row) * ld + 4 * lc);
+        float4 p4;
+        float4 wj0, wj1, wj2, wj3;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FLY) {
+            p4 = fly_chain(er_tile[row], s_w2[lc], s_w2[nchunk + lc], s_w2[2 * nchunk + lc], s_w2[3 * nchunk + lc], s_w2[8 * nchunk + lc]);
+            wj0 = s_w2[4 * nchunk + lc]; wj1 = s_w2[5 * nchunk + lc]; wj2 = s_w2[6 * nchunk + lc]; wj3 = s_w2[7 * nchunk + lc];
+        } else {
+            p4 = ld4(P + (size_t)(r0 + row) * ld + 4 * lc);
+        }
         const float4 w0 = s_we[lc], w1v = s_we[nchunk + lc];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         if (in_lds) {
@@ -856,7 +909,7 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
                 }
                 float4 q_[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) q_[u] = er_tile[s_[u] * nchunk + lc];
+                for (int u = 0; u < 4; ++u) q_[u] = FLY ? fly_chain(er_tile[s_[u]], wj0, wj1, wj2, wj3, zero4) : er_tile[s_[u] * nchunk + lc];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     float4 v = add4(p4, q_[u]);
@@ -870,13 +923,13 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
                 int id = eid[p];
                 id = id >= e_stored ? id - e_stored : id;
                 const float2 a2 = *reinterpret_cast<const float2*>(ea + (size_t)id * 2);
-                float4 v = add4(p4, er_tile[(nbr[p] - r0) * nchunk + lc]);
+                float4 v = add4(p4, FLY ? fly_chain(er_tile[nbr[p] - r0], wj0, wj1, wj2, wj3, zero4) : er_tile[(nbr[p] - r0) * nchunk + lc]);
                 v = fma4(a2.x, w0, v);
                 v = fma4(a2.y, w1v, v);
                 acc = add4(acc, relu4(v));
             }
         }
-        if (!out) {
+        if (FLY || !out) {
             st4(S + (size_t)(r0 + row) * ld + 4 * lc, acc);
         } else {   // this chunk's share of the four output dot products; q[] (dead since the prologue) keeps it until the tile is free
             q[r].x = dot4(acc, s_w2[lc]);
@@ -886,7 +939,7 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    if (!out) return;
+    if (FLY || !out) return;
     __syncthreads();                             // every walk is done with the Q tile: it now holds the partials
 #pragma unroll
     for (int r = 0; r < ER_IPT; ++r)
@@ -915,22 +968,35 @@ bool edge_fwd_out_ok(int fe, int h, int fo, int ldo) { return fe == 2 && fo >= 1
 int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
     if (g.n == 0) return PFN_OK;
     const int nchunk = a.ld / 4;
+    const bool fly = a.x0 != nullptr;
+    if (fly && (a.fe != 2 || a.fi != 4 || !a.b1 || a.out || a.P || a.Q)) {
+        set_error("edge stage: P | Q from x0 needs Fi = 4, Fe = 2, a bias and a layer that is not the last (internal)");
+        return PFN_EINVAL;
+    }
     if (a.seg > 0 && a.fe == 2 && !a.mask && g.n % a.seg == 0) {   // inference on a big batch of small graphs
         static const bool off = diag_env("PFN_NO_EDGE_ROWS") != nullptr;      // A/B switch: the generic gather kernel
         const int ngraphs = g.n / a.seg, gpb = edge_rows_graphs_per_block(a.seg, nchunk);
         if (!off && gpb > 0 && (long)(ngraphs + gpb - 1) / gpb >= 4L * device_cus()) {
             const int rows_pb = gpb * a.seg;
-            const size_t fixed = (size_t)rows_pb * nchunk * 16 + (size_t)6 * nchunk * 16 + (size_t)((rows_pb + 2 + 7) & ~7) * 2;
+            const size_t fixed = (fly ? (size_t)rows_pb * 16 + (size_t)11 * nchunk * 16 : (size_t)rows_pb * nchunk * 16 + (size_t)6 * nchunk * 16) +
+                                 (size_t)((rows_pb + 2 + 7) & ~7) * 2;
             const size_t per_slot = 8 + 2;
             const size_t want = (size_t)(2 * (int64_t)g.e_stored / std::max(1, ngraphs) * gpb + 64);
             const size_t lds_total = std::min((size_t)80 * 1024, fixed + want * per_slot + 16);
             const int nb_cap = (int)((lds_total - fixed - 16) / per_slot) & ~3;
-            static std::atomic<uint64_t> lds_raised_er{0};
-            PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(edge_rows_fwd_kernel), 160 * 1024, lds_raised_er));
+            static std::atomic<uint64_t> lds_raised_er{0}, lds_raised_erf{0};
             ProfScope ps("edge_rows_fwd", 0.0, 0.0, s);
-            edge_rows_fwd_kernel<<<(g.n + rows_pb - 1) / rows_pb, ER_THREADS, lds_total, s>>>(
-                g.n, rows_pb, nchunk, nb_cap, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi,
-                a.w2, a.b2, g.deg, a.out, a.fo);
+            if (fly) {
+                PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(edge_rows_fwd_kernel<true>), 160 * 1024, lds_raised_erf));
+                edge_rows_fwd_kernel<true><<<(g.n + rows_pb - 1) / rows_pb, ER_THREADS, lds_total, s>>>(
+                    g.n, rows_pb, nchunk, nb_cap, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.x0, a.x0, a.edge_attr, a.w1, a.S, a.ld, a.h,
+                    a.fi, nullptr, nullptr, g.deg, nullptr, 0, a.b1);
+            } else {
+                PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(edge_rows_fwd_kernel<false>), 160 * 1024, lds_raised_er));
+                edge_rows_fwd_kernel<false><<<(g.n + rows_pb - 1) / rows_pb, ER_THREADS, lds_total, s>>>(
+                    g.n, rows_pb, nchunk, nb_cap, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi,
+                    a.w2, a.b2, g.deg, a.out, a.fo, nullptr);
+            }
             PFN_CHECK_LAUNCH();
             return PFN_OK;
         }
@@ -956,12 +1022,18 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
     }
 #define PFN_EDGE_FWD(FE_, M_)                                                                                                  \
     edge_fwd_kernel<FE_, M_><<<blocks, 256, lds, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q,          \
-                                                      a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe, a.mask, g.rp4)
-    if (a.fe == 2 && a.mask) PFN_EDGE_FWD(2, true);
+                                                      a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe, a.mask, g.rp4, nullptr)
+#define PFN_EDGE_FWD_FLY(M_)                                                                                                   \
+    edge_fwd_kernel<2, M_, true><<<blocks, 256, lds + (size_t)9 * a.ld * sizeof(float), s>>>(                                  \
+        g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.x0, a.x0, a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe, a.mask, g.rp4, a.b1)
+    if (fly && a.mask) PFN_EDGE_FWD_FLY(true);
+    else if (fly) PFN_EDGE_FWD_FLY(false);
+    else if (a.fe == 2 && a.mask) PFN_EDGE_FWD(2, true);
     else if (a.fe == 2) PFN_EDGE_FWD(2, false);
     else if (a.mask) PFN_EDGE_FWD(0, true);
     else PFN_EDGE_FWD(0, false);
 #undef PFN_EDGE_FWD
+#undef PFN_EDGE_FWD_FLY
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
@@ -1398,7 +1470,7 @@ __global__ __launch_bounds__(256) void edge_attr_grad_kernel(int e_stored, const
                                                              const float* __restrict__ P, const float* __restrict__ Q,
                                                              const float* __restrict__ dS, const float* __restrict__ ea,
                                                              const float* __restrict__ w1, float* __restrict__ gea,
-                                                             int ld, int h, int fi, int fe) {
+                                                             int ld, int h, int fi, int fe, float* __restrict__ tmp) {
     // work item: one (destination row, slot) pair = one effective edge; a wave per effective edge
     const int wave = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
@@ -1411,8 +1483,8 @@ __global__ __launch_bounds__(256) void edge_attr_grad_kernel(int e_stored, const
         if (rowptr_in[mid] <= wave) lo = mid; else hi = mid;
     }
     const int dst = lo, src = in_src[wave];
-    int id = in_eid[wave];
-    id = id >= e_stored ? id - e_stored : id;
+    const int id_copy = in_eid[wave];            // [0, 2 e_stored): the stored edge, or e_stored + the stored edge for its mirror copy
+    const int id = id_copy >= e_stored ? id_copy - e_stored : id_copy;
     const int ldw = 2 * fi + fe;
     float part[PFN_MAX_FE];
     for (int f = 0; f < fe; ++f) part[f] = 0.f;
@@ -1425,8 +1497,17 @@ __global__ __launch_bounds__(256) void edge_attr_grad_kernel(int e_stored, const
     for (int f = 0; f < fe; ++f) {
         float v = part[f];
         for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-        if (lane == 0) atomicAdd(&gea[(size_t)id * fe + f], v);   // at most two copies per stored edge
+        if (lane != 0) continue;
+        if (tmp) tmp[(size_t)id_copy * fe + f] = v;   // one slot per copy; edge_attr_grad_fold_kernel adds them in a fixed order
+        else atomicAdd(&gea[(size_t)id * fe + f], v);   // single layer, gea zeroed by the caller: at most two terms, order-free
     }
+}
+// gea[e][f] += tmp[e][f] + tmp[e_stored + e][f]: a network's layers all add into one gea, and with atomics three or more terms met
+// in an order that changed from run to run (last-bit differences); tmp is zeroed per layer (a copy that does not exist adds 0)
+__global__ __launch_bounds__(256) void edge_attr_grad_fold_kernel(long count, long mirror, const float* __restrict__ tmp,
+                                                                  float* __restrict__ gea) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) gea[i] += tmp[i] + tmp[mirror + i];
 }
 
 int launch_edge_attr_grad(const GraphView& g, const EdgeBwdArgs& a, hipStream_t s) {
@@ -1439,9 +1520,15 @@ int launch_edge_attr_grad(const GraphView& g, const EdgeBwdArgs& a, hipStream_t 
     // backward pass (pfn_mpn_backward, pfn_edge_aggr_backward).  A memset here made the model-level gradient the LAST layer's alone.
     const long waves = 2l * g.e_stored;   // upper bound on effective edges
     const int blocks = (int)((waves * 64 + 255) / 256);
+    const long count = (long)g.e_stored * a.fe;
+    if (a.gea_tmp) PFN_CHECK_HIP(hipMemsetAsync(a.gea_tmp, 0, (size_t)2 * count * sizeof(float), s));
     edge_attr_grad_kernel<<<blocks, 256, 0, s>>>(g.e_stored, g.rowptr_in, g.in_src, g.in_eid, g.n, a.P, a.Q, a.dS,
-                                                 a.edge_attr, a.w1, a.grad_edge_attr, a.ld, a.h, a.fi, a.fe);
+                                                 a.edge_attr, a.w1, a.grad_edge_attr, a.ld, a.h, a.fi, a.fe, a.gea_tmp);
     PFN_CHECK_LAUNCH();
+    if (a.gea_tmp) {
+        edge_attr_grad_fold_kernel<<<(int)((count + 255) / 256), 256, 0, s>>>(count, count, a.gea_tmp, a.grad_edge_attr);
+        PFN_CHECK_LAUNCH();
+    }
     return PFN_OK;
 }
 

@@ -115,7 +115,7 @@ __device__ __forceinline__ void front_fwd_body(const FrontFwdArgs& a, int bid, i
             st4f(a.x0 + (size_t)row * 4, o);
         }
         __syncthreads();
-        if (on) {
+        if (on && a.P) {                            // (P null: the first edge stage forms P | Q rows from x0 itself, edge.hip FLY)
             const float4 v = vec[r];
             float p[4], q[4];
 #pragma unroll
@@ -207,7 +207,7 @@ __device__ __forceinline__ void front_fwd_wave_body(const FrontFwdArgs& a, int b
             st4f(a.maskf + (size_t)row * 4, m);
             st4f(a.x0 + (size_t)row * 4, o);
         }
-        if (lane_on) {
+        if (lane_on && a.P) {
             float pv[4], qv[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -224,8 +224,83 @@ __device__ __forceinline__ void front_fwd_wave_body(const FrontFwdArgs& a, int b
     }
 }
 
+// Inference behind an edge stage that forms P | Q itself (EdgeFwdArgs::x0): nothing H-wide is written (no me_h, no P | Q), the
+// front's whole output is 32 bytes per row.  One THREAD per row then: every weight index is uniform across the wave (scalar
+// loads, the values ride in SGPRs), no LDS, no barriers, coalesced 16-byte loads and stores.  (The block kernel, whose 33
+// chunk-lanes per row exist to make H-wide stores coalesced, took 92 us for 241,664 rows with nothing left to store.)
+// x0's four dot products are summed in the BLOCK kernel's order -- per chunk of four units an fma chain from zero, chunk k into
+// sub-sum k % 8 in chunk order, the eight sub-sums in order (row_sum) -- so a forward pass under no_grad returns the bits of a
+// training forward (which stores me_h and takes the block kernel); eight independent chains also hide the fma latency.
+__device__ __forceinline__ void front_fwd_thread_body(const FrontFwdArgs& a, int bid, int nblk, int nchunk) {
+    const int n = a.n, h = a.h;
+    const float4 bb4 = make_float4(a.bb[0], a.bb[1], a.bb[2], a.bb[3]);
+    // (read through the constant address space: the compiler then issues SCALAR loads for these wave-uniform addresses; as plain
+    //  global pointers inside a struct it could not prove the weights read-only and emitted ~1,160 vector loads per row)
+    typedef const float __attribute__((address_space(4))) * cptr;
+    const cptr wa = (cptr)a.wa, ba = (cptr)a.ba, wb = (cptr)a.wb;
+    for (int row = bid * 256 + (int)threadIdx.x; row < n; row += nblk * 256) {
+        float4 m;                                   // pred_mask.float() (networks/MPN.py:533)
+        if (a.mask_dtype == 0) {
+            const int64_t* mp = static_cast<const int64_t*>(a.mask) + (size_t)row * 4;
+            m = make_float4((float)mp[0], (float)mp[1], (float)mp[2], (float)mp[3]);
+        } else {
+            m = ld4f(static_cast<const float*>(a.mask) + (size_t)row * 4);
+        }
+        const float4 xi = ld4f(a.x + (size_t)row * 4);
+        float4 sub[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sub[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (units past H: the block kernel multiplies zeroed weights there, i.e. adds exact zeros -- skipped here)
+#define PFN_FRONT_UNIT(u_)                                                                                                      \
+    {                                                                                                                           \
+        float v = ba[u_];                                                                                                       \
+        v = fmaf(wa[4 * (u_)], m.x, v); v = fmaf(wa[4 * (u_) + 1], m.y, v); v = fmaf(wa[4 * (u_) + 2], m.z, v);                 \
+        v = fmaf(wa[4 * (u_) + 3], m.w, v);                                                                                     \
+        v = fmaxf(v, 0.f);                                                                                                      \
+        acc.x = fmaf(wb[u_], v, acc.x); acc.y = fmaf(wb[h + (u_)], v, acc.y);                                                   \
+        acc.z = fmaf(wb[2 * h + (u_)], v, acc.z); acc.w = fmaf(wb[3 * h + (u_)], v, acc.w);                                     \
+    }
+        const int nfull8 = (h >> 2) & ~7;           // chunks that come in branch-free groups of eight whole chunks (a branch per
+        int k0 = 0;                                 // unit made every scalar weight load wait for the one before it: 41 us)
+        for (; k0 < nfull8; k0 += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) PFN_FRONT_UNIT(4 * (k0 + j) + i)
+                sub[j].x += acc.x; sub[j].y += acc.y; sub[j].z += acc.z; sub[j].w += acc.w;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {               // the last group: chunks and units may run out (uniform branches)
+            const int k = k0 + j;
+            if (k >= nchunk) break;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = 4 * k + i;
+                if (u >= h) break;
+                PFN_FRONT_UNIT(u)
+            }
+            sub[j].x += acc.x; sub[j].y += acc.y; sub[j].z += acc.z; sub[j].w += acc.w;
+        }
+#undef PFN_FRONT_UNIT
+        float4 t = sub[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) {
+            if (j >= nchunk) break;
+            t.x += sub[j].x; t.y += sub[j].y; t.z += sub[j].z; t.w += sub[j].w;
+        }
+        st4f(a.maskf + (size_t)row * 4, m);
+        st4f(a.x0 + (size_t)row * 4, make_float4(xi.x + (t.x + bb4.x), xi.y + (t.y + bb4.y), xi.z + (t.z + bb4.z), xi.w + (t.w + bb4.w)));
+    }
+}
+
 // Blocks [0, nb_front) run the front, the rest the weight re-layout jobs of the same forward pass (block p -> job p / pack_bx,
 // share p % pack_bx): two independent pieces of work, one launch floor (~5 us) less per step.
+// (one instantiation per front body -- MODE 0: one row per wave, 1: block per row group, 2: one row per thread -- so that each
+//  gets its own register allocation: as one kernel the thread body's unrolled groups cost the block body its occupancy)
+template <int MODE>
 __global__ __launch_bounds__(256) void front_pack_kernel(const FrontFwdArgs f, const PackArgs pa, int nb_front, int pack_bx,
                                                          int ld, int nchunk, int rows_pb) {
     extern __shared__ __attribute__((aligned(16))) float4 fl[];
@@ -233,7 +308,8 @@ __global__ __launch_bounds__(256) void front_pack_kernel(const FrontFwdArgs f, c
     if (pa.rng_advance && blockIdx.x == 0 && threadIdx.x == 0) pa.rng_advance[1] += 1;
     slot_ea_body(pa.slot_ea, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
     if ((int)blockIdx.x < nb_front) {
-        if (rows_pb == 0) front_fwd_wave_body(f, blockIdx.x, nb_front, ld, nchunk);   // (rows_pb == 0: one row per wave)
+        if (MODE == 2) front_fwd_thread_body(f, blockIdx.x, nb_front, nchunk);
+        else if (MODE == 0) front_fwd_wave_body(f, blockIdx.x, nb_front, ld, nchunk);
         else front_fwd_body(f, blockIdx.x, nb_front, ld, nchunk, rows_pb, fl);
         return;
     }
@@ -432,6 +508,9 @@ static bool front_row_per_wave(int nchunk, int n) {
     static const bool off = diag_env("PFN_FRONT_BLOCK_ROWS") != nullptr;   // A/B switch: the block-per-row-group kernels
     return !off && nchunk <= 64 && n <= wave_max_rows();
 }
+// Few rows (the latency regime, where one row per wave serves): the front keeps writing the first layer's P | Q and the edge walk
+// gathers them -- forming them in the walk cost more than it saved there (118 rows: edge stage 2.0 -> 2.8 us; 15 k rows: 8.0 -> 12.3 us)
+bool front_latency_regime(int h, int n) { return front_row_per_wave(ld_of(h) / 4, n); }
 static void front_shape(int h, int& ld, int& nchunk, int& rows_pb, size_t& lds) {
     ld = ld_of(h);
     nchunk = ld / 4;
@@ -463,18 +542,57 @@ int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs,
     }
     const int pack_bx = (int)std::min<long>(std::max<long>(1, (biggest + 255) / 256), 64);
     const bool per_wave = front_row_per_wave(nchunk, f.n);
-    if (per_wave) {   // one row per wave: four rows per 256-thread block, no LDS
-        rows_pb = 0;
+    static const bool no_thread_rows = diag_env("PFN_FRONT_NO_THREAD_ROWS") != nullptr;   // A/B switch
+    const bool per_thread = !per_wave && !f.P && !f.me_h && !no_thread_rows;   // (instead of the block kernel: same bits)
+    if (per_wave || per_thread) {   // one row per wave: four rows per 256-thread block, no LDS
+        rows_pb = per_thread ? -1 : 0;
         lds = 0;
     }
-    const int nb_front = f.n > 0 ? std::min((f.n + (per_wave ? 4 : rows_pb) - 1) / (per_wave ? 4 : rows_pb), (per_wave ? wave_blocks_per_cu(0) : 8) * device_cus()) : 0;
+    const int rows_per_block = per_thread ? 256 : per_wave ? 4 : rows_pb;
+    const int nb_front = f.n > 0 ? std::min((f.n + rows_per_block - 1) / rows_per_block, (per_thread ? 16 : per_wave ? wave_blocks_per_cu(0) : 8) * device_cus()) : 0;
     const int nblocks = nb_front + pack_bx * pa.njobs;
     if (nblocks > 0 || rng_advance) {
         ProfScope ps("front_fwd+pack", 0.0, 0.0, s);
-        front_pack_kernel<<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
+        if (per_thread) front_pack_kernel<2><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
+        else if (per_wave) front_pack_kernel<0><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
+        else front_pack_kernel<1><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
         PFN_CHECK_LAUNCH();
     }
     if (njobs > pa.njobs) return launch_pack(jobs + pa.njobs, njobs - pa.njobs, nullptr, s);
+    return PFN_OK;
+}
+
+// P | Q of the first EdgeAggregation layer written out after the fact, with the front's own fma chains (bit-identical to what the
+// front stores and to what the edge stage forms on the fly): for the callers that need the rows in memory when the forward pass
+// skipped them -- a backward pass that was asked for edge-attribute gradients, the gate export.  Thread = (row, chunk).
+__global__ __launch_bounds__(256) void front_pq_kernel(int n, int h, int ld, int nchunk, int ldw1, const float* __restrict__ x0,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       float* __restrict__ P, float* __restrict__ Q) {
+    const long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = (int)(item / nchunk), c = (int)(item - (long)row * nchunk);
+    if (row >= n) return;
+    const float4 v = ld4f(x0 + (size_t)row * 4);
+    float p[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = 4 * c + i, uc = min(u, h - 1);
+        const float* w = w1 + (size_t)uc * ldw1;
+        float pa = b1[uc];
+        pa = fmaf(w[0], v.x, pa); pa = fmaf(w[1], v.y, pa); pa = fmaf(w[2], v.z, pa); pa = fmaf(w[3], v.w, pa);
+        float qb = 0.f;
+        qb = fmaf(w[4], v.x, qb); qb = fmaf(w[5], v.y, qb); qb = fmaf(w[6], v.z, qb); qb = fmaf(w[7], v.w, qb);
+        p[i] = u < h ? pa : 0.f;
+        q[i] = u < h ? qb : 0.f;
+    }
+    st4f(P + (size_t)row * ld + 4 * c, make_float4(p[0], p[1], p[2], p[3]));
+    st4f(Q + (size_t)row * ld + 4 * c, make_float4(q[0], q[1], q[2], q[3]));
+}
+int launch_front_pq(int n, int h, int ldw1, const float* x0, const float* w1, const float* b1, float* P, float* Q, hipStream_t s) {
+    if (n == 0) return PFN_OK;
+    const int ld = ld_of(h), nchunk = ld / 4;
+    ProfScope ps("front_pq", 0.0, 0.0, s);
+    front_pq_kernel<<<(int)(((long)n * nchunk + 255) / 256), 256, 0, s>>>(n, h, ld, nchunk, ldw1, x0, w1, b1, P, Q);
+    PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
 

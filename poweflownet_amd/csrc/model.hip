@@ -91,7 +91,7 @@ typedef Deferred PairList;
 
 // ---------------------------------------------------------------------------------- EdgeAggregation
 struct EaSaved { float *P, *Q, *S; };
-struct EaScratch { float *dS, *dP, *dQ, *dWe; ReduceWs red; };
+struct EaScratch { float *dS, *dP, *dQ, *dWe; ReduceWs red; float* gea_tmp = nullptr; };
 struct EaPack { const float *w1i_t, *w1j_t, *w2_t, *w2_d, *w1i_d, *w1j_d; };
 
 static EaPack ea_pack(Packer& pk, int fi, int fe, int h, int fo, const float* w1, const float* w2) {
@@ -114,7 +114,7 @@ static bool back_fused_ok() {
 static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
                       const float* w1, const float* b1, const float* w2, const float* b2, const EaPack& pw, float* out, int ldo,
                       const Act& act, const EaSaved& sv, hipStream_t s, bool pq_ready = false, int seg = 0,
-                      const float* ea_in = nullptr, unsigned* relu_mask = nullptr) {
+                      const float* ea_in = nullptr, unsigned* relu_mask = nullptr, bool pq_fly = false) {
     const int ld = ld_of(h);
     // batches of small graphs: the P | Q GEMM and the edge walk in one launch, graph-resident in LDS (ea_seg.hip)
     const bool seg_walk = !pq_ready && ea_in && ea_seg_fit(seg, g.n, fe, ld, false);
@@ -139,6 +139,11 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
         EdgeFwdArgs e{sv.P, sv.Q, ea, w1, sv.S, ld, h, fi, fe};
         e.mask = relu_mask;   // (a backward pass will follow: it reads the masks instead of recomputing the pre-activations)
         e.seg = seg;
+        if (pq_fly) {         // layer 0 behind the front: P | Q were not written, the walk forms them from x0 (first_layer_fly)
+            e.P = e.Q = nullptr;
+            e.x0 = x;
+            e.b1 = b1;
+        }
         if (out_in_walk) {
             e.out = out;
             e.w2 = w2;
@@ -194,6 +199,7 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
     }
     EdgeBwdArgs e{sv.P, sv.Q, sc.dS, ea, w1, sc.dP, sc.dQ, sc.dWe, gea, ld, h, fi, fe};
     if (!gea && fe == 2) e.mask = relu_mask;   // written by this layer's generic forward walk (ea_saves_mask)
+    e.gea_tmp = sc.gea_tmp;
     if (ds_in_walk) {
         e.gout = gout;
         e.w2 = w2;
@@ -497,6 +503,7 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     lo.dh = cv.take<float>(nld);
     lo.eas.dS = cv.take<float>(nld);
     lo.eas.dP = lo.eas.dQ = lo.eas.dWe = nullptr;
+    lo.eas.gea_tmp = cv.take<float>((size_t)2 * e * lo.fe);   // (edge-attribute gradients: one slot per edge copy, edge.hip)
     lo.tags.G = cv.take<float>(nld * (lo.K + 1));
     lo.tags.z0 = cv.take<float>(nld);
     lo.tags.z1 = cv.take<float>(nld);
@@ -516,6 +523,16 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
 static bool ea_saves_mask(const pfn_mpn_config& c, const Layout& lo, int seg, bool fused_front, int i) {
     const bool generic_fwd = !ea_seg_fit(seg, lo.n, lo.fe, lo.ld, false) || (fused_front && i == 0);
     return c.need_backward != 0 && lo.fe == 2 && generic_fwd && !ea_seg_fit(seg, lo.n, lo.fe, lo.ld, true);
+}
+
+// Layer 0 behind the 4-wide front: are its P | Q rows left unwritten (the edge walk forms them from the 16-byte x0 rows with
+// the front's own fma chains, edge.hip FLY)?  Yes when nothing later reads them from memory: inference, or a training pass whose
+// backward walks read the saved ReLU masks.  (A backward pass that was asked for edge-attribute gradients and the gate export
+// write the rows then, launch_front_pq.)  Forward, backward and the export evaluate the same predicate.
+static bool first_layer_fly(const pfn_mpn_config& c, const Layout& lo, int seg, bool fused_front) {
+    static const bool off = diag_env("PFN_NO_L0_FLY") != nullptr;   // A/B switch: the front writes P | Q, the walk gathers them
+    return !off && fused_front && lo.nlayers > 1 && lo.fe == 2 && lo.f0 == 4 && !front_latency_regime(lo.h, lo.n) &&
+           (c.need_backward == 0 || ea_saves_mask(c, lo, seg, fused_front, 0));
 }
 
 static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
@@ -538,6 +555,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     }
     // mask_embd(mask) + x   (networks/MPN.py:533,:537)
     const bool fused_front = front_fused_ok(lo.f0, lo.h);
+    const bool l0_fly = first_layer_fly(c, lo, seg, fused_front);
     if (fused_front) {
         // ONE launch: the weight re-layout (which also advances the dropout stream for this forward) next to the front --
         // pred_mask.float(), mask_embd, the residual add and the first EdgeAggregation's P | Q (front.hip)
@@ -545,7 +563,9 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         f.n = lo.n; f.h = lo.h; f.ldw1 = 2 * lo.f0 + lo.fe; f.mask_dtype = mask_dtype;
         f.x = x; f.mask = pred_mask;
         f.wa = me[0]; f.ba = me[1]; f.wb = me[2]; f.bb = me[3]; f.w1 = params[0]; f.b1 = params[1];
-        f.maskf = lo.maskf; f.me_h = c.need_backward ? lo.me_h : nullptr; f.x0 = lo.x0; f.P = lo.ea[0].P; f.Q = lo.ea[0].Q;
+        f.maskf = lo.maskf; f.me_h = c.need_backward ? lo.me_h : nullptr; f.x0 = lo.x0;
+        f.P = l0_fly ? nullptr : lo.ea[0].P;
+        f.Q = l0_fly ? nullptr : lo.ea[0].Q;
         PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s, seg_ea ? &se : nullptr));
     } else {
         // ... the pack launch also advances the dropout stream for this forward and converts pred_mask to float32
@@ -590,7 +610,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
             const int fo = last ? lo.fo : lo.h;
             PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
                                params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0, seg, seg_ea ? lo.ea_in : nullptr,
-                               ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr));
+                               ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr, l0_fly && i == 0));
             pi += 4;
             fcur = fo;
         } else {
@@ -648,6 +668,9 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
             sc.dP = lo.dP[i];
             sc.dQ = lo.dQ[i];
             sc.dWe = lo.dWe[i];
+            // the forward pass left layer 0's P | Q unwritten and the edge-attribute gradient recomputes the pre-activations
+            if (i == 0 && gea && first_layer_fly(c, lo, seg, fused_front))
+                PFN_TRY(launch_front_pq(lo.n, lo.h, 2 * lo.f0 + lo.fe, lo.x0, params[0], params[1], lo.ea[0].P, lo.ea[0].Q, s));
             // (layer 0 with the fused front: its input gradient is formed together with mask_embd's, below)
             PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], params[p0 + 2], mp.ea[i], gcur, ldg, gate,
                                 (fused_front && i == 0) ? nullptr : gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2],
@@ -1025,6 +1048,8 @@ int pfn_mpn_export_gates(const pfn_mpn_config* c, const void* gws, int64_t n, in
         int pi = 0;
         for (int i = 0; i < layer; ++i) pi += is_ea(i) ? 4 : lo.K + 2;
         const int fi = layer == 0 ? lo.f0 : lo.h;
+        if (layer == 0 && first_layer_fly(*c, lo, (int)seg_nodes, front_fused_ok(lo.f0, lo.h)))   // (the forward left them unwritten)
+            PFN_TRY(launch_front_pq(lo.n, lo.h, 2 * lo.f0 + lo.fe, lo.x0, params[0], params[1], lo.ea[0].P, lo.ea[0].Q, s));
         export_edge_gates_kernel<<<blocks, 256, 0, s>>>(g.n, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, lo.ea[layer].P, lo.ea[layer].Q,
                                                        edge_attr, params[pi], lo.ld, lo.h, fi, lo.fe, out);
     } else if (kind == 1) {

@@ -322,6 +322,10 @@ struct EdgeFwdArgs {
     int fo = 0;
     int seg = 0;                     // > 0: the batch is a union of graphs of this many nodes (pfn_graph_segments): big batches of
                                      // small graphs take edge_rows_fwd_kernel (the graph's Q rows LDS-resident)
+    // first layer behind the 4-wide front (Fi = 4, Fe = 2): P and Q null, the walk forms P[i] = b1 + W1i x0[i] and Q[j] = W1j x0[j]
+    // from the 16-byte x0 rows itself, with the front's fma chains (front.hip) -- 2 N H floats neither written nor read back
+    const float* x0 = nullptr;
+    const float* b1 = nullptr;
 };
 bool edge_fwd_out_ok(int fe, int h, int fo, int ldo);
 int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s);
@@ -376,6 +380,8 @@ struct EdgeBwdArgs {
     const float* w2 = nullptr;
     int fo = 0;
     const unsigned* mask = nullptr;        // the forward walk's ReLU masks (Fe = 2): P, Q and the residue weights are not read
+    float* gea_tmp = nullptr;              // optional [2 e_stored][fe] scratch: grad_edge_attr accumulates in a fixed order (a network's
+                                           // layers all add into it); null: atomics, order-free only for a zeroed grad_edge_attr
 };
 int edge_bwd_dst_blocks(const GraphView& g, int ld);   // number of dWe partials the dst walk emits (<= 1024)
 int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t* edge_index_unused, hipStream_t s);
@@ -442,6 +448,7 @@ int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, 
 // front.hip: mask_embd + residual + the first EdgeAggregation's P | Q in one launch (forward), and the gradient w.r.t. x0 +
 // mask_embd's hidden-layer gradient in one launch (backward).  Only for nfeature_dim == 4 (what the reference asserts).
 bool front_fused_ok(int f0, int h);
+bool front_latency_regime(int h, int n);   // few rows: one row per wave, P | Q of the first layer stored (front.hip)
 // the last layer's second Linear (Fo <= 4) as one row per wave, for small batches (front.hip)
 bool lin_out4_ok(int h, int fo, int ldo, int n);
 int launch_lin_out4(int n, int h, int fo, const float* S, const float* w2, const float* b2, const float* deg, float* out,
@@ -451,13 +458,16 @@ struct FrontFwdArgs {
     const float* x;
     const void* mask;
     const float *wa, *ba, *wb, *bb, *w1, *b1;
-    float *maskf, *me_h, *x0, *P, *Q;      // maskf: pred_mask.float() (networks/MPN.py:533), kept for the weight gradients
+    float *maskf, *me_h, *x0, *P, *Q;      // maskf: pred_mask.float() (networks/MPN.py:533), kept for the weight gradients;
+                                           // P, Q null: not written (the first edge stage forms them from x0, EdgeFwdArgs::x0)
 };
 // the front AND the weight re-layout of a forward pass (independent of each other) in one launch; `rng_advance` as in launch_pack
 int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s,
                           const SlotEa* slot_ea = nullptr);
 int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, const float* me_h, const float* w1,
                      const float* wb, float* g0, float* dh, hipStream_t s);
+// P | Q of the first layer written from x0 after the fact (FrontFwdArgs::P null in the forward pass), bit-identical to the front's
+int launch_front_pq(int n, int h, int ldw1, const float* x0, const float* w1, const float* b1, float* P, float* Q, hipStream_t s);
 
 // ------------------------------------------------------------------------------------ small kernels
 int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t f,

@@ -827,6 +827,57 @@ torch.save({{"out": out.detach().cpu(), "gx": d.x.grad.cpu(), "g": m.flat_grad()
         assert_close(res[tag]["g"], res["generic"]["g"], RTOL, f"{tag}: flat parameter gradient")
 
 
+def test_first_layer_pq_from_x0_is_bit_identical_to_stored_pq(tmp_path):
+    """Beyond the latency regime (> 32,768 rows) the first EdgeAggregation layer's P | Q rows are not written when nothing reads
+    them from memory (inference; training whose backward walks read saved ReLU masks): the edge walk forms them from the 16-byte
+    x0 rows with the front's own fma chains (edge.hip FLY, model.hip first_layer_fly), and the inference front, left with 32
+    bytes of output per row, runs one row per thread with the block kernel's summation order (front.hip).  Same operands in the
+    same order -> the SAME BITS as the path that stores and gathers the rows (PFN_NO_L0_FLY=1) and as the block front
+    (PFN_FRONT_NO_THREAD_ROWS=1; switches are read once per process -> child processes): outputs, every gradient, and the
+    exported edge gates of layer 0 (which, like a backward pass asked for edge-attribute gradients, first writes the rows:
+    launch_front_pq).  Covers the generic walk with and without mask saving (300 graphs x 118 buses, graph-resident kernels off)
+    and the LDS-resident rows kernel (1,100 graphs)."""
+    import os
+    import subprocess
+    import sys
+    script = f"""
+import sys, torch
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+from poweflownet_amd.synth import make_batch
+torch.manual_seed(3)
+m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.0).to("cuda:0").eval()
+res = {{}}
+d = make_batch("118", 300, seed=4).to("cuda:0")
+d.x.requires_grad_(True)
+out = m(d)                                        # training-mode autograd, masks saved (the graph-resident kernels are off)
+res["gates0"] = m.export_gates()["edge"][0].cpu()
+torch.nn.MSELoss()(out, d.y).backward()
+res["out"], res["gx"], res["g"] = out.detach().cpu(), d.x.grad.cpu(), m.flat_grad().cpu()
+m.zero_grad(set_to_none=True)
+d2 = make_batch("118", 300, seed=5).to("cuda:0")
+d2.edge_attr.requires_grad_(True)                 # edge-attribute gradient: the backward recomputes pre-activations from P | Q
+out2 = m(d2)
+torch.nn.MSELoss()(out2, d2.y).backward()
+res["out2"], res["gea"], res["g2"] = out2.detach().cpu(), d2.edge_attr.grad.cpu(), m.flat_grad().cpu()
+with torch.no_grad():
+    res["inf_generic"] = m(d).cpu()
+    res["inf_rows"] = m(make_batch("118", 1100, seed=7).to("cuda:0")).cpu()
+torch.save(res, sys.argv[1])
+"""
+    res = {}
+    for tag, env in (("fly", {"PFN_NO_SEG_EA": "1"}), ("stored", {"PFN_NO_SEG_EA": "1", "PFN_NO_L0_FLY": "1"}),
+                     ("block_front", {"PFN_NO_SEG_EA": "1", "PFN_FRONT_NO_THREAD_ROWS": "1"})):
+        path = str(tmp_path / f"{tag}.pt")
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=300)
+        res[tag] = torch.load(path)
+    for tag in ("stored", "block_front"):
+        for key in res["fly"]:
+            assert torch.equal(res["fly"][key], res[tag][key]), f"{key}: default path differs from {tag}"
+    assert res["fly"]["gea"].abs().max() > 0 and res["fly"]["inf_rows"].abs().max() > 0
+    assert torch.equal(res["fly"]["inf_generic"], res["fly"]["out"])   # (no_grad forward = training forward, bit for bit)
+
+
 def test_two_models_two_streams_two_threads_do_not_share_state():
     """The library holds no stream / event / device binding of its own (include/pfn_hip.h): two models, each on its own
     torch stream, driven (a) interleaved from one thread and (b) concurrently from two host threads, produce
