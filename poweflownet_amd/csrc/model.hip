@@ -52,7 +52,7 @@ struct Packer {
         off += packed_floats(K, ld_out);
         PackJob j;
         j.src = W; j.dst = dst; j.ldw = ldw; j.wk0 = wk0; j.wn0 = wn0; j.trans = trans; j.K = K; j.ncols = ncols;
-        j.ld_out = ld_out; j.pad_ = 0;
+        j.ld_out = ld_out; j.split = pack_wants_split(K, ld_out) ? 1 : 0;
         jobs.push_back(j);
         return dst ? dst : reinterpret_cast<const float*>(0x10);   // non-null sentinel while measuring
     }

@@ -878,6 +878,42 @@ torch.save(res, sys.argv[1])
     assert torch.equal(res["fly"]["inf_generic"], res["fly"]["out"])   # (no_grad forward = training forward, bit for bit)
 
 
+def test_bf16_split_gemm_experiment_matches_fp32_mfma_path(tmp_path):
+    """The opt-in large-M GEMM kernel (gemm_nt_bx_kernel, PFN_NT_BX_MIN_TILES=1: from one row tile per wave = 65,536 rows): every
+    fp32 operand is split EXACTLY into three bf16 parts, the nine bf16 x bf16 partial products (each exact in fp32) are accumulated
+    in fp32 on v_mfma_f32_32x32x16_bf16 -- no operand rounding, so outputs and gradients agree with the fp32-MFMA kernels to fp32
+    summation-order tolerance.  600 graphs x 118 buses = 70,800 rows (ragged last row tile), graph-resident kernels off so that
+    every 129 x 129 product of forward and backward takes the GEMM path; switches are read once per process -> child processes."""
+    import os
+    import subprocess
+    import sys
+    script = f"""
+import sys, torch
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+from poweflownet_amd.synth import make_batch
+torch.manual_seed(3)
+m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.0).to("cuda:0").eval()
+d = make_batch("118", 600, seed=4).to("cuda:0")
+d.x.requires_grad_(True)
+out = m(d)
+torch.nn.MSELoss()(out, d.y).backward()
+torch.save({{"out": out.detach().cpu(), "gx": d.x.grad.cpu(), "g": m.flat_grad().cpu()}}, sys.argv[1])
+"""
+    res = {}
+    for tag, env in (("fp32", {"PFN_NO_SEG_EA": "1"}), ("bf16x9", {"PFN_NO_SEG_EA": "1", "PFN_NT_BX_MIN_TILES": "1"})):
+        path = str(tmp_path / f"{tag}.pt")
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=300)
+        res[tag] = torch.load(path)
+    assert not torch.equal(res["bf16x9"]["out"], res["fp32"]["out"])       # (the other kernel did run)
+    assert_close(res["bf16x9"]["out"], res["fp32"]["out"], RTOL, "bf16-split GEMM: out")
+    # gradients: the two forward passes differ in the last bits, so a few of the 70,800 x 129 ReLU pre-activations that sit at zero
+    # land on the other side (the full-size oracle checks equalise the gates for exactly this reason, _assert_grads_on_hip_gates);
+    # each flip moves a gradient entry by a discrete amount
+    assert_close(res["bf16x9"]["g"], res["fp32"]["g"], 1e-3, "bf16-split GEMM: flat parameter gradient")
+    assert_close(res["bf16x9"]["gx"], res["fp32"]["gx"], 1e-2, "bf16-split GEMM: grad x")
+
+
 def test_two_models_two_streams_two_threads_do_not_share_state():
     """The library holds no stream / event / device binding of its own (include/pfn_hip.h): two models, each on its own
     torch stream, driven (a) interleaved from one thread and (b) concurrently from two host threads, produce
