@@ -414,6 +414,9 @@ def main():
         L.profile_enable(False)
         rep = L.profile_report(reset=True)
         ab = alg_bytes(n_nodes, e_eff, h, 2, K, train)
+        # beyond 32,768 rows the first layer's P | Q are formed in the edge walk from x0 (inference; training whose backward
+        # walks read saved masks, i.e. when the graph-resident backward kernels are not in use): model.hip first_layer_fly
+        l0_fly = n_nodes > 32768 and (not train or "ea_seg_bwd" not in rep)
         # every event-pair interval has had the live-measured interval of an EMPTY pair subtracted by the library
         event_pair_overhead_us = round(1e3 * rep.pop("__event_pair_overhead", {"ms": 0.0})["ms"], 3)
         step_flops = 0.0
@@ -424,8 +427,16 @@ def main():
                    "ms_per_step": round(r["ms"] / args.profile_steps, 4)}
             step_flops += r["flops"] / args.profile_steps
             if name in ab:
-                row.update(bound="hbm", achieved=round(ab[name] / avg_s / 1e9, 1), unit="GB/s",
-                           frac=round(ab[name] / avg_s / HBM_PEAK, 4), per_launch=ab[name])
+                nbytes = ab[name]
+                if name in ("edge_fwd", "edge_rows_fwd") and l0_fly:
+                    # the first layer's launch reads 16-byte x0 rows where the others read (gather) H-wide P / Q rows: its own
+                    # smaller byte count enters the class average, not the H-wide one
+                    launches_ps = r["count"] / args.profile_steps
+                    first = nbytes - 4.0 * (n_nodes * h + (n_nodes if name == "edge_rows_fwd" else e_eff) * h) \
+                        + 4.0 * (4 * n_nodes + (0 if name == "edge_rows_fwd" else 4 * e_eff))
+                    nbytes = (nbytes * (launches_ps - 1) + first) / max(launches_ps, 1)
+                row.update(bound="hbm", achieved=round(nbytes / avg_s / 1e9, 1), unit="GB/s",
+                           frac=round(nbytes / avg_s / HBM_PEAK, 4), per_launch=nbytes)
                 if name.startswith("fused_hops"):
                     # what K separate hop launches would have moved (K x B_sa(H)) over this kernel's time: NOT a roofline fraction
                     row["equiv_unfused_GBps"] = round(K * ab["hop_norm"] / avg_s / 1e9, 1)

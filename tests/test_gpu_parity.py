@@ -1347,6 +1347,45 @@ def test_big_graph_hops_with_unequal_edge_counts():
     _assert_grads_on_hip_gates(m, ref, data, "big-graph hops, unequal edge counts", out)
 
 
+def test_rows_kernels_with_unequal_edge_counts(tmp_path):
+    """Big inference batches of small graphs take the whole-rows LDS kernels (row_hops_kernel, edge_rows_fwd_kernel -- the first
+    layer's launch forming P | Q from x0).  Their staged adjacency / attribute lists are sized for an EQUAL share of the edges per
+    graph; here ten of 2,100 fifty-bus graphs have four times the edges of the others, so the blocks that hold them read indices
+    and attributes from global memory instead.  Against the generic kernels (PFN_NO_ROW_HOPS=1 PFN_NO_EDGE_ROWS=1; switches are
+    read once per process -> child processes) on the whole batch, and against the CPU oracle on the first (heavy) graph alone."""
+    import os
+    import subprocess
+    import sys
+    from poweflownet_amd.synth import make_graph, make_topology
+    script = f"""
+import sys, torch
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+from poweflownet_amd.data import Batch
+from poweflownet_amd.synth import make_graph, make_topology
+torch.manual_seed(11)
+m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 3, 0.0).to("cuda:0").eval()
+n = 50
+graphs = [make_graph(n, 240 if i < 10 else 60, seed=300 + i, edge_index=make_topology(n, 240 if i < 10 else 60, seed=900 + i)) for i in range(2100)]
+d = Batch.from_data_list(graphs).to("cuda:0")
+with torch.no_grad():
+    out = m(d)
+assert m._graphs._graph.seg_nodes == n
+torch.save({{"out": out.cpu(), "state": {{k: v.cpu() for k, v in m.state_dict().items()}}}}, sys.argv[1])
+"""
+    res = {}
+    for tag, env in (("rows", {}), ("generic", {"PFN_NO_ROW_HOPS": "1", "PFN_NO_EDGE_ROWS": "1"})):
+        path = str(tmp_path / f"{tag}.pt")
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=600)
+        res[tag] = torch.load(path)
+    assert_close(res["rows"]["out"], res["generic"]["out"], RTOL, "whole-rows LDS kernels vs generic kernels, unequal edge counts")
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 3, 3, 0.0).eval()
+    ref.load_state_dict(res["rows"]["state"])
+    g0 = make_graph(50, 240, seed=300, edge_index=make_topology(50, 240, seed=900))
+    with torch.no_grad():
+        assert_close(res["rows"]["out"][:50], ref(g0), RTOL, "heavy graph 0 of the batch vs the CPU oracle on that graph alone")
+
+
 def test_k6_big_graphs_streaming_gemm_reads_chunk_major_hops():
     """K = 6 on 56 graphs of 2,500 nodes (140,000 rows): the hops run in big_graph_hops_kernel and come out CHUNK-major; the
     7-term TAGConv products then take gemm_nt_ws_kernel (weight streaming, whole rounds) plus the stationary kernel on the tail rows,
