@@ -298,7 +298,50 @@ __device__ __forceinline__ void front_fwd_thread_body(const FrontFwdArgs& a, int
 
 // Blocks [0, nb_front) run the front, the rest the weight re-layout jobs of the same forward pass (block p -> job p / pack_bx,
 // share p % pack_bx): two independent pieces of work, one launch floor (~5 us) less per step.
-// (one instantiation per front body -- MODE 0: one row per wave, 1: block per row group, 2: one row per thread -- so that each
+// Training beyond the latency regime with P | Q formed in the edge walk: the one H-wide tensor left to write is mask_embd's hidden
+// layer (kept for the backward pass).  Its workgroups need no reduction and no barrier -- thread (row group slot, chunk) keeps its
+// chunk's slices of Wa and ba in registers and walks rows, a row group's chunks are one contiguous 528-byte store -- while x0 and
+// maskf come from front_fwd_thread_body in OTHER workgroups of the same launch (independent work; same fma chains as the block
+// kernel, so the same bits).  6470rte x 64: 82 us for what the block kernel did in 159 us of barrier-separated phases.
+__device__ __forceinline__ void front_meh_body(const FrontFwdArgs& a, int bid, int nblk, int ld, int nchunk) {
+    const int n = a.n, h = a.h;
+    const int rows_pb = 256 / nchunk;
+    const int r = threadIdx.x / nchunk, c = threadIdx.x - r * nchunk;
+    if (r >= rows_pb) return;
+    float rwa[4][4], rba[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // (unconditional clamped loads + select, see front_fwd_body)
+        const int u = 4 * c + i, uc = min(u, h - 1);
+        const bool ok = u < h;
+        const float vba = a.ba[uc];
+        rba[i] = ok ? vba : 0.f;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) {
+            const float va = a.wa[(size_t)uc * 4 + f];
+            rwa[i][f] = ok ? va : 0.f;
+        }
+    }
+    for (int row = bid * rows_pb + r; row < n; row += nblk * rows_pb) {
+        float4 m;
+        if (a.mask_dtype == 0) {
+            const int64_t* mp = static_cast<const int64_t*>(a.mask) + (size_t)row * 4;
+            m = make_float4((float)mp[0], (float)mp[1], (float)mp[2], (float)mp[3]);
+        } else {
+            m = ld4f(static_cast<const float*>(a.mask) + (size_t)row * 4);
+        }
+        float hv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = rba[i];
+            v = fmaf(rwa[i][0], m.x, v); v = fmaf(rwa[i][1], m.y, v); v = fmaf(rwa[i][2], m.z, v); v = fmaf(rwa[i][3], m.w, v);
+            hv[i] = fmaxf(v, 0.f);
+        }
+        st4f(a.me_h + (size_t)row * ld + 4 * c, make_float4(hv[0], hv[1], hv[2], hv[3]));
+    }
+}
+
+// (one instantiation per front body -- MODE 0: one row per wave, 1: block per row group, 2: one row per thread, 3: one row per
+//  thread for x0 in the first rows_pb workgroups + front_meh_body in the rest -- so that each
 //  gets its own register allocation: as one kernel the thread body's unrolled groups cost the block body its occupancy)
 template <int MODE>
 __global__ __launch_bounds__(256) void front_pack_kernel(const FrontFwdArgs f, const PackArgs pa, int nb_front, int pack_bx,
@@ -308,7 +351,10 @@ __global__ __launch_bounds__(256) void front_pack_kernel(const FrontFwdArgs f, c
     if (pa.rng_advance && blockIdx.x == 0 && threadIdx.x == 0) pa.rng_advance[1] += 1;
     slot_ea_body(pa.slot_ea, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
     if ((int)blockIdx.x < nb_front) {
-        if (MODE == 2) front_fwd_thread_body(f, blockIdx.x, nb_front, nchunk);
+        if (MODE == 3) {
+            if ((int)blockIdx.x < rows_pb) front_fwd_thread_body(f, blockIdx.x, rows_pb, nchunk);
+            else front_meh_body(f, blockIdx.x - rows_pb, nb_front - rows_pb, ld, nchunk);
+        } else if (MODE == 2) front_fwd_thread_body(f, blockIdx.x, nb_front, nchunk);
         else if (MODE == 0) front_fwd_wave_body(f, blockIdx.x, nb_front, ld, nchunk);
         else front_fwd_body(f, blockIdx.x, nb_front, ld, nchunk, rows_pb, fl);
         return;
@@ -544,16 +590,24 @@ int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs,
     const bool per_wave = front_row_per_wave(nchunk, f.n);
     static const bool no_thread_rows = diag_env("PFN_FRONT_NO_THREAD_ROWS") != nullptr;   // A/B switch
     const bool per_thread = !per_wave && !f.P && !f.me_h && !no_thread_rows;   // (instead of the block kernel: same bits)
+    const bool split_meh = !per_wave && !f.P && f.me_h && !no_thread_rows;     // training: x0 per thread + me_h in other workgroups
     if (per_wave || per_thread) {   // one row per wave: four rows per 256-thread block, no LDS
         rows_pb = per_thread ? -1 : 0;
         lds = 0;
     }
     const int rows_per_block = per_thread ? 256 : per_wave ? 4 : rows_pb;
-    const int nb_front = f.n > 0 ? std::min((f.n + rows_per_block - 1) / rows_per_block, (per_thread ? 16 : per_wave ? wave_blocks_per_cu(0) : 8) * device_cus()) : 0;
+    int nb_front = f.n > 0 ? std::min((f.n + rows_per_block - 1) / rows_per_block, (per_thread ? 16 : per_wave ? wave_blocks_per_cu(0) : 8) * device_cus()) : 0;
+    if (split_meh && f.n > 0) {   // rows_pb carries the number of x0 workgroups (they come first: the longer chains start first)
+        const int nb_meh = std::min((f.n + rows_pb - 1) / rows_pb, 8 * device_cus());
+        rows_pb = std::min((f.n + 255) / 256, 16 * device_cus());
+        nb_front = rows_pb + nb_meh;
+        lds = 0;
+    }
     const int nblocks = nb_front + pack_bx * pa.njobs;
     if (nblocks > 0 || rng_advance) {
         ProfScope ps("front_fwd+pack", 0.0, 0.0, s);
-        if (per_thread) front_pack_kernel<2><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
+        if (split_meh) front_pack_kernel<3><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
+        else if (per_thread) front_pack_kernel<2><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
         else if (per_wave) front_pack_kernel<0><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
         else front_pack_kernel<1><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
         PFN_CHECK_LAUNCH();
