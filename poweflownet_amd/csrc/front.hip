@@ -14,6 +14,7 @@
 // H-wide outputs are 4 + 8 FMAs per element straight from registers, the 4-wide ones a dot product over H reduced through
 // LDS in a fixed order (deterministic).  ~30 MFLOP in total: one launch of a few microseconds per direction.
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
 
@@ -646,6 +647,244 @@ int launch_front_pq(int n, int h, int ldw1, const float* x0, const float* w1, co
     const int ld = ld_of(h), nchunk = ld / 4;
     ProfScope ps("front_pq", 0.0, 0.0, s);
     front_pq_kernel<<<(int)(((long)n * nchunk + 255) / 256), 256, 0, s>>>(n, h, ld, nchunk, ldw1, x0, w1, b1, P, Q);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+// ---- the backward front beyond the latency regime when mask_embd's hidden layer was NOT stored (FrontFwdArgs::me_h null in a
+// training forward: model.hip front_recomputes_meh).  me_h is four fmas per element away from the 16-byte mask row, and dh, which
+// the block kernel above writes, has ONE reader: the weight-gradient pair (dh, maskf).  So this kernel recomputes me_h (the
+// forward's chain: the same gate bits), forms g0 and dh as above, and accumulates mask_embd's four weight gradients itself
+//     dWb[f][u] += g0[row][f] me_h[row][u]   dbb[f] += g0[row][f]   dWa[u][f] += dh[row][u] mask[row][f]   dba[u] += dh[row][u]
+// per thread over the rows it visits, per workgroup over its row slots in slot order, per launch over the workgroups in a
+// second kernel in workgroup order (fixed order throughout: deterministic).  Neither me_h nor dh touches memory: the forward front
+// writes 32 bytes per row, this kernel reads dP and dQ and writes 16 bytes per row, and two N x H pairs leave the weight-gradient
+// launch.  Partial sums per workgroup: [9][ld] floats (dWb f = 0..3, dWa f = 0..3, dba) + dbb[4].
+// a workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL access (vmcnt(0)),
+// which would pull the prefetched next row group in front of each of the four barriers of a trip
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// row_sum (pfn_internal.hpp) on that barrier: same two-level order, same result
+__device__ __forceinline__ void row_sum_lb(float4* part, int r, int c, int nchunk, bool on) {
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on && c < 8) {
+        for (int k = c; k < nchunk; k += 8) {
+            const float4 p = part[r * nchunk + k];
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+    }
+    lds_barrier();
+    if (on && c < 8) part[r * nchunk + c] = s;
+    lds_barrier();
+    if (on && c == 0) {
+        float4 t = part[r * nchunk];
+        const int m = nchunk < 8 ? nchunk : 8;
+        for (int k = 1; k < m; ++k) {
+            const float4 p = part[r * nchunk + k];
+            t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+        }
+        part[r * nchunk] = t;
+    }
+}
+constexpr int FWG_SLOTS = 9;
+__host__ __device__ inline int fwg_stride(int ld) { return FWG_SLOTS * ld + 4; }
+__global__ __launch_bounds__(256) void front_bwd_wg_kernel(int n, int h, int ld, int nchunk, int rows_pb, int ldw1,
+                                                           const float* __restrict__ dP, const float* __restrict__ dQ,
+                                                           const float* __restrict__ maskf, const float* __restrict__ w1,
+                                                           const float* __restrict__ wa, const float* __restrict__ ba,
+                                                           const float* __restrict__ wb, float* __restrict__ g0,
+                                                           float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float4 fl[];   // part [rows_pb][nchunk] | vec [rows_pb] | w1 [4][2][nchunk] | wb, wa [4][nchunk] | ba [nchunk]
+    float4* part = fl;
+    float4* vec = fl + (size_t)rows_pb * nchunk;
+    float4* s_w1 = vec + rows_pb;
+    float4* s_wb = s_w1 + (size_t)nchunk * 8;
+    float4* s_wa = s_wb + (size_t)nchunk * 4;
+    float4* s_ba = s_wa + (size_t)nchunk * 4;                       // [nchunk] float4 = the chunk's four biases
+    const int r = threadIdx.x / nchunk, c = threadIdx.x - r * nchunk;
+    const bool lane_on = r < rows_pb;
+    // W1's and Wb's slices live in LDS (read per row group: with them in registers next to the 40 accumulators the kernel held 144
+    // VGPRs -- three workgroups per CU, too few loads in flight: 187 us for half the bytes of the 183-us kernel above), Wa's and ba's
+    // too.  Zero past H: the pad units then contribute exact zeros.
+    for (int k = threadIdx.x; k < nchunk * 4; k += blockDim.x) {
+        const int u = k, uc = min(u, h - 1);
+        const bool ok = u < h;
+        const float* w = w1 + (size_t)uc * ldw1;
+        const int kc = k >> 2, ki = k & 3;           // unit k = 4 kc + ki -> plane-major [ki][kc]: a row's chunk-lanes read consecutive float4s
+        s_w1[(2 * ki) * nchunk + kc] = ok ? make_float4(w[0], w[1], w[2], w[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_w1[(2 * ki + 1) * nchunk + kc] = ok ? make_float4(w[4], w[5], w[6], w[7]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_wb[ki * nchunk + kc] = ok ? make_float4(wb[uc], wb[(size_t)h + uc], wb[(size_t)2 * h + uc], wb[(size_t)3 * h + uc]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s_wa[ki * nchunk + kc] = ok ? make_float4(wa[(size_t)uc * 4], wa[(size_t)uc * 4 + 1], wa[(size_t)uc * 4 + 2], wa[(size_t)uc * 4 + 3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        reinterpret_cast<float*>(s_ba)[k] = ok ? ba[uc] : 0.f;
+    }
+    __syncthreads();
+    float aWb[4][4], aWa[4][4], aba[4];   // [f][i]: unit 4c + i
+    float4 abb = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        aba[f] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) aWb[f][i] = aWa[f][i] = 0.f;
+    }
+    // (the row group after this one is requested BEFORE this one's barriers: with four workgroups per CU a trip's load -> barrier ->
+    //  row sum -> barrier chain is otherwise all the latency hiding there is)
+    float4 m_n = make_float4(0.f, 0.f, 0.f, 0.f), p_n = m_n, q_n = m_n;
+    {
+        const int row = blockIdx.x * rows_pb + r;
+        if (lane_on && row < n) {
+            m_n = ld4f(maskf + (size_t)row * 4);
+            p_n = ld4f(dP + (size_t)row * ld + 4 * c);
+            q_n = ld4f(dQ + (size_t)row * ld + 4 * c);
+        }
+    }
+    for (int row0 = blockIdx.x * rows_pb; row0 < n; row0 += gridDim.x * rows_pb) {
+        const int row = row0 + r;
+        const bool on = lane_on && row < n;
+        const float4 m = m_n, p4 = p_n, q4 = q_n;
+        {
+            const int rown = row + gridDim.x * rows_pb;
+            if (lane_on && rown < n) {
+                m_n = ld4f(maskf + (size_t)rown * 4);
+                p_n = ld4f(dP + (size_t)rown * ld + 4 * c);
+                q_n = ld4f(dQ + (size_t)rown * ld + 4 * c);
+            }
+        }
+        if (on) {
+            const float pv[4] = {p4.x, p4.y, p4.z, p4.w}, qv[4] = {q4.x, q4.y, q4.z, q4.w};
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 wi = s_w1[(2 * i) * nchunk + c], wj = s_w1[(2 * i + 1) * nchunk + c];
+                acc.x = fmaf(pv[i], wi.x, acc.x); acc.y = fmaf(pv[i], wi.y, acc.y);
+                acc.z = fmaf(pv[i], wi.z, acc.z); acc.w = fmaf(pv[i], wi.w, acc.w);
+                acc.x = fmaf(qv[i], wj.x, acc.x); acc.y = fmaf(qv[i], wj.y, acc.y);
+                acc.z = fmaf(qv[i], wj.z, acc.z); acc.w = fmaf(qv[i], wj.w, acc.w);
+            }
+            part[r * nchunk + c] = acc;
+        }
+        lds_barrier();
+        row_sum_lb(part, r, c, nchunk, on);
+        if (on && c == 0) {
+            const float4 s = part[r * nchunk];
+            vec[r] = s;
+            st4f(g0 + (size_t)row * 4, s);
+        }
+        lds_barrier();
+        if (on) {
+            const float4 g = vec[r];
+            const float gv[4] = {g.x, g.y, g.z, g.w}, mv[4] = {m.x, m.y, m.z, m.w};
+            const float4 b4 = s_ba[c];
+            const float rba[4] = {b4.x, b4.y, b4.z, b4.w};
+            float rwb[4][4], rwa[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 w = s_wb[i * nchunk + c], a4 = s_wa[i * nchunk + c];
+                rwb[i][0] = w.x; rwb[i][1] = w.y; rwb[i][2] = w.z; rwb[i][3] = w.w;
+                rwa[i][0] = a4.x; rwa[i][1] = a4.y; rwa[i][2] = a4.z; rwa[i][3] = a4.w;
+            }
+            if (c == 0) { abb.x += g.x; abb.y += g.y; abb.z += g.z; abb.w += g.w; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float y = rba[i];                    // mask_embd's hidden unit, the forward's chain (front_fwd_body / front_meh_body)
+                y = fmaf(rwa[i][0], m.x, y); y = fmaf(rwa[i][1], m.y, y); y = fmaf(rwa[i][2], m.z, y); y = fmaf(rwa[i][3], m.w, y);
+                y = fmaxf(y, 0.f);
+                float v = 0.f;
+                v = fmaf(g.x, rwb[i][0], v); v = fmaf(g.y, rwb[i][1], v); v = fmaf(g.z, rwb[i][2], v); v = fmaf(g.w, rwb[i][3], v);
+                const float d = y > 0.f ? v : 0.f;   // dh[row][4c + i]
+                aba[i] += d;
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    aWb[f][i] = fmaf(gv[f], y, aWb[f][i]);
+                    aWa[f][i] = fmaf(d, mv[f], aWa[f][i]);
+                }
+            }
+        }
+    }
+    // ---- the workgroup's partial sums: over its row slots in slot order, one quantity (a float4 of four units) at a time
+    float* mine = partial + (size_t)blockIdx.x * fwg_stride(ld);
+#pragma unroll
+    for (int slot = 0; slot < FWG_SLOTS + 1; ++slot) {
+        __syncthreads();
+        if (lane_on) {
+            float4 v;
+            if (slot < 4) v = make_float4(aWb[slot][0], aWb[slot][1], aWb[slot][2], aWb[slot][3]);
+            else if (slot < 8) v = make_float4(aWa[slot - 4][0], aWa[slot - 4][1], aWa[slot - 4][2], aWa[slot - 4][3]);
+            else if (slot == 8) v = make_float4(aba[0], aba[1], aba[2], aba[3]);
+            else v = abb;
+            part[r * nchunk + c] = v;
+        }
+        __syncthreads();
+        if (lane_on && r == 0 && (slot < FWG_SLOTS || c == 0)) {
+            float4 t = part[c];
+            for (int k = 1; k < rows_pb; ++k) {
+                const float4 p = part[k * nchunk + c];
+                t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+            }
+            st4f(slot < FWG_SLOTS ? mine + slot * ld + 4 * c : mine + FWG_SLOTS * ld, t);
+        }
+    }
+}
+// sums the workgroups' partials into the four gradients in a fixed order: thread (e, j) of a 4 x 64 workgroup adds the partials of
+// workgroups j, j + 64, ... for element e (64 independent chains per element instead of one of 2,048 dependent loads: 181 us as a
+// single chain, 41 us with sixteen), then the 64 sub-sums are added in j order
+__global__ __launch_bounds__(256) void front_wgrad_reduce_kernel(int nblk, int h, int ld, const float* __restrict__ partial,
+                                                                 float* __restrict__ gwa, float* __restrict__ gba,
+                                                                 float* __restrict__ gwb, float* __restrict__ gbb) {
+    __shared__ float sub[64][5];
+    const int el = threadIdx.x & 3, j = threadIdx.x >> 2;
+    const int e = blockIdx.x * 4 + el, stride = fwg_stride(ld);
+    float sacc = 0.f;
+    if (e < stride)
+        for (int b = j; b < nblk; b += 64) sacc += partial[(size_t)b * stride + e];
+    sub[j][el] = sacc;
+    __syncthreads();
+    if (j != 0 || e >= stride) return;
+    float t = sub[0][el];
+    for (int k = 1; k < 64; ++k) t += sub[k][el];
+    const int slot = e / ld, u = e - slot * ld;
+    if (slot >= FWG_SLOTS) gbb[u] = t;                        // (u < 4: the four floats behind the slots)
+    else if (u >= h) return;
+    else if (slot < 4) gwb[(size_t)slot * h + u] = t;           // dWb [4][h]
+    else if (slot < 8) gwa[(size_t)u * 4 + (slot - 4)] = t;     // dWa [h][4]
+    else gba[u] = t;
+}
+size_t front_bwd_wg_scratch_floats(int n, int h) {
+    int ld, nchunk, rows_pb;
+    size_t lds;
+    front_shape(h, ld, nchunk, rows_pb, lds);
+    return (size_t)std::min((n + rows_pb - 1) / rows_pb, 8 * device_cus()) * fwg_stride(ld);
+}
+int launch_front_bwd_wg(int n, int h, int ldw1, const float* dP, const float* dQ, const float* maskf, const float* w1, const float* wa,
+                        const float* ba, const float* wb, float* g0, float* scratch, float* gwa, float* gba, float* gwb, float* gbb,
+                        hipStream_t s) {
+    if (n == 0) return PFN_OK;
+    int ld, nchunk, rows_pb;
+    size_t lds;
+    front_shape(h, ld, nchunk, rows_pb, lds);
+    const int nblk = std::min((n + rows_pb - 1) / rows_pb, 8 * device_cus());
+    {
+        ProfScope ps("front_bwd", 0.0, 0.0, s);
+        front_bwd_wg_kernel<<<nblk, 256, lds + (size_t)nchunk * 17 * sizeof(float4), s>>>(n, h, ld, nchunk, rows_pb, ldw1, dP, dQ, maskf, w1, wa, ba, wb, g0, scratch);
+        PFN_CHECK_LAUNCH();
+    }
+    ProfScope ps("front_wgrad_reduce", 0.0, 0.0, s);
+    front_wgrad_reduce_kernel<<<(fwg_stride(ld) + 3) / 4, 256, 0, s>>>(nblk, h, ld, scratch, gwa, gba, gwb, gbb);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+// mask_embd's hidden layer written out after the fact (the gate export, when the forward did not store it)
+__global__ __launch_bounds__(256) void front_meh_kernel(const FrontFwdArgs f, int ld, int nchunk) {
+    front_meh_body(f, blockIdx.x, gridDim.x, ld, nchunk);
+}
+int launch_front_meh(int n, int h, const void* mask, int mask_dtype, const float* wa, const float* ba, float* me_h, hipStream_t s) {
+    if (n == 0) return PFN_OK;
+    int ld, nchunk, rows_pb;
+    size_t lds;
+    front_shape(h, ld, nchunk, rows_pb, lds);
+    FrontFwdArgs f;
+    memset(&f, 0, sizeof(f));
+    f.n = n; f.h = h; f.mask_dtype = mask_dtype; f.mask = mask; f.wa = wa; f.ba = ba; f.me_h = me_h;
+    ProfScope ps("front_meh", 0.0, 0.0, s);
+    front_meh_kernel<<<std::min((n + rows_pb - 1) / rows_pb, 8 * device_cus()), 256, 0, s>>>(f, ld, nchunk);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

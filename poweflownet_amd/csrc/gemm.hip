@@ -552,7 +552,10 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
         const int max_split = (int)std::max<int64_t>(1, M / (64 * T3_WAVES));
         int nblocks = 0;
         size_t part = 0;
-        for (double want = want_env > 0 ? want_env : ncu; ; want *= 0.8) {
+        // ... and never more workgroups than the chip runs at once (one per CU): the shares are rounded per task, and a plan of
+        // 260 workgroups on 256 CUs is a second round for four of them -- +45 % (seen when two narrow pairs left the list)
+        const int limit = want_env > 0 ? std::max(want_env, 1) : ncu;
+        for (double want = limit; ; want *= 0.97) {
             nblocks = 0;
             part = 0;
             for (int t = 0; t < ta.ntasks; ++t) {
@@ -572,7 +575,7 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
                 tk.part0 = (int)part;
                 if (tk.nsplit > 1) part += (size_t)tk.nsplit * (tk.wb ? 2 : 1) * t3_quads(tk.wa ? 4 : 1, tk.wb ? 2 : 1) * 64;
             }
-            if (part <= cap_f4 || want < 2.0) break;
+            if ((part <= cap_f4 && nblocks <= limit) || want < 2.0) break;
         }
         if (part > cap_f4) {
             set_error("launch_weight_grads: reduction workspace too small");

@@ -535,6 +535,15 @@ static bool first_layer_fly(const pfn_mpn_config& c, const Layout& lo, int seg, 
            (c.need_backward == 0 || ea_saves_mask(c, lo, seg, fused_front, 0));
 }
 
+// Training beyond the latency regime with layer 0 on the fly: mask_embd's hidden layer is not stored either -- the backward front
+// recomputes it from the 16-byte mask rows and forms mask_embd's weight gradients itself (front.hip front_bwd_wg_kernel), so
+// neither me_h nor dh touches memory and two N x H pairs leave the weight-gradient launch.  (The gate export writes me_h first.)
+static bool front_recomputes_meh(const pfn_mpn_config& c, const Layout& lo, int seg, bool fused_front) {
+    static const bool off = diag_env("PFN_FRONT_STORE_MEH") != nullptr;   // A/B switch: me_h stored, the (dY, X) pairs in gemm_tn
+    return !off && c.need_backward != 0 && first_layer_fly(c, lo, seg, fused_front) &&
+           front_bwd_wg_scratch_floats(lo.n, lo.h) <= (size_t)lo.n * lo.ld;   // (the partial sums live in the unused me_h buffer)
+}
+
 static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
                          const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr, float* out,
                          uint64_t* rng, int seg, hipStream_t s) {
@@ -563,7 +572,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         f.n = lo.n; f.h = lo.h; f.ldw1 = 2 * lo.f0 + lo.fe; f.mask_dtype = mask_dtype;
         f.x = x; f.mask = pred_mask;
         f.wa = me[0]; f.ba = me[1]; f.wb = me[2]; f.bb = me[3]; f.w1 = params[0]; f.b1 = params[1];
-        f.maskf = lo.maskf; f.me_h = c.need_backward ? lo.me_h : nullptr; f.x0 = lo.x0;
+        f.maskf = lo.maskf; f.me_h = (c.need_backward && !front_recomputes_meh(c, lo, seg, fused_front)) ? lo.me_h : nullptr; f.x0 = lo.x0;
         f.P = l0_fly ? nullptr : lo.ea[0].P;
         f.Q = l0_fly ? nullptr : lo.ea[0].Q;
         PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s, seg_ea ? &se : nullptr));
@@ -685,7 +694,11 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
     }
     // mask_embd backward: x0 = me_h Wb^T + bb + x ; me_h = relu(maskf Wa^T + ba)
     float* const* gme = grads + (nparams - 4);
-    if (fused_front) {   // g0 = dP0 W1i + dQ0 W1j and dh = (g0 Wb) [me_h > 0] in one launch (front.hip)
+    const bool meh_rc = front_recomputes_meh(c, lo, seg, fused_front);
+    if (meh_rc) {        // ... and mask_embd's weight gradients too, me_h recomputed (front_bwd_wg_kernel; partials in the me_h buffer)
+        PFN_TRY(launch_front_bwd_wg(lo.n, lo.h, 2 * lo.f0 + lo.fe, lo.dP[0], lo.dQ[0], lo.maskf, params[0], params[nparams - 4],
+                                    params[nparams - 3], params[nparams - 2], lo.gin[0], lo.me_h, gme[0], gme[1], gme[2], gme[3], s));
+    } else if (fused_front) {   // g0 = dP0 W1i + dQ0 W1j and dh = (g0 Wb) [me_h > 0] in one launch (front.hip)
         PFN_TRY(launch_front_bwd(lo.n, lo.h, 2 * lo.f0 + lo.fe, lo.dP[0], lo.dQ[0], lo.me_h, params[0], params[nparams - 2],
                                  lo.gin[0], lo.dh, s));
     } else {
@@ -697,8 +710,10 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         a.ldg = lo.ld;
         PFN_TRY(launch_gemm_nt(a, s));
     }
-    pairs.pairs.push_back(tn_pair(gcur, lo.ld0, lo.f0, lo.me_h, lo.ld, lo.h, gme[2], lo.h, 0, gme[3], nullptr));     // dWb, dbb
-    pairs.pairs.push_back(tn_pair(lo.dh, lo.ld, lo.h, lo.maskf, lo.ld0, lo.f0, gme[0], lo.f0, 0, gme[1], nullptr));  // dWa, dba
+    if (!meh_rc) {
+        pairs.pairs.push_back(tn_pair(gcur, lo.ld0, lo.f0, lo.me_h, lo.ld, lo.h, gme[2], lo.h, 0, gme[3], nullptr));     // dWb, dbb
+        pairs.pairs.push_back(tn_pair(lo.dh, lo.ld, lo.h, lo.maskf, lo.ld0, lo.f0, gme[0], lo.f0, 0, gme[1], nullptr));  // dWa, dba
+    }
     // the dWe partial reductions ride in the weight-gradient launch (independent work, one launch floor less)
     if ((int)pairs.dwe.size() <= DWE_MAX_JOBS && lo.n > 0 && !pairs.pairs.empty()) {
         DweRide ride;
@@ -1057,6 +1072,10 @@ int pfn_mpn_export_gates(const pfn_mpn_config* c, const void* gws, int64_t n, in
         const int cm = is_ea(layer) && tag_input_cm((int)seg_nodes, lo.ld, lo.n, e, lo.K);
         export_row_gates_kernel<<<blocks, 256, 0, s>>>(n, lo.h, lo.ld, lo.y[layer], out, cm);
     } else if (kind == 2) {
+        if (front_recomputes_meh(*c, lo, (int)seg_nodes, front_fused_ok(lo.f0, lo.h))) {   // (the forward did not store it)
+            const int np = pfn_mpn_num_params(c);
+            PFN_TRY(launch_front_meh(lo.n, lo.h, lo.maskf, 1, params[np - 4], params[np - 3], lo.me_h, s));
+        }
         export_row_gates_kernel<<<blocks, 256, 0, s>>>(n, lo.h, lo.ld, lo.me_h, out, 0);
     } else {
         set_error("pfn_mpn_export_gates: kind must be 0 (edge stage), 1 (layer output) or 2 (mask_embd hidden)");

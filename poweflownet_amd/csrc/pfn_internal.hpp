@@ -523,6 +523,15 @@ int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs,
                           const SlotEa* slot_ea = nullptr);
 int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, const float* me_h, const float* w1,
                      const float* wb, float* g0, float* dh, hipStream_t s);
+// The backward front beyond the latency regime when the forward did not store mask_embd's hidden layer (FrontFwdArgs::me_h null
+// in training): recomputes it, forms g0, and accumulates mask_embd's four weight gradients itself (neither me_h nor dh touches
+// memory); `scratch` >= front_bwd_wg_scratch_floats(n, h) floats of per-workgroup partial sums
+size_t front_bwd_wg_scratch_floats(int n, int h);
+int launch_front_bwd_wg(int n, int h, int ldw1, const float* dP, const float* dQ, const float* maskf, const float* w1, const float* wa,
+                        const float* ba, const float* wb, float* g0, float* scratch, float* gwa, float* gba, float* gwb, float* gbb,
+                        hipStream_t s);
+// mask_embd's hidden layer written from the float mask rows after the fact (the gate export), bit-identical to the front's
+int launch_front_meh(int n, int h, const void* mask, int mask_dtype, const float* wa, const float* ba, float* me_h, hipStream_t s);
 // P | Q of the first layer written from x0 after the fact (FrontFwdArgs::P null in the forward pass), bit-identical to the front's
 int launch_front_pq(int n, int h, int ldw1, const float* x0, const float* w1, const float* b1, float* P, float* Q, hipStream_t s);
 

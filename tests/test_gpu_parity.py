@@ -851,7 +851,8 @@ res = {{}}
 d = make_batch("118", 300, seed=4).to("cuda:0")
 d.x.requires_grad_(True)
 out = m(d)                                        # training-mode autograd, masks saved (the graph-resident kernels are off)
-res["gates0"] = m.export_gates()["edge"][0].cpu()
+_g = m.export_gates()
+res["gates0"], res["gates_me"] = _g["edge"][0].cpu(), _g["mask_embd"].cpu()
 torch.nn.MSELoss()(out, d.y).backward()
 res["out"], res["gx"], res["g"] = out.detach().cpu(), d.x.grad.cpu(), m.flat_grad().cpu()
 m.zero_grad(set_to_none=True)
@@ -866,8 +867,12 @@ with torch.no_grad():
 torch.save(res, sys.argv[1])
 """
     res = {}
-    for tag, env in (("fly", {"PFN_NO_SEG_EA": "1"}), ("stored", {"PFN_NO_SEG_EA": "1", "PFN_NO_L0_FLY": "1"}),
-                     ("block_front", {"PFN_NO_SEG_EA": "1", "PFN_FRONT_NO_THREAD_ROWS": "1"})):
+    # (with layer 0 on the fly a training pass does not store mask_embd's hidden layer either: the backward front recomputes it and
+    #  sums mask_embd's four weight gradients itself, in another order than gemm_tn -- PFN_FRONT_STORE_MEH=1 holds that off for the
+    #  bit comparison; the default is compared below: outputs, input gradients and gates bit for bit, weight gradients to fp32 tolerance)
+    keep = {"PFN_NO_SEG_EA": "1", "PFN_FRONT_STORE_MEH": "1"}
+    for tag, env in (("fly", keep), ("stored", dict(keep, PFN_NO_L0_FLY="1")), ("block_front", dict(keep, PFN_FRONT_NO_THREAD_ROWS="1")),
+                     ("default", {"PFN_NO_SEG_EA": "1"})):
         path = str(tmp_path / f"{tag}.pt")
         subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=300)
         res[tag] = torch.load(path)
@@ -876,6 +881,14 @@ torch.save(res, sys.argv[1])
             assert torch.equal(res["fly"][key], res[tag][key]), f"{key}: default path differs from {tag}"
     assert res["fly"]["gea"].abs().max() > 0 and res["fly"]["inf_rows"].abs().max() > 0
     assert torch.equal(res["fly"]["inf_generic"], res["fly"]["out"])   # (no_grad forward = training forward, bit for bit)
+    n_me = 4 * 129 + 129 + 4 * 129 + 4                 # mask_embd's parameters are the last four of the flat gradient
+    for key in res["fly"]:
+        if key in ("g", "g2"):   # (the other weight gradients too: with two pairs fewer gemm_tn splits the rows differently)
+            assert not torch.equal(res["default"][key][-n_me:], res["fly"][key][-n_me:])      # (the recomputing backward front did run)
+            assert_close(res["default"][key][-n_me:], res["fly"][key][-n_me:], RTOL, f"{key}: mask_embd gradients formed in the backward front")
+            assert_close(res["default"][key], res["fly"][key], RTOL, f"{key}: flat parameter gradient")
+        else:
+            assert torch.equal(res["default"][key], res["fly"][key]), f"{key}: recomputed mask_embd hidden layer"
 
 
 def test_bf16_split_gemm_experiment_matches_fp32_mfma_path(tmp_path):
