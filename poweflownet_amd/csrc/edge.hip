@@ -669,9 +669,14 @@ __device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored,
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int q = min(p + u, last);
+#ifndef PFN_EXP_EDGE_NOL2   /* tools experiment switch (never defined in the product build): neighbour / edge ids WITHOUT the index loads */
                 s_[u] = nbr[q];
                 const int id = eid[q];
                 id_[u] = id >= e_stored ? id - e_stored : id;
+#else
+                s_[u] = max(row - u, 0);
+                id_[u] = min(q, e_stored - 1);
+#endif
             }
             float4 q_[4];
             float2 a_[4];
