@@ -239,6 +239,7 @@ int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  *   PFN_NO_ROW_HOPS=1       TAGConv hops of big batches of small graphs: the two-tile column-slice kernel instead of whole rows per block
  *   PFN_NO_EDGE_ROWS=1      the edge stage of big inference batches of small graphs: the generic gather kernel instead of the LDS-resident one
  *   PFN_NO_L0_FLY=1         the front writes the first layer's P | Q and the edge walk gathers them (default: the walk forms them from x0)
+ *   PFN_EDGE_FWD_BPC=N      workgroups per CU of the persistent generic forward edge walk (default 8; a large N = one workgroup per 256 items)
  *   PFN_FRONT_STORE_MEH=1   training beyond 32 k rows: mask_embd's hidden layer is stored and its weight gradients go through gemm_tn
  *                           (default: recomputed in the backward front, which forms those gradients itself)
  *   PFN_NT_BX_MIN_TILES=N   opt-in experiment: large-M GEMMs (K = 129, 129 columns, >= N row tiles per wave) as nine exact bf16 partial

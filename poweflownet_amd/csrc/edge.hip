@@ -725,19 +725,32 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
     extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld] (| FLY: wi [4][ld] | wj [4][ld] | b1 [ld])
     const int fe = FE > 0 ? FE : fe_rt;
     const int ldw = 2 * fi + fe;
-    const long item = (long)exp_block(blockIdx.x, gridDim.x) * blockDim.x + threadIdx.x;
-    const int row = (int)(item / nchunk);
-    const int col = (int)(item - (long)row * nchunk) * 4;
+    // PERSISTENT over the (row, chunk) items (grid = the workgroups the chip holds at once, launch_edge_fwd): the residue weights
+    // are staged -- a round of loads and a barrier -- once per workgroup instead of once per 256 items, and an item's head (row
+    // pointers, its P chunk) is requested while the item before it is walked: one level less in every item's chain of dependent loads
+    const long stride = (long)gridDim.x * blockDim.x, total = (long)n * nchunk;
+    long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int row = (int)(item / nchunk);
+    int col = (int)(item - (long)row * nchunk) * 4;
     EdgeRowHead hd;
-    if (row < n) hd = edge_row_head<MASK, FLY>(row, col, rowptr, P, ld, rp4);
+    if (item < total) hd = edge_row_head<MASK, FLY>(row, col, rowptr, P, ld, rp4);
     for (int i = threadIdx.x; i < fe * ld; i += blockDim.x) {
         const int f = i / ld, k = i - f * ld;
         we[i] = k < h ? w1[(size_t)k * ldw + 2 * fi + f] : 0.f;
     }
     if (FLY) stage_fly_weights(we + fe * ld, w1, b1, ld, h, ldw);
     __syncthreads();
-    if (row >= n) return;
-    st4(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK, FLY>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, hd));
+    while (item < total) {
+        const long nitem = item + stride;
+        const int nrow = (int)(nitem / nchunk), ncol = (int)(nitem - (long)nrow * nchunk) * 4;
+        EdgeRowHead hn = hd;
+        if (nitem < total) hn = edge_row_head<MASK, FLY>(nrow, ncol, rowptr, P, ld, rp4);
+        st4(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK, FLY>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, hd));
+        hd = hn;
+        item = nitem;
+        row = nrow;
+        col = ncol;
+    }
 }
 
 // The network's LAST EdgeAggregation layer (Fo <= 4, no activation): the second Linear rides in the same launch.  Block =
@@ -1007,8 +1020,12 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
         }
     }
     const long items = (long)g.n * nchunk;
-    const int blocks = (int)((items + 255) / 256);
+    const int all_blocks = (int)((items + 255) / 256);
     const size_t lds = (size_t)a.fe * a.ld * sizeof(float);
+    // the generic walk is persistent: as many workgroups as the chip holds at once (PFN_EDGE_FWD_BPC tunes)
+    static const int bpc_env = diag_env("PFN_EDGE_FWD_BPC") ? std::max(1, atoi(diag_env("PFN_EDGE_FWD_BPC"))) : 0;
+    const int bpc = bpc_env > 0 ? bpc_env : (fly ? 5 : 7);   // (what the kernels' 86 / 72 VGPRs let a CU hold)
+    const int blocks = (int)std::min<long>(all_blocks, (long)bpc * device_cus());
     ProfScope ps("edge_fwd", 0.0, 0.0, s);
     if (a.out) {   // last layer: S and out = S W2^T + deg b2 in one launch (edge_fwd_out_ok)
         const int rows_pb = 256 / nchunk;
