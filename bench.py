@@ -213,7 +213,12 @@ def dp_overhead(fb, opt, model, dev, steps, base_ms):
         port = sk.getsockname()[1]
     try:
         with dp.stdout_to_stderr():               # (RCCL's version banner must not land on the JSON line's stdout)
-            dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+            # an explicit store of our own: under torchrun (TORCHELASTIC_USE_AGENT_STORE) a tcp:// init_method makes this process
+            # a CLIENT of a store nobody serves at that port, and init_process_group waits for it for half an hour
+            import datetime
+            store = dist.TCPStore("127.0.0.1", port, 1, is_master=True, timeout=datetime.timedelta(seconds=60))
+            dist.init_process_group(backend="nccl", store=store, rank=0, world_size=1, device_id=dev,
+                                    timeout=datetime.timedelta(seconds=120))
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):         # creates the communicator outside any capture
