@@ -177,3 +177,22 @@ def test_bench_rccl_collective_path_world1():
     d = json.loads(lines[0])
     # the collective is INSIDE the replayed graph (dp.GraphedStep): one hipGraph per data-parallel step
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["config"]["launch"] == "hipGraph replay: one graph incl. RCCL all-reduce", d["config"]
+
+
+def test_bench_under_torchrun_world1_with_rccl_overhead_probe():
+    """The driver's launch form at ONE rank (`python -m torch.distributed.run --nproc-per-node 1 ... bench.py --gpus 1`): no process
+    group is needed, but the `dp_overhead_ms` probe creates a private world-size-1 RCCL group.  Under torchrun
+    (TORCHELASTIC_USE_AGENT_STORE) a `tcp://` init made the rank a CLIENT of a store nobody serves and the bench sat in
+    init_process_group for half an hour; the probe now brings its own TCPStore.  One JSON line, the probe's numbers in it."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PFN_HANG_DUMP="150")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PFN_FORCE_DIST"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2",
+           "--profile-steps", "2", "--no-cpu-baseline", "--no-live-traffic", "--case", "14", "--batch", "16"]
+    out, err = _run(cmd, env, 300)
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out[-2000:] + err[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0, d
+    assert d.get("dp_graph_mode") == "one graph incl. RCCL all-reduce" and "dp_overhead_error" not in d, d
