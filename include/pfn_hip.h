@@ -227,6 +227,8 @@ int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  * library behaves as DESIGN.md describes.  There is no switch that routes work off the GPU or through another backend.
  *   PFN_NO_SEG_EA=1         EdgeAggregation of small-graph batches: generic gemm_nt + edge walks instead of the graph-resident kernels
  *   PFN_SEG_EA_PER_CU=<n>   ... use the graph-resident kernels up to n workgroups per CU (default 4)
+ *   PFN_NO_SEG_LIN_HOPS=1   small-graph batches: the Linear in front of a TAGConv's hops and the hops as two launches (gemm_nt + fused hops)
+ *                           instead of one graph-resident launch (seg_lin_hops.hip; bit-identical results)
  *   PFN_NO_FUSED_FRONT=1    mask_embd + first P|Q as generic GEMMs instead of front.hip's one launch
  *   PFN_NO_FUSED_BACK=1     the last layer's Linear / dS outside the edge walks (generic GEMMs)
  *   PFN_FRONT_BLOCK_ROWS=1  front.hip: the block-per-row-group kernels instead of one row per wave

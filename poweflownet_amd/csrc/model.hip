@@ -114,7 +114,10 @@ static bool back_fused_ok() {
 static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const float* x, int ldx, const float* ea,
                       const float* w1, const float* b1, const float* w2, const float* b2, const EaPack& pw, float* out, int ldo,
                       const Act& act, const EaSaved& sv, hipStream_t s, bool pq_ready = false, int seg = 0,
-                      const float* ea_in = nullptr, unsigned* relu_mask = nullptr, bool pq_fly = false) {
+                      const float* ea_in = nullptr, unsigned* relu_mask = nullptr, bool pq_fly = false, float* hop_xk = nullptr,
+                      int hop_K = 0) {
+    // hop_xk / hop_K: the TAGConv behind this layer takes its K hops from here (seg_lin_hops.hip: the S W2^T Linear and the hops
+    // in one launch; the caller has asked seg_lin_hops_fit)
     const int ld = ld_of(h);
     // batches of small graphs: the P | Q GEMM and the edge walk in one launch, graph-resident in LDS (ea_seg.hip)
     const bool seg_walk = !pq_ready && ea_in && ea_seg_fit(seg, g.n, fe, ld, false);
@@ -154,6 +157,13 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
     }
     if (!out_in_walk && w2 && act.act == ACT_NONE && lin_out4_ok(h, fo, ldo, g.n)) {
         PFN_TRY(launch_lin_out4(g.n, h, fo, sv.S, w2, b2, g.deg, out, s));   // the last layer at small batches: one row per wave
+    } else if (!out_in_walk && hop_xk) {   // out = act(S W2^T + deg * b2) and the next TAGConv's K hops over it, one launch
+        SegLinHopsArgs f;
+        memset(&f, 0, sizeof(f));
+        f.A0 = sv.S; f.B0 = pw.w2_t; f.rowscale = g.deg; f.rowbias = b2; f.rng = act.rng; f.rng_stream = act.stream;
+        f.y = out; f.xk = hop_xk; f.stride = (size_t)g.n * ldo; f.gate_scale = 1.f; f.p_drop = act.p; f.act = act.act;
+        f.lda = ld; f.K = h; f.ld = ldo; f.ncols = fo; f.nhops = hop_K; f.adjt = 0;
+        PFN_TRY(launch_seg_lin_hops(g, f, seg, s));
     } else if (!out_in_walk) {   // out = S W2^T + deg * b2   (the second Linear commutes with the segment sum)
         GemmArgs a = gemm_defaults(g.n, fo, ldo);
         a.C[0] = out;
@@ -178,7 +188,10 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
                        const float* w1, const float* w2, const EaPack& pw, const float* gout, int ldgo, const Gate& gate, float* gx,
                        int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
                        const EaScratch& sc, hipStream_t s, PairList* defer, int seg = 0, const float* ea_in = nullptr,
-                       const float* ea_out = nullptr, const unsigned* relu_mask = nullptr, int gx_cm = 0) {
+                       const float* ea_out = nullptr, const unsigned* relu_mask = nullptr, int gx_cm = 0, float* hop_out = nullptr,
+                       int hop_K = 0) {
+    // hop_out / hop_K: gx is the output gradient of a TAGConv whose backward hops it K times over A_hat^T first: the dx Linear and
+    // those hops in one launch (seg_lin_hops.hip; the caller has asked seg_lin_hops_fit)
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
     // batches of small graphs: the dS GEMM and both backward walks in one launch, graph-resident in LDS (ea_seg.hip)
     const bool seg_walk = !gea && ea_in && ea_out && ea_seg_fit(seg, g.n, fe, ld, true) && (fo > 4 || ldgo == 4);
@@ -207,7 +220,14 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
     }
     if (!seg_walk) PFN_TRY(launch_edge_bwd(g, e, nullptr, s));
     if (gea) PFN_TRY(launch_edge_attr_grad(g, e, s));
-    if (gx) {   // dx = dP W1[:, :Fi] + dQ W1[:, Fi:2Fi], gated by the producing layer's activation
+    if (gx && hop_out) {
+        SegLinHopsArgs f;
+        memset(&f, 0, sizeof(f));
+        f.A0 = sc.dP; f.A1 = sc.dQ; f.B0 = pw.w1i_d; f.B1 = pw.w1j_d; f.gate = gate.y; f.ldg = gate.ld; f.gate_scale = gate.scale;
+        f.y = gx; f.xk = hop_out; f.stride = (size_t)g.n * ldgx; f.act = ACT_NONE;
+        f.lda = ld; f.K = h; f.ld = ldgx; f.ncols = fi; f.nhops = hop_K; f.adjt = 1;
+        PFN_TRY(launch_seg_lin_hops(g, f, seg, s));
+    } else if (gx) {   // dx = dP W1[:, :Fi] + dQ W1[:, Fi:2Fi], gated by the producing layer's activation
         GemmArgs a = gemm_defaults(g.n, fi, ldgx);
         a.C[0] = gx;
         a.nterm = 2;
@@ -249,7 +269,8 @@ static TagPack tag_pack(Packer& pk, int cin, int cout, int K, const float* const
 
 static int tag_forward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
                        const float* bias, float* out, int ldo, const Act& act, float* xk, hipStream_t s, int seg = 0,
-                       int x_cm = 0) {
+                       int x_cm = 0, bool hops_done = false) {
+    // hops_done: the layer in front already wrote the K hop buffers (seg_lin_hops.hip)
     // xk: K buffers of n * ldx floats holding A_hat^k x, k = 1..K.  x_cm > 0: x itself is chunk-major (the producing layer wrote
     // it so because this TAGConv takes the big-graph hop kernel)
     const size_t stride = (size_t)g.n * ldx;
@@ -258,7 +279,8 @@ static int tag_forward(const GraphView& g, int cin, int cout, int K, const float
         set_error("TAGConv: chunk-major input without the big-graph hop kernel (internal)");
         return PFN_EINVAL;
     }
-    if (K > 0 && fused_hops_fit(seg, ldx, g.n)) {
+    if (hops_done) {
+    } else if (K > 0 && fused_hops_fit(seg, ldx, g.n)) {
         FusedHopsArgs fh{x, xk, nullptr, nullptr, nullptr, 1.f, stride, ldx, K, 0, seg};
         PFN_TRY(launch_fused_hops(g, fh, s));
     } else if (K > 0 && big_hops_fit(seg, g.n, g.e_stored)) {
@@ -294,7 +316,8 @@ struct TagScratch { float* G; float *z0, *z1; ReduceWs red; };
 static int tag_backward(const GraphView& g, int cin, int cout, int K, const float* x, int ldx, const TagPack& pw,
                         const float* gout, int ldgo, const Gate& gate, float* gx, int ldgx, float* const* gw,
                         float* gbias, const float* xk, const TagScratch& sc, hipStream_t s, PairList* defer, int seg = 0,
-                        int x_cm = 0, int gout_cm = 0) {
+                        int x_cm = 0, int gout_cm = 0, bool hops_done = false) {
+    // hops_done: the layer behind (whose dx Linear produced gout) already hopped it into sc.G (seg_lin_hops.hip)
     const size_t stride = (size_t)g.n * ldx;
     float* hk = sc.G;
     if (gout_cm && !(gx && K > 0 && ldgo <= ldx && tag_uses_big_hops(seg, ldgo, g.n, g.e_stored, K))) {
@@ -312,7 +335,8 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             // one output instead of K + 1 (measured 607 vs 754 us for the GEMM at 414 k nodes) and no Horner pass.
             const size_t gstride = (size_t)g.n * ldgo;
             int hk_cm = 0;
-            if (fused_hops_fit(seg, ldgo, g.n)) {
+            if (hops_done) {
+            } else if (fused_hops_fit(seg, ldgo, g.n)) {
                 FusedHopsArgs fh{gout, hk, nullptr, nullptr, nullptr, 1.f, gstride, ldgo, K, 0, seg, 1};
                 PFN_TRY(launch_fused_hops(g, fh, s));
             } else if (big_hops_fit(seg, g.n, g.e_stored)) {
@@ -341,7 +365,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
             a.aux_cm_rows = gate.cm;
             PFN_TRY(launch_gemm_nt(a, s));
         } else {
-            if (gate.cm || x_cm || gout_cm) {
+            if (gate.cm || x_cm || gout_cm || hops_done) {
                 set_error("TAGConv backward: chunk-major tensors on the Horner path (internal)");
                 return PFN_EINVAL;
             }
@@ -601,6 +625,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     }
     const float* cur = lo.x0;
     int ldc = lo.ld0, fcur = lo.f0, pi = 0;
+    bool hops_fused = false;
     for (int i = 0; i < lo.nlayers; ++i) {
         const bool last = i + 1 == lo.nlayers;
         Act act;
@@ -617,13 +642,18 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         if (is_ea(i) && !last) act.out_cm = big_cm;
         if (is_ea(i)) {
             const int fo = last ? lo.fo : lo.h;
+            // batches of small graphs: this layer's second Linear also runs the K hops of the TAGConv behind it (seg_lin_hops.hip)
+            hops_fused = !last && !big_cm && seg_lin_hops_fit(seg, lo.n, lo.ld, lo.h, lo.h, lo.K, 1);
             PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
                                params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0, seg, seg_ea ? lo.ea_in : nullptr,
-                               ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr, l0_fly && i == 0));
+                               ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr, l0_fly && i == 0,
+                               hops_fused ? lo.xk[i + 1] : nullptr, lo.K));
             pi += 4;
             fcur = fo;
         } else {
-            PFN_TRY(tag_forward(g, lo.h, lo.h, lo.K, cur, ldc, mp.tag[i], params[pi + lo.K + 1], y, ldy, act, lo.xk[i], s, seg, big_cm));
+            PFN_TRY(tag_forward(g, lo.h, lo.h, lo.K, cur, ldc, mp.tag[i], params[pi + lo.K + 1], y, ldy, act, lo.xk[i], s, seg, big_cm,
+                                hops_fused));
+            hops_fused = false;
             pi += lo.K + 2;
         }
         cur = y;
@@ -653,6 +683,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
     const bool fused_front = front_fused_ok(lo.f0, lo.h);
     const float* gcur = gout;
     int ldg = lo.ldo;
+    bool hops_fused = false;
     for (int i = lo.nlayers - 1; i >= 0; --i) {
         const bool last = i + 1 == lo.nlayers;
         const float* inp = i == 0 ? lo.x0 : lo.y[i - 1];
@@ -681,13 +712,17 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
             if (i == 0 && gea && first_layer_fly(c, lo, seg, fused_front))
                 PFN_TRY(launch_front_pq(lo.n, lo.h, 2 * lo.f0 + lo.fe, lo.x0, params[0], params[1], lo.ea[0].P, lo.ea[0].Q, s));
             // (layer 0 with the fused front: its input gradient is formed together with mask_embd's, below)
+            // batches of small graphs: the dx Linear also runs the backward hops of the TAGConv in front (seg_lin_hops.hip)
+            hops_fused = i >= 2 && !gx_cm && !gate.cm && seg_lin_hops_fit(seg, lo.n, lo.ld, lo.h, lo.h, lo.K, 2);
             PFN_TRY(ea_backward(g, fi, lo.fe, lo.h, fo, inp, ldi, edge_attr, params[p0], params[p0 + 2], mp.ea[i], gcur, ldg, gate,
                                 (fused_front && i == 0) ? nullptr : gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2],
                                 grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs, seg, lo.ea_in, lo.ea_out,
-                                ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr, gx_cm));
+                                ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr, gx_cm,
+                                hops_fused ? lo.tags.G : nullptr, lo.K));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
-                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg, big_cm, gout_cm));
+                                 grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg, big_cm, gout_cm, hops_fused));
+            hops_fused = false;
         }
         gcur = gnext;
         ldg = ldi;

@@ -421,6 +421,29 @@ int ea_seg_blocks(int seg, int n, int ld);
 int launch_ea_seg_fwd(const GraphView& g, const EaSegFwdArgs& a, int seg, hipStream_t s);
 int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStream_t s);
 
+// A per-node Linear (one or two terms, K = H = 129-shaped) and the K TAGConv hops over its output in ONE launch, graph-resident
+// in LDS (seg_lin_hops.hip): forward  y = act(S W2^T + deg b2), x^(k) = A_hat x^(k-1);  backward  g = (dP W1i + dQ W1j)[gate > 0],
+// g^(k) = A_hat^T g^(k-1).  Bit-identical to gemm_nt + fused_hops (two launches), which remain the path for every other shape.
+struct SegLinHopsArgs {
+    const float* A0;        // operand of term 0, N x lda, K real columns
+    const float* A1;        // operand of term 1 (same lda / K), or null: one term
+    const float* B0;        // packed images (K -> ncols, ld_out = ld)
+    const float* B1;
+    const float* rowscale;  // [N] or null:  + rowscale[row] * rowbias[col]
+    const float* rowbias;   // [ncols]
+    const float* gate;      // [N x ldg] or null:  out *= gate > 0 ? gate_scale : 0
+    const uint64_t* rng;    // device {seed, offset} (ACT_DROPOUT_RELU)
+    float* y;               // N x ld: the Linear's output after the epilogue (= hop 0)
+    float* xk;              // hop k = 1..nhops -> xk + (k - 1) * stride
+    size_t stride;
+    float gate_scale, p_drop;
+    uint32_t rng_stream;
+    int act, lda, K, ld, ncols, ldg, nhops;
+    int adjt;               // 0: by-destination rows (A_hat), 1: by-source rows (A_hat^T)
+};
+bool seg_lin_hops_fit(int seg, int n, int ld, int K, int ncols, int nhops, int nterm);
+int launch_seg_lin_hops(const GraphView& g, const SegLinHopsArgs& a, int seg, hipStream_t s);
+
 struct EdgeBwdArgs {
     const float* P;
     const float* Q;

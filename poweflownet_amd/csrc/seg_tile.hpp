@@ -86,4 +86,54 @@ __device__ __forceinline__ f32x16 seg_mma(const SegA& t, const float* bl, int K8
     return K8 == 8 * SG_NCH ? seg_mma_t<true>(t, bl, K8, lane) : seg_mma_t<false>(t, bl, K8, lane);
 }
 
+
+// ---- geometry and small helpers shared by the graph-resident kernels (ea_seg.hip, seg_lin_hops.hip)
+constexpr int SG_THREADS = 512;
+constexpr int SG_TW = 36;            // LDS tile row stride (floats): 32 quarter columns + up to 4 trailing VALU columns
+constexpr int SG_MAX_ROWS = 128;     // rows of whole graphs per workgroup (4 row tiles: one MFMA task per wave at most)
+constexpr int SG_LDS_BYTES = 78 * 1024;   // two workgroups per CU
+
+__device__ __forceinline__ float4 sg_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void sg_st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// accumulator register 4g + e of lane (r32, kh) = row 8g + 4kh + e, column r32
+__device__ __forceinline__ void seg_store_tile(const f32x16& acc, int q, const float* __restrict__ bias, int ncols, float* tile,
+                                               int trow0, int lane) {
+    const int r32 = lane & 31, kh = lane >> 5;
+    const int col = 32 * q + r32;
+    const float cb = (bias && col < ncols) ? bias[col] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) tile[(size_t)(trow0 + 8 * (j >> 2) + 4 * kh + (j & 3)) * SG_TW + r32] = acc[j] + cb;
+}
+
+// column-slice geometry shared by the kernels: block y = q covers the 32-column quarter q (up to 8 float4 chunks); the LAST
+// quarter's block also owns the `remv` trailing columns (one more chunk, LDS tile columns 32..35)
+struct SegCols {
+    int q, nq, remv, cw, col0;   // cw = float4 chunks of this block's slice
+    bool rem;                    // this block owns the trailing columns
+};
+__device__ __forceinline__ SegCols seg_cols(int ld) {
+    SegCols c;
+    col_plan(ld, c.remv, c.nq);
+    // (reversed: the last quarter's block, which also owns the trailing columns and is the launch's critical path, is dispatched
+    //  first -- the second half of a launch's workgroups reaches its first barrier ~3.6 us later than the first half, measured)
+    c.q = c.nq - 1 - (int)blockIdx.y;
+    c.rem = c.remv > 0 && c.q == c.nq - 1;
+    c.col0 = 32 * c.q;
+    c.cw = min(8, (ld - c.remv - c.col0) >> 2) + (c.rem ? 1 : 0);
+    return c;
+}
+// LDS tile column of chunk lc / its global column
+__device__ __forceinline__ int seg_tcol(const SegCols& c, int lc) { return (c.rem && lc == c.cw - 1) ? 32 : 4 * lc; }
+__device__ __forceinline__ int seg_gcol(const SegCols& c, int lc) { return (c.rem && lc == c.cw - 1) ? 32 * c.nq : c.col0 + 4 * lc; }
+// global column of LDS tile column t (0..31: the quarter; 32..35: the trailing columns), -1: not in this block
+__device__ __forceinline__ int seg_col_of_tile(const SegCols& c, int t) { return t < 32 ? c.col0 + t : (c.rem && t - 32 < c.remv ? 32 * c.nq + t - 32 : -1); }
+
+__device__ __forceinline__ float4 sg_add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float4 sg_fma4(float a, float4 x, float4 acc) {
+    return make_float4(fmaf(a, x.x, acc.x), fmaf(a, x.y, acc.y), fmaf(a, x.z, acc.z), fmaf(a, x.w, acc.w));
+}
+__device__ __forceinline__ float4 sg_relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
+
+
 }  // namespace pfn

@@ -827,6 +827,68 @@ torch.save({{"out": out.detach().cpu(), "gx": d.x.grad.cpu(), "g": m.flat_grad()
         assert_close(res[tag]["g"], res["generic"]["g"], RTOL, f"{tag}: flat parameter gradient")
 
 
+def test_fused_linear_hops_are_bit_identical_to_two_launches(tmp_path):
+    """seg_lin_hops.hip: for batches of small graphs the Linear in front of a TAGConv's hops -- forward `act(S W2^T + deg b2)`, backward
+    `(dP W1i + dQ W1j)[gate]` -- and the K hops over its output run in ONE launch per (graph, 32-column quarter) (networks/MPN.py:541-547:
+    the E -> act -> T loop).  It repeats gemm_nt's MFMA k / term order, trailing-column chains and epilogue expressions and
+    fused_hops_kernel's edge order, so every output and every gradient carries the SAME BITS as the two-launch path
+    (PFN_NO_SEG_LIN_HOPS=1; read once per process -> child processes): eval and train mode (dropout: the same Philox draw per
+    (row, column group)), case118v2 x 128 (one graph per workgroup, gemm_nt's stationary kernel on the other side), case14 x 37 (nine
+    graphs per workgroup, a last block with fewer rows), and dense 16-node graphs whose edges exceed the LDS adjacency slice."""
+    import os
+    import subprocess
+    import sys
+    script = f"""
+import sys, torch
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+from poweflownet_amd.synth import make_batch, make_graph, make_topology
+from poweflownet_amd.data import Batch
+from poweflownet_amd import _lib as L
+res = {{}}
+def run(tag, m, d):
+    d = d.to("cuda:0")
+    d.x.requires_grad_(True)
+    L.profile_report(reset=True); L.profile_enable(True)
+    out = m(d)
+    torch.nn.MSELoss()(out, d.y).backward()
+    torch.cuda.synchronize()
+    L.profile_enable(False)
+    rep = L.profile_report(reset=True)
+    res[tag + ".launches"] = {{k: v["count"] for k, v in rep.items() if not k.startswith("__")}}
+    res[tag + ".out"], res[tag + ".gx"], res[tag + ".g"] = out.detach().cpu(), d.x.grad.cpu(), m.flat_grad().cpu()
+    m.zero_grad(set_to_none=True)
+torch.manual_seed(5)
+m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.2).to("cuda:0")
+m.seed_dropout(77)
+m.train()
+run("train118", m, make_batch("118v2", 128, seed=1))
+m.eval()
+run("eval118", m, make_batch("118v2", 128, seed=2))
+run("eval14", m, make_batch("14", 37, seed=3))
+topo = make_topology(16, 100, 0)
+run("dense16", m, Batch.from_data_list([make_graph(16, 100, seed=50 + b, edge_index=topo) for b in range(21)]))
+torch.save(res, sys.argv[1])
+"""
+    res = {}
+    # (below 256 row tiles gemm_nt hands one-group products to its split-K kernel, whose per-term partial sums and `x + rs * b`
+    #  epilogue are another fp32 order: PFN_NT_TINY_MAX_TILES=0 keeps the weight-stationary kernel on the two-launch side)
+    for tag, env in (("fused", {"PFN_NT_TINY_MAX_TILES": "0"}), ("two", {"PFN_NT_TINY_MAX_TILES": "0", "PFN_NO_SEG_LIN_HOPS": "1"})):
+        path = str(tmp_path / f"{tag}.pt")
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=600)
+        res[tag] = torch.load(path)
+    for case in ("train118", "eval118", "eval14", "dense16"):
+        lf, lt = res["fused"][case + ".launches"], res["two"][case + ".launches"]
+        # L = 4: three E -> T transitions per direction ride in the fused launches; the two-launch path has none of them
+        assert lf.get("seg_lin_hops_fwd") == 3 and lf.get("seg_lin_hops_bwd") == 3 and "fused_hops_fwd" not in lf, lf
+        assert "seg_lin_hops_fwd" not in lt and lt.get("fused_hops_fwd") == 3 and lt.get("fused_hops_bwd") == 3, lt
+        assert lf["gemm_nt"] == lt["gemm_nt"] - 6, (lf, lt)
+        for key in ("out", "gx", "g"):
+            a, b = res["fused"][f"{case}.{key}"], res["two"][f"{case}.{key}"]
+            assert a.abs().max() > 0 and torch.isfinite(a).all()
+            assert torch.equal(a, b), f"{case}.{key}: fused Linear + hops differs from gemm_nt + fused_hops by {(a - b).abs().max().item():.3e}"
+
+
 def test_first_layer_pq_from_x0_is_bit_identical_to_stored_pq(tmp_path):
     """Beyond the latency regime (> 32,768 rows) the first EdgeAggregation layer's P | Q rows are not written when nothing reads
     them from memory (inference; training whose backward walks read saved ReLU masks): the edge walk forms them from the 16-byte
