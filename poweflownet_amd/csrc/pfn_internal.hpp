@@ -580,8 +580,11 @@ __host__ __device__ __forceinline__ DropKey drop_key(uint64_t seed, uint64_t off
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        // (one 64-bit product per multiplier -- v_mad_u64_u32 -- instead of v_mul_hi_u32 + v_mul_lo_u32: 32-bit integer multiplies
+        //  are quarter rate, and the ten rounds are most of a dropout epilogue's instruction time)
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         c[0] = hi1 ^ c[1] ^ k0;
         c[1] = lo1;
         c[2] = hi0 ^ c[3] ^ k1;

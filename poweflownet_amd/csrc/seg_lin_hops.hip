@@ -27,6 +27,22 @@ __device__ __forceinline__ float4 slh_sel4(bool k, float4 a, float4 b) {   // (e
     return make_float4(k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z, k ? a.w : b.w);
 }
 
+// tools/ubench experiment switches (never defined in the product build): SLH_EXP_TS = wall-clock (100 MHz) timestamps of the phases,
+// one record per workgroup of the LAST launch, read back with pfn_debug_slh_ts(); SLH_EXP_COAL = the A fragments loaded from
+// CONTIGUOUS addresses (same instruction and byte count, wrong results): what the row-per-lane gather costs
+#ifdef SLH_EXP_TS
+__device__ unsigned long long slh_ts[4096 * 8];
+#define SLH_TS(slot)                                                                                                  \
+    do {                                                                                                              \
+        if (threadIdx.x == 0) {                                                                                       \
+            const int b_ = blockIdx.y * gridDim.x + blockIdx.x;                                                       \
+            if (b_ < 4096) slh_ts[b_ * 8 + (slot)] = wall_clock64();                                                  \
+        }                                                                                                             \
+    } while (0)
+#else
+#define SLH_TS(slot) do { } while (0)
+#endif
+
 constexpr int SLH_REM_FLOATS = SG_NCH * 32;   // trailing-column image of one term: 34 k groups x [4 columns][4 k's]
 
 struct SlhLds {
@@ -93,6 +109,9 @@ __device__ __forceinline__ void slh_mma(f32x16& acc, float& racc, const SegA& t,
         }
         b = bn;
         r = rn;
+        // (left alone, the scheduler sinks the trailing column's 65 fmas and their LDS reads BEHIND the last MFMA as one serial
+        //  chain: +2 us on the block that owns the column -- the launch's critical path; measured with phase timestamps)
+        if (REM) __builtin_amdgcn_sched_barrier(0);
     }
 }
 // the raw accumulator tile of one wave <-> LDS (register 4g + e of lane (r32, kh) = row 8g + 4kh + e, column r32)
@@ -118,9 +137,25 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
     const int K8 = 8 * SG_NCH;                       // (the launcher admits K8 == 136 only: straight-line multiply)
     // ---- prologue: EVERY global load is requested before the first LDS store (cf. ea_seg.hip)
     SegA ta;
+    SLH_TS(0);
+#ifdef SLH_EXP_NOA
+    if (mfma_on) {
+#pragma unroll
+        for (int m = 0; m < SG_NCH; ++m) ta.av[m] = f32x4{1.f * m, 2.f, 3.f, 1.f * lane};
+    }
+#elif !defined(SLH_EXP_COAL)
     if (mfma_on) seg_load_a(ta, (NTERM > 1 && mterm) ? a.A1 : a.A0, a.lda, K8, r0 + 32 * mtile, r0 + rows - 1, lane);
+#else
+    if (mfma_on) {
+        const float* base = ((NTERM > 1 && mterm) ? a.A1 : a.A0) + (size_t)(r0 + 24 * mtile) * a.lda;
+#pragma unroll
+        for (int m = 0; m < SG_NCH; ++m) ta.av[m] = *reinterpret_cast<const f32x4*>(base + m * 256 + lane * 4);
+    }
+#endif
+#ifndef SLH_EXP_NOB
     seg_copy_b(l.B[0], a.B0, sc.q, K8, wave, lane);
     if (NTERM > 1) seg_copy_b(l.B[1], a.B1, sc.q, K8, wave, lane);
+#endif
     const int e0 = rowptr[r0], ne = rowptr[r0 + rows] - e0;
     const bool nb_in_lds = ne <= cap;
     const int rpv = tid <= rows ? rowptr[r0 + tid] : 0;
@@ -167,6 +202,7 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
         gbits |= ((gv[j].x > 0.f ? 1u : 0u) | (gv[j].y > 0.f ? 2u : 0u) | (gv[j].z > 0.f ? 4u : 0u) | (gv[j].w > 0.f ? 8u : 0u)) << (4 * j);
     seg_dma_wait();
     __syncthreads();
+    SLH_TS(1);
     // ---- the Linear's tiles.  The terms of a tile go into ONE accumulator chain in term order (gemm_nt's order: bit-identical
     // sums): the wave that owns (tile, term 1) takes over the accumulators -- and the trailing column's two half-chains -- that
     // the wave of (tile, term 0) leaves in LDS.  (One wave running both terms needs the second fragment refilled in place under
@@ -196,6 +232,7 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
         }
         __syncthreads();
     }
+    SLH_TS(2);
     // ---- epilogue, item = (row, float4 chunk): gemm_nt's expressions element for element; result -> y and back into the tile
     DropKey dk = DropKey{0u, 0u, 0u, 0u};
     float keep_scale = 1.f;
@@ -236,55 +273,118 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
             sg_st4(a.y + (size_t)(r0 + lr) * a.ld + gc, o4);
         }
     }
-    __syncthreads();
-    // ---- K hops, ping-pong between the two tiles (fused_hops_kernel's walk: four slots per trip, edge-id order)
-    float* cur = l.t0;
-    float* nxt = l.t1;
-    for (int k = 1; k <= a.nhops; ++k) {
-        const bool last = k == a.nhops;
-        float* gout = a.xk + (size_t)(k - 1) * a.stride;
+    seg_lds_barrier();   // (not __syncthreads(): the y stores drain while the hops run)
+    SLH_TS(3);
+    // ---- K hops, ping-pong between the two tiles (fused_hops_kernel's walk: four slots per trip, edge-id order).  A row's first
+    // four slots -- all of most rows of a power grid -- are planned ONCE for the K hops: tile offsets of the neighbour rows and the
+    // edge weights dinv[src] * dinv[dst] in registers, so a hop is four independent tile reads and four fmas per item instead of
+    // a chain of dependent LDS reads (row pointer -> index -> weight | row) per hop: 5-6 us of a launch were three such hops.
+    // Items past the end are clamped to the last item (branch-free: the three items' reads interleave) and not stored.
+    // (The tiles are addressed as 32-bit float offsets into the block's LDS: two swapped `float*` are flat 64-bit addresses.)
+    uint32_t cur = 0, nxt = (uint32_t)(trows * SG_TW);
+    // one item's hop, unplanned (the third item of the few threads that have one, and blocks whose indices are not in LDS)
+    auto walk_item = [&](int it, float* gout, bool last) {
+        const int lr = it / sc.cw, lc = it - lr * sc.cw;
+        const int tc = seg_tcol(sc, lc), gc = seg_gcol(sc, lc);
+        const float di = l.dinv[lr];
+        const int beg = l.rp[lr], end = l.rp[lr + 1], lastp = end - 1;
+        float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = beg; p < end; p += 4) {
+            int s_[4];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int it = tid + j * SG_THREADS;
-            if (it < nitems) {
-                const int lr = it / sc.cw, lc = it - lr * sc.cw;
-                const int tc = seg_tcol(sc, lc), gc = seg_gcol(sc, lc);
-                const int beg = l.rp[lr], end = l.rp[lr + 1];
-                const float di = l.dinv[lr];
-                float4 h = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (nb_in_lds) {
-                    const int lastp = end - 1;
-                    for (int p = beg; p < end; p += 4) {
+            for (int u = 0; u < 4; ++u) s_[u] = nb_in_lds ? l.nb[min(p + u, lastp)] : nbr[e0 + min(p + u, lastp)] - r0;
+            float w_[4];
+            float4 x_[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w_[u] = l.dinv[s_[u]] * di;
+                x_[u] = sg_ld4(slh_smem + cur + (uint32_t)(s_[u] * SG_TW + tc));
+            }
+            h = sg_fma4(w_[0], x_[0], h);
+            h = slh_sel4(p + 1 < end, sg_fma4(w_[1], x_[1], h), h);
+            h = slh_sel4(p + 2 < end, sg_fma4(w_[2], x_[2], h), h);
+            h = slh_sel4(p + 3 < end, sg_fma4(w_[3], x_[3], h), h);
+        }
+        if (!last) sg_st4(slh_smem + nxt + (uint32_t)(lr * SG_TW + tc), h);
+        sg_st4(gout + (size_t)(r0 + lr) * a.ld + gc, h);
+    };
+    if (nb_in_lds) {
+        uint32_t h_to[2], h_go[2], h_so[2][4];
+        int h_tc[2], h_beg[2], h_cnt[2];
+        float h_di[2], h_w[2][4];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int it = min(tid + j * SG_THREADS, nitems - 1);
+            const int lr = it / sc.cw, lc = it - lr * sc.cw;
+            h_tc[j] = seg_tcol(sc, lc);
+            h_to[j] = (uint32_t)(lr * SG_TW + h_tc[j]);
+            h_go[j] = (uint32_t)((r0 + lr) * a.ld + seg_gcol(sc, lc));
+            h_beg[j] = l.rp[lr];
+            h_cnt[j] = l.rp[lr + 1] - h_beg[j];
+            h_di[j] = l.dinv[lr];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {   // (slots past the row's end re-read its last edge; an empty row reads slot 0 of the block, unused)
+                const int sv = l.nb[max(h_beg[j] + min(u, h_cnt[j] - 1), 0)];
+                h_so[j][u] = (uint32_t)(sv * SG_TW + h_tc[j]);
+                h_w[j][u] = l.dinv[sv] * h_di[j];
+            }
+        }
+        for (int k = 1; k <= a.nhops; ++k) {
+            const bool last = k == a.nhops;
+            float* gout = a.xk + (size_t)(k - 1) * a.stride;
+            float4 v_[2][4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v_[j][u] = sg_ld4(slh_smem + cur + h_so[j][u]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 h = slh_sel4(h_cnt[j] > 0, sg_fma4(h_w[j][0], v_[j][0], z), z);
+                h = slh_sel4(h_cnt[j] > 1, sg_fma4(h_w[j][1], v_[j][1], h), h);
+                h = slh_sel4(h_cnt[j] > 2, sg_fma4(h_w[j][2], v_[j][2], h), h);
+                h = slh_sel4(h_cnt[j] > 3, sg_fma4(h_w[j][3], v_[j][3], h), h);
+                if (h_cnt[j] > 4) {   // the rest of a longer row: the generic walk
+                    const int end = h_beg[j] + h_cnt[j], lastp = end - 1;
+                    for (int p = h_beg[j] + 4; p < end; p += 4) {
                         int s_[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) s_[u] = l.nb[min(p + u, lastp)];
                         float w_[4];
-                        float4 v_[4];
+                        float4 x_[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) {
-                            w_[u] = l.dinv[s_[u]] * di;
-                            v_[u] = sg_ld4(cur + (size_t)s_[u] * SG_TW + tc);
+                            w_[u] = l.dinv[s_[u]] * h_di[j];
+                            x_[u] = sg_ld4(slh_smem + cur + (uint32_t)(s_[u] * SG_TW + h_tc[j]));
                         }
-                        h = sg_fma4(w_[0], v_[0], h);
-                        h = slh_sel4(p + 1 < end, sg_fma4(w_[1], v_[1], h), h);
-                        h = slh_sel4(p + 2 < end, sg_fma4(w_[2], v_[2], h), h);
-                        h = slh_sel4(p + 3 < end, sg_fma4(w_[3], v_[3], h), h);
-                    }
-                } else {   // a block with more edges than its LDS slice holds: indices from global memory
-                    for (int p = beg; p < end; ++p) {
-                        const int ls = nbr[e0 + p] - r0;
-                        h = sg_fma4(l.dinv[ls] * di, sg_ld4(cur + (size_t)ls * SG_TW + tc), h);
+                        h = sg_fma4(w_[0], x_[0], h);
+                        h = slh_sel4(p + 1 < end, sg_fma4(w_[1], x_[1], h), h);
+                        h = slh_sel4(p + 2 < end, sg_fma4(w_[2], x_[2], h), h);
+                        h = slh_sel4(p + 3 < end, sg_fma4(w_[3], x_[3], h), h);
                     }
                 }
-                if (!last) sg_st4(nxt + (size_t)lr * SG_TW + tc, h);
-                sg_st4(gout + (size_t)(r0 + lr) * a.ld + gc, h);
+                if (tid + j * SG_THREADS < nitems) {
+                    if (!last) sg_st4(slh_smem + nxt + h_to[j], h);
+                    sg_st4(gout + h_go[j], h);
+                }
             }
+            for (int it = tid + 2 * SG_THREADS; it < nitems; it += SG_THREADS) walk_item(it, gout, last);
+            seg_lds_barrier();
+            const uint32_t t = cur;
+            cur = nxt;
+            nxt = t;
         }
-        __syncthreads();
-        float* t = cur;
-        cur = nxt;
-        nxt = t;
+    } else {   // a block with more edges than its LDS slice holds: indices from global memory, hop by hop
+        for (int k = 1; k <= a.nhops; ++k) {
+            float* gout = a.xk + (size_t)(k - 1) * a.stride;
+            for (int it = tid; it < nitems; it += SG_THREADS) walk_item(it, gout, k == a.nhops);
+            seg_lds_barrier();
+            const uint32_t t = cur;
+            cur = nxt;
+            nxt = t;
+        }
     }
+    SLH_TS(4);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -340,3 +440,9 @@ int launch_seg_lin_hops(const GraphView& g, const SegLinHopsArgs& a, int seg, hi
 }
 
 }  // namespace pfn
+
+#ifdef SLH_EXP_TS
+extern "C" int pfn_debug_slh_ts(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::slh_ts), (size_t)n * sizeof(unsigned long long));
+}
+#endif
