@@ -52,7 +52,9 @@ typedef struct pfn_mpn_config {
                              * forward edge walks also save their ReLU masks, which the backward walks then read instead of
                              * recomputing the edge pre-activations.  0: inference: nothing extra is written and tensors only
                              * the backward reads (mask_embd's hidden layer) are not stored; pfn_mpn_backward then returns
-                             * PFN_EINVAL.  pfn_mpn_backward must be given the value the forward call had.                */
+                             * PFN_EINVAL.  pfn_mpn_backward must be given the value the forward call had: the forward stamps
+                             * its workspace on the device, and a backward pass on a workspace whose LAST forward ran with
+                             * need_backward = 0 (the host cannot tell) writes every parameter gradient as NaN.          */
 } pfn_mpn_config;
 
 /* The library keeps NO process-global mutable state: no stream, event, cache or "first caller" device binding of its own
@@ -226,34 +228,20 @@ int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
  * replaces, the tuning scripts under tools/ to sweep a launch parameter -- and none of them is needed in production: unset, the
  * library behaves as DESIGN.md describes.  There is no switch that routes work off the GPU or through another backend.
  *   PFN_NO_SEG_EA=1         EdgeAggregation of small-graph batches: generic gemm_nt + edge walks instead of the graph-resident kernels
- *   PFN_SEG_EA_PER_CU=<n>   ... use the graph-resident kernels up to n workgroups per CU (default 4)
  *   PFN_NO_SEG_LIN_HOPS=1   small-graph batches: the Linear in front of a TAGConv's hops and the hops as two launches (gemm_nt + fused hops)
  *                           instead of one graph-resident launch (seg_lin_hops.hip; bit-identical results)
  *   PFN_NO_FUSED_FRONT=1    mask_embd + first P|Q as generic GEMMs instead of front.hip's one launch
  *   PFN_NO_FUSED_BACK=1     the last layer's Linear / dS outside the edge walks (generic GEMMs)
  *   PFN_FRONT_BLOCK_ROWS=1  front.hip: the block-per-row-group kernels instead of one row per wave
- *   PFN_WAVE_MAX_ROWS=<n>   front.hip: largest batch (rows) that takes the row-per-wave kernels (default 32768)
- *   PFN_WAVE_BPC=a,b,c      front.hip: workgroups per CU of the three row-per-wave kernels
- *   PFN_FUSED_HOPS=0|1      TAGConv hops: never / always LDS-resident per graph when they fit (default: when they fit)
- *   PFN_FH_BLOCKS=<n>       fused hops: target number of workgroups (default 1024)
  *   PFN_NO_BIG_HOPS=1       TAGConv hops of large graphs (one LDS tile + registers per graph and column chunk): K generic hop launches instead
- *   PFN_NO_CM_INPUT=1       ... and the layer in front of such a TAGConv writes its output row-major instead of chunk-major
  *   PFN_NO_ROW_HOPS=1       TAGConv hops of big batches of small graphs: the two-tile column-slice kernel instead of whole rows per block
  *   PFN_NO_EDGE_ROWS=1      the edge stage of big inference batches of small graphs: the generic gather kernel instead of the LDS-resident one
  *   PFN_NO_L0_FLY=1         the front writes the first layer's P | Q and the edge walk gathers them (default: the walk forms them from x0)
  *   PFN_EDGE_FWD_BPC=N      workgroups per CU of the persistent generic forward edge walk (default 8; a large N = one workgroup per 256 items)
  *   PFN_FRONT_STORE_MEH=1   training beyond 32 k rows: mask_embd's hidden layer is stored and its weight gradients go through gemm_tn
  *                           (default: recomputed in the backward front, which forms those gradients itself)
- *   PFN_NT_BX_MIN_TILES=N   opt-in experiment: large-M GEMMs (K = 129, 129 columns, >= N row tiles per wave) as nine exact bf16 partial
- *                           products per fp32 product on v_mfma_f32_32x32x16_bf16 (gemm_nt_bx_kernel); default 0 = never
  *   PFN_FRONT_NO_THREAD_ROWS=1   inference front: the row-per-wave / block kernels instead of one row per thread
- *   PFN_NO_CM_GRAD=1        ... and the layer behind it hands its gradient down row-major instead of chunk-major
- *   PFN_FH_ONE_PER_CU=1     fused hops: whole rows per workgroup (one 125 KB workgroup per CU) instead of two half-LDS ones
- *   PFN_TN_BLOCKS=<n>       gemm_tn: target number of workgroups (default: one per CU)
- *   PFN_TN_NOGROUP=1        gemm_tn: do not co-schedule tasks that share an operand
- *   PFN_NT_TPS=1|2|4        gemm_nt: at most that many 32-column quarters per LDS slice
  *   PFN_NT_CT=1|2           gemm_nt: quarters per wave
- *   PFN_NT_LS4=1            gemm_nt: four MFMA steps in the last k chunk although K = 129 needs one
  *   PFN_NT_TINY_MAX_TILES=<n> gemm_nt: the split-K small-batch kernel up to n row tiles of 32 rows (default 256; 0 = never)
  *   PFN_NT_WS_MIN_TILES=<n> gemm_nt: weight-streaming kernel from n row tiles per wave (default 2; 0 = never)                     */
 

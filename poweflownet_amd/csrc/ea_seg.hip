@@ -691,7 +691,7 @@ bool ea_seg_fit(int seg, int n, int fe, int ld, bool bwd) {
     // Only in the latency regime: with a few blocks per CU a launch is one MFMA tile and one walk deep and the saved launches
     // and HBM round trips win (case118 x 128: -5 % of the step); with many blocks per CU the weight-stationary persistent
     // gemm_nt amortises its prologue and is the faster GEMM (case118 x 2048 inference: 3.39 vs 3.11 ms, measured)
-    static const long per_cu = diag_env("PFN_SEG_EA_PER_CU") ? atol(diag_env("PFN_SEG_EA_PER_CU")) : 4L;   // tuning aid
+    const long per_cu = 4L;
     return !off && fe == 2 && seg_plan(seg, n, ld, p, bwd) && (long)p.nblocks * p.ny <= per_cu * device_cus();
 }
 int ea_seg_blocks(int seg, int n, int ld) {

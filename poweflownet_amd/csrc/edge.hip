@@ -122,12 +122,10 @@ bool fused_hops_fit(int seg, int ld, int n) {
     // A hop acts on every column independently, so a block may take a COLUMN SLICE of its graph(s): small batches still
     // fill the chip (case118 x 128: 128 graphs x 7 slices of 5 float4 columns = 896 blocks, 21 KB of LDS each) and the K
     // hops cost one launch instead of K (measured 47 -> ~11 us per TAGConv at 128 graphs).  Needs two
-    // tiles of at least one float4 column of a whole graph in LDS.  PFN_FUSED_HOPS=0/1 forces the choice (experiments).
-    static const char* force = diag_env("PFN_FUSED_HOPS");
+    // tiles of at least one float4 column of a whole graph in LDS.
     (void)ld;
     (void)n;
     if (seg <= 0 || (size_t)2 * seg * 4 * sizeof(float) + (size_t)(2 * seg + 1) * sizeof(int) > (size_t)FH_LDS_BYTES / 2) return false;
-    if (force) return force[0] == '1';
     return true;
 }
 
@@ -376,7 +374,7 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
     }
     // (1024: case118 x 128 = 7 slices of 5 float4 columns, 896 blocks, 11.0-11.6 us per launch; 512 blocks of 9 columns: 12.1-12.8 us;
     //  11 slices of 3 columns: 13.4 us -- 48-byte row segments waste most of every cache line, hence the floor of 4 columns)
-    static const int want = diag_env("PFN_FH_BLOCKS") ? atoi(diag_env("PFN_FH_BLOCKS")) : 1024;   // tuning aid
+    const int want = 1024;
     int cs = std::max(1, std::min(nchunk, (want + ngraphs - 1) / std::max(1, ngraphs)));   // slices wanted
     int cw = std::max((nchunk + cs - 1) / cs, std::min(nchunk, 4));
     cw = std::min(cw, max_cw);
@@ -388,8 +386,7 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
     {
         const size_t half = (size_t)FH_LDS_BYTES / 2;
         const int half_cw = (int)((half - (size_t)(2 * a.seg + 1) * sizeof(int)) / per_chunk_graph);
-        static const bool off = diag_env("PFN_FH_ONE_PER_CU") != nullptr;   // experiments
-        if (!off && (long)ngraphs * cs >= 2L * device_cus() && half_cw >= 8) {
+        if ((long)ngraphs * cs >= 2L * device_cus() && half_cw >= 8) {
             budget = half;
             lds_cap /= 2;
             if (cw > half_cw) {
@@ -564,8 +561,7 @@ bool tag_uses_big_hops(int seg, int ld, int n, int64_t e_stored, int K) {
     return K > 0 && !fused_hops_fit(seg, ld, n) && big_hops_fit(seg, n, e_stored);
 }
 bool tag_input_cm(int seg, int ld, int n, int64_t e_stored, int K) {
-    static const bool off = diag_env("PFN_NO_CM_INPUT") != nullptr;   // A/B switch: the TAGConv input stays row-major
-    return !off && tag_uses_big_hops(seg, ld, n, e_stored, K);
+    return tag_uses_big_hops(seg, ld, n, e_stored, K);
 }
 
 int launch_big_graph_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s) {

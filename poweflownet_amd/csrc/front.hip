@@ -22,25 +22,14 @@
 
 namespace pfn {
 
-static int wave_max_rows() {   // the row-per-wave kernels serve batches up to this many rows (tuning aid: PFN_WAVE_MAX_ROWS)
-    static const int v = diag_env("PFN_WAVE_MAX_ROWS") ? atoi(diag_env("PFN_WAVE_MAX_ROWS")) : 32768;
-    return v;
-}
+static int wave_max_rows() { return 32768; }   // the row-per-wave kernels serve batches up to this many rows
 // 256-thread blocks per CU of the row-per-wave kernels (which: 0 forward, 1 backward, 2 lin_out4).  Every wave first loads its
 // lanes' slices of the weights (72 values per lane in the forward), so FEWER, longer-lived waves win as long as the CU still
 // has enough of them to hide a row's load chain: case118 x 128 (15 k rows) with 8 / 4 / 3 / 2 / 1 blocks per CU: forward
 // 22.5 / 18.1 / 17.1 / 17.0 / 22.4 us, backward 11.9 / 9.7 / 9.8 / 10.5 / - us, lin_out4 7.3 / 7.6 / 6.5 / 8.1 / - us.
-// Tuning aid: PFN_WAVE_BPC="f,b,l"
 static int wave_blocks_per_cu(int which) {
-    static int v[3] = {0, 0, 0};
-    if (v[0] == 0) {
-        int a = 3, b = 3, c = 3;
-        if (const char* e = diag_env("PFN_WAVE_BPC")) sscanf(e, "%d,%d,%d", &a, &b, &c);
-        v[1] = std::max(1, b);
-        v[2] = std::max(1, c);
-        v[0] = std::max(1, a);
-    }
-    return v[which];
+    (void)which;
+    return 3;
 }
 
 __device__ __forceinline__ float4 ld4f(const float* p) { return *reinterpret_cast<const float4*>(p); }
@@ -350,6 +339,7 @@ __global__ __launch_bounds__(256) void front_pack_kernel(const FrontFwdArgs f, c
     extern __shared__ __attribute__((aligned(16))) float4 fl[];
     // the dropout stream advances once per forward, before any kernel of that forward reads it
     if (pa.rng_advance && blockIdx.x == 0 && threadIdx.x == 0) pa.rng_advance[1] += 1;
+    if (pa.stamp && blockIdx.x == 0 && threadIdx.x == 0) *pa.stamp = pa.stamp_value;
     slot_ea_body(pa.slot_ea, (int64_t)blockIdx.x * blockDim.x + threadIdx.x, (int64_t)gridDim.x * blockDim.x);
     if ((int)blockIdx.x < nb_front) {
         if (MODE == 3) {
@@ -566,7 +556,7 @@ static void front_shape(int h, int& ld, int& nchunk, int& rows_pb, size_t& lds) 
 }
 
 int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s,
-                          const SlotEa* slot_ea) {
+                          const SlotEa* slot_ea, int* stamp, int stamp_value) {
     if (f.mask_dtype != 0 && f.mask_dtype != 1) {
         set_error("pred_mask dtype code %d unsupported (0: int64, 1: float32)", f.mask_dtype);
         return PFN_EINVAL;
@@ -578,6 +568,8 @@ int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs,
     if (slot_ea) pa.slot_ea = *slot_ea;
     pa.njobs = std::min(njobs, PACK_MAX_JOBS);
     pa.rng_advance = rng_advance;
+    pa.stamp = stamp;
+    pa.stamp_value = stamp_value;
     pa.mask = nullptr;
     pa.maskf = nullptr;
     pa.mask_count = 0;
@@ -605,7 +597,7 @@ int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs,
         lds = 0;
     }
     const int nblocks = nb_front + pack_bx * pa.njobs;
-    if (nblocks > 0 || rng_advance) {
+    if (nblocks > 0 || rng_advance || stamp) {
         ProfScope ps("front_fwd+pack", 0.0, 0.0, s);
         if (split_meh) front_pack_kernel<3><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);
         else if (per_thread) front_pack_kernel<2><<<std::max(1, nblocks), 256, lds, s>>>(f, pa, nb_front, pack_bx, ld, nchunk, rows_pb);

@@ -66,9 +66,11 @@ struct T3Task {
 struct T3Args {
     TnPair pair[T3_MAX_PAIRS];
     T3Task task[T3_MAX_TASKS];
-    int ntasks, M, nblocks, pad_;
+    int ntasks, M, nblocks, stamp_want;
     float4* partial;
+    const int* stamp;      // optional guard word (model.hip WS_STAMP_*): if *stamp != stamp_want every gradient is written as NaN
 };
+__device__ __forceinline__ bool t3_bad(const T3Args& a) { return a.stamp != nullptr && *a.stamp != a.stamp_want; }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 template <int W>
@@ -88,10 +90,12 @@ __device__ __forceinline__ void frag_zero(float& v) { v = 0.f; }
 // Extras: quad X+0 = odd column (dW[.][nb-1]) for the lane's TA rows, X+1 = bias for the same rows (both: half 0 only),
 // X+2 = odd row (dW[na-1][.]) for the lane's TB columns, X+3 = {corner, corner bias, -, -} (half 0 only).
 template <int TA, int TB>
-__device__ __forceinline__ void t3_emit(const TnPair& pr, const T3Task& tk, int half, int Q, float4 s, int c, int kh, int lane) {
+__device__ __forceinline__ void t3_emit(const TnPair& pr, const T3Task& tk, int half, int Q, float4 s, int c, int kh, int lane,
+                                        bool bad) {
     const bool f_xcol = tk.flags & TNF_XCOL, f_bias = tk.flags & TNF_BIAS, f_xrow = tk.flags & TNF_XROW;
     const int na_main = pr.na - (f_xrow ? 1 : 0), nb_main = pr.nb - (f_xcol ? 1 : 0);
-    const float e4[4] = {s.x, s.y, s.z, s.w};
+    const float nan_ = __builtin_nanf("");
+    const float e4[4] = {bad ? nan_ : s.x, bad ? nan_ : s.y, bad ? nan_ : s.z, bad ? nan_ : s.w};
     constexpr int NT = TA * TB * 4;
     if (Q < NT) {
         const int t = Q >> 2, g = Q & 3, ta = t / TB, tb = t % TB;
@@ -375,8 +379,9 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     if (wr != 0) return;
     // ---- one block: write the gradient; several: publish the partial for tn_combine_kernel
     if (tk.nsplit == 1) {
+        const bool bad = t3_bad(a);
 #pragma unroll
-        for (int Q = 0; Q < NQ; ++Q) t3_emit<TA, TB>(pr, tk, half, Q, v[Q], c, kh, lane);
+        for (int Q = 0; Q < NQ; ++Q) t3_emit<TA, TB>(pr, tk, half, Q, v[Q], c, kh, lane, bad);
         return;
     }
     float4* mine = a.partial + tk.part0 + ((size_t)bx * NH + half) * NQ * 64;
@@ -452,10 +457,11 @@ __global__ __launch_bounds__(256) void tn_combine_kernel(const T3Args a) {
     }
     const TnPair& pr = a.pair[tk.pair];
     const int c = lane & 31, kh = lane >> 5;
-    if (tk.wa && tk.wb) t3_emit<4, 2>(pr, tk, half, Q, s, c, kh, lane);
-    else if (tk.wa) t3_emit<4, 1>(pr, tk, half, Q, s, c, kh, lane);
-    else if (tk.wb) t3_emit<1, 2>(pr, tk, half, Q, s, c, kh, lane);
-    else t3_emit<1, 1>(pr, tk, half, Q, s, c, kh, lane);
+    const bool bad = t3_bad(a);
+    if (tk.wa && tk.wb) t3_emit<4, 2>(pr, tk, half, Q, s, c, kh, lane, bad);
+    else if (tk.wa) t3_emit<4, 1>(pr, tk, half, Q, s, c, kh, lane, bad);
+    else if (tk.wb) t3_emit<1, 2>(pr, tk, half, Q, s, c, kh, lane, bad);
+    else t3_emit<1, 1>(pr, tk, half, Q, s, c, kh, lane, bad);
 }
 
 constexpr size_t T3_MAX_PARTIAL_F4 = (size_t)400 * 2 * t3_quads(4, 2) * 64;   // ~one workgroup per CU, with slack   // float4 capacity of the partial buffer
@@ -465,7 +471,8 @@ size_t reduce_ws_floats(int64_t M, int max_na, int max_nb, int max_pairs) {
     return T3_MAX_PARTIAL_F4 * 4 + 256;
 }
 
-int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s, const DweRide* ride) {
+int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s, const DweRide* ride,
+                        const int* stamp, int stamp_want) {
     if (npairs == 0 || M == 0) {
         // no rows: every gradient is an empty sum
         for (int p = 0; p < npairs; ++p) {
@@ -480,7 +487,7 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
     static std::atomic<uint64_t> lds_raised{0}, lds_raised_runs{0};
     PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_tn_kernel<false>), T3_LDS_BYTES, lds_raised));
     PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_tn_kernel<true>), T3_LDS_BYTES, lds_raised_runs));
-    static const int want_env = diag_env("PFN_TN_BLOCKS") ? atoi(diag_env("PFN_TN_BLOCKS")) : 0;   // tuning aid
+    const int want_env = 0;
     const int ncu = device_cus();
     bool ride_done = false;
     int p = 0;
@@ -489,6 +496,8 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
         memset(&ta, 0, sizeof(ta));
         ta.M = (int)M;
         ta.partial = reinterpret_cast<float4*>(ws.partial);
+        ta.stamp = stamp;
+        ta.stamp_want = stamp_want;
         int np_here = 0;
         double cost_total = 0.0, flops = 0.0, bytes = 0.0;
         double cost[T3_MAX_TASKS];
@@ -532,8 +541,7 @@ int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws,
             int gsz = 1;
             const TnPair& p0 = ta.pair[ta.task[t].pair];
             const bool single = t + 1 >= ta.ntasks || ta.task[t + 1].pair != ta.task[t].pair;
-            static const bool no_group = diag_env("PFN_TN_NOGROUP") != nullptr;   // experiments
-            while (!no_group && single && t + gsz < ta.ntasks && gsz < 8) {
+            while (single && t + gsz < ta.ntasks && gsz < 8) {
                 const T3Task& nx = ta.task[t + gsz];
                 const TnPair& pn = ta.pair[nx.pair];
                 const bool nx_single = (t + gsz + 1 >= ta.ntasks || ta.task[t + gsz + 1].pair != nx.pair) && nx.pair != ta.task[t + gsz - 1].pair;

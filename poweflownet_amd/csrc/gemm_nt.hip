@@ -49,6 +49,7 @@ constexpr int NT_LDS_BYTES = 160 * 1024;
 __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     // the dropout stream advances once per forward, before any kernel of that forward reads it
     if (a.rng_advance && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) a.rng_advance[1] += 1;
+    if (a.stamp && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *a.stamp = a.stamp_value;
     if (a.mask_count > 0) {   // the rider: pred_mask.float() (networks/MPN.py:533), spread over every block of the launch
         const int64_t nthr = (int64_t)gridDim.x * gridDim.y * blockDim.x;
         for (int64_t i = ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x; i < a.mask_count; i += nthr)
@@ -60,28 +61,21 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const PackArgs a) {
     pack_job_body(a.job[blockIdx.y], blockIdx.x, gridDim.x);
 }
 
-// The bf16-split GEMM (gemm_nt_bx_kernel) is an opt-in experiment: PFN_NT_BX_MIN_TILES=N routes large-M launches with at least N
-// row tiles per wave to it (0 / unset: never; the pack step then writes no split images and reserves no room for them).
-static int bx_min_tiles() {
-    static const int v = diag_env("PFN_NT_BX_MIN_TILES") ? atoi(diag_env("PFN_NT_BX_MIN_TILES")) : 0;
-    return v;
-}
-bool pack_wants_split(int K, int ld_out) { return bx_min_tiles() > 0 && bx_shape(K, ld_out); }
-size_t packed_floats(int K, int ld_out) {
-    return packed_fp32_floats(K, ld_out) + (pack_wants_split(K, ld_out) ? (size_t)2 * BX_HALF_WORDS : 0);   // (+ the bf16-split image)
-}
+size_t packed_floats(int K, int ld_out) { return packed_fp32_floats(K, ld_out); }
 
 int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s, const void* mask, int mask_dtype,
-                float* maskf, int64_t mask_count, const SlotEa* slot_ea) {
+                float* maskf, int64_t mask_count, const SlotEa* slot_ea, int* stamp, int stamp_value) {
     if (mask && mask_dtype != 0 && mask_dtype != 1) {
         set_error("pred_mask dtype code %d unsupported (0: int64, 1: float32)", mask_dtype);
         return PFN_EINVAL;
     }
-    for (int j0 = 0; j0 < njobs || (j0 == 0 && (mask || slot_ea)); j0 += PACK_MAX_JOBS) {
+    for (int j0 = 0; j0 < njobs || (j0 == 0 && (mask || slot_ea || stamp)); j0 += PACK_MAX_JOBS) {
         PackArgs a;
         if (j0 == 0 && slot_ea) a.slot_ea = *slot_ea;
         a.njobs = std::max(0, std::min(PACK_MAX_JOBS, njobs - j0));
         a.rng_advance = j0 == 0 ? rng_advance : nullptr;
+        a.stamp = j0 == 0 ? stamp : nullptr;
+        a.stamp_value = stamp_value;
         const bool rider = j0 == 0 && mask != nullptr && mask_count > 0;
         a.mask = rider ? mask : nullptr;
         a.maskf = maskf;
@@ -94,7 +88,7 @@ int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream
         }
         const int bx = (int)std::min<long>(std::max<long>(1, (biggest + 255) / 256), 64);
         ProfScope ps("pack_weights", 0.0, 0.0, s);
-        if (a.njobs == 0 && !rider && !a.slot_ea.ea_in) continue;
+        if (a.njobs == 0 && !rider && !a.slot_ea.ea_in && !a.stamp) continue;
         pack_weights_kernel<<<dim3(bx, std::max(1, a.njobs)), 256, 0, s>>>(a);
         PFN_CHECK_LAUNCH();
     }
@@ -971,458 +965,6 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
 }
 
 
-// ------------------------------------------------------------------- NT, fp32 through the bf16 matrix cores (large M)
-// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate of the same matrix cores, and the large-M products sit at the fp32 MFMA
-// roof.  An fp32 value is the exact sum of three bf16 values (bf16_split3, pfn_internal.hpp), so a * b is the exact sum of nine
-// bf16 x bf16 products, each of which is exact in fp32: nine v_mfma_f32_32x32x16_bf16 per 16 k's compute what eight fp32 steps
-// do in 9 x 32 instead of 8 x 64 cycles -- fp32 accumulation, no operand rounding anywhere (the products are formed exactly; an
-// fp32 FMA rounds each one).  Same data flow as the streaming kernel above: a wave owns full rows (four quarters + the trailing
-// column) of one 32-row tile per round and reads its A rows once; the weights stream through LDS as pre-split operand images
-// (pack step), one K HALF of one term at a time (50 KB), double-buffered behind one barrier per half.  Per half a lane holds
-// 4 steps x 8 consecutive k's of its row (two 16-byte loads per step), splits them in registers (4 VALU ops per element + 3
-// byte-permutes per pair), and refills them in place for the next half; k = 128 (K = 129) is one fp32 MFMA step per quarter.
-// vmcnt bookkeeping (VMEM returns in order), per half and wave: 7 DMAs (behind the barrier), 8 fragment refills (four behind each
-// odd step) and 1 tail refill (behind the tail): at an even step the ops younger than the chunk it needs are 14, at an odd step 12,
-// at the tail 15, and the DMAs of the next half are complete once at most the 9 refills issued after them are outstanding.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-constexpr int BX_DMAS = 7;                                   // per wave and half: 50 one-KiB slots over 8 waves (6 repeats)
-constexpr int BX_SLOTS = BX_HALF_WORDS * 4 / 1024;           // 50
-
-// splits eight fp32 values (two float4) into the three bf16x8 operands
-__device__ __forceinline__ void bx_split8(const f32x4& x0, const f32x4& x1, u32x4& hi, u32x4& mid, u32x4& lo) {
-    uint32_t h[8], m[8], l[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = j < 4 ? x0[j] : x1[j - 4];
-        const uint32_t xb = __builtin_bit_cast(uint32_t, x);
-        h[j] = xb;                                            // (the permute takes the top halves: no mask needed for packing)
-        const float r1 = x - __builtin_bit_cast(float, xb & 0xffff0000u);
-        m[j] = __builtin_bit_cast(uint32_t, r1);
-        const float r2 = r1 - __builtin_bit_cast(float, m[j] & 0xffff0000u);
-        l[j] = __builtin_bit_cast(uint32_t, r2);
-    }
-#pragma unroll
-    for (int j2 = 0; j2 < 4; ++j2) {                          // dword j2 = (element 2 j2 + 1 : element 2 j2), top 16 bits of each
-        hi[j2] = __builtin_amdgcn_perm(h[2 * j2 + 1], h[2 * j2], 0x07060302u);
-        mid[j2] = __builtin_amdgcn_perm(m[2 * j2 + 1], m[2 * j2], 0x07060302u);
-        lo[j2] = __builtin_amdgcn_perm(l[2 * j2 + 1], l[2 * j2], 0x07060302u);
-    }
-}
-__device__ __forceinline__ u32x4 bx_ldb(const u32x4* p) {
-#ifndef PFN_EXP_BX_NOLDS   /* tools/ubench experiment switch (never defined in the product build): no LDS reads of B operands */
-    return *p;
-#else
-    u32x4 r = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-    asm volatile("" : "+v"(r) : "v"(p));
-    return r;
-#endif
-}
-__device__ __forceinline__ f32x16 bx_mfma(const u32x4& a, const u32x4& b, const f32x16& c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
-}
-
-__global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_bx_kernel(const NtArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int CT = 4;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r32 = lane & 31, kh = lane >> 5;
-    const int nrt = (a.M + 31) >> 5;
-    const int rt_step = gridDim.x * NT_WAVES;
-    const int nround = (nrt + rt_step - 1) / rt_step;       // every wave of every block runs the same number of halves (barriers)
-    const int nhalf = 2 * a.npiece;
-    const int total = nround * nhalf;
-    int rt = blockIdx.x * NT_WAVES + wave;
-    const int rem_col = 128;
-    const int bias_off = 2 * BX_HALF_WORDS;
-
-    auto a_base = [&](int rt2, int p2) -> const char* {
-        const int rc = rt2 < nrt ? rt2 : nrt - 1;           // a wave past the last row tile keeps pace on the last tile; it stores nothing
-        return reinterpret_cast<const char*>(a.piece[p2].A + (size_t)rc * 32 * a.piece[p2].lda);
-    };
-    auto a_voff = [&](int rt2, int p2) -> uint32_t {
-        const int rc = rt2 < nrt ? rt2 : nrt - 1;
-        const int lrow = min(r32, a.M - 1 - rc * 32);
-        return (uint32_t)(lrow * a.piece[p2].lda) * 4u;
-    };
-    // the split image of term p2 lies behind its fp32 image (pack step): half h2 -> LDS buffer `buf`, 50 one-KiB slots
-    auto issue_dma = [&](int p2, int h2, int buf) {
-        float* dst0 = lds + buf * BX_HALF_WORDS;
-        const char* src = reinterpret_cast<const char*>(a.piece[p2].Bq + packed_fp32_floats(129, 132) + (size_t)h2 * BX_HALF_WORDS) + lane * 16;
-#pragma unroll
-        for (int j = 0; j < BX_DMAS; ++j) {
-            int slot = wave + NT_WAVES * j;
-            if (slot >= BX_SLOTS) slot -= BX_SLOTS;         // (six slots are copied twice: every wave issues exactly seven)
-            dma_1k(src + ((size_t)slot << 10), dst0 + (slot << 8));
-        }
-    };
-
-    // ---- first A fragment (half 0 of piece 0), first weight half, bias image
-    f32x4 a_cur[8], a_tail;
-    {
-        const char* b0 = a_base(rt, 0);
-        const uint32_t v0 = a_voff(rt, 0);
-        const uint32_t ks0 = (uint32_t)a.piece[0].kscale;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            a_cur[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            vload_x4(a_cur[m], b0, v0 + ks0 * (uint32_t)(16 * (m >> 1) + 8 * kh + 4 * (m & 1)));
-        }
-        a_tail = f32x4{0.f, 0.f, 0.f, 0.f};
-        vload_x4(a_tail, b0, v0 + ks0 * 128u);
-    }
-    issue_dma(0, 0, 0);
-    {
-        const float* bsrc = a.rowscale ? a.rowbias : a.bias;
-        for (int i = tid; i < a.ldc; i += NT_THREADS) lds[bias_off + i] = (bsrc && i < a.ncols) ? bsrc[i] : 0.f;
-    }
-
-    EpiCfg ep;
-    ep.ncols = a.ncols;
-    ep.act = a.act;
-    ep.has_rowscale = a.rowscale != nullptr;
-    ep.has_resid = a.resid != nullptr;
-    ep.has_gate = a.gate != nullptr;
-    ep.p_drop = a.p_drop;
-    ep.gate_scale = a.gate_scale;
-    ep.dk = DropKey{0u, 0u, 0u, 0u};
-    ep.keep_scale = 1.f;
-    if (a.act == ACT_DROPOUT_RELU) {
-        ep.dk = drop_key(a.rng[0], a.rng[1], a.rng_stream);
-        ep.keep_scale = 1.0f / (1.0f - a.p_drop);
-    }
-    f32x16 acc[CT];
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
-    float racc[4] = {0.f, 0.f, 0.f, 0.f};
-    const float* extra = a.gate ? a.gate : a.resid;         // at most one of rowscale / gate / resid per GEMM
-    const int ldx = a.gate ? a.ldg : a.ldr;
-    uint32_t kh8 = 8u * kh;
-
-    // the half after (p2, h2), and the row tile it belongs to
-    auto advance = [&](int& p2, int& h2, int& rt2) {
-        if (h2 == 0) { h2 = 1; return; }
-        h2 = 0;
-        if (++p2 == a.npiece) { p2 = 0; rt2 += rt_step; }
-    };
-    // ---- software pipeline.  Entering a step its three operand parts (ah, am, al) and the B operands of its first two quarters
-    // (bA) are in registers.  The step then (1) requests the B operands of quarters 2, 3 (bB), (2) issues the 18 MFMAs of quarters
-    // 0, 1 with the wait for, and the split of, the NEXT step's eight A values slotted in between them (one element per MFMA
-    // pair: the VALU work and the LDS latency run in the shadow of the matrix pipe instead of in front of it), (3) requests the
-    // next step's bA, (4) issues the 18 MFMAs of quarters 2, 3.  The last step of a half splits step 0 of the NEXT half, and
-    // the barrier that hands the LDS buffers over sits between its two MFMA groups (behind the last reads of the old buffer,
-    // in front of the first read of the new one), with 18 MFMAs after it to absorb the skew.
-    // vmcnt bookkeeping (VMEM returns in order).  Per half a wave issues: refills of slots 0-3 (step 0), of slots 4-7 (step 2),
-    // 7 DMAs (step 3, behind the barrier: the half after next), the tail refill (end).  Ops younger than the chunk a step's
-    // split needs: step 0 (slots 2, 3) 12, step 1 (slots 4, 5) 14, step 2 (slots 6, 7) 12, step 3 (slots 0, 1 of the next half) 6;
-    // the DMAs of the next half and the tail are older than what step 3 waits for.
-    u32x4 ah, am, al, bA[2][3], bB[2][3];
-    {
-        int p1 = 0, h1 = 0, rt1 = rt;
-        advance(p1, h1, rt1);
-        issue_dma(total > 1 ? p1 : 0, total > 1 ? h1 : 0, 1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");
-        bx_split8(a_cur[0], a_cur[1], ah, am, al);
-        const u32x4* bimg0 = reinterpret_cast<const u32x4*>(lds) + lane;
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int pt = 0; pt < 3; ++pt) bA[q][pt] = bx_ldb(bimg0 + (q * 3 + pt) * 64);
-    }
-    int p = 0, h = 0;
-    for (int s = 0; s < total; ++s) {
-        asm volatile("" : "+v"(kh8));   // opaque per half: keeps the refill offsets from being hoisted into registers
-        int np = p, nh = h, nrt_ = rt;
-        advance(np, nh, nrt_);
-        int p2 = np, h2 = nh, rt2_ = nrt_;
-        advance(p2, h2, rt2_);
-        const bool last = s + 1 == total, last2 = s + 2 >= total;
-        const int group = a.piece[p].group;
-        const bool flush_after = h == 1 && (last || np == 0 || a.piece[np].group != group);
-        {
-            const int pi = last ? p : np, hi_ = last ? h : nh, rti = last ? rt : nrt_;
-            const char* nbase = a_base(rti, pi);
-            const uint32_t nvoff = a_voff(rti, pi), nks = (uint32_t)a.piece[pi].kscale;
-            const uint32_t nk0 = 64u * hi_ + kh8;
-            const float* buf = lds + (s & 1) * BX_HALF_WORDS;
-            const u32x4* bimg = reinterpret_cast<const u32x4*>(buf) + lane;
-            const u32x4* bimg_n = reinterpret_cast<const u32x4*>(lds + ((s + 1) & 1) * BX_HALF_WORDS) + lane;
-            const float* wrem = buf + 12288 + kh8;
-            float btail[CT] = {0.f, 0.f, 0.f, 0.f}, wtail = 0.f;
-#ifndef PFN_EXP_BX_NOMFMA   /* experiment switch: no bf16 MFMAs at all */
-#define PFN_BX_M2(A_, B_, P_, Q_)                                   \
-    acc[Q_] = bx_mfma(A_, B_[0][P_], acc[Q_]);                      \
-    acc[Q_ + 1] = bx_mfma(A_, B_[1][P_], acc[Q_ + 1]);
-#else
-#define PFN_BX_M2(A_, B_, P_, Q_) asm volatile("" : "+v"(acc[Q_]), "+v"(acc[Q_ + 1]) : "v"(A_), "v"(B_[0][P_]), "v"(B_[1][P_]));
-#endif
-// one pair of elements of the next step's eight: split, and packed straight into dword JP_ of the three new operands (top 16 bits
-// of each part; the byte permute takes them from the unmasked words)
-#define PFN_BX_ELEM2(JP_)                                                                                 \
-    {                                                                                                     \
-        const float xa_ = (JP_) < 2 ? xn0[2 * ((JP_) & 1)] : xn1[2 * ((JP_) & 1)];                        \
-        const float xb_ = (JP_) < 2 ? xn0[2 * ((JP_) & 1) + 1] : xn1[2 * ((JP_) & 1) + 1];                \
-        const uint32_t ba_ = __builtin_bit_cast(uint32_t, xa_), bb_ = __builtin_bit_cast(uint32_t, xb_);  \
-        const float ra1_ = xa_ - __builtin_bit_cast(float, ba_ & 0xffff0000u);                            \
-        const float rb1_ = xb_ - __builtin_bit_cast(float, bb_ & 0xffff0000u);                            \
-        const uint32_t ma_ = __builtin_bit_cast(uint32_t, ra1_), mb_ = __builtin_bit_cast(uint32_t, rb1_); \
-        const float ra2_ = ra1_ - __builtin_bit_cast(float, ma_ & 0xffff0000u);                           \
-        const float rb2_ = rb1_ - __builtin_bit_cast(float, mb_ & 0xffff0000u);                           \
-        nh4[JP_] = __builtin_amdgcn_perm(bb_, ba_, 0x07060302u);                                          \
-        nm4[JP_] = __builtin_amdgcn_perm(mb_, ma_, 0x07060302u);                                          \
-        nl4[JP_] = __builtin_amdgcn_perm(__builtin_bit_cast(uint32_t, rb2_), __builtin_bit_cast(uint32_t, ra2_), 0x07060302u); \
-        __builtin_amdgcn_sched_barrier(0);                                                                \
-    }
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                // (1) the B operands of quarters 2, 3; the trailing column's weights of the step whose values are split below
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int pt = 0; pt < 3; ++pt) bB[q][pt] = bx_ldb(bimg + ((st * 4 + 2 + q) * 3 + pt) * 64);
-                f32x4 wn0 = f32x4{0.f, 0.f, 0.f, 0.f}, wn1 = wn0, wc0 = wn0, wc1 = wn0;
-                if (st < 3) {
-                    wn0 = *reinterpret_cast<const f32x4*>(wrem + 16 * (st + 1));
-                    wn1 = *reinterpret_cast<const f32x4*>(wrem + 16 * (st + 1) + 4);
-                }
-                if (st == 0) {   // (step 0's own values were split in the previous half, before this buffer could be read)
-                    wc0 = *reinterpret_cast<const f32x4*>(wrem);
-                    wc1 = *reinterpret_cast<const f32x4*>(wrem + 4);
-                }
-                if (st == 3 && h == 1) {   // k = 128: the last reads of this buffer (it is handed over below)
-#pragma unroll
-                    for (int q = 0; q < CT; ++q) btail[q] = buf[12352 + q * 64 + lane];
-                    wtail = buf[12608 + kh];
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // (2) quarters 0, 1 -- nine exact partial products each, small ones first -- around the next step's split
-                PFN_BX_M2(al, bA, 2, 0)
-                __builtin_amdgcn_sched_barrier(0);
-                const int sn = (st + 1) & 3;                   // slots 2 sn, 2 sn + 1 hold the next step's values
-                if (st == 0) { wait_a<12>(a_cur[2]); wait_a<12>(a_cur[3]); }
-                else if (st == 1) { wait_a<14>(a_cur[4]); wait_a<14>(a_cur[5]); }
-                else if (st == 2) { wait_a<12>(a_cur[6]); wait_a<12>(a_cur[7]); }
-                else { wait_a<6>(a_cur[0]); wait_a<6>(a_cur[1]); }
-                if (st == 0) {   // the trailing column's products of step 0 (its values are still in slots 0, 1: refilled below)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) racc[0] = fmaf(a_cur[0][j], wc0[j], racc[0]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) racc[0] = fmaf(a_cur[1][j], wc1[j], racc[0]);
-                }
-                const f32x4 xn0 = a_cur[2 * sn], xn1 = a_cur[2 * sn + 1];
-                u32x4 nh4, nm4, nl4;
-                PFN_BX_ELEM2(0) PFN_BX_M2(al, bA, 1, 0) PFN_BX_M2(am, bA, 2, 0) __builtin_amdgcn_sched_barrier(0);
-                PFN_BX_ELEM2(1) PFN_BX_M2(al, bA, 0, 0) PFN_BX_M2(ah, bA, 2, 0) __builtin_amdgcn_sched_barrier(0);
-                PFN_BX_ELEM2(2) PFN_BX_M2(am, bA, 1, 0) PFN_BX_M2(am, bA, 0, 0) __builtin_amdgcn_sched_barrier(0);
-                PFN_BX_ELEM2(3) PFN_BX_M2(ah, bA, 1, 0) PFN_BX_M2(ah, bA, 0, 0) __builtin_amdgcn_sched_barrier(0);
-                if (st < 3) {   // the trailing column's products of the step just split (this buffer's weights)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) racc[0] = fmaf(xn0[j], wn0[j], racc[0]);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) racc[0] = fmaf(xn1[j], wn1[j], racc[0]);
-                }
-                // slots consumed: refill in place for the next half -- per PAIR of steps (a row's two steps are one 128-byte line;
-                // requested a step apart the line has left L1 in between, cf. nt_multiply)
-                if (st == 0 || st == 2) {
-#pragma unroll
-                    for (int m = 2 * st; m < 2 * st + 4; ++m)
-#ifndef PFN_EXP_BX_NOREFILL   /* experiment switch: every refill re-reads one cache line */
-                        vload_x4(a_cur[m], nbase, nvoff + nks * (nk0 + 16u * (m >> 1) + 4u * (m & 1)));
-#else
-                        vload_x4(a_cur[m], nbase, 0u * (nvoff + nks * (nk0 + 16u * (m >> 1) + 4u * (m & 1))));
-#endif
-                }
-                if (st == 3) {
-                    // every read of this buffer has been requested: once they are back (and this wave's share of the next half's
-                    // image has landed -- older than what step 3 waited for), the buffers change hands
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    asm volatile("s_barrier" ::: "memory");
-                    issue_dma(last2 ? p : p2, last2 ? h : h2, s & 1);   // (nothing follows the last halves: a harmless copy keeps the counts)
-                }
-                // (3) the next step's B operands of quarters 0, 1 (bA is free: its MFMAs have been issued)
-#pragma unroll
-                for (int q = 0; q < 2; ++q)
-#pragma unroll
-                    for (int pt = 0; pt < 3; ++pt)
-                        bA[q][pt] = bx_ldb(st < 3 ? bimg + (((st + 1) * 4 + q) * 3 + pt) * 64 : bimg_n + (q * 3 + pt) * 64);
-                __builtin_amdgcn_sched_barrier(0);
-                // (4) quarters 2, 3
-                PFN_BX_M2(al, bB, 2, 2) PFN_BX_M2(al, bB, 1, 2) PFN_BX_M2(am, bB, 2, 2) PFN_BX_M2(al, bB, 0, 2) PFN_BX_M2(ah, bB, 2, 2)
-                PFN_BX_M2(am, bB, 1, 2) PFN_BX_M2(am, bB, 0, 2) PFN_BX_M2(ah, bB, 1, 2) PFN_BX_M2(ah, bB, 0, 2)
-                __builtin_amdgcn_sched_barrier(0);
-                ah = nh4; am = nm4; al = nl4;
-            }
-#undef PFN_BX_M2
-#undef PFN_BX_ELEM2
-            if (h == 1) {   // k = 128 (and the zero pad k = 129): one fp32 step per quarter, the trailing column's last product
-                const float av = kh ? a_tail[1] : a_tail[0];   // (the tail refill is older than what step 3 waited for)
-#pragma unroll
-                for (int q = 0; q < CT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, btail[q], acc[q], 0, 0, 0);
-                racc[0] = fmaf(av, wtail, racc[0]);
-            }
-            vload_x4(a_tail, nbase, nvoff + nks * 128u);
-        }
-        if (flush_after) {
-            // the accumulators are still being written by the last MFMAs (see the stationary kernel's flush)
-            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-            const int rbase = rt * 32;
-            int r32f = r32, khf = kh;   // opaque copies: the row-offset products below are then formed HERE, not once before the
-            asm volatile("" : "+v"(r32f), "+v"(khf));   // loop and kept in (spilled) registers across it
-            const bool live = rt < nrt;
-            float* C = a.C[group];
-            const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
-            const bool has_aux = a.rowscale || extra;
-            f32x4 aux[CT][4], raux;
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) aux[ct][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-            raux = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (has_aux) {
-                if (a.rowscale) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = rbase + (r32f & 3) + 8 * g + 4 * khf;
-                        aux[0][g][0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
-                    }
-                    const int row = rbase + r32f;
-                    raux[0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
-                } else {
-#pragma unroll
-                    for (int ct = 0; ct < CT; ++ct) {
-                        const int col0 = 32 * ct + (r32f & ~3);
-#pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int row = rbase + (r32f & 3) + 8 * g + 4 * khf;
-                            aux[ct][g] = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, col0, ldx, a.aux_cm_rows));
-                        }
-                    }
-                    const int row = rbase + r32f;
-                    raux = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, rem_col, ldx, a.aux_cm_rows));
-                }
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(aux[0][0]), "+v"(aux[0][1]), "+v"(aux[0][2]), "+v"(aux[0][3]), "+v"(aux[1][0]), "+v"(aux[1][1]),
-                               "+v"(aux[1][2]), "+v"(aux[1][3]), "+v"(aux[2][0]), "+v"(aux[2][1]), "+v"(aux[2][2]), "+v"(aux[2][3]),
-                               "+v"(aux[3][0]), "+v"(aux[3][1]), "+v"(aux[3][2]), "+v"(aux[3][3]), "+v"(raux));
-                if (a.rowscale) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const float rs = aux[0][g][0];
-#pragma unroll
-                        for (int ct = 0; ct < CT; ++ct) aux[ct][g] = f32x4{rs, rs, rs, rs};
-                    }
-                    raux = f32x4{raux[0], raux[0], raux[0], raux[0]};
-                }
-            }
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int col0 = 32 * ct + (r32f & ~3);
-                float v[4][4];
-                const int row_base = rbase + (r32f & 3) + 4 * khf;
-                auto row_of = [&](int g) { return row_base + 8 * g; };
-                auto dst_of = [&](int g) {
-                    const int rw_ = row_of(g);
-                    return C + act_off(rw_ < a.M ? rw_ : a.M - 1, col0, a.ldc, a.c_cm_rows);
-                };
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float t[4] = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
-                    quad_transpose(t, lane);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[g][e] = t[e];
-                }
-                const f32x4 cb4 = *reinterpret_cast<const f32x4*>(lds + bias_off + col0);
-                if (use_bias && !ep.has_rowscale) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] += cb4[e];
-                }
-                if (ep.has_rowscale) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] = fmaf(aux[ct][g][e], cb4[e], v[g][e]);
-                }
-                if (ep.has_resid) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] += aux[ct][g][e];
-                }
-                if (ep.act == ACT_RELU) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] = fmaxf(v[g][e], 0.f);
-                } else if (ep.act == ACT_DROPOUT_RELU) {
-                    uint32_t cgv = (uint32_t)(col0 >> 2);
-                    asm volatile("" : "+v"(cgv));
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        float u[4];
-                        dropout_uniform4(ep.dk, (uint32_t)(row_of(g) + a.row0), cgv, u);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] = (u[e] >= ep.p_drop && v[g][e] > 0.f) ? v[g][e] * ep.keep_scale : 0.f;
-                    }
-                }
-                if (ep.has_gate) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[g][e] = aux[ct][g][e] > 0.f ? v[g][e] * ep.gate_scale : 0.f;
-                }
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    if (live && row_of(g) < a.M) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
-            }
-            {   // the trailing column (129th): the two k halves, lane half 0 stores
-                float v0 = racc[0] + __shfl_xor(racc[0], 32);
-                const int row = rbase + r32f;
-                if (khf == 0 && live && row < a.M) {
-                    const f32x4 rcb = *reinterpret_cast<const f32x4*>(lds + bias_off + rem_col);
-                    float x = v0 + ((use_bias && !ep.has_rowscale) ? rcb[0] : 0.f);
-                    if (ep.has_rowscale) x = fmaf(raux[0], rcb[0], x);
-                    if (ep.has_resid) x += raux[0];
-                    if (ep.act == ACT_RELU) {
-                        x = fmaxf(x, 0.f);
-                    } else if (ep.act == ACT_DROPOUT_RELU) {
-                        float ud[4];
-                        uint32_t cgv = (uint32_t)(rem_col >> 2);
-                        asm volatile("" : "+v"(cgv));
-                        dropout_uniform4(ep.dk, (uint32_t)(row + a.row0), cgv, ud);
-                        x = (ud[0] >= ep.p_drop && x > 0.f) ? x * ep.keep_scale : 0.f;
-                    }
-                    if (ep.has_gate) x = raux[0] > 0.f ? x * ep.gate_scale : 0.f;
-                    vstore_x4(C + act_off(row, rem_col, a.ldc, a.c_cm_rows), f32x4{x, 0.f, 0.f, 0.f});
-                }
-            }
-#pragma unroll
-            for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
-            racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
-            // the next step's operands once more (its values are still in slots 0, 1; the buffers changed hands in step 3): redefining
-            // them HERE takes the 36 registers out of the flush's live set -- with them the flush spilled, and a scratch access is a
-            // VMEM op that every hand-counted wait would then have to wait for
-            bx_split8(a_cur[0], a_cur[1], ah, am, al);
-            const u32x4* bimg_n = reinterpret_cast<const u32x4*>(lds + ((s + 1) & 1) * BX_HALF_WORDS) + lane;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int pt = 0; pt < 3; ++pt) bA[q][pt] = bx_ldb(bimg_n + (q * 3 + pt) * 64);
-        }
-        p = np;
-        h = nh;
-        rt = nrt_;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last DMA / refills: nothing of this block is in flight past here
-}
-
 // ------------------------------------------------------------------------------------- NT, small M (latency)
 // A batch of ONE graph (118 rows: the per-sample latency the reference itself measures, perfomance_evaluator.py:61-74) is four row
 // tiles: the kernels above give each wave a whole tile x all terms -- 260 dependent MFMAs = 7 us on one SIMD while 250 CUs idle --
@@ -1591,7 +1133,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     const size_t lds_budget = (size_t)NT_LDS_BYTES - bias_bytes;
     int tps = 0;
     if (nq > 0) {
-        static const int tps_cap = diag_env("PFN_NT_TPS") ? atoi(diag_env("PFN_NT_TPS")) : 4;   // tuning aid: 1, 2 or 4 quarters per slice at most
+        const int tps_cap = 4;
         const int start = std::min(nq >= 3 ? 4 : nq, std::max(1, tps_cap));
         for (tps = start; tps >= 1; tps >>= 1) {
             size_t tot = 0;
@@ -1650,26 +1192,6 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
             k.npiece = (int)pieces.size();
             for (size_t i = 0; i < pieces.size(); ++i) k.piece[i] = pieces[i];
             gemm_nt_tiny_kernel<<<dim3(nrt, 4), 64 * k.npiece, 0, s>>>(k);
-            PFN_CHECK_LAUNCH();
-            return PFN_OK;
-        }
-    }
-    if (top) {   // large M, every piece K = 129, 129 output columns: fp32 through the bf16 matrix cores (gemm_nt_bx_kernel)
-        const int bx_min = bx_min_tiles();
-        const long per_round = (long)ncu * NT_WAVES;
-        bool bx_ok = bx_min > 0 && nq == 4 && remv == 4 && nrem == 1 && pieces.size() <= (size_t)NT_MAX_PIECES &&
-                     (long)nrt >= (long)bx_min * per_round;
-        for (int t = 0; t < a.nterm; ++t) bx_ok = bx_ok && a.term[t].K == 129;
-        for (size_t i = 0; i < pieces.size(); ++i) bx_ok = bx_ok && pieces[i].klen == KP && last_steps[i] == 1;
-        if (bx_ok) {
-            k.npiece = (int)pieces.size();
-            for (size_t i = 0; i < pieces.size(); ++i) k.piece[i] = pieces[i];
-            k.kuni = KP;
-            k.klast = 1;
-            const size_t lb = ((size_t)2 * BX_HALF_WORDS + (size_t)a.ldc) * sizeof(float);
-            static std::atomic<uint64_t> lds_raised_bx{0};
-            PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_bx_kernel), NT_LDS_BYTES, lds_raised_bx));
-            gemm_nt_bx_kernel<<<(int)std::min<long>(ncu, (nrt + NT_WAVES - 1) / NT_WAVES), NT_THREADS, lb, s>>>(k);
             PFN_CHECK_LAUNCH();
             return PFN_OK;
         }
@@ -1745,8 +1267,6 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
             seen[g] |= here[g];
         }
         int rc = PFN_EINVAL;
-        static const bool ls4 = diag_env("PFN_NT_LS4") != nullptr;   // A/B switch: four MFMA steps in the last chunk although K = 129
-        if (ls4) k.klast = 4;
         const int var = pick_variant(k, CT);
         const size_t lb = used + bias_bytes;
 #define PFN_NT_CASE(CT_, V_) if (CT == CT_ && var == V_) rc = launch_variant<CT_, V_>(k, grid, lb, s)

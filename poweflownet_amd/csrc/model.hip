@@ -52,13 +52,14 @@ struct Packer {
         off += packed_floats(K, ld_out);
         PackJob j;
         j.src = W; j.dst = dst; j.ldw = ldw; j.wk0 = wk0; j.wn0 = wn0; j.trans = trans; j.K = K; j.ncols = ncols;
-        j.ld_out = ld_out; j.split = pack_wants_split(K, ld_out) ? 1 : 0;
+        j.ld_out = ld_out;
         jobs.push_back(j);
         return dst ? dst : reinterpret_cast<const float*>(0x10);   // non-null sentinel while measuring
     }
     int flush(hipStream_t s, uint64_t* rng_advance = nullptr, const void* mask = nullptr, int mask_dtype = 0,
-              float* maskf = nullptr, int64_t mask_count = 0, const SlotEa* slot_ea = nullptr) {
-        return launch_pack(jobs.data(), (int)jobs.size(), rng_advance, s, mask, mask_dtype, maskf, mask_count, slot_ea);
+              float* maskf = nullptr, int64_t mask_count = 0, const SlotEa* slot_ea = nullptr, int* stamp = nullptr,
+              int stamp_value = 0) {
+        return launch_pack(jobs.data(), (int)jobs.size(), rng_advance, s, mask, mask_dtype, maskf, mask_count, slot_ea, stamp, stamp_value);
     }
 };
 
@@ -416,6 +417,7 @@ static int tag_backward(const GraphView& g, int cin, int cout, int K, const floa
 struct Layout {
     // dims
     int n, e, f0, fe, fo, h, L, K, ld, ld0, ldo, nlayers;
+    int* stamp;                  // guard word: WS_STAMP_TRAIN after a forward that saved what the backward pass reads
     // forward-saved
     float *maskf, *me_h, *x0, *packed;
     float *ea_in, *ea_out;       // edge attributes in CSR slot order (Fe = 2; SlotEa), filled once per forward
@@ -434,6 +436,11 @@ struct Layout {
     size_t bytes;
 };
 static bool is_ea(int i) { return (i & 1) == 0; }
+// The forward pass stamps its workspace (a rider of its first launch): TRAIN when it saved what a backward pass reads
+// (need_backward), INFER otherwise.  pfn_mpn_backward hands the word to its weight-gradient launch, which writes every
+// parameter gradient as NaN unless it reads TRAIN -- a caller that ran the forward with need_backward = 0 on a training-sized
+// workspace (nothing on the host can tell) gets NaN gradients instead of plausible garbage.  Device-side, no host sync.
+enum { WS_STAMP_INFER = 0x1f0e4e00, WS_STAMP_TRAIN = 0x7a11e7a1 };
 
 // packed-weight plan of the whole network (identical walk in forward, which fills it, and backward, which reads it)
 struct ModelPack {
@@ -484,6 +491,7 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
         plan_pack(measure, lo.f0, lo.fe, lo.fo, lo.h, lo.L, lo.K, nullptr, mp);
         lo.packed_floats = measure.off;
     }
+    lo.stamp = cv.take<int>(4);
     lo.packed = cv.take<float>(lo.packed_floats);
     lo.maskf = cv.take<float>((size_t)n * lo.ld0);
     lo.ea_in = cv.take<float>((size_t)4 * e + 4);
@@ -589,6 +597,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     // mask_embd(mask) + x   (networks/MPN.py:533,:537)
     const bool fused_front = front_fused_ok(lo.f0, lo.h);
     const bool l0_fly = first_layer_fly(c, lo, seg, fused_front);
+    const int ws_stamp = c.need_backward ? WS_STAMP_TRAIN : WS_STAMP_INFER;
     if (fused_front) {
         // ONE launch: the weight re-layout (which also advances the dropout stream for this forward) next to the front --
         // pred_mask.float(), mask_embd, the residual add and the first EdgeAggregation's P | Q (front.hip)
@@ -599,10 +608,12 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         f.maskf = lo.maskf; f.me_h = (c.need_backward && !front_recomputes_meh(c, lo, seg, fused_front)) ? lo.me_h : nullptr; f.x0 = lo.x0;
         f.P = l0_fly ? nullptr : lo.ea[0].P;
         f.Q = l0_fly ? nullptr : lo.ea[0].Q;
-        PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s, seg_ea ? &se : nullptr));
+        PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s, seg_ea ? &se : nullptr, lo.stamp,
+                                      ws_stamp));
     } else {
         // ... the pack launch also advances the dropout stream for this forward and converts pred_mask to float32
-        PFN_TRY(pk.flush(s, drop ? rng : nullptr, pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0, seg_ea ? &se : nullptr));
+        PFN_TRY(pk.flush(s, drop ? rng : nullptr, pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0, seg_ea ? &se : nullptr, lo.stamp,
+                         ws_stamp));
         {
             GemmArgs a = gemm_defaults(lo.n, lo.h, lo.ld);
             a.C[0] = lo.me_h;
@@ -700,8 +711,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         if (!is_ea(i)) gate.cm = big_cm;     // a TAGConv's input is the EdgeAggregation output before it (model_forward)
         // ... and the gradient an EdgeAggregation hands DOWN to a TAGConv (layers 2, 4, ...: their input is a TAGConv's output) is
         // written chunk-major too: the TAGConv's backward hops, its GEMM and the weight-gradient pairs read it through the flags
-        static const bool no_cm_grad = diag_env("PFN_NO_CM_GRAD") != nullptr;   // A/B switch: that gradient stays row-major
-        const int gx_cm = (is_ea(i) && i >= 2 && !no_cm_grad) ? big_cm : 0, gout_cm = (!is_ea(i) && !no_cm_grad) ? big_cm : 0;
+        const int gx_cm = (is_ea(i) && i >= 2) ? big_cm : 0, gout_cm = !is_ea(i) ? big_cm : 0;
         if (is_ea(i)) {
             const int fi = i == 0 ? lo.f0 : lo.h, fo = last ? lo.fo : lo.h;
             EaScratch sc = lo.eas;
@@ -755,10 +765,10 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         ride.njobs = (int)pairs.dwe.size();
         for (int j = 0; j < ride.njobs; ++j) ride.jobs.job[j] = pairs.dwe[j];
         ride.fe = lo.fe; ride.ld = lo.ld; ride.h = lo.h;
-        PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s, &ride));
+        PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s, &ride, lo.stamp, WS_STAMP_TRAIN));
     } else {
         PFN_TRY(launch_dwe_reduce_multi(pairs.dwe.data(), (int)pairs.dwe.size(), lo.fe, lo.ld, lo.h, s));
-        PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s));
+        PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s, nullptr, lo.stamp, WS_STAMP_TRAIN));
     }
     if (gx) PFN_CHECK_HIP(hipMemcpyAsync(gx, gcur, (size_t)lo.n * lo.ld0 * sizeof(float), hipMemcpyDeviceToDevice, s));
     return PFN_OK;

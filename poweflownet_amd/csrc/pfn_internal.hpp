@@ -107,7 +107,6 @@ struct PackJob {
     const float* src;
     float* dst;
     int ldw, wk0, wn0, trans, K, ncols, ld_out;
-    int split;   // 1: a bf16-split image follows the fp32 one (bx_shape launches with the opt-in kernel on: pack_wants_split)
 };
 constexpr int PACK_MAX_JOBS = 64;
 // optional rider of the pack launches: the edge attributes gathered ONCE per forward into CSR slot order (by destination and by
@@ -138,6 +137,8 @@ struct PackArgs {
     SlotEa slot_ea;
     int njobs;
     uint64_t* rng_advance;   // device {seed, offset}: offset += 1 (dropout stream), or null
+    int* stamp;              // optional: *stamp = stamp_value (the forward pass marks its workspace: training / inference)
+    int stamp_value;
     // optional rider (one launch floor less per forward): pred_mask -> float32, spread over all blocks of the launch
     const void* mask;
     float* maskf;
@@ -145,20 +146,6 @@ struct PackArgs {
     int mask_dtype;          // 0: int64, 1: float32
 };
 size_t packed_floats(int K, int ld_out);
-bool pack_wants_split(int K, int ld_out);   // host: PackJob::split for a weight of this shape (the opt-in bf16-split kernel is on)
-// ---- bf16-SPLIT images (gemm_nt_bx_kernel, gemm_nt.hip): an fp32 value is the EXACT sum of three bf16 values
-//   x = hi + mid + lo,   hi = x truncated to 8 significant bits, mid = (x - hi) truncated, lo = x - hi - mid (<= 8 bits left)
-// so an fp32 product a * b is the exact sum of nine bf16 x bf16 products, each exact in fp32: the matrix cores' bf16 rate (16x the
-// fp32 MFMA rate on gfx950) buys an fp32 GEMM at 16 / 9 of the fp32 MFMA rate with fp32 accumulation and NO operand rounding.
-// For the shape the large graphs produce (K = 129, 129 output columns) the pack step appends such an image to the fp32 one: two
-// K halves of BX_HALF_WORDS dwords (one LDS buffer each),
-//   words [0, 12288)      : for local k step sl < 4, quarter q < 4, part p < 3 (hi, mid, lo): 1 KiB = 64 lanes x 8 bf16, lane l holds
-//                           B[64 h + 16 sl + 8 (l >> 5) + j][32 q + (l & 31)], j < 8  (the B operand of v_mfma_f32_32x32x16_bf16)
-//   words [12288, 12352)  : fp32 B[64 h + kk][128], kk < 64   (the trailing column: VALU dot products)
-//   h = 1: [12352, 12608) : fp32 B[128 + (l >> 5)][32 q + (l & 31)], q < 4   (k = 128: one fp32 MFMA step per quarter)
-//          [12608, 12612) : fp32 B[128 + i][128]
-constexpr int BX_HALF_WORDS = 12800;
-__host__ __device__ inline bool bx_shape(int K, int ld_out) { return K == 129 && ld_out == 132; }
 __host__ __device__ inline size_t packed_fp32_floats(int K, int ld_out) {
     int remv, nq;
     const int m = ld_out & 31;
@@ -166,13 +153,6 @@ __host__ __device__ inline size_t packed_fp32_floats(int K, int ld_out) {
     nq = (ld_out - remv + 31) / 32;
     const int G = ((K + 7) & ~7) >> 2;
     return (size_t)(((int64_t)nq * G * 128 + (int64_t)G * 16 + 255) / 256 * 256);
-}
-__host__ __device__ inline void bf16_split3(float x, uint32_t& hi, uint32_t& mid, uint32_t& lo) {   // the parts as fp32 bit patterns
-    hi = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
-    const float r1 = x - __builtin_bit_cast(float, hi);
-    mid = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-    const float r2 = r1 - __builtin_bit_cast(float, mid);
-    lo = __builtin_bit_cast(uint32_t, r2) & 0xffff0000u;   // (nothing is cut here unless r2 underflowed)
 }
 // column plan of an output of `ld` (padded) columns: `remv` trailing columns (0 or 4) go to the VALU path when that
 // saves a whole MFMA quarter; `nq` 32-column MFMA quarters.
@@ -204,36 +184,10 @@ __device__ inline void pack_job_body(const PackJob& jb, int bx, int nbx) {
             v = jb.trans ? jb.src[(size_t)(jb.wn0 + n) * jb.ldw + jb.wk0 + k] : jb.src[(size_t)(jb.wk0 + k) * jb.ldw + jb.wn0 + n];
         jb.dst[i] = v;
     }
-    if (!jb.split) return;
-    uint32_t* sp = reinterpret_cast<uint32_t*>(jb.dst + packed_fp32_floats(jb.K, jb.ld_out));
-    auto B = [&](int k, int n) -> float {
-        if (k >= jb.K || n >= jb.ncols) return 0.f;
-        return jb.trans ? jb.src[(size_t)(jb.wn0 + n) * jb.ldw + jb.wk0 + k] : jb.src[(size_t)(jb.wk0 + k) * jb.ldw + jb.wn0 + n];
-    };
-    for (int w = bx * blockDim.x + threadIdx.x; w < 2 * BX_HALF_WORDS; w += nbx * blockDim.x) {
-        const int h = w / BX_HALF_WORDS, o = w - h * BX_HALF_WORDS;
-        uint32_t val = 0u;
-        if (o < 12288) {
-            const int blk = o >> 8, lane = (o & 255) >> 2, j2 = o & 3;
-            const int sl = blk / 12, q = (blk / 3) & 3, part = blk % 3;
-            const int col = 32 * q + (lane & 31), k0 = 64 * h + 16 * sl + 8 * (lane >> 5) + 2 * j2;
-            uint32_t pa[3], pb[3];
-            bf16_split3(B(k0, col), pa[0], pa[1], pa[2]);
-            bf16_split3(B(k0 + 1, col), pb[0], pb[1], pb[2]);
-            val = (pa[part] >> 16) | pb[part];
-        } else if (o < 12352) {
-            val = __builtin_bit_cast(uint32_t, B(64 * h + o - 12288, 128));
-        } else if (h == 1 && o < 12608) {
-            const int t = o - 12352, q = t >> 6, lane = t & 63;
-            val = __builtin_bit_cast(uint32_t, B(128 + (lane >> 5), 32 * q + (lane & 31)));
-        } else if (h == 1 && o < 12612) {
-            val = __builtin_bit_cast(uint32_t, B(128 + o - 12608, 128));
-        }
-        sp[w] = val;
-    }
 }
 int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s, const void* mask = nullptr,
-                int mask_dtype = 0, float* maskf = nullptr, int64_t mask_count = 0, const SlotEa* slot_ea = nullptr);
+                int mask_dtype = 0, float* maskf = nullptr, int64_t mask_count = 0, const SlotEa* slot_ea = nullptr,
+                int* stamp = nullptr, int stamp_value = 0);
 
 // C[g] (M x ldc) = sum over terms t with t.group == g of  A_t (M x K_t) * B_t (K_t x ncols)  + epilogue,
 // B_t given as a packed image (Bp).
@@ -287,7 +241,10 @@ struct ReduceWs {
     size_t floats;
 };
 size_t reduce_ws_floats(int64_t M, int max_na, int max_nb, int max_pairs);
-int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s, const struct DweRide* ride = nullptr);
+// stamp / stamp_want: optional device guard word -- when *stamp != stamp_want every gradient of the launch is written as NaN
+// (pfn_mpn_backward on a workspace whose last forward did not save what the backward reads: model.hip WS_STAMP_TRAIN)
+int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s, const struct DweRide* ride = nullptr,
+                        const int* stamp = nullptr, int stamp_want = 0);
 
 // ------------------------------------------------------------------------------------- edge kernels
 // y[i] = (add ? add[i] : 0) + dinv[i] * sum_{e in row i} dinv[nbr(e)] * x[nbr(e)]   (normalize)
@@ -543,7 +500,7 @@ struct FrontFwdArgs {
 };
 // the front AND the weight re-layout of a forward pass (independent of each other) in one launch; `rng_advance` as in launch_pack
 int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s,
-                          const SlotEa* slot_ea = nullptr);
+                          const SlotEa* slot_ea = nullptr, int* stamp = nullptr, int stamp_value = 0);
 int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, const float* me_h, const float* w1,
                      const float* wb, float* g0, float* dh, hipStream_t s);
 // The backward front beyond the latency regime when the forward did not store mask_embd's hidden layer (FrontFwdArgs::me_h null

@@ -407,7 +407,7 @@ static bool slh_plan(int seg, int n, int ld, int nterm, SlhPlan& p) {
 // step in the last chunk, one trailing column: what the MaskEmbdMultiMPN layers between a TAGConv and an EdgeAggregation are)
 bool seg_lin_hops_fit(int seg, int n, int ld, int K, int ncols, int nhops, int nterm) {
     static const bool off = diag_env("PFN_NO_SEG_LIN_HOPS") != nullptr;   // A/B switch: gemm_nt + fused_hops, two launches
-    static const long per_cu = diag_env("PFN_SEG_EA_PER_CU") ? atol(diag_env("PFN_SEG_EA_PER_CU")) : 4L;   // (ea_seg.hip's tuning aid)
+    const long per_cu = 4L;   // (ea_seg_fit's bound)
     SlhPlan p;
     int remv, nq;
     col_plan(ld, remv, nq);

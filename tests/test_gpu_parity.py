@@ -953,40 +953,59 @@ torch.save(res, sys.argv[1])
             assert torch.equal(res["default"][key], res["fly"][key]), f"{key}: recomputed mask_embd hidden layer"
 
 
-def test_bf16_split_gemm_experiment_matches_fp32_mfma_path(tmp_path):
-    """The opt-in large-M GEMM kernel (gemm_nt_bx_kernel, PFN_NT_BX_MIN_TILES=1: from one row tile per wave = 65,536 rows): every
-    fp32 operand is split EXACTLY into three bf16 parts, the nine bf16 x bf16 partial products (each exact in fp32) are accumulated
-    in fp32 on v_mfma_f32_32x32x16_bf16 -- no operand rounding, so outputs and gradients agree with the fp32-MFMA kernels to fp32
-    summation-order tolerance.  600 graphs x 118 buses = 70,800 rows (ragged last row tile), graph-resident kernels off so that
-    every 129 x 129 product of forward and backward takes the GEMM path; switches are read once per process -> child processes."""
-    import os
-    import subprocess
-    import sys
-    script = f"""
-import sys, torch
-sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
-from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
-from poweflownet_amd.synth import make_batch
-torch.manual_seed(3)
-m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.0).to("cuda:0").eval()
-d = make_batch("118", 600, seed=4).to("cuda:0")
-d.x.requires_grad_(True)
-out = m(d)
-torch.nn.MSELoss()(out, d.y).backward()
-torch.save({{"out": out.detach().cpu(), "gx": d.x.grad.cpu(), "g": m.flat_grad().cpu()}}, sys.argv[1])
-"""
-    res = {}
-    for tag, env in (("fp32", {"PFN_NO_SEG_EA": "1"}), ("bf16x9", {"PFN_NO_SEG_EA": "1", "PFN_NT_BX_MIN_TILES": "1"})):
-        path = str(tmp_path / f"{tag}.pt")
-        subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=300)
-        res[tag] = torch.load(path)
-    assert not torch.equal(res["bf16x9"]["out"], res["fp32"]["out"])       # (the other kernel did run)
-    assert_close(res["bf16x9"]["out"], res["fp32"]["out"], RTOL, "bf16-split GEMM: out")
-    # gradients: the two forward passes differ in the last bits, so a few of the 70,800 x 129 ReLU pre-activations that sit at zero
-    # land on the other side (the full-size oracle checks equalise the gates for exactly this reason, _assert_grads_on_hip_gates);
-    # each flip moves a gradient entry by a discrete amount
-    assert_close(res["bf16x9"]["g"], res["fp32"]["g"], 1e-3, "bf16-split GEMM: flat parameter gradient")
-    assert_close(res["bf16x9"]["gx"], res["fp32"]["gx"], 1e-2, "bf16-split GEMM: grad x")
+def test_backward_after_an_inference_forward_gives_nan_gradients_not_garbage():
+    """C-ABI misuse the host cannot see: `pfn_mpn_forward` with need_backward = 0 on a TRAINING-sized workspace,
+    then `pfn_mpn_backward` with need_backward = 1 on it -- the forward saved nothing the backward reads.  The forward stamps the
+    workspace on the device (a rider of its first launch) and the weight-gradient launch writes NaN unless the stamp says
+    "training": every parameter gradient is NaN, no host sync, no extra launch; the proper sequence on the same workspace then
+    gives the gradients of the autograd path, bit for bit."""
+    import ctypes as C
+    from poweflownet_amd import _lib as L
+    from poweflownet_amd.networks.MPN import _padded
+    lib = L.load()
+    torch.manual_seed(9)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.0).to(DEV).eval()
+    d = make_batch("118", 5, seed=3).to(DEV)
+    out_ref = m(d)
+    torch.nn.MSELoss()(out_ref, d.y).backward()
+    g_ref = m.flat_grad().clone()
+    graph = m._graphs._graph
+    params = m._ordered_params()
+    n = d.x.shape[0]
+    cfg = m._config()
+    cfg.need_backward = 1
+    nbytes = lib.pfn_mpn_workspace_bytes(C.byref(cfg), n, graph.e_stored)
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+    out = torch.empty(n, _padded(4), dtype=torch.float32, device=DEV)
+    gout = (2.0 * (out_ref.detach() - d.y) / out_ref.numel()).contiguous()
+    sizes = [p.numel() for p in params]
+
+    def fwd(need_backward):
+        cfg.need_backward = need_backward
+        L.check(lib.pfn_mpn_forward(C.byref(cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params), d.x.data_ptr(),
+                                    d.pred_mask.data_ptr(), 0 if d.pred_mask.dtype == torch.int64 else 1, d.edge_attr.data_ptr(),
+                                    out.data_ptr(), ws.data_ptr(), nbytes, None, graph.seg_nodes, L.stream_ptr()), "pfn_mpn_forward")
+
+    def bwd():
+        cfg.need_backward = 1
+        flat = torch.zeros(sum(sizes), dtype=torch.float32, device=DEV)
+        grads = [g if p.dim() == 1 else g.view(p.shape) for g, p in zip(flat.split_with_sizes(sizes), params)]
+        L.check(lib.pfn_mpn_backward(C.byref(cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params), L.ptr_table(grads),
+                                     d.x.data_ptr(), d.pred_mask.data_ptr(), 0 if d.pred_mask.dtype == torch.int64 else 1,
+                                     d.edge_attr.data_ptr(), gout.data_ptr(), None, None, ws.data_ptr(), nbytes, graph.seg_nodes,
+                                     L.stream_ptr()), "pfn_mpn_backward")
+        torch.cuda.synchronize()
+        return flat
+
+    fwd(0)                                           # inference forward on the training-sized workspace
+    assert torch.equal(out[:, :4], out_ref.detach())
+    bad = bwd()
+    assert torch.isnan(bad).all(), f"{int(torch.isnan(bad).sum())} of {bad.numel()} gradient entries are NaN"
+    fwd(1)
+    good = bwd()
+    assert torch.equal(good, g_ref)
+    fwd(1); fwd(0)                                   # the LAST forward on the workspace decides
+    assert torch.isnan(bwd()).all()
 
 
 def test_two_models_two_streams_two_threads_do_not_share_state():
