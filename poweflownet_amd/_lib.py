@@ -21,7 +21,7 @@ SYMBOLS = (
     "pfn_mpn_num_params", "pfn_mpn_workspace_bytes", "pfn_mpn_forward", "pfn_mpn_backward", "pfn_mpn_export_gates",
     "pfn_edge_aggr_workspace_bytes", "pfn_edge_aggr_forward", "pfn_edge_aggr_backward",
     "pfn_tag_conv_workspace_bytes", "pfn_tag_conv_forward", "pfn_tag_conv_backward",
-    "pfn_scatter_add", "pfn_pad_rows", "pfn_mse_loss", "pfn_masked_l2_loss", "pfn_power_imbalance", "pfn_dropout_mask", "pfn_adamw_step", "pfn_adamw_step_dev",
+    "pfn_scatter_add", "pfn_pad_rows", "pfn_mse_loss", "pfn_masked_l2_loss", "pfn_power_imbalance", "pfn_dropout_mask", "pfn_adamw_step", "pfn_adamw_step_dev", "pfn_adamw_step_guarded",
     "pfn_profile_enable", "pfn_profile_report",
 )
 
@@ -34,7 +34,7 @@ class MpnConfig(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def load() -> C.CDLL:
@@ -80,6 +80,7 @@ def load() -> C.CDLL:
         "pfn_dropout_mask": (C.c_int, [p, C.c_int32, i64, i64, f32, p, p]),
         "pfn_adamw_step": (C.c_int, [p, p, p, p, i64, f32, f32, f32, f32, f32, p, p]),
         "pfn_adamw_step_dev": (C.c_int, [p, p, p, p, i64, p, p, p]),
+        "pfn_adamw_step_guarded": (C.c_int, [p, p, p, p, i64, p, p, p, p]),
         "pfn_profile_enable": (C.c_int, [i32]),
         "pfn_profile_report": (C.c_int, [C.c_char_p, sz, i32]),
     }

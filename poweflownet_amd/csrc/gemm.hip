@@ -396,7 +396,7 @@ __global__ __launch_bounds__(T3_THREADS, 1) void gemm_tn_kernel(const T3Args a, 
         const int r = blockIdx.x - a.nblocks, bx_per = (ride.fe * ride.h + 15) / 16;
         const int job = r / bx_per;
         if (job < ride.njobs) dwe_reduce_body<T3_THREADS / 16>(ride.jobs.job[job], r - job * bx_per, ride.fe, ride.ld, ride.h,
-                                                               reinterpret_cast<float (*)[17]>(t3_lds));
+                                                               reinterpret_cast<float (*)[17]>(t3_lds), t3_bad(a));
         return;
     }
     // task and row split of this workgroup.  Groups own consecutive id ranges; inside a group the ids run

@@ -908,7 +908,13 @@ static int adamw_blocks(int64_t count) { return (int)std::max<int64_t>(1, std::m
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n, float lr,
                                                     float b1, float b2, float eps, float wd, int64_t* step,
-                                                    const float* __restrict__ hp) {
+                                                    const float* __restrict__ hp, const float* __restrict__ guard) {
+    // guard (optional): a device scalar -- normally the step's loss; not finite = the batch was flagged bad on the device
+    // (pfn_graph_poison_if_bad): every block sees the same value and leaves, nothing is updated, the step is not counted
+    if (guard) {
+        const float gv = *guard;
+        if (!(fabsf(gv) <= 3.402823466e+38f)) return;
+    }
     // 16 bytes per lane and array when the four flat buffers allow it (they are whole allocations: 256-byte aligned); the
     // update is a chain of dependent loads per element otherwise (10 us for 355 k parameters, 2x its memory time).  A thread's
     // FIRST four-element group is requested before the hyper-parameters are even read: their load -> powf chain and this load
@@ -1336,7 +1342,7 @@ int pfn_adamw_step(float* p, const float* g, float* m, float* v, int64_t count, 
                    float eps, float wd, int64_t* step, void* stream) {
     PFN_CHECK_ARG(p && g && m && v && step, "pfn_adamw_step: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    adamw_kernel<<<adamw_blocks(count), 256, 0, s>>>(p, g, m, v, count, lr, b1, b2, eps, wd, step, nullptr);
+    adamw_kernel<<<adamw_blocks(count), 256, 0, s>>>(p, g, m, v, count, lr, b1, b2, eps, wd, step, nullptr, nullptr);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
@@ -1345,7 +1351,16 @@ int pfn_adamw_step_dev(float* p, const float* g, float* m, float* v, int64_t cou
                        void* stream) {
     PFN_CHECK_ARG(p && g && m && v && step && hyper, "pfn_adamw_step_dev: null pointer");
     hipStream_t s = static_cast<hipStream_t>(stream);
-    adamw_kernel<<<adamw_blocks(count), 256, 0, s>>>(p, g, m, v, count, 0.f, 0.f, 0.f, 0.f, 0.f, step, hyper);
+    adamw_kernel<<<adamw_blocks(count), 256, 0, s>>>(p, g, m, v, count, 0.f, 0.f, 0.f, 0.f, 0.f, step, hyper, nullptr);
+    PFN_CHECK_LAUNCH();
+    return PFN_OK;
+}
+
+int pfn_adamw_step_guarded(float* p, const float* g, float* m, float* v, int64_t count, const float* hyper, int64_t* step,
+                           const float* guard, void* stream) {
+    PFN_CHECK_ARG(p && g && m && v && step && hyper && guard, "pfn_adamw_step_guarded: null pointer");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    adamw_kernel<<<adamw_blocks(count), 256, 0, s>>>(p, g, m, v, count, 0.f, 0.f, 0.f, 0.f, 0.f, step, hyper, guard);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

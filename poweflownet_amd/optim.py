@@ -32,6 +32,9 @@ class FlatAdamW(torch.optim.Optimizer):
         self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count = torch.zeros(2, dtype=torch.int64, device=flat.device)   # {steps done, arrival scratch}
         self._gather = None
+        # optional device scalar (a loss): the update is SKIPPED on the device when it is not finite -- set by a caller whose
+        # step may be fed a batch it could not validate on the host (GraphedTrainStep with per-batch topologies)
+        self.guard = None
         # {lr, beta1, beta2, eps, weight_decay} live on the device: the update kernel reads them there, so a captured step
         # follows a scheduler (OneCycleLR moves lr AND beta1) through a 20-byte copy instead of a re-capture
         self.hyper = torch.zeros(5, dtype=torch.float32, device=flat.device)
@@ -54,20 +57,8 @@ class FlatAdamW(torch.optim.Optimizer):
 
     def _flat_grad(self) -> torch.Tensor:
         fg = self._model.flat_grad() if hasattr(self._model, "flat_grad") else None
-        if fg is not None:
-            # (the full walk over 35 tensors costs ~30 us per step: a verdict is remembered per flat buffer and re-confirmed on
-            #  the first and the last parameter, as in dp.allreduce_gradients)
-            ps, key = self._params, (fg.data_ptr(), fg.numel())
-            g0, gl = ps[0].grad, ps[-1].grad
-            seen = self.__dict__.setdefault("_views_keys", set())    # (eager: the allocator alternates between a few addresses)
-            if (key in seen and g0 is not None and gl is not None and g0.data_ptr() == key[0] and
-                    gl.data_ptr() + 4 * gl.numel() == key[0] + 4 * key[1]):
-                return fg
-            if _grads_are_views_of(fg, ps):
-                if len(seen) < 8:
-                    seen.add(key)
-                return fg
-            seen.discard(key)
+        if fg is not None and _grads_are_views_of(fg, self._params):   # (every parameter, every call: ~15 us)
+            return fg
         # generic path (gradients accumulated elsewhere): gather into a scratch buffer
         if self._gather is None:
             self._gather = torch.empty_like(self.flat_param)
@@ -87,7 +78,13 @@ class FlatAdamW(torch.optim.Optimizer):
         grad = self._flat_grad()
         with torch.cuda.device(self.flat_param.device):
             self.sync_hyper()
-            L.check(L.load().pfn_adamw_step_dev(self.flat_param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
-                                                self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.hyper.data_ptr(),
-                                                self.step_count.data_ptr(), L.stream_ptr()), "pfn_adamw_step_dev")
+            if self.guard is not None:
+                L.check(L.load().pfn_adamw_step_guarded(self.flat_param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                        self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.hyper.data_ptr(),
+                                                        self.step_count.data_ptr(), self.guard.data_ptr(), L.stream_ptr()),
+                        "pfn_adamw_step_guarded")
+            else:
+                L.check(L.load().pfn_adamw_step_dev(self.flat_param.data_ptr(), grad.data_ptr(), self.exp_avg.data_ptr(),
+                                                    self.exp_avg_sq.data_ptr(), self.flat_param.numel(), self.hyper.data_ptr(),
+                                                    self.step_count.data_ptr(), L.stream_ptr()), "pfn_adamw_step_dev")
         return loss

@@ -75,6 +75,10 @@ class PowerImbalance(nn.Module):
         self.edgemean, self.edgestd = edgemean, edgestd
         self._stats = None
         self._graphs = None
+        # True: every forward rebuilds the adjacency from the batch's edge_index on the device, no host sync (like
+        # MaskEmbdMultiMPN.dynamic_topology: a captured training step whose topology changes per batch -- GraphedTrainStep sets
+        # both; with the cache a replayed step would keep walking the CAPTURE-time topology)
+        self.dynamic_topology = False
         from ..loss import POWER_IMBALANCE_WS_FLOATS, _Workspace
         self._ws = _Workspace(POWER_IMBALANCE_WS_FLOATS)
 
@@ -89,7 +93,7 @@ class PowerImbalance(nn.Module):
                 raise RuntimeError("PowerImbalance: expected 4 node and 2 branch statistics")
         if self._graphs is None:
             self._graphs = _GraphCache()
-        graph = self._graphs.get(edge_index, x.shape[0], -1)
+        graph = self._graphs.get(edge_index, x.shape[0], -1, rebuild=self.dynamic_topology)
         return power_imbalance(x, graph, edge_attr, self._stats, self._ws)
 
     @staticmethod

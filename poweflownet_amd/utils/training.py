@@ -71,6 +71,23 @@ class GraphedTrainStep:
         # (model.dynamic_topology: pfn_graph_build + the on-device checks, no host sync), and every batch's edge_index is copied
         # into the captured buffer like x / y / edge_attr -- still one graph launch per batch
         self.dynamic = False
+        self._held = []            # GraphCSRs whose workspaces the captured launches read (kept alive as long as the graph is)
+
+    def _topology_owners(self):
+        """Everything that keeps an adjacency per `edge_index`: the model and the loss modules that walk the grid themselves
+        (PowerImbalance, also inside MixedMSEPoweImbalance)."""
+        owners = [self.model] if hasattr(self.model, "dynamic_topology") else []
+        if isinstance(self.loss_fn, nn.Module):
+            owners += [m for m in self.loss_fn.modules() if hasattr(m, "dynamic_topology")]
+        return owners
+
+    def _set_dynamic_topology(self, on: bool):
+        for o in self._topology_owners():
+            o.dynamic_topology = bool(on)
+
+    def _drop_graph(self):
+        self.graph = self.static = None
+        self._held = []
 
     def _hyper_key(self):
         """Every optimiser scalar a captured update would hold BY VALUE (as a kernel argument): lr, betas (OneCycleLR
@@ -138,21 +155,47 @@ class GraphedTrainStep:
         self.static = data.clone()
         if not self.dynamic:
             self.static.edge_index = data.edge_index               # identity matters: the model's adjacency cache keys on it
-        # (dynamic: the clone IS the captured edge_index buffer; model.dynamic_topology makes the captured forward rebuild from it)
+        # dynamic: the clone IS the captured edge_index buffer.  `dynamic_topology` is raised on the model AND on every loss
+        # module that keeps an adjacency of its own (PowerImbalance: with its cache the replayed loss kept walking the
+        # capture-time topology) for the warm-up and the capture only: the captured launches rebuild from the
+        # buffer; forwards outside the graph (evaluation, the short last batch) keep the validated, cached build.
         snap = self._snapshot()
         if self.side is None:
             self.side = torch.cuda.Stream()
         side = self.side
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                              # warm-up off the capture stream (allocator, adjacency cache)
-            for _ in range(2):
-                self._eager_body(self.static)
-        torch.cuda.current_stream().wait_stream(side)
-        self._restore(snap)
-        self.opt.zero_grad(set_to_none=True)
-        self.graph = dp.GraphedStep(lambda: self._fwd_bwd(self.static), self.opt.step, self.model, self.allreduce).capture()
+        prev = [(o, o.dynamic_topology) for o in self._topology_owners()]
+        if self.dynamic:
+            self._set_dynamic_topology(True)
+        guarded = self.dynamic and hasattr(self.opt, "guard")
+        try:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                          # warm-up off the capture stream (allocator, adjacency cache)
+                for _ in range(2):
+                    self._eager_body(self.static)
+            torch.cuda.current_stream().wait_stream(side)
+            self._restore(snap)
+            self.opt.zero_grad(set_to_none=True)
+            box = {}
+
+            def fwd_bwd():
+                box["loss"] = self._fwd_bwd(self.static)
+                if guarded:
+                    # unverified batches: a bad one (ids out of range, edges across the claimed graph boundaries) reaches the
+                    # step as a NaN loss (pfn_graph_poison_if_bad); the captured update then SKIPS instead of turning every
+                    # parameter NaN for good (the reference would have raised before the step)
+                    self.opt.guard = box["loss"]
+                return box["loss"]
+            self.graph = dp.GraphedStep(fwd_bwd, self.opt.step, self.model, self.allreduce).capture()
+        finally:
+            if guarded:
+                self.opt.guard = None
+            for o, was in prev:
+                o.dynamic_topology = was
         self.loss = self.graph.out
         self.key = self._hyper_key()
+        # static mode: the captured launches read the workspaces of the adjacencies built during the warm-up, whose only other
+        # owner is a one-entry cache -- a batch with another edge_index (evaluation, a short last batch) would evict and free them
+        self._held = [o._graphs._graph for o in self._topology_owners() if getattr(o, "_graphs", None) is not None]
         return self.loss                                           # the capture pass does not execute: caller replays
 
     def _same_shapes(self, data):
@@ -171,17 +214,21 @@ class GraphedTrainStep:
         if self.disabled or not data.x.is_cuda:
             return self._eager(data)
         if self.graph is not None and self.key != self._hyper_key():
-            self.graph = self.static = None                        # a scheduler moved lr / betas / ...: capture again
+            self._drop_graph()                                     # a scheduler moved lr / betas / ...: capture again
         if self.graph is None:
             snap = self._snapshot()
             try:
                 self._capture(data)
             except Exception as exc:                               # noqa: BLE001  (the eager body is always available)
+                if self.allreduce and dp.world_size() > 1:
+                    # ranks must not disagree on how a step is launched (one would wait in a collective the other never
+                    # enters): under data parallelism a failed capture is an error, not a silent change of mode
+                    raise
                 import warnings
                 warnings.warn(f"GraphedTrainStep: hipGraph capture failed ({exc}); running eager launches from here on")
                 torch.cuda.synchronize()
                 self._restore(snap)
-                self.graph = self.static = None
+                self._drop_graph()
                 self.disabled = True
                 return self._eager(data)
         if not self._compatible(data):
@@ -189,8 +236,7 @@ class GraphedTrainStep:
                 # same shapes, another edge_index tensor: this loader changes (or re-collates) the topology per batch.  Capture
                 # once more with the adjacency build inside the graph; from here on every batch of this shape replays.
                 self.dynamic = True
-                self.model.dynamic_topology = True
-                self.graph = self.static = None
+                self._drop_graph()
                 return self(data)
             return self._eager(data)                               # e.g. the short last batch of an epoch
         if hasattr(self.opt, "sync_hyper"):
@@ -217,7 +263,7 @@ def train_epoch(model: nn.Module, loader, loss_fn: Callable, optimizer, device, 
         from tqdm import tqdm
         it = tqdm(loader, total=len(loader), desc="Training")
     if graph is not None and graph.allreduce != bool(allreduce):
-        graph.graph = graph.static = None       # the replayed step contains (or not) the collective: capture again
+        graph._drop_graph()                     # the replayed step contains (or not) the collective: capture again
         graph.allreduce = bool(allreduce)
     for data in it:
         data = data.to(device)
