@@ -250,6 +250,34 @@ def dp_overhead(fb, opt, model, dev, steps, base_ms):
             pass
 
 
+def device_identity(dev, local_rank) -> str:
+    """What makes this rank's GPU distinguishable from every other rank's: PCI domain:bus:device + the UUID the driver reports."""
+    pr = torch.cuda.get_device_properties(dev)
+    pci = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), getattr(pr, "pci_bus_id", 0), getattr(pr, "pci_device_id", 0))
+    return f"hip:{local_rank} pci {pci} uuid {getattr(pr, 'uuid', '?')} {pr.name} ({getattr(pr, 'gcnArchName', '?')})"[:160]
+
+
+def rank_roster(dev, local_rank, own_ms, world, dist_on):
+    """`ranks` of the JSON line: every rank's device identity and ITS OWN ms per step over the timed region (the headline takes
+    the maximum), all-gathered over the process group -- a line with n_gpus = N carries N distinct devices or says so."""
+    ident = device_identity(dev, local_rank)
+    if not dist_on:
+        return {"ranks": [{"rank": 0, "device": ident, "ms_per_step": round(own_ms, 4)}], "distinct_devices": 1}
+    buf = torch.zeros(168, dtype=torch.uint8, device=dev)
+    raw = ident.encode()[:160]
+    buf[:len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    buf[160:168] = torch.tensor([own_ms], dtype=torch.float64).view(torch.uint8)
+    allb = [torch.zeros_like(buf) for _ in range(world)]
+    torch.distributed.all_gather(allb, buf)
+    ranks = []
+    for r, b in enumerate(allb):
+        b = b.cpu()
+        ranks.append({"rank": r, "device": bytes(b[:160].tolist()).rstrip(b"\0").decode(errors="replace"),
+                      "ms_per_step": round(float(b[160:168].view(torch.float64).item()), 4)})
+    pci = {x["device"].split(" uuid ")[0].split("pci ")[-1] + "|" + x["device"].split(" uuid ")[-1].split(" ")[0] for x in ranks}
+    return {"ranks": ranks, "distinct_devices": len(pci)}
+
+
 def self_launch(args) -> int:
     """`python bench.py --gpus N` without a torchrun environment: re-run this very command line under torch.distributed.run
     (one process per GPU, RCCL over xGMI, rendezvous on 127.0.0.1 at a free port).  Returns the launcher's exit code."""
@@ -383,12 +411,14 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    own_elapsed = elapsed
     if dist_on:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     ms_per_step = 1e3 * elapsed / args.steps
     value = args.batch * world * args.steps / elapsed
+    ranks_info = rank_roster(dev, local_rank, 1e3 * own_elapsed / args.steps, world, dist_on)
     # the same K steps once more with one event per step boundary: median / min step time (SURVEY 8d asks for the median; the
     # contract's timed region above stays free of event records, each of which costs a few microseconds on the stream)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -629,7 +659,7 @@ def main():
             "step_gemm_flops": step_flops,
             "step_mfma_frac": None if not step_flops else round(step_flops / (1e-3 * ms_per_step) / MFMA_F32_PEAK, 4),
             "fractions_rejected": bad,
-            "final_loss": final_loss, **extras,
+            "final_loss": final_loss, **ranks_info, **extras,
             "roofline": roofline, "scatter_add": scatter, "cpu_baseline": cpu, "kernels": kernels,
         }
         if cpu:

@@ -103,6 +103,11 @@ def test_bench_two_ranks_on_one_gpu_gloo():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["config"]["parallelism"] == "dp2"
     assert d["value"] > 0 and d["roofline"] is not None
     assert d["config"]["launch"] == "hipGraph replay: graph(fwd+bwd) -> eager all-reduce -> graph(optimizer)"
+    # the line proves who took part: one entry per rank with the device it ran on and its own step time (here both ranks share
+    # the box's one GPU -- the roster says so instead of pretending to two devices)
+    assert [r["rank"] for r in d["ranks"]] == [0, 1] and d["distinct_devices"] == 1
+    assert all("pci" in r["device"] and r["ms_per_step"] > 0 for r in d["ranks"])
+    assert max(r["ms_per_step"] for r in d["ranks"]) <= d["ms_per_step"] * 1.0001
 
 
 def test_bench_self_launches_its_ranks():
