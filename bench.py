@@ -57,6 +57,8 @@ def parse():
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)   # a counter pass of live_traffic(): timing loops only
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) behind roofline.traffic")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short runs of BASELINE.json's other single-GPU configurations (reported under `other_configs`)")
     ap.add_argument("--loss", default="mse", choices=["mse", "masked_l2"],
                     help="mse = BASELINE.json's metric (train.py:103); masked_l2 = the reference's default --train_loss_fn")
     return ap.parse_args()
@@ -276,6 +278,36 @@ def rank_roster(dev, local_rank, own_ms, world, dist_on):
                       "ms_per_step": round(float(b[160:168].view(torch.float64).item()), 4)})
     pci = {x["device"].split(" uuid ")[0].split("pci ")[-1] + "|" + x["device"].split(" uuid ")[-1].split(" ")[0] for x in ranks}
     return {"ranks": ranks, "distinct_devices": len(pci)}
+
+
+OTHER_CONFIGS = {   # BASELINE.json configs[2] and configs[3] (configs[1] is the headline; configs[4] = configs[3] per rank under --gpus 8)
+    "case118v2 inference batch=2048": ["--mode", "infer", "--batch", "2048", "--steps", "20", "--warmup", "5"],
+    "case6470rte training batch=64": ["--case", "6470rte", "--batch", "64", "--steps", "6", "--warmup", "2"],
+}
+
+
+def other_configs():
+    """The default invocation also times BASELINE.json's other single-GPU configurations, briefly (a child process each: its own
+    workspace, a few replayed steps, the per-kernel pass for the dominant kernel's roofline fraction; no CPU baseline, no counter
+    passes), so that the record a driver keeps of `python bench.py` holds a number for every configuration -- not a headline."""
+    import subprocess
+    out = {}
+    for name, extra in OTHER_CONFIGS.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--child", "--no-cpu-baseline", "--no-live-traffic", "--no-dp-overhead",
+               "--no-other-configs", "--profile-steps", "2"] + extra
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(line[-1])
+            rf = d.get("roofline") or {}
+            out[name] = {"ms_per_step": d["ms_per_step"], "value": d["value"], "unit": d["unit"], "steps": d["steps"],
+                         "launch": d["config"]["launch"], "step_mfma_frac": d.get("step_mfma_frac"), "step_hbm_frac": d.get("step_hbm_frac"),
+                         "dominant_kernel": rf.get("kernel"), "dominant_frac": rf.get("frac"), "dominant_bound": rf.get("bound"),
+                         "kernels_ms_per_step": {k: v["ms_per_step"] for k, v in sorted(d.get("kernels", {}).items(),
+                                                                                         key=lambda kv: -kv[1]["ms_per_step"])[:6]}}
+        except Exception as exc:                  # noqa: BLE001
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"[:200]}
+    return out
 
 
 def self_launch(args) -> int:
@@ -629,6 +661,13 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args, (h, Lg, K), data_cpu, args.cpu_seconds)
 
+    others = None
+    if rank == 0 and world == 1 and not args.child and not args.no_other_configs and train and str(args.case) == "118v2" \
+            and args.batch == 128 and args.config == "standard" and not under_profiler():
+        del data, model                                # (the children need the memory more than this process does from here on)
+        torch.cuda.empty_cache()
+        others = other_configs()
+
     if rank == 0:
         n_case, e_case = CASES[str(args.case)]
         # a fraction above 1 is a broken denominator, not a fast kernel: never print one
@@ -662,6 +701,8 @@ def main():
             "final_loss": final_loss, **ranks_info, **extras,
             "roofline": roofline, "scatter_add": scatter, "cpu_baseline": cpu, "kernels": kernels,
         }
+        if others is not None:
+            out["other_configs"] = others
         if cpu:
             out["speedup_vs_cpu"] = round(value / cpu["value"], 1)
         print(json.dumps(out))

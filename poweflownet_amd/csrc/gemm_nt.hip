@@ -699,9 +699,16 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 constexpr int WS_IMG = KP * (32 * 4) + 768;                  // floats per LDS buffer: 4 quarter images + 3 KiB for the 2,176-byte
                                                              // trailing-column image (copied as three 1 KiB DMAs)
 constexpr int WS_DMAS = 9;                                   // DMAs per wave and piece: 4 x 17 + 3 = 71 -> 72 slots over 8 waves
+// REM / LS: the H = 129 shape (4 quarters + the trailing column, one real step in a piece's last chunk: <true, 1>), or a WIDE
+// product (round 4: hidden_dim 512 = the reference's configs/large.json) -- no trailing column, output columns in slices of 128
+// (blockIdx.y), every piece a full 136-k one thanks to the piece-padded images (k8_of): <false, 4>.  Such a product does not fit
+// the stationary kernel's LDS even as 32-column slices (4 terms x 512 k); it used to run as several launches accumulating raw
+// sums into C with every operand row read once per 64-column slice (0.40 of the MFMA peak at case118v2 x 128).
+template <bool REM, int LS>
 __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CT = 4;
+    const int cq0 = 4 * (int)blockIdx.y, c0 = 128 * (int)blockIdx.y;   // first quarter / column of this block's slice
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, kh = lane >> 5;
@@ -733,9 +740,10 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
 #pragma unroll
         for (int j = 0; j < WS_DMAS; ++j) {
             const int slot = wave + NT_WAVES * j;
-            if (slot < 68) {
-                const int q = slot / 17, c = slot - 17 * q;
-                dma_1k(bq + q * qbytes + ((size_t)c << 10), dst0 + q * (KP * 32) + (c << 8));
+            if (slot < 68 || !REM) {                        // (no trailing column: slots 68..71 repeat slots 0..3 -- every wave issues 9)
+                const int s2 = slot < 68 ? slot : slot - 68;
+                const int q = s2 / 17, c = s2 - 17 * q;
+                dma_1k(bq + (cq0 + q) * qbytes + ((size_t)c << 10), dst0 + q * (KP * 32) + (c << 8));
             } else {
                 const int c = slot == 71 ? 0 : slot - 68;
                 dma_1k(br + ((size_t)c << 10), dst0 + 4 * (KP * 32) + (c << 8));
@@ -811,8 +819,8 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
         // ---- multiply out of buffer s & 1, refilling the fragment for the next piece / row tile
         {
             const int pi = last ? p : np, rti = last ? rt : nrt_;
-            nt_multiply<CT, 1, NCH, 1, WS_DMAS>(acc, racc, a_cur, lds + (s & 1) * WS_IMG, KP, 4, 0, kh4, r32, a_base(rti, pi),
-                                                 a_voff(rti, pi), a.piece[pi].kmax, (uint32_t)a.piece[pi].kscale);
+            nt_multiply<CT, REM ? 1 : 0, NCH, LS, WS_DMAS>(acc, racc, a_cur, lds + (s & 1) * WS_IMG, KP, 4, 0, kh4, r32, a_base(rti, pi),
+                                                           a_voff(rti, pi), a.piece[pi].kmax, (uint32_t)a.piece[pi].kscale);
         }
         if (flush_after) {
             // the accumulators are still being written by the last MFMAs (see the stationary kernel's flush)
@@ -837,11 +845,11 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
                         aux[0][g][0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
                     }
                     const int row = rbase + r32;
-                    raux[0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
+                    if (REM) raux[0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
                 } else {
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct) {
-                        const int col0 = 32 * ct + (r32 & ~3);
+                        const int col0 = c0 + 32 * ct + (r32 & ~3);
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
@@ -849,7 +857,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
                         }
                     }
                     const int row = rbase + r32;
-                    raux = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, rem_col, ldx, a.aux_cm_rows));
+                    if (REM) raux = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, rem_col, ldx, a.aux_cm_rows));
                 }
                 asm volatile("s_waitcnt vmcnt(0)"
                              : "+v"(aux[0][0]), "+v"(aux[0][1]), "+v"(aux[0][2]), "+v"(aux[0][3]), "+v"(aux[1][0]), "+v"(aux[1][1]),
@@ -867,7 +875,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
             }
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                const int col0 = 32 * ct + (r32 & ~3);
+                const int col0 = c0 + 32 * ct + (r32 & ~3);
                 float v[4][4];
                 const int row_base = rbase + (r32 & 3) + 4 * kh;
                 auto row_of = [&](int g) { return row_base + 8 * g; };
@@ -931,7 +939,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
                     if (live && row_of(g) < 0) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
 #endif
             }
-            {   // the trailing column (129th): the two k halves, lane half 0 stores
+            if (REM) {   // the trailing column (129th): the two k halves, lane half 0 stores
                 float v0 = racc[0] + __shfl_xor(racc[0], 32);
                 const int row = rbase + r32;
                 if (kh == 0 && live && row < a.M) {
@@ -1107,7 +1115,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
         }
         flops += 2.0 * a.M * tm.K * a.ncols;
         bytes += (double)a.M * tm.K * 4.0;
-        const int K8 = (tm.K + 7) & ~7, qstride = (K8 >> 2) * 128;
+        const int K8 = k8_of(tm.K), qstride = (K8 >> 2) * 128;
         for (int k0 = 0; k0 < K8; k0 += KP) {
             NtPiece pc;
             pc.A = tm.cm_rows > 0 ? tm.A + (size_t)(k0 >> 2) * tm.cm_rows * 4 : tm.A + k0;
@@ -1219,8 +1227,8 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
             k.M = (int)rows_ws;
             const size_t lb = ((size_t)2 * WS_IMG + (size_t)a.ldc) * sizeof(float);
             static std::atomic<uint64_t> lds_raised{0};
-            PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_ws_kernel), NT_LDS_BYTES, lds_raised));
-            gemm_nt_ws_kernel<<<ncu, NT_THREADS, lb, s>>>(k);
+            PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_ws_kernel<true, 1>), NT_LDS_BYTES, lds_raised));
+            gemm_nt_ws_kernel<true, 1><<<ncu, NT_THREADS, lb, s>>>(k);
             PFN_CHECK_LAUNCH();
             if (rows_ws == a.M) return PFN_OK;
             GemmArgs t = a;                       // the rest of the rows: the same product on offset operands
@@ -1233,6 +1241,26 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
             if (a.resid) t.resid = a.resid + (size_t)rows_ws * (a.aux_cm_rows > 0 ? 4 : a.ldr);
             if (a.gate) t.gate = a.gate + (size_t)rows_ws * (a.aux_cm_rows > 0 ? 4 : a.ldg);
             return launch_gemm_nt_rows(t, s, false);
+        }
+    }
+    if (top) {   // WIDE products (hidden_dim 512: configs/large.json): no trailing column, whole slices of 128 output columns, more
+        // weight than the stationary kernel can hold two 32-column quarters of -> the weight-streaming kernel over ALL rows
+        // (every piece is a full one: piece-padded images), one launch, every operand row read once per 128 columns
+        bool wide_ok = remv == 0 && nq >= 8 && nq % 4 == 0 && pieces.size() <= (size_t)NT_MAX_PIECES && a.ldc == 32 * nq;
+        for (size_t i = 0; i < pieces.size(); ++i) wide_ok = wide_ok && pieces[i].klen == KP;
+        if (wide_ok) {
+            k.npiece = (int)pieces.size();
+            for (size_t i = 0; i < pieces.size(); ++i) k.piece[i] = pieces[i];
+            k.kuni = KP;
+            k.klast = 4;
+            const int nsl = nq / 4;
+            const int gx = std::max(1, std::min((nrt + NT_WAVES - 1) / NT_WAVES, std::max(1, ncu / nsl)));
+            const size_t lb = ((size_t)2 * WS_IMG + (size_t)a.ldc) * sizeof(float);
+            static std::atomic<uint64_t> lds_raised_w{0};
+            PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_ws_kernel<false, 4>), NT_LDS_BYTES, lds_raised_w));
+            gemm_nt_ws_kernel<false, 4><<<dim3(gx, nsl), NT_THREADS, lb, s>>>(k);
+            PFN_CHECK_LAUNCH();
+            return PFN_OK;
         }
     }
     bool seen[8] = {false, false, false, false, false, false, false, false};

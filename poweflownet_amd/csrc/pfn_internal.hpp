@@ -146,12 +146,16 @@ struct PackArgs {
     int mask_dtype;          // 0: int64, 1: float32
 };
 size_t packed_floats(int K, int ld_out);
+// k rows of a packed image: K rounded up to a multiple of 8 -- or, beyond one 136-k piece, to whole PIECES (hidden_dim 512 ->
+// 544): every piece of a wide product is then the straight-line 17-chunk kind (the zero rows multiply clamped A reads), which is
+// what lets the weight-streaming kernel take it
+__host__ __device__ inline int k8_of(int K) { return K <= 136 ? ((K + 7) & ~7) : (K + 135) / 136 * 136; }
 __host__ __device__ inline size_t packed_fp32_floats(int K, int ld_out) {
     int remv, nq;
     const int m = ld_out & 31;
     remv = (m != 0 && m <= 4) ? m : 0;
     nq = (ld_out - remv + 31) / 32;
-    const int G = ((K + 7) & ~7) >> 2;
+    const int G = k8_of(K) >> 2;
     return (size_t)(((int64_t)nq * G * 128 + (int64_t)G * 16 + 255) / 256 * 256);
 }
 // column plan of an output of `ld` (padded) columns: `remv` trailing columns (0 or 4) go to the VALU path when that
@@ -165,7 +169,7 @@ __host__ __device__ inline void col_plan(int ld, int& remv, int& nq) {
 __device__ inline void pack_job_body(const PackJob& jb, int bx, int nbx) {
     int remv, nq;
     col_plan(jb.ld_out, remv, nq);
-    const int G = ((jb.K + 7) & ~7) >> 2;       // groups of four k's
+    const int G = k8_of(jb.K) >> 2;             // groups of four k's
     const long main_floats = (long)nq * G * 128, total = main_floats + (long)G * 16;
     for (long i = (long)bx * blockDim.x + threadIdx.x; i < total; i += (long)nbx * blockDim.x) {
         int k, n;

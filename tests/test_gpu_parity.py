@@ -1146,6 +1146,19 @@ def test_config2_full_size_vs_oracle():
     _check_full_size(m, ref, make_batch("118v2", 128, seed=0), "config 2")
 
 
+def test_large_json_h512_case118_batch128_vs_oracle():
+    """The reference's own configs/large.json (hidden_dim 512, n_gnn_layers 5, K 3; train.py:52-58 takes the width from the JSON)
+    at the metric's batch: case118v2 x 128.  H = 512 = 16 quarters, no trailing column, K = 512 = four 136-k pieces per term:
+    none of the H = 129-shaped fast paths apply (weights stream through LDS / split launches, generic edge walks); forward and all
+    44 parameter gradients at 1e-5 against the oracle (see _check_full_size)."""
+    torch.manual_seed(1234)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 512, 5, 3, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 512, 5, 3, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    _check_full_size(m, ref, make_batch("118v2", 128, seed=0), "large.json (H512 L5 K3), case118v2 x 128")
+
+
 def test_config3_size_training_step_vs_oracle():
     """configs[2]'s size (case118v2 x 2048 = 241,664 nodes) as a TRAINING step: the persistent gemm_nt + two-workgroups-per-CU
     fused-hop path with its backward, forward and all parameter gradients against the oracle (see _check_full_size)."""
