@@ -431,13 +431,24 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
 constexpr int BH_THREADS = 1024;
 constexpr int BH_RPT = 8;                       // rows per thread at most: graphs up to 8,192 nodes
 constexpr int BH_NBPT = 20;                     // staged neighbour ids per thread at most: 20,480 directed edges per graph
+// High-degree buses (a "hub" substation: 100+ lines) are NOT walked by their owner thread -- a 170-edge row was one thread's
+// 43 serial trips per hop while the block's other 1,023 threads waited at the barrier (hub grid: 343 vs 268 us per launch).
+// Rows above BH_HUB_DEG edges are listed once, and in every hop a WAVE sums such a row: lane l adds the edges l, l + 64, ... in
+// that order, the 64 partial sums are combined by a fixed xor tree (deterministic; not the sequential order of a scatter_add:
+// these rows match the oracle to fp32 tolerance, not bit for bit), the result goes back to the owner through LDS.
+constexpr int BH_HUB_DEG = 32;
+constexpr int BH_HUB_CAP = 128;                 // listed hub rows per graph (more: the rest stay with their owners)
+__host__ __device__ constexpr size_t bh_hub_bytes() { return (size_t)BH_HUB_CAP * 16 + (size_t)BH_HUB_CAP * 2 + 16; }
 __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int nchunk, int ngraphs, int nb_cap,
                                                                     const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                                     const float* __restrict__ dinv, const float* __restrict__ x0,
                                                                     float* __restrict__ xk, size_t stride, int ld, int K, int n_total,
                                                                     int x0_cm) {
-    extern __shared__ __attribute__((aligned(16))) float4 bh_tile[];          // [seg] | rp u16 [seg + 2] | nb u16 [nb_cap]
-    unsigned short* s_rp = reinterpret_cast<unsigned short*>(bh_tile + seg);
+    extern __shared__ __attribute__((aligned(16))) float4 bh_tile[];          // [seg] | hub sums [BH_HUB_CAP] | hub rows u16 | count | rp u16 [seg + 2] | nb u16 [nb_cap]
+    float4* s_hub_y = bh_tile + seg;
+    unsigned short* s_hub_row = reinterpret_cast<unsigned short*>(s_hub_y + BH_HUB_CAP);
+    int* s_hub_n = reinterpret_cast<int*>(s_hub_row + BH_HUB_CAP);
+    unsigned short* s_rp = reinterpret_cast<unsigned short*>(s_hub_n + 4);
     unsigned short* s_nb = s_rp + ((seg + 2 + 7) & ~7);
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
     const int c = j % nchunk, gi = (j / nchunk) * 8 + xcd;
@@ -451,6 +462,7 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
     float di[BH_RPT];
     float4 z[BH_RPT];
     int rpv[BH_RPT + 1], nbv[BH_NBPT];
+    if (t == 0) s_hub_n[0] = 0;
 #pragma unroll
     for (int r = 0; r < BH_RPT; ++r) {
         const int row = t + r * BH_THREADS;
@@ -494,14 +506,50 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
             if (i < ne) s_nb[i] = (unsigned short)(nbv[jn] - r0);
         }
     }
+    __syncthreads();                            // (also publishes the zeroed hub counter)
+    // hub rows: listed once (the slot order is arrival order -- it decides which wave sums a row, not what the sum is)
+    int hubslot[BH_RPT];
+#pragma unroll
+    for (int r = 0; r < BH_RPT; ++r) {
+        hubslot[r] = -1;
+        const int row = t + r * BH_THREADS;
+        if (nb_in_lds && row < seg && (int)s_rp[row + 1] - (int)s_rp[row] > BH_HUB_DEG) {
+            const int sl = atomicAdd(s_hub_n, 1);
+            if (sl < BH_HUB_CAP) {
+                hubslot[r] = sl;
+                s_hub_row[sl] = (unsigned short)row;
+            }
+        }
+    }
     __syncthreads();
+    const int nhub = min(s_hub_n[0], BH_HUB_CAP);
+    const int wave_ = t >> 6, lane_ = t & 63;
     for (int k = 1; k <= K; ++k) {
         float* outk = xk + (size_t)(k - 1) * stride;
+        // ---- hub rows first: one wave per row, lanes stride over its edges, fixed xor tree
+        for (int hs = wave_; hs < nhub; hs += BH_THREADS / 64) {
+            const int row = s_hub_row[hs];
+            const int beg = s_rp[row], end = s_rp[row + 1];
+            float4 part = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int p = beg + lane_; p < end; p += 64) part = add4(part, bh_tile[s_nb[p]]);
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                part.x += __shfl_xor(part.x, off);
+                part.y += __shfl_xor(part.y, off);
+                part.z += __shfl_xor(part.z, off);
+                part.w += __shfl_xor(part.w, off);
+            }
+            if (lane_ == 0) s_hub_y[hs] = part;
+        }
+        if (nhub > 0) __syncthreads();
 #pragma unroll
         for (int r = 0; r < BH_RPT; ++r) {
             const int row = t + r * BH_THREADS;
             if (row >= seg) continue;
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hubslot[r] >= 0) {
+                acc = s_hub_y[hubslot[r]];
+            } else
 #ifdef BH_EXP_NOGATHER   /* tools/ubench experiment switches: never defined in the product build */
             acc = bh_tile[row];
             if (false) {
@@ -554,7 +602,7 @@ bool big_hops_fit(int seg, int n, int64_t e_stored) {
     static const bool off = diag_env("PFN_NO_BIG_HOPS") != nullptr;   // A/B switch: K generic hop launches instead
     if (off || seg <= 0 || n <= 0 || n % seg != 0 || seg > BH_RPT * BH_THREADS || seg >= 65536) return false;
     (void)e_stored;
-    return (size_t)seg * 16 + (size_t)((seg + 2 + 7) & ~7) * 2 + 1024 <= (size_t)160 * 1024;
+    return (size_t)seg * 16 + bh_hub_bytes() + (size_t)((seg + 2 + 7) & ~7) * 2 + 1024 <= (size_t)160 * 1024;
 }
 
 bool tag_uses_big_hops(int seg, int ld, int n, int64_t e_stored, int K) {
@@ -571,7 +619,7 @@ int launch_big_graph_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_
         return PFN_EINVAL;
     }
     const int nchunk = a.ld / 4, ngraphs = g.n / a.seg;
-    const size_t fixed = (size_t)a.seg * 16 + (size_t)((a.seg + 2 + 7) & ~7) * 2;
+    const size_t fixed = (size_t)a.seg * 16 + bh_hub_bytes() + (size_t)((a.seg + 2 + 7) & ~7) * 2;
     // neighbour list: an equal share of the (undirected) edges per graph, with slack; the kernel reads indices from global memory
     // for a graph that has more
     const size_t want_nb = (size_t)(2 * (int64_t)g.e_stored / std::max(1, ngraphs) + 64) * 2;

@@ -1226,7 +1226,7 @@ def test_inference_forward_equals_training_forward_bitwise(batch):
     assert all(torch.isfinite(p.grad).all() and p.grad.abs().max() > 0 for p in m.parameters())
 
 
-@pytest.mark.parametrize("hub,B", [(0.0, 64), (0.2, 64), (0.0, 16)])
+@pytest.mark.parametrize("hub,B", [(0.0, 64), (0.2, 64), (0.0, 16), (0.2, 16)])
 def test_config4_case6470_batch64_vs_oracle(hub, B):
     """configs[3]: case6470rte training batch 64 (and the high-degree 'hub' variant) at FULL size against the CPU oracle:
     forward (fp32 and float64 oracle) and all parameter gradients at 1e-5 (see _check_full_size); graphs of the batch against
