@@ -266,8 +266,8 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tc);
         const size_t o = (size_t)(r0 + lr) * a.ld + gc;
 #ifndef SG_EXP_NOSTORE
-        sg_st4(a.P + o, p4);
-        sg_st4(a.Q + o, sg_ld4(l.Q + (size_t)lr * SG_TW + tc));
+        sg_st4_wt(a.P + o, p4);
+        sg_st4_wt(a.Q + o, sg_ld4(l.Q + (size_t)lr * SG_TW + tc));
 #endif
         const float4 w0 = sg_ld4(l.we + tc), w1 = sg_ld4(l.we + SG_TW + tc);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -315,9 +315,9 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             }
         }
 #ifndef SG_EXP_NOSTORE
-        sg_st4(a.S + o, acc);
+        sg_st4_wt(a.S + o, acc);
 #else
-        if (acc.x == 123.456f) sg_st4(a.S + o, acc);
+        if (acc.x == 123.456f) sg_st4_wt(a.S + o, acc);
 #endif
     }
     SG_TS(3);
@@ -606,11 +606,11 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             else
                 seg_bwd_row_slow(l, cin, cout, lr, tc, r0, in_src, out_dst, a.ea_in, a.ea_out, w0, w1, accP, accQ, dwe0, dwe1);
 #ifndef SG_EXP_NOSTORE
-            sg_st4(a.dP + (size_t)(r0 + lr) * a.ld + gc, accP);
-            sg_st4(a.dQ + (size_t)(r0 + lr) * a.ld + gc, accQ);
+            sg_st4_wt(a.dP + (size_t)(r0 + lr) * a.ld + gc, accP);
+            sg_st4_wt(a.dQ + (size_t)(r0 + lr) * a.ld + gc, accQ);
 #else
-            if (accP.x == 123.456f) sg_st4(a.dP + (size_t)(r0 + lr) * a.ld + gc, accP);
-            if (accQ.x == 123.456f) sg_st4(a.dQ + (size_t)(r0 + lr) * a.ld + gc, accQ);
+            if (accP.x == 123.456f) sg_st4_wt(a.dP + (size_t)(r0 + lr) * a.ld + gc, accP);
+            if (accQ.x == 123.456f) sg_st4_wt(a.dQ + (size_t)(r0 + lr) * a.ld + gc, accQ);
 #endif
         }
     };
@@ -627,10 +627,10 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
                 float4 acc;
                 if (threadIdx.x & 1) {
                     seg_bwd_row_src(l, cout, lr, 32, w0, w1, acc);
-                    sg_st4(a.dQ + (size_t)(r0 + lr) * a.ld + gc, acc);
+                    sg_st4_wt(a.dQ + (size_t)(r0 + lr) * a.ld + gc, acc);
                 } else {
                     seg_bwd_row_dst(l, cin, lr, 32, w0, w1, acc, rwe0, rwe1);
-                    sg_st4(a.dP + (size_t)(r0 + lr) * a.ld + gc, acc);
+                    sg_st4_wt(a.dP + (size_t)(r0 + lr) * a.ld + gc, acc);
                 }
             } else if (!(threadIdx.x & 1)) {
                 walk_rows(lr, SG_THREADS, 32, gc, rwe0, rwe1);
@@ -660,7 +660,7 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         if (c2 < sc.cw) {
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int w = 0; w < SG_WAVES; ++w) s = sg_add4(s, l.part[(w * 16 + c2) * 2 + f]);
-            sg_st4(a.dWe_partial + ((size_t)blockIdx.x * 2 + f) * a.ld + seg_gcol(sc, c2), s);
+            sg_st4_wt(a.dWe_partial + ((size_t)blockIdx.x * 2 + f) * a.ld + seg_gcol(sc, c2), s);
         }
     }
     SG_TS(4);

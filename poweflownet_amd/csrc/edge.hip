@@ -789,7 +789,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
         const int nrow = (int)(nitem / nchunk), ncol = (int)(nitem - (long)nrow * nchunk) * 4;
         EdgeRowHead hn = hd;
         if (nitem < total) hn = edge_row_head<MASK, FLY>(nrow, ncol, rowptr, P, ld, rp4);
-        st4(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK, FLY>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, hd));
+        st4_wt(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK, FLY>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, hd));
         hd = hn;
         item = nitem;
         row = nrow;

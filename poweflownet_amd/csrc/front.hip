@@ -33,7 +33,7 @@ static int wave_blocks_per_cu(int which) {
 }
 
 __device__ __forceinline__ float4 ld4f(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ void st4f(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4f(float* p, float4 v) { st4_wt(p, v); }   // (every store of this file is a kernel output)
 
 // block = rows_pb rows x nchunk chunk-lanes (nchunk = ld / 4), PERSISTENT over row groups: a thread keeps ONE chunk of four
 // hidden units for every row it visits, so its slices of all five weights live in registers for the whole kernel (as

@@ -386,7 +386,8 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     }
     float4* mine = a.partial + tk.part0 + ((size_t)bx * NH + half) * NQ * 64;
 #pragma unroll
-    for (int Q = 0; Q < NQ; ++Q) mine[Q * 64 + lane] = v[Q];
+    for (int Q = 0; Q < NQ; ++Q) st4_wt(reinterpret_cast<float*>(mine + Q * 64 + lane), v[Q]);   // (write-through: ~9 MB of partials
+                                                                                                  //  that the combine launch would wait for)
 }
 
 template <bool RUNS>

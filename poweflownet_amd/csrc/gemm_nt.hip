@@ -199,10 +199,17 @@ __device__ __forceinline__ float vload_x1_addr(const float* p) {
     asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
     return r;
 }
+template <bool WT = false>
 __device__ __forceinline__ void vstore_x4(float* p, f32x4 v) {
     // the s_nop is the ISA's "VMEM store wider than 64 bits -> VALU overwrites its data registers" hazard (2 wait states),
-    // which hipcc fills in for its own stores but cannot see inside inline asm (without it: intermittently wrong elements)
-    asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    // which hipcc fills in for its own stores but cannot see inside inline asm (without it: intermittently wrong elements).
+    // WT = WRITE-THROUGH (sc1), the small-M kernels (CT < 2: one row tile per wave, the latency regime): a kernel's plain stores
+    // leave its output dirty in the XCD's L2 and the kernel boundary then waits for the write-back (MI355X_MICROARCH.md
+    // "boundary": + B / 6 TB/s behind B dirty bytes) -- ~1 us per launch of a chain whose every link is 10-30 us long; written
+    // through, the lines drain while the waves still multiply (back to back at 15,104 rows: 12.7 -> 11.9 / 18.9 -> 17.9 /
+    // 29.5 -> 28.7 us for 1 / 2 / 4 terms; `nt`: no change).  At large M it buys nothing and costs a few per cent: plain.
+    if (WT) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" : : "v"(p), "v"(v) : "memory");
 }
 // float offset of element (row, col) of an activation tensor: row-major [rows][ld] -- or chunk-major [ld / 4 planes][cm_rows][float4]
 // when cm_rows > 0 (col a multiple of 4 here: the kernels move float4s)
@@ -368,7 +375,11 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         for (int m = 0; m < NCH; ++m) {
             const uint32_t kk = min((uint32_t)(8 * m + 4 * kh), (uint32_t)kmax0);
             a_cur[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifndef PFN_EXP_COALFIRST   /* experiment switch (wrong results): the first fragment from CONTIGUOUS addresses, 1 KiB per instruction */
             vload_x4(a_cur[m], b0, v0 + ks0 * kk);
+#else
+            vload_x4(a_cur[m], b0, (uint32_t)(m * 1024 + lane * 16) + 0u * (v0 + ks0 * kk));
+#endif
         }
     }
     // ---- weights of every piece -> LDS, once: 1 KiB DMA pieces dealt round-robin to the 8 waves
@@ -607,9 +618,9 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #ifndef PFN_EXP_NOSTORE   /* experiment switch */
-                        if (row_of(g) < a.M) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+                        if (row_of(g) < a.M) vstore_x4<(CT < 2)>(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
 #else
-                        if (row_of(g) < 0) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+                        if (row_of(g) < 0) vstore_x4<(CT < 2)>(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
 #endif
                 }
             }
@@ -646,7 +657,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                             v[e] = rem_col + e < ep.ncols ? x : 0.f;
                         }
                     }
-                    vstore_x4(dst, f32x4{v[0], v[1], v[2], v[3]});
+                    vstore_x4<(CT < 2)>(dst, f32x4{v[0], v[1], v[2], v[3]});
                 }
             }
 #pragma unroll

@@ -956,9 +956,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         upd(p4.y, g4.y, m4.y, v4.y);
         upd(p4.z, g4.z, m4.z, v4.z);
         upd(p4.w, g4.w, m4.w, v4.w);
-        reinterpret_cast<float4*>(p)[i] = p4;
-        reinterpret_cast<float4*>(m)[i] = m4;
-        reinterpret_cast<float4*>(v)[i] = v4;
+        st4_wt(p + 4 * i, p4);      // (write-through: the next step's first kernel does not wait for 4 MB of dirty lines)
+        st4_wt(m + 4 * i, m4);
+        st4_wt(v + 4 * i, v4);
     }
     for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float pi = p[i], mi = m[i], vi = v[i];

@@ -523,6 +523,20 @@ int launch_front_pq(int n, int h, int ldw1, const float* x0, const float* w1, co
 int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int64_t rows, int64_t f,
                     hipStream_t s);
 
+// 16-byte WRITE-THROUGH store of a kernel OUTPUT (global memory only; sc1).  A chain kernel's plain stores leave its output dirty
+// in the XCD's L2, and the kernel boundary then waits for the write-back (MI355X_MICROARCH.md "boundary"); written through, the
+// lines drain while the kernel still runs.  Inline asm (hipcc has no 128-bit scoped store); the s_nop is the ISA's "VMEM store
+// wider than 64 bits -> VALU overwrites its data registers" hazard, invisible to hipcc inside the asm.
+__device__ __forceinline__ void st4_wt(float* p, float4 v) {
+    typedef float f4wt_ __attribute__((ext_vector_type(4)));
+    const f4wt_ d = {v.x, v.y, v.z, v.w};
+#ifdef PFN_EXP_ST_PLAIN      /* experiment switch: the plain store */
+    *reinterpret_cast<float4*>(p) = v;
+#else
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
+#endif
+}
+
 // ---------------------------------------------------------------------------------------- dropout RNG
 // Philox4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3", SC'11): counter-based, so the mask of a
 // forward pass is a pure function of (seed, offset, layer, element) -- nothing is stored, any kernel can re-derive it.

@@ -270,7 +270,7 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
             for (int e = 0; e < 4; ++e) v[e] = gc + e < a.ncols ? v[e] : 0.f;   // (pad columns stay zero: the layout invariant)
             const float4 o4 = make_float4(v[0], v[1], v[2], v[3]);
             sg_st4(l.t0 + (size_t)lr * SG_TW + tc, o4);
-            sg_st4(a.y + (size_t)(r0 + lr) * a.ld + gc, o4);
+            sg_st4_wt(a.y + (size_t)(r0 + lr) * a.ld + gc, o4);
         }
     }
     seg_lds_barrier();   // (not __syncthreads(): the y stores drain while the hops run)
@@ -306,7 +306,7 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
             h = slh_sel4(p + 3 < end, sg_fma4(w_[3], x_[3], h), h);
         }
         if (!last) sg_st4(slh_smem + nxt + (uint32_t)(lr * SG_TW + tc), h);
-        sg_st4(gout + (size_t)(r0 + lr) * a.ld + gc, h);
+        sg_st4_wt(gout + (size_t)(r0 + lr) * a.ld + gc, h);
     };
     if (nb_in_lds) {
         uint32_t h_to[2], h_go[2], h_so[2][4];
@@ -365,7 +365,7 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
                 }
                 if (tid + j * SG_THREADS < nitems) {
                     if (!last) sg_st4(slh_smem + nxt + h_to[j], h);
-                    sg_st4(gout + h_go[j], h);
+                    sg_st4_wt(gout + h_go[j], h);
                 }
             }
             for (int it = tid + 2 * SG_THREADS; it < nitems; it += SG_THREADS) walk_item(it, gout, last);

@@ -52,6 +52,7 @@ __device__ __forceinline__ void seg_dma_1k(const char* g, float* lds_dst) {
 // a round trip of 1-2 us under load that a kernel pays at every barrier that follows its output stores (phase timestamps: 1.5 us
 // per hop of seg_lin_hops_kernel).  Use only where no thread reads another thread's GLOBAL writes after the barrier.
 __device__ __forceinline__ void seg_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void sg_st4_wt(float* p, float4 v) { st4_wt(p, v); }   // (pfn_internal.hpp: write-through output store)
 __device__ __forceinline__ void seg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // quarter q of a packed image (G * 128 floats, whole KiBs) -> LDS, the 1 KiB pieces dealt round-robin to the block's waves
 __device__ __forceinline__ void seg_copy_b(float* dst, const float* __restrict__ Bp, int q, int K8, int wave, int lane,

@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
     const size_t pf = packed_floats(K, ldc);
     CK(hipMalloc(&dP, pf * 4)); CK(hipMalloc(&dC, (size_t)M * ldc * 4 * ngroup));
-    PackJob pj; pj.src = dW; pj.dst = dP; pj.ldw = K; pj.wk0 = 0; pj.wn0 = 0; pj.trans = 1; pj.K = K; pj.ncols = N; pj.ld_out = ldc; pj.split = pack_wants_split(K, ldc) ? 1 : 0;
+    PackJob pj; pj.src = dW; pj.dst = dP; pj.ldw = K; pj.wk0 = 0; pj.wn0 = 0; pj.trans = 1; pj.K = K; pj.ncols = N; pj.ld_out = ldc;
     if (launch_pack(&pj, 1, nullptr, 0) != 0) { printf("pack failed: %s\n", pfn_last_error()); return 1; }
     GemmArgs a; memset(&a, 0, sizeof(a));
     a.M = M; a.ncols = N; a.ldc = ldc; a.ngroup = ngroup; a.gate_scale = 1.f; a.bias_group = -1; a.nterm = nterm;
