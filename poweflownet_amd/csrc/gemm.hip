@@ -472,8 +472,24 @@ size_t reduce_ws_floats(int64_t M, int max_na, int max_nb, int max_pairs) {
     return T3_MAX_PARTIAL_F4 * 4 + 256;
 }
 
+static int launch_weight_grads_uniform(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s, const DweRide* ride,
+                                       const int* stamp, int stamp_want);
 int launch_weight_grads(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s, const DweRide* ride,
                         const int* stamp, int stamp_want) {
+    // A launch with a chunk-major operand anywhere runs the runs-of-four kernel form for ALL its pairs (gemm_tn_kernel<true>:
+    // shorter prefetch distance, 0.59 against 0.68 of the MFMA peak on row-major operands at 6470rte x 64).  A list that mixes
+    // the two kinds (the big-graph configuration: the TAGConv pairs are chunk-major, the EdgeAggregation pairs are not) goes out as
+    // two launches, each kind on its own kernel form, each planned for the whole chip.
+    int ncm = 0;
+    for (int q = 0; q < npairs; ++q) ncm += (pairs[q].a_cm_rows > 0 || pairs[q].b_cm_rows > 0) ? 1 : 0;
+    if (ncm == 0 || ncm == npairs || M == 0) return launch_weight_grads_uniform(pairs, npairs, M, ws, s, ride, stamp, stamp_want);
+    std::vector<TnPair> rm, cm;
+    for (int q = 0; q < npairs; ++q) ((pairs[q].a_cm_rows > 0 || pairs[q].b_cm_rows > 0) ? cm : rm).push_back(pairs[q]);
+    PFN_TRY(launch_weight_grads_uniform(cm.data(), (int)cm.size(), M, ws, s, ride, stamp, stamp_want));
+    return launch_weight_grads_uniform(rm.data(), (int)rm.size(), M, ws, s, nullptr, stamp, stamp_want);
+}
+static int launch_weight_grads_uniform(const TnPair* pairs, int npairs, int64_t M, ReduceWs ws, hipStream_t s, const DweRide* ride,
+                                       const int* stamp, int stamp_want) {
     if (npairs == 0 || M == 0) {
         // no rows: every gradient is an empty sum
         for (int p = 0; p < npairs; ++p) {
