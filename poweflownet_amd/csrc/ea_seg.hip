@@ -324,6 +324,253 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     SG_TS(4);
 }
 
+
+// ------------------------------------------------------------------------------------------------ forward, layer 0
+// The network's FRONT (mask_embd + residual, networks/MPN.py:533-537) and the whole first EdgeAggregation edge stage in ONE launch
+// for batches of small graphs -- what front.hip's row-per-wave kernel and the generic edge walk did as two (18.8 + 9.2 us at
+// case118v2 x 128).  Layer 0's node "GEMM" has K = 4: no matrix core, just the front's fma chains.  Block = (whole graph(s), one
+// 32-column quarter), as everywhere in this file:
+//   * every wave takes rows of the block round-robin, ONE ROW PER WAVE with front_fwd_wave_body's lane = four-unit chunk layout,
+//     weight slices in registers, the same fma chains and the same xor-butterfly row sum -> x0 carries the bits of the front
+//     kernel (all four quarter-blocks of a graph compute it: 2 kFLOP per row; the block of quarter 0 stores x0 and maskf);
+//   * the lanes whose chunk lies in the block's quarter store their me_h units (the backward front reads them), form P | Q of
+//     their chunk from x0 (the front's chains), drop them into the LDS tiles and store them (ea_seg_bwd reads them);
+//   * the walk over the incoming edges runs on the tiles exactly as in ea_seg_fwd_kernel (edge attributes through the edge ids:
+//     the slot-ordered copy is written by the pack blocks of this very launch).
+// The weight re-layout ("pack") blocks of the forward pass ride behind the graph blocks, as they did behind the front's.
+__device__ __forceinline__ float4 sg_wave_sum4(float4 v) {   // (front.hip wave_sum4: fixed butterfly, every lane ends with the same sum)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        v.x += __shfl_xor(v.x, off);
+        v.y += __shfl_xor(v.y, off);
+        v.z += __shfl_xor(v.z, off);
+        v.w += __shfl_xor(v.w, off);
+    }
+    return v;
+}
+__global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void front_seg_fwd_kernel(const FrontFwdArgs f, const PackArgs pa, int nseg_x, int nseg_y, int pack_bx, int rows_pb, int trows, int cap,
+                          int e_stored, const int* __restrict__ rowptr, const int* __restrict__ nbr, const int* __restrict__ eid,
+                          const float* __restrict__ ea, float* __restrict__ S, int ld) {
+    extern __shared__ __attribute__((aligned(16))) float sg_smem[];
+    const int tid = threadIdx.x;
+    // riders of the forward pass's first launch (front.hip front_pack_kernel): dropout stream, workspace stamp, slot-ordered attributes
+    if (pa.rng_advance && blockIdx.x == 0 && tid == 0) pa.rng_advance[1] += 1;
+    if (pa.stamp && blockIdx.x == 0 && tid == 0) *pa.stamp = pa.stamp_value;
+    slot_ea_body(pa.slot_ea, (int64_t)blockIdx.x * blockDim.x + tid, (int64_t)gridDim.x * blockDim.x);
+    // the weight re-layout jobs: ONE workgroup per job, FIRST in the grid (every workgroup of this launch holds half a CU's LDS:
+    // behind the graph blocks the jobs would start when those retire; dealt to the graph blocks they cost every block a loop
+    // over all jobs, +10 us)
+    // pack_bx > 0: the jobs have workgroups of their own, FIRST in the grid (few graph blocks: a small batch); pack_bx < 0: every
+    // job is dealt to -pack_bx consecutive GRAPH blocks, which run their share after their walk (a few elements per thread) --
+    // every workgroup of this launch holds half a CU's LDS, so job workgroups push a 512-block grid past one round of the chip,
+    // and one workgroup per job is 36 dependent gather -> store trips (31 us)
+    const int npack = pack_bx > 0 ? pack_bx * pa.njobs : 0;
+    if ((int)blockIdx.x < npack) {
+        const int job = (int)blockIdx.x / pack_bx;
+        pack_job_body(pa.job[job], (int)blockIdx.x - job * pack_bx, pack_bx);
+        return;
+    }
+    const int sb = (int)blockIdx.x - npack;
+    const int bx = sb % nseg_x, by = sb / nseg_x;
+    const SegLds l = seg_lds(sg_smem, trows, rows_pb, cap, false);
+    const int n = f.n, h = f.h, ldw1 = f.ldw1;
+    const int r0 = bx * rows_pb, rows = min(rows_pb, n - r0);
+    const SegCols sc = seg_cols(ld, by);
+    const int nchunk = ld >> 2;
+    const float4 bb4 = make_float4(f.bb[0], f.bb[1], f.bb[2], f.bb[3]);
+    // LDS behind the tiles / CSR slice: x0 and mask rows of the block, and the front weights of this block's (<= 9) chunks
+    float4* s_x0 = reinterpret_cast<float4*>(l.B0);              // [rows_pb]   (B0 / B1: the weight-image room, unused here)
+    float4* s_m = s_x0 + rows_pb;                                // [rows_pb]
+    float* s_w = reinterpret_cast<float*>(s_m + rows_pb);        // [9 chunks][4 units][14]: wa[4] | ba | w1[8] | b1
+    // ---- adjacency slice (by destination) and its edge attributes, through the edge ids
+    SegCsr cin = l.in;
+    cin.e0 = rowptr[r0];
+    cin.ne = rowptr[r0 + rows] - cin.e0;
+    cin.in_lds = cin.ne <= cap;
+    const int rpv = tid <= rows ? rowptr[r0 + tid] : 0;
+    const float wev = we_issue(sc, f.w1, h, 4);
+    int nbv = 0, idv = 0;
+    if (cin.in_lds && tid < cin.ne) {
+        nbv = nbr[cin.e0 + tid];
+        idv = eid[cin.e0 + tid];
+    }
+    // front weights of the block's chunks: value t = (local chunk lc, unit i, slot k)
+    float fwv = 0.f;
+    if (tid < sc.cw * 56) {
+        const int lc = tid / 56, r = tid - lc * 56, i = r / 14, k = r - i * 14;
+        const int u = seg_gcol(sc, lc) + i;
+        if (u < h) fwv = k < 4 ? f.wa[(size_t)u * 4 + k] : k == 4 ? f.ba[u] : k < 13 ? f.w1[(size_t)u * ldw1 + (k - 5)] : f.b1[u];
+    }
+    float2 eav = make_float2(0.f, 0.f);
+    if (cin.in_lds && tid < cin.ne) eav = *reinterpret_cast<const float2*>(ea + (size_t)(idv >= e_stored ? idv - e_stored : idv) * 2);
+    if (tid <= rows) cin.rp[tid] = rpv - cin.e0;
+    if (cin.in_lds && tid < cin.ne) {
+        cin.nb[tid] = nbv - r0;
+        cin.ea[tid] = eav;
+    }
+    we_commit(l.we, wev);
+    if (tid < sc.cw * 56) s_w[tid] = fwv;
+    // mask_embd's weights as one 48-byte record per hidden unit: wa[4] | ba, wb[0..2] | wb[3], 0, 0, 0  (three 16-byte LDS reads
+    // per unit; as scalar loads inside the per-row loop every unit waited ~300 cycles for its own loads: 40 us)
+    float4* s_me = reinterpret_cast<float4*>(s_w + 9 * 56);      // [h][3]
+    if (tid < h) {
+        const float4 a4 = sg_ld4(f.wa + (size_t)tid * 4);
+        const float b0 = f.ba[tid], w0_ = f.wb[tid], w1_ = f.wb[h + tid], w2_ = f.wb[2 * h + tid], w3_ = f.wb[3 * h + tid];
+        s_me[3 * tid] = a4;
+        s_me[3 * tid + 1] = make_float4(b0, w0_, w1_, w2_);
+        s_me[3 * tid + 2] = make_float4(w3_, 0.f, 0.f, 0.f);
+    }
+    seg_lds_barrier();
+    // ---- x0 = x + bb + Wb relu(Wa mask + ba): FOUR THREADS PER ROW.  The chunk sums a[c] (four hidden units each, an fma chain
+    // from zero) are added in the order of the row-per-wave kernel's xor butterfly (front.hip wave_sum4, lane 0's tree:
+    // s[c] = a[c] + a[c + 32]; t = s[c] + s[c + 16]; u = t[c] + t[c + 8]; v = u[c] + u[c + 4]; w = v[c] + v[c + 2]; w[0] + w[1]), so
+    // x0 carries the bits that kernel stores: thread p of a row forms v[p], two quad shuffles finish the tree.  (As a butterfly
+    // per row in every one of a graph's four blocks the LDS crossbar was the whole kernel: 24 ds_bpermute per row.)
+    {
+        const int lr = tid >> 2, pq = tid & 3;
+        const bool on = lr < rows;
+        const int row = r0 + min(lr, rows - 1);
+        float4 m;
+        if (f.mask_dtype == 0) {
+            const int64_t* mp = static_cast<const int64_t*>(f.mask) + (size_t)row * 4;
+            m = make_float4((float)mp[0], (float)mp[1], (float)mp[2], (float)mp[3]);
+        } else {
+            m = sg_ld4(static_cast<const float*>(f.mask) + (size_t)row * 4);
+        }
+        const float4 xi = sg_ld4(f.x + (size_t)row * 4);
+        auto chunk_sum = [&](int c) -> float4 {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < nchunk) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int u = 4 * c + i;
+                    if (u < h) {
+                        const float4 ra = s_me[3 * u], rb = s_me[3 * u + 1], rc = s_me[3 * u + 2];
+                        float v = rb.x;
+                        v = fmaf(ra.x, m.x, v); v = fmaf(ra.y, m.y, v); v = fmaf(ra.z, m.z, v); v = fmaf(ra.w, m.w, v);
+                        v = fmaxf(v, 0.f);
+                        acc.x = fmaf(rb.y, v, acc.x); acc.y = fmaf(rb.z, v, acc.y);
+                        acc.z = fmaf(rb.w, v, acc.z); acc.w = fmaf(rc.x, v, acc.w);
+                    }
+                }
+            }
+            return acc;
+        };
+        float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), vp = u0;
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), tt = t0;
+#pragma unroll
+            for (int c3 = 0; c3 < 2; ++c3) {
+                const int c = pq + 4 * c2 + 8 * c3;
+                const float4 sa = sg_add4(chunk_sum(c), chunk_sum(c + 32)), sb = sg_add4(chunk_sum(c + 16), chunk_sum(c + 48));
+                const float4 t = sg_add4(sa, sb);
+                if (c3 == 0) t0 = t; else tt = sg_add4(t0, t);
+            }
+            if (c2 == 0) u0 = tt; else vp = sg_add4(u0, tt);
+        }
+        // w[p & 1] = v[p & 1] + v[(p & 1) + 2] (partner: lane ^ 2), then w[0] + w[1] (partner: lane ^ 1): lower index first
+        float4 vo;
+        vo.x = __shfl_xor(vp.x, 2); vo.y = __shfl_xor(vp.y, 2); vo.z = __shfl_xor(vp.z, 2); vo.w = __shfl_xor(vp.w, 2);
+        const float4 wp = (pq & 2) ? sg_add4(vo, vp) : sg_add4(vp, vo);
+        float4 wo;
+        wo.x = __shfl_xor(wp.x, 1); wo.y = __shfl_xor(wp.y, 1); wo.z = __shfl_xor(wp.z, 1); wo.w = __shfl_xor(wp.w, 1);
+        const float4 s4 = (pq & 1) ? sg_add4(wo, wp) : sg_add4(wp, wo);
+        const float4 o = make_float4(xi.x + (s4.x + bb4.x), xi.y + (s4.y + bb4.y), xi.z + (s4.z + bb4.z), xi.w + (s4.w + bb4.w));
+        if (on && pq == 0) {
+            s_x0[lr] = o;
+            s_m[lr] = m;
+            if (by == 0) {   // (one of the graph's blocks stores the 4-wide tensors)
+                sg_st4_wt(f.maskf + (size_t)row * 4, m);
+                sg_st4_wt(f.x0 + (size_t)row * 4, o);
+            }
+        }
+    }
+    seg_lds_barrier();
+    // ---- me_h, P | Q of the block's chunks: item = (row, chunk), the row-per-wave kernel's fma chains
+    for (int it = tid; it < rows * sc.cw; it += SG_THREADS) {
+        const int lr = it / sc.cw, lc = it - lr * sc.cw;
+        const int tcw = seg_tcol(sc, lc), gc = seg_gcol(sc, lc), row = r0 + lr;
+        const float4 m = s_m[lr], o = s_x0[lr];
+        const float* wv = s_w + lc * 56;
+        float hv[4], pv[4], qv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* w14 = wv + i * 14;
+            float v = w14[4];
+            v = fmaf(w14[0], m.x, v); v = fmaf(w14[1], m.y, v); v = fmaf(w14[2], m.z, v); v = fmaf(w14[3], m.w, v);
+            hv[i] = fmaxf(v, 0.f);
+            float pa_ = w14[13];
+            pa_ = fmaf(w14[5], o.x, pa_); pa_ = fmaf(w14[6], o.y, pa_); pa_ = fmaf(w14[7], o.z, pa_); pa_ = fmaf(w14[8], o.w, pa_);
+            float qb = 0.f;
+            qb = fmaf(w14[9], o.x, qb); qb = fmaf(w14[10], o.y, qb); qb = fmaf(w14[11], o.z, qb); qb = fmaf(w14[12], o.w, qb);
+            pv[i] = pa_;
+            qv[i] = qb;
+        }
+        if (f.me_h) sg_st4_wt(f.me_h + (size_t)row * ld + gc, make_float4(hv[0], hv[1], hv[2], hv[3]));
+        const float4 p4 = make_float4(pv[0], pv[1], pv[2], pv[3]), q4 = make_float4(qv[0], qv[1], qv[2], qv[3]);
+        sg_st4(l.P + (size_t)lr * SG_TW + tcw, p4);
+        sg_st4(l.Q + (size_t)lr * SG_TW + tcw, q4);
+        sg_st4_wt(f.P + (size_t)row * ld + gc, p4);
+        sg_st4_wt(f.Q + (size_t)row * ld + gc, q4);
+    }
+    seg_lds_barrier();
+    // ---- the walk (ea_seg_fwd_kernel's: four slots per trip, edge-id order)
+    for (int it = tid; it < rows * sc.cw; it += SG_THREADS) {
+        const int lr = it / sc.cw, lc = it - lr * sc.cw;
+        const int tcw = seg_tcol(sc, lc), gc = seg_gcol(sc, lc);
+        const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tcw);
+        const float4 w0 = sg_ld4(l.we + tcw), w1 = sg_ld4(l.we + SG_TW + tcw);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int beg = cin.rp[lr], end = cin.rp[lr + 1];
+        if (cin.in_lds) {
+            const int last = end - 1;
+            for (int p = beg; p < end; p += 4) {
+                int s_[4];
+                float2 a_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int q = min(p + u, last);
+                    s_[u] = cin.nb[q];
+                    a_[u] = cin.ea[q];
+                }
+                float4 q_[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) q_[u] = sg_ld4(l.Q + (size_t)s_[u] * SG_TW + tcw);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float4 v = sg_add4(p4, q_[u]);
+                    v = sg_fma4(a_[u].x, w0, v);
+                    v = sg_fma4(a_[u].y, w1, v);
+                    const float4 r = sg_add4(acc, sg_relu4(v));
+                    const bool k = p + u < end;
+                    acc.x = k ? r.x : acc.x;
+                    acc.y = k ? r.y : acc.y;
+                    acc.z = k ? r.z : acc.z;
+                    acc.w = k ? r.w : acc.w;
+                }
+            }
+        } else {
+            for (int p = beg; p < end; ++p) {
+                const int ls = nbr[cin.e0 + p] - r0;
+                int id = eid[cin.e0 + p];
+                id = id >= e_stored ? id - e_stored : id;
+                const float2 a2 = *reinterpret_cast<const float2*>(ea + (size_t)id * 2);
+                float4 v = sg_add4(p4, sg_ld4(l.Q + (size_t)ls * SG_TW + tcw));
+                v = sg_fma4(a2.x, w0, v);
+                v = sg_fma4(a2.y, w1, v);
+                acc = sg_add4(acc, sg_relu4(v));
+            }
+        }
+        sg_st4_wt(S + (size_t)(r0 + lr) * ld + gc, acc);
+    }
+    if (pack_bx < 0) {
+        const int per = -pack_bx, job = sb / per;
+        if (job < pa.njobs) pack_job_body(pa.job[job], sb - job * per, per);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ backward
 // One row's two backward walks for one column chunk:
 //   by destination: dP[i] = sum_{e -> i} dh_e, dWe[f] += a_e[f] dh_e ;  by source: dQ[j] = sum_{e: src(e) = j} dh_e
@@ -697,6 +944,53 @@ bool ea_seg_fit(int seg, int n, int fe, int ld, bool bwd) {
 int ea_seg_blocks(int seg, int n, int ld) {
     SegPlan p;
     return seg_plan(seg, n, ld, p) ? p.nblocks : 0;
+}
+
+// the front + first edge stage in one launch (front_seg_fwd_kernel): latency regime, nfeature_dim 4, Fe = 2
+bool front_seg_fit(int seg, int n, int h, int fe) {
+    static const bool off = diag_env("PFN_NO_SEG_FRONT") != nullptr;   // A/B switch: front.hip's launch + the generic edge walk
+    const int ld = ld_of(h);
+    return !off && ld / 4 <= 64 && front_latency_regime(h, n) && ea_seg_fit(seg, n, fe, ld, false);
+}
+int launch_front_seg_fwd(const GraphView& g, const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance,
+                         const SlotEa* slot_ea, int* stamp, int stamp_value, const float* ea, float* S, int seg, hipStream_t s) {
+    const int ld = ld_of(f.h);
+    SegPlan p;
+    if (!seg_plan(seg, g.n, ld, p, false)) {
+        set_error("front_seg_fwd: %d-row graphs do not fit", seg);
+        return PFN_EINVAL;
+    }
+    if (f.mask_dtype != 0 && f.mask_dtype != 1) {
+        set_error("pred_mask dtype code %d unsupported (0: int64, 1: float32)", f.mask_dtype);
+        return PFN_EINVAL;
+    }
+    PackArgs pa;
+    if (slot_ea) pa.slot_ea = *slot_ea;
+    pa.njobs = std::min(njobs, PACK_MAX_JOBS);
+    pa.rng_advance = rng_advance;
+    pa.stamp = stamp;
+    pa.stamp_value = stamp_value;
+    pa.mask = nullptr;
+    pa.maskf = nullptr;
+    pa.mask_count = 0;
+    pa.mask_dtype = 0;
+    long biggest = 0;
+    for (int j = 0; j < pa.njobs; ++j) {
+        pa.job[j] = jobs[j];
+        biggest = std::max<long>(biggest, (long)packed_floats(jobs[j].K, jobs[j].ld_out));
+    }
+    (void)biggest;
+    const int nseg = p.nblocks * p.ny;
+    const int pack_bx = pa.njobs == 0 ? 0 : nseg >= 4 * pa.njobs ? -(nseg / pa.njobs) : 8;
+    static std::atomic<uint64_t> raised{0};
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(front_seg_fwd_kernel), SG_LDS_BYTES, raised));
+    ProfScope ps("front_seg_fwd+pack", 0.0, 0.0, s);
+    const int nblocks = nseg + (pack_bx > 0 ? pack_bx * pa.njobs : 0);
+    front_seg_fwd_kernel<<<nblocks, SG_THREADS, seg_lds_bytes(p.trows, p.rows_pb, p.cap, false), s>>>(
+        f, pa, p.nblocks, p.ny, pack_bx, p.rows_pb, p.trows, p.cap, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, ea, S, ld);
+    PFN_CHECK_LAUNCH();
+    if (njobs > pa.njobs) return launch_pack(jobs + pa.njobs, njobs - pa.njobs, nullptr, s);   // (deep networks: > 64 weights)
+    return PFN_OK;
 }
 
 int launch_ea_seg_fwd(const GraphView& g, const EaSegFwdArgs& a, int seg, hipStream_t s) {

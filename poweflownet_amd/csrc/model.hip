@@ -116,7 +116,8 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
                       const float* w1, const float* b1, const float* w2, const float* b2, const EaPack& pw, float* out, int ldo,
                       const Act& act, const EaSaved& sv, hipStream_t s, bool pq_ready = false, int seg = 0,
                       const float* ea_in = nullptr, unsigned* relu_mask = nullptr, bool pq_fly = false, float* hop_xk = nullptr,
-                      int hop_K = 0) {
+                      int hop_K = 0, bool walk_done = false) {
+    // walk_done: layer 0 behind front_seg_fwd_kernel -- P, Q AND S are already written (ea_seg.hip)
     // hop_xk / hop_K: the TAGConv behind this layer takes its K hops from here (seg_lin_hops.hip: the S W2^T Linear and the hops
     // in one launch; the caller has asked seg_lin_hops_fit)
     const int ld = ld_of(h);
@@ -138,8 +139,8 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
         PFN_TRY(launch_gemm_nt(a, s));
     }
     // the network's last layer (Fo <= 4, no activation): the second Linear rides in the edge walk's launch (edge_fwd_out_kernel)
-    const bool out_in_walk = !seg_walk && w2 && act.act == ACT_NONE && edge_fwd_out_ok(fe, h, fo, ldo) && back_fused_ok();
-    if (!seg_walk) {
+    const bool out_in_walk = !seg_walk && !walk_done && w2 && act.act == ACT_NONE && edge_fwd_out_ok(fe, h, fo, ldo) && back_fused_ok();
+    if (!seg_walk && !walk_done) {
         EdgeFwdArgs e{sv.P, sv.Q, ea, w1, sv.S, ld, h, fi, fe};
         e.mask = relu_mask;   // (a backward pass will follow: it reads the masks instead of recomputing the pre-activations)
         e.seg = seg;
@@ -598,6 +599,8 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     const bool fused_front = front_fused_ok(lo.f0, lo.h);
     const bool l0_fly = first_layer_fly(c, lo, seg, fused_front);
     const int ws_stamp = c.need_backward ? WS_STAMP_TRAIN : WS_STAMP_INFER;
+    // batches of small graphs: the front AND layer 0's edge stage in one graph-resident launch (ea_seg.hip front_seg_fwd_kernel)
+    const bool seg_front = fused_front && seg_ea && !l0_fly && lo.nlayers > 1 && front_seg_fit(seg, lo.n, lo.h, lo.fe);
     if (fused_front) {
         // ONE launch: the weight re-layout (which also advances the dropout stream for this forward) next to the front --
         // pred_mask.float(), mask_embd, the residual add and the first EdgeAggregation's P | Q (front.hip)
@@ -608,8 +611,12 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         f.maskf = lo.maskf; f.me_h = (c.need_backward && !front_recomputes_meh(c, lo, seg, fused_front)) ? lo.me_h : nullptr; f.x0 = lo.x0;
         f.P = l0_fly ? nullptr : lo.ea[0].P;
         f.Q = l0_fly ? nullptr : lo.ea[0].Q;
-        PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s, seg_ea ? &se : nullptr, lo.stamp,
-                                      ws_stamp));
+        if (seg_front)
+            PFN_TRY(launch_front_seg_fwd(g, f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, &se, lo.stamp, ws_stamp, edge_attr,
+                                         lo.ea[0].S, seg, s));
+        else
+            PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s, seg_ea ? &se : nullptr, lo.stamp,
+                                          ws_stamp));
     } else {
         // ... the pack launch also advances the dropout stream for this forward and converts pred_mask to float32
         PFN_TRY(pk.flush(s, drop ? rng : nullptr, pred_mask, mask_dtype, lo.maskf, (int64_t)lo.n * lo.ld0, seg_ea ? &se : nullptr, lo.stamp,
@@ -658,7 +665,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
             PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
                                params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0, seg, seg_ea ? lo.ea_in : nullptr,
                                ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr, l0_fly && i == 0,
-                               hops_fused ? lo.xk[i + 1] : nullptr, lo.K));
+                               hops_fused ? lo.xk[i + 1] : nullptr, lo.K, seg_front && i == 0));
             pi += 4;
             fcur = fo;
         } else {

@@ -171,22 +171,33 @@ __device__ inline void pack_job_body(const PackJob& jb, int bx, int nbx) {
     col_plan(jb.ld_out, remv, nq);
     const int G = k8_of(jb.K) >> 2;             // groups of four k's
     const long main_floats = (long)nq * G * 128, total = main_floats + (long)G * 16;
-    for (long i = (long)bx * blockDim.x + threadIdx.x; i < total; i += (long)nbx * blockDim.x) {
-        int k, n;
-        if (i < main_floats) {
-            const int q = (int)(i / ((long)G * 128));
-            const int r = (int)(i - (long)q * G * 128);
-            k = 4 * (r >> 7) + (r & 3);
-            n = 32 * q + ((r & 127) >> 2);
-        } else {
-            const int r = (int)(i - main_floats);
-            k = 4 * (r >> 4) + (r & 3);
-            n = 32 * nq + ((r & 15) >> 2);
+    // four elements per trip, all four (strided, transposing) loads requested before the first store: one element per trip was a
+    // chain of dependent gather -> store round trips (a workgroup with 36 trips: 30 us)
+    const long step = (long)nbx * blockDim.x;
+    for (long i0 = (long)bx * blockDim.x + threadIdx.x; i0 < total; i0 += 4 * step) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long i = i0 + u * step < total ? i0 + u * step : i0;
+            int k, n;
+            if (i < main_floats) {
+                const int q = (int)(i / ((long)G * 128));
+                const int r = (int)(i - (long)q * G * 128);
+                k = 4 * (r >> 7) + (r & 3);
+                n = 32 * q + ((r & 127) >> 2);
+            } else {
+                const int r = (int)(i - main_floats);
+                k = 4 * (r >> 4) + (r & 3);
+                n = 32 * nq + ((r & 15) >> 2);
+            }
+            const bool in = k < jb.K && n < jb.ncols;
+            const int kc = in ? k : 0, nc = in ? n : 0;
+            const float x = jb.trans ? jb.src[(size_t)(jb.wn0 + nc) * jb.ldw + jb.wk0 + kc] : jb.src[(size_t)(jb.wk0 + kc) * jb.ldw + jb.wn0 + nc];
+            v[u] = in ? x : 0.f;
         }
-        float v = 0.f;
-        if (k < jb.K && n < jb.ncols)
-            v = jb.trans ? jb.src[(size_t)(jb.wn0 + n) * jb.ldw + jb.wk0 + k] : jb.src[(size_t)(jb.wk0 + k) * jb.ldw + jb.wn0 + n];
-        jb.dst[i] = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * step < total) jb.dst[i0 + u * step] = v[u];
     }
 }
 int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s, const void* mask = nullptr,
@@ -378,6 +389,11 @@ struct EaSegBwdArgs {
     int ldgo, fo, ld, h, fi;
 };
 bool ea_seg_fit(int seg, int n, int fe, int ld, bool bwd);
+// mask_embd + residual AND the first EdgeAggregation's edge stage in one graph-resident launch (ea_seg.hip front_seg_fwd_kernel),
+// carrying the forward pass's weight re-layout jobs like launch_front_fwd_pack; writes maskf, me_h (when f.me_h), x0, P, Q, S
+bool front_seg_fit(int seg, int n, int h, int fe);
+int launch_front_seg_fwd(const GraphView& g, const struct FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance,
+                         const SlotEa* slot_ea, int* stamp, int stamp_value, const float* ea, float* S, int seg, hipStream_t s);
 int ea_seg_blocks(int seg, int n, int ld);
 int launch_ea_seg_fwd(const GraphView& g, const EaSegFwdArgs& a, int seg, hipStream_t s);
 int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStream_t s);

@@ -117,12 +117,13 @@ struct SegCols {
     int q, nq, remv, cw, col0;   // cw = float4 chunks of this block's slice
     bool rem;                    // this block owns the trailing columns
 };
-__device__ __forceinline__ SegCols seg_cols(int ld) {
+__device__ __forceinline__ SegCols seg_cols(int ld, int by = -1) {
     SegCols c;
     col_plan(ld, c.remv, c.nq);
+    if (by < 0) by = (int)blockIdx.y;
     // (reversed: the last quarter's block, which also owns the trailing columns and is the launch's critical path, is dispatched
     //  first -- the second half of a launch's workgroups reaches its first barrier ~3.6 us later than the first half, measured)
-    c.q = c.nq - 1 - (int)blockIdx.y;
+    c.q = c.nq - 1 - by;
     c.rem = c.remv > 0 && c.q == c.nq - 1;
     c.col0 = 32 * c.q;
     c.cw = min(8, (ld - c.remv - c.col0) >> 2) + (c.rem ? 1 : 0);

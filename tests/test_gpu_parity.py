@@ -889,6 +889,67 @@ torch.save(res, sys.argv[1])
             assert torch.equal(a, b), f"{case}.{key}: fused Linear + hops differs from gemm_nt + fused_hops by {(a - b).abs().max().item():.3e}"
 
 
+def test_fused_front_and_first_edge_stage_are_bit_identical_to_two_launches(tmp_path):
+    """ea_seg.hip front_seg_fwd_kernel: for batches of small graphs mask_embd + residual (networks/MPN.py:533-537) AND the first
+    EdgeAggregation's edge stage run in ONE graph-resident launch per (graph, 32-column quarter) -- front.hip's row-per-wave
+    chains and butterfly row sum for x0 / me_h / P | Q, ea_seg's walk for S -- instead of front.hip's launch + the generic edge
+    walk (PFN_NO_SEG_FRONT=1; read once per process -> child processes).  Same operands in the same order: outputs, input
+    gradient and every parameter gradient carry the same bits; int64 and float masks, train and eval mode, a last block with
+    fewer graphs (case14 x 37), dense 16-node graphs whose edges exceed the LDS adjacency slice, and a no_grad forward."""
+    import os
+    import subprocess
+    import sys
+    script = f"""
+import sys, torch
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+from poweflownet_amd.synth import make_batch, make_graph, make_topology
+from poweflownet_amd.data import Batch
+from poweflownet_amd import _lib as L
+res = {{}}
+def run(tag, m, d, float_mask=False):
+    d = d.to("cuda:0")
+    if float_mask:
+        d.pred_mask = d.pred_mask.float()
+    d.x.requires_grad_(True)
+    L.profile_report(reset=True); L.profile_enable(True)
+    out = m(d)
+    torch.nn.MSELoss()(out, d.y).backward()
+    torch.cuda.synchronize()
+    L.profile_enable(False)
+    rep = L.profile_report(reset=True)
+    res[tag + ".launches"] = {{k: v["count"] for k, v in rep.items() if not k.startswith("__")}}
+    res[tag + ".out"], res[tag + ".gx"], res[tag + ".g"] = out.detach().cpu(), d.x.grad.cpu(), m.flat_grad().cpu()
+    m.zero_grad(set_to_none=True)
+    with torch.no_grad():
+        res[tag + ".nograd"] = m(d).cpu()
+torch.manual_seed(6)
+m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.2).to("cuda:0")
+m.seed_dropout(78)
+m.train()
+run("train118", m, make_batch("118v2", 128, seed=1))
+m.eval()
+run("eval118f", m, make_batch("118v2", 16, seed=2), float_mask=True)
+run("eval14", m, make_batch("14", 37, seed=3))
+topo = make_topology(16, 100, 0)
+run("dense16", m, Batch.from_data_list([make_graph(16, 100, seed=50 + b, edge_index=topo) for b in range(21)]))
+torch.save(res, sys.argv[1])
+"""
+    res = {}
+    for tag, env in (("fused", {}), ("two", {"PFN_NO_SEG_FRONT": "1"})):
+        path = str(tmp_path / f"{tag}.pt")
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=600)
+        res[tag] = torch.load(path)
+    for case in ("train118", "eval118f", "eval14", "dense16"):
+        lf, lt = res["fused"][case + ".launches"], res["two"][case + ".launches"]
+        assert lf.get("front_seg_fwd+pack") == 1 and "front_fwd+pack" not in lf and "edge_fwd" not in lf, lf
+        assert lt.get("front_fwd+pack") == 1 and lt.get("edge_fwd") == 1 and "front_seg_fwd+pack" not in lt, lt
+        for key in ("out", "gx", "g", "nograd"):
+            a, b = res["fused"][f"{case}.{key}"], res["two"][f"{case}.{key}"]
+            assert a.abs().max() > 0 and torch.isfinite(a).all()
+            assert torch.equal(a, b), f"{case}.{key}: fused front + edge stage differs from the two launches by {(a - b).abs().max().item():.3e}"
+
+
 def test_first_layer_pq_from_x0_is_bit_identical_to_stored_pq(tmp_path):
     """Beyond the latency regime (> 32,768 rows) the first EdgeAggregation layer's P | Q rows are not written when nothing reads
     them from memory (inference; training whose backward walks read saved ReLU masks): the edge walk forms them from the 16-byte
