@@ -3,9 +3,9 @@
 # two separate PMC passes (FETCH_SIZE / WRITE_SIZE) on a short eager run.  Summaries land in gpurun_out/prof_round/.
 #   tools/profile_round.sh [tag]     (BENCH_ARGS="--case ... --batch ..." selects another workload)
 cd /tmp && export TMPDIR=/tmp
-TAG=${1:-r03_case118_b128_train}
+TAG=${1:-r04_case118_b128_train}
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_round; rm -rf /tmp/pr; mkdir -p $O /tmp/pr
-timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pr/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-live-traffic --no-dp-overhead $BENCH_ARGS > $O/${TAG}_bench_under_rocprof.json 2> /tmp/pr/trace.err
+timeout 600 rocprofv3 --kernel-trace --stats -f csv -d /tmp/pr/trace -o bench -- python $R/bench.py --no-cpu-baseline --no-live-traffic --no-dp-overhead --no-other-configs $BENCH_ARGS > $O/${TAG}_bench_under_rocprof.json 2> /tmp/pr/trace.err
 find /tmp/pr/trace -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats.csv \;
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --kernel-trace -f csv -d /tmp/pr/$c -o pmc -- python $R/bench.py --child --no-cpu-baseline --no-live-traffic --no-dp-overhead --no-graph --steps 3 --warmup 1 --profile-steps 0 $BENCH_ARGS > /tmp/pr/$c.out 2> /tmp/pr/$c.err
@@ -70,7 +70,8 @@ def read(c):
 f, w = read("FETCH_SIZE"), read("WRITE_SIZE")
 cls = {"gemm_nt": "gemm_nt_kernel", "gemm_tn": "gemm_tn_kernel", "hop_norm": "hop_kernel<true>", "edge_fwd": "edge_fwd_kernel",
        "edge_bwd": "edge_bwd_kernel", "fused_hops_fwd": "_hops_kernel", "fused_hops_bwd": "_hops_kernel",
-       "ea_seg_fwd": "ea_seg_fwd_kernel", "ea_seg_bwd": "ea_seg_bwd_kernel"}
+       "ea_seg_fwd": "ea_seg_fwd_kernel", "ea_seg_bwd": "ea_seg_bwd_kernel", "seg_lin_hops_fwd": "seg_lin_hops_kernel<1>",
+       "seg_lin_hops_bwd": "seg_lin_hops_kernel<2>", "front_seg_fwd": "front_seg_fwd_kernel"}
 case = re.search(r"--case (\S+)", bargs); batch = re.search(r"--batch (\d+)", bargs); mode = re.search(r"--mode (\S+)", bargs)
 cfg = re.search(r"--config (\S+)", bargs); hub = re.search(r"--hub-frac (\S+)", bargs)
 key = f"{case.group(1) if case else '118v2'}:{batch.group(1) if batch else 128}:{mode.group(1) if mode else 'train'}"
