@@ -140,7 +140,7 @@ def cpu_baseline(args, cfg, data_cpu, seconds):
 
 
 KERNEL_OF_CLASS = {"gemm_nt": "gemm_nt_kernel", "gemm_tn": "gemm_tn_kernel", "hop_norm": "hop_kernel<true", "edge_fwd": "edge_fwd_", "edge_rows_fwd": "edge_rows_fwd_kernel",
-                   "edge_bwd": "edge_bwd_", "fused_hops_fwd": "_hops_kernel", "fused_hops_bwd": "_hops_kernel",
+                   "edge_bwd": "edge_bwd_", "fused_hops_fwd": "_hops_kernel(", "fused_hops_bwd": "_hops_kernel(",
                    "ea_seg_fwd": "ea_seg_fwd_kernel", "ea_seg_bwd": "ea_seg_bwd_kernel",
                    "seg_lin_hops_fwd": "seg_lin_hops_kernel<1>", "seg_lin_hops_bwd": "seg_lin_hops_kernel<2>", "front_fwd": "front_fwd", "front_bwd": "front_bwd"}
 

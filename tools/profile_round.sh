@@ -69,7 +69,7 @@ def read(c):
     return d
 f, w = read("FETCH_SIZE"), read("WRITE_SIZE")
 cls = {"gemm_nt": "gemm_nt_kernel", "gemm_tn": "gemm_tn_kernel", "hop_norm": "hop_kernel<true>", "edge_fwd": "edge_fwd_kernel",
-       "edge_bwd": "edge_bwd_kernel", "fused_hops_fwd": "_hops_kernel", "fused_hops_bwd": "_hops_kernel",
+       "edge_bwd": "edge_bwd_kernel", "fused_hops_fwd": "_hops_kernel$", "fused_hops_bwd": "_hops_kernel$",
        "ea_seg_fwd": "ea_seg_fwd_kernel", "ea_seg_bwd": "ea_seg_bwd_kernel", "seg_lin_hops_fwd": "seg_lin_hops_kernel<1>",
        "seg_lin_hops_bwd": "seg_lin_hops_kernel<2>", "front_seg_fwd": "front_seg_fwd_kernel"}
 case = re.search(r"--case (\S+)", bargs); batch = re.search(r"--batch (\d+)", bargs); mode = re.search(r"--mode (\S+)", bargs)
@@ -80,12 +80,14 @@ if hub and float(hub.group(1)) > 0: key += ":hub" + hub.group(1)
 out = {"_note": "bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) KiB * 1024, averaged over all launches of the class in a 3-step "
                 "eager run; separate rocprofv3 --pmc passes.  The counters are fabric-side (L2 <-> Infinity Cache/HBM) and "
                 "include Infinity-Cache hits; at case118v2 x 128 the whole working set sits in the 256 MiB Infinity Cache."}
+def hit(pat, k):   # (names are cut at "(": a trailing $ anchors the pattern at the end -- seg_lin_hops_kernel<N> is its own class)
+    return k.endswith(pat[:-1]) if pat.endswith("$") else pat in k
 for c, pat in cls.items():
-    nf = [v for k, v in f.items() if pat in k]
+    nf = [v for k, v in f.items() if hit(pat, k)]
     if not nf: continue
     launches = sum(n for n, _ in nf)                      # all template instantiations of the class, launch-weighted
     fv = sum(t for _, t in nf) / launches
-    wv = sum(t for k, (n, t) in w.items() if pat in k) / launches
+    wv = sum(t for k, (n, t) in w.items() if hit(pat, k)) / launches
     out[f"{c}:{key}"] = int((2 * fv + wv) * 1024)
 print(json.dumps(out, indent=1))
 PY
