@@ -901,7 +901,7 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         l.part[(wave * 16 + 8) * 2] = rwe0;
         l.part[(wave * 16 + 8) * 2 + 1] = rwe1;
     }
-    __syncthreads();
+    seg_lds_barrier();   // (not __syncthreads(): the dP / dQ stores of the walks drain meanwhile)
     if (threadIdx.x < 32) {
         const int f = threadIdx.x >> 4, c2 = threadIdx.x & 15;
         if (c2 < sc.cw) {
