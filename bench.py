@@ -41,8 +41,8 @@ CONFIGS = {"standard": (129, 4, 3), "wide": (129, 6, 6), "small": (64, 2, 3), "l
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--case", default="118v2")
     ap.add_argument("--batch", type=int, default=128, help="graphs per GPU")
     ap.add_argument("--config", default="standard", choices=sorted(CONFIGS))
