@@ -327,6 +327,47 @@ __device__ unsigned long long nt_ts[4096 * 4];
 #define NT_TS2
 #define NT_TS_END
 #endif
+// tools/ubench experiment switch (never defined in the product build): per-WAVE shader-cycle accounting of the round loop
+// (s_memtime = shader cycles, tools/ubench/mfma_clock.hip) -- cycles inside nt_multiply, inside the flush (four sub-phases),
+// elsewhere; pieces, flushes; the wall clock beside it (-> the shader clock the loop ran at) -- per wave for the LAST launch
+// (pfn_debug_nt_ts2) and summed per launch class over a sample of the SIMD pairs of every launch (pfn_debug_nt_ts2_dump;
+// tools/ubench/run_gemm_nt_ts2.sh, run_gemm_nt_ts2_step.sh)
+#ifdef NT_EXP_TS2
+__device__ unsigned long long nt_ts2[4096 * 8];
+__device__ unsigned long long nt_ts2_sum[8 * 8];   // per launch class (pieces per tile): sums over the sampled waves of every launch since load
+__device__ unsigned long long nt_ts2_fp[8 * 4];    // per class: flush sub-phases
+#define NT_T2_DECL unsigned long long c_mul_ = 0, c_fl_ = 0, c_np_ = 0, c_nf_ = 0, c_beg_ = __builtin_amdgcn_s_memtime(), c_a_ = 0, c_b_ = 0, c_w0_ = wall_clock64(), c_pp_ = 0, c_fp_[4] = {0, 0, 0, 0}
+#define NT_T2_A c_a_ = __builtin_amdgcn_s_memtime()
+#define NT_T2_B do { c_b_ = __builtin_amdgcn_s_memtime(); c_mul_ += c_b_ - c_a_; ++c_np_; } while (0)
+#define NT_T2_C do { c_fl_ += __builtin_amdgcn_s_memtime() - c_b_; ++c_nf_; } while (0)
+#define NT_T2_P(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_fp_[i] += t_ - c_pp_; c_pp_ = t_; } while (0)
+#define NT_T2_P0 c_pp_ = __builtin_amdgcn_s_memtime()
+#define NT_T2_END                                                                                                        \
+    do {                                                                                                                 \
+        unsigned long long tot_ = __builtin_amdgcn_s_memtime() - c_beg_, wtot_ = wall_clock64() - c_w0_;                 \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tot_), "+s"(wtot_));   /* both clocks read BEFORE the contended atomics below */ \
+        const int w_ = (blockIdx.y * gridDim.x + blockIdx.x) * NT_WAVES + wave;                                          \
+        if (lane == 0 && w_ < 4096) {                                                                                    \
+            nt_ts2[w_ * 8] = c_mul_; nt_ts2[w_ * 8 + 1] = c_fl_; nt_ts2[w_ * 8 + 2] = c_np_; nt_ts2[w_ * 8 + 3] = c_nf_; \
+            nt_ts2[w_ * 8 + 4] = tot_;                                                                                   \
+        }                                                                                                                \
+        if (lane == 0 && (wave & 3) == 0 && (blockIdx.x & 3) == 0) {   /* a sample of the SIMD pairs: the atomics serialise */ \
+            unsigned long long* s_ = nt_ts2_sum + 8 * (a.npiece < 8 ? a.npiece : 7);                                     \
+            atomicAdd(s_, c_mul_); atomicAdd(s_ + 1, c_fl_); atomicAdd(s_ + 2, c_np_); atomicAdd(s_ + 3, c_nf_);         \
+            atomicAdd(s_ + 4, tot_); atomicAdd(s_ + 5, wtot_);                                                           \
+            atomicAdd(s_ + 6, 1ull);                                                                                     \
+            for (int i_ = 0; i_ < 4; ++i_) atomicAdd(nt_ts2_fp + 4 * (a.npiece < 8 ? a.npiece : 7) + i_, c_fp_[i_]);     \
+        }                                                                                                                \
+    } while (0)
+#else
+#define NT_T2_DECL
+#define NT_T2_P(i)
+#define NT_T2_P0
+#define NT_T2_A
+#define NT_T2_B
+#define NT_T2_C
+#define NT_T2_END
+#endif
 
 // VAR = the multiply variant of the launch (all pieces of a launch share it; chosen on the host, so that a kernel holds at most
 // TWO instantiations of the round loop -- with / without the trailing VALU column, a per-wave property; with more of them in one
@@ -412,6 +453,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     __syncthreads();   // the only barrier: from here on the waves run free
     NT_TS1;
     if (rt >= nrt || !(mfma_on || rem_on)) return;
+    NT_T2_DECL;
 
     EpiCfg ep;
     ep.ncols = a.ncols;
@@ -501,11 +543,14 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         {
             const float* S = lds + a.piece[p].lds_off;
             const int klen = a.piece[p].klen, tsel = cg * CT;
+            NT_T2_A;
             nt_multiply<CT, NR, NFAST, LS>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax,
                                            (uint32_t)a.piece[pi].kscale);
+            NT_T2_B;
         }
         if (flush_after) {
             NT_TS2;
+            NT_T2_P0;
             // ---- flush straight from registers: acc[q] of lane (r32, kh) is D[row (q&3) + 8 (q>>2) + 4 kh][col r32];
             // after the quad transpose lane (u = r32 >> 2, j = r32 & 3) holds, for register group g, row
             // rbase + j + 8 g + 4 kh and the four columns col0 .. col0 + 3
@@ -535,6 +580,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                     raux = f32x4{raux[0], raux[0], raux[0], raux[0]};
                 }
             }
+            NT_T2_P(0);   // the accumulator hazard wait + the epilogue operands
             // Every epilogue stage is ONE kernel-uniform branch around straight-line code for all 16 values of a tile (a
             // per-element `switch` cost 7 us per flush).  Columns past ncols need no masking: packed weights, bias and
             // rowbias are zero there and the pad columns of resid / gate are zero by the layout invariant, so every stage
@@ -615,6 +661,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                                 for (int e = 0; e < 4; ++e) v[g][e] = aux[ct][g][e] > 0.f ? v[g][e] * ep.gate_scale : 0.f;
                         }
                     }
+                    NT_T2_P(1);   // transposes + epilogue arithmetic
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #ifndef PFN_EXP_NOSTORE   /* experiment switch */
@@ -622,6 +669,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #else
                         if (row_of(g) < 0) vstore_x4<(CT < 2)>(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
 #endif
+                    NT_T2_P(2);   // store issue
                 }
             }
             if (rem_on) {
@@ -665,6 +713,8 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
             racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
+            NT_T2_P(3);   // trailing column + clearing the accumulators
+            NT_T2_C;
         }
         if (!more) break;
         p = np;
@@ -687,6 +737,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         rounds(I0{}, I4{}, I4{});
     }
     NT_TS_END;
+    NT_T2_END;
     // CT == 2 exists only for the straight-line variants (the launcher never pairs it with the generic one: two tiles plus
     // four trailing columns plus per-chunk guards do not fit the register file without spills)
 }
@@ -1322,6 +1373,28 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
 
 }  // namespace pfn
 
+#ifdef NT_EXP_TS2
+extern "C" int pfn_debug_nt_ts2(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::nt_ts2), (size_t)n * sizeof(unsigned long long));
+}
+extern "C" int pfn_debug_nt_ts2_dump() {   // per launch class, over the sampled waves of every launch so far
+    unsigned long long h[64], fp[32];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(pfn::nt_ts2_sum), sizeof(h)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(fp, HIP_SYMBOL(pfn::nt_ts2_fp), sizeof(fp)) != hipSuccess) return -1;
+    for (int c = 0; c < 8; ++c) {
+        const unsigned long long* s = h + 8 * c;
+        if (s[6] == 0) continue;
+        const double np = (double)s[2], nf = (double)s[3], nw = (double)s[6];
+        printf("    flush of class %d: hazard wait + operands %.0f | transposes + epilogue %.0f | store issue %.0f | trailing column + clear %.0f cycles\n", c,
+               fp[4 * c] / nf, fp[4 * c + 1] / nf, fp[4 * c + 2] / nf, fp[4 * c + 3] / nf);
+        printf("gemm_nt class %d pieces/tile: %.0f waves | per piece: multiply %.0f cycles, elsewhere %.0f | per flush %.0f | loop cycles per wave %.0f | "
+               "shader clock over the loop %.3f GHz | matrix-pipe cycles needed per piece and SIMD-pair / spent = %.3f\n", c, nw, s[0] / np,
+               ((double)s[4] - s[0] - s[1]) / np, s[1] / nf, s[4] / nw, (double)s[4] / ((double)s[5] * 10.0),
+               (np * 65 * 2 * 64 * 2) / (double)s[4]);
+    }
+    return 0;
+}
+#endif
 #ifdef NT_EXP_TS
 extern "C" int pfn_debug_nt_ts(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::nt_ts), (size_t)n * sizeof(unsigned long long));

@@ -6,11 +6,17 @@
 #include <math.h>
 #include <stdlib.h>
 #include <vector>
+#include <algorithm>
+#include <utility>
 #include "../../poweflownet_amd/csrc/pfn_internal.hpp"
 using namespace pfn;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 #ifdef NT_EXP_TS
 extern "C" int pfn_debug_nt_ts(unsigned long long*, int);
+#endif
+#ifdef NT_EXP_TS2
+extern "C" int pfn_debug_nt_ts2(unsigned long long*, int);
+extern "C" int pfn_debug_nt_ts2_dump();
 #endif
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 15104, K = argc > 2 ? atoi(argv[2]) : 129, N = argc > 3 ? atoi(argv[3]) : 129;
@@ -73,6 +79,39 @@ int main(int argc, char** argv) {
         }
         printf("    %d workgroups: start mean %.2f max %.2f | to first barrier %.2f | multiply %.2f | flush %.2f | last end %.2f us\n", cnt,
                s0 / cnt, m0, s1 / cnt, s2 / cnt, s3 / cnt, m3);
+    }
+#endif
+#ifdef NT_EXP_TS2   /* built against a -DNT_EXP_TS2 library (tools/ubench/run_gemm_nt_ts2.sh): per-wave cycle accounting of the LAST launch */
+    {
+        static unsigned long long ts[4096 * 8];
+        CK(hipDeviceSynchronize());
+        pfn_debug_nt_ts2(ts, 4096 * 8);
+        double mul = 0, fl = 0, np = 0, nf = 0, tot = 0, totmax = 0; int cnt = 0;
+        for (int w = 0; w < 4096; ++w) {
+            if (ts[w * 8 + 4] == 0) continue;
+            mul += ts[w * 8]; fl += ts[w * 8 + 1]; np += ts[w * 8 + 2]; nf += ts[w * 8 + 3]; tot += ts[w * 8 + 4];
+            if ((double)ts[w * 8 + 4] > totmax) totmax = (double)ts[w * 8 + 4]; ++cnt;
+        }
+        printf("    %d waves: %.1f pieces, %.1f flushes per wave | cycles per piece in multiply %.0f | per flush %.0f | loop total mean %.0f max %.0f | elsewhere per piece %.0f\n",
+               cnt, np / cnt, nf / cnt, mul / np, fl / nf, tot / cnt, totmax, (tot - mul - fl) / np);
+        pfn_debug_nt_ts2_dump();
+        // where do the slow waves sit?  wave w of block b (grid x = blocks per slice): by XCD (b mod 8), by wave slot, by tile count
+        double xs[8] = {0}, xn[8] = {0}, ws[8] = {0}, wn[8] = {0}, ps[64] = {0}, pn[64] = {0}, cyc_pp[8] = {0};
+        for (int w = 0; w < 4096; ++w) {
+            if (ts[w * 8 + 4] == 0) continue;
+            const int b = w / 8, x = b % 8, wi = w % 8; const double t = (double)ts[w * 8 + 4]; const int npc = (int)ts[w * 8 + 2];
+            xs[x] += t; xn[x] += 1; ws[wi] += t; wn[wi] += 1; if (npc < 64) { ps[npc] += t; pn[npc] += 1; } cyc_pp[x] += t / (npc > 0 ? npc : 1);
+        }
+        printf("    loop cycles by XCD (block mod 8):"); for (int x = 0; x < 8; ++x) printf(" %.0f", xn[x] ? xs[x] / xn[x] : 0.0); printf("\n");
+        printf("    loop cycles per piece by XCD    :"); for (int x = 0; x < 8; ++x) printf(" %.0f", xn[x] ? cyc_pp[x] / xn[x] : 0.0); printf("\n");
+        printf("    loop cycles by wave slot        :"); for (int x = 0; x < 8; ++x) printf(" %.0f", wn[x] ? ws[x] / wn[x] : 0.0); printf("\n");
+        printf("    loop cycles by pieces per wave  :"); for (int x = 0; x < 64; ++x) if (pn[x]) printf(" [%d: %.0f waves, %.0f]", x, pn[x], ps[x] / pn[x]); printf("\n");
+        // the ten slowest waves
+        std::vector<std::pair<double, int>> v; for (int w = 0; w < 4096; ++w) if (ts[w * 8 + 4]) v.push_back({(double)ts[w * 8 + 4], w});
+        std::sort(v.begin(), v.end());
+        printf("    slowest:"); for (int i = 0; i < 10 && i < (int)v.size(); ++i) { auto& e = v[v.size() - 1 - i]; printf(" (b%d w%d %.0f)", e.second / 8, e.second % 8, e.first); } printf("\n");
+        printf("    fastest:"); for (int i = 0; i < 6 && i < (int)v.size(); ++i) { auto& e = v[i]; printf(" (b%d w%d %.0f)", e.second / 8, e.second % 8, e.first); } printf("\n");
+        printf("    percentiles of the loop total: p10 %.0f p50 %.0f p90 %.0f p99 %.0f max %.0f\n", v[v.size() / 10].first, v[v.size() / 2].first, v[v.size() * 9 / 10].first, v[v.size() * 99 / 100].first, v.back().first);
     }
 #endif
     return 0;
