@@ -38,7 +38,11 @@ namespace pfn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NT_THREADS = 512;
+#ifndef PFN_EXP_NT_THREADS   /* tools/ubench experiment switch (run_gemm_nt_waves.sh): 768 = three waves per SIMD; the stationary kernel only
+                                (the streaming kernel's DMA deal assumes 8 waves) */
+#define PFN_EXP_NT_THREADS 512
+#endif
+constexpr int NT_THREADS = PFN_EXP_NT_THREADS;
 constexpr int NT_WAVES = NT_THREADS / 64;
 constexpr int NCH = 17;                         // eight-wide k chunks per piece
 constexpr int KP = 8 * NCH;                     // 136 k's per piece: H = 129 is ONE piece
@@ -199,6 +203,17 @@ __device__ __forceinline__ float vload_x1_addr(const float* p) {
     asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
     return r;
 }
+__device__ __forceinline__ float vload_x1_sv(const char* sbase, uint32_t voff) {
+    float r;
+    asm volatile("global_load_dword %0, %1, %2" : "=v"(r) : "v"(voff), "s"(sbase) : "memory");
+    return r;
+}
+// wave-uniform 64-bit base (SGPRs) + 32-bit per-lane byte offset: the address costs the VECTOR unit nothing (see vstore_x4 for WT and the s_nop)
+template <bool WT = false>
+__device__ __forceinline__ void vstore_x4_sv(const char* sbase, uint32_t voff, f32x4 v) {
+    if (WT) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+    else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
+}
 template <bool WT = false>
 __device__ __forceinline__ void vstore_x4(float* p, f32x4 v) {
     // the s_nop is the ISA's "VMEM store wider than 64 bits -> VALU overwrites its data registers" hazard (2 wait states),
@@ -231,7 +246,7 @@ __device__ __forceinline__ void wait_a(f32x4& v) {   // the fragment chunk about
 // than strictly needed, never for the stores).
 //   XW   : vector-memory ops the wave issues between the end of one piece's refills and the first chunk of the next (the
 //          streaming kernel's 9 weight DMAs): they are younger than every pending fragment chunk, so every wait count grows by XW.
-template <int CT, int NR, int NFAST, int LS, int XW = 0>
+template <int CT, int NR, int NFAST, int LS, int XW = 0, bool DIET = true>
 __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], float (&racc)[4], f32x4 (&a_cur)[NCH],
                                             const float* S, int klen, int tps, int tsel, uint32_t kh4, int r32,
                                             const char* nbase, uint32_t nvoff, int nkmax, uint32_t nkscale) {
@@ -242,6 +257,7 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
     const float* Rt = S + tps * tile_floats + kh4 * 4;
     // B operands are software-pipelined ONE chunk ahead by hand, and a scheduling barrier closes every chunk: left to
     // itself the scheduler hoists the LDS reads of all 17 chunks to the top and spills.
+    const uint32_t vlane0 = nvoff + nkscale * kh4;   // the lane's byte offset of chunk 0 of the NEXT piece's fragment (see the refills)
     f32x4 b_nxt[CTE], r_nxt[NRE];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) b_nxt[ct] = *reinterpret_cast<const f32x4*>(Bt + ct * tile_floats);
@@ -293,11 +309,23 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
         if ((m & 3) == 3 || m == NCH - 1) {
 #pragma unroll
             for (int mm = m & ~3; mm <= m; ++mm) {
-                const uint32_t kk = min(kh4 + 8u * mm, (uint32_t)nkmax);
 #ifndef PFN_EXP_NOREFILL   /* experiment switch: every refill re-reads ONE cache line (the wave's first row) */
-                vload_x4(a_cur[mm], nbase, nvoff + nkscale * kk);
+                // VALU diet (round 4: an fp32 MFMA stream and the VALU do not overlap on a SIMD -- every vector instruction between
+                // MFMAs is matrix-pipe time, profiles/r04_gemm_nt_cycle_accounting.txt): when only the LAST chunk of a piece can
+                // reach past the operand's row (DIET: the launcher / caller guarantees it -- true for K <= 136; NOT for the last
+                // piece of a piece-padded wide image, whose real k's end several chunks early), every other chunk takes the lane's
+                // chunk-0 offset (one multiply-add per piece) and its distance from chunk 0 goes into the wave-uniform BASE (scalar
+                // unit) -- was a min, a multiply and an add per refill: 51 vector instructions per piece and wave.  (Decided per
+                // chunk at run time instead -- a uniform test of nkmax -- both forms of every refill exist and the fragment's
+                // registers get copies: 90-140 spills.)
+                if (FAST && DIET && mm < NFAST - 1) {
+                    vload_x4(a_cur[mm], nbase + (size_t)mm * 8u * nkscale, vlane0);
+                } else {
+                    const uint32_t kk = min(kh4 + 8u * mm, (uint32_t)nkmax);
+                    vload_x4(a_cur[mm], nbase, nvoff + nkscale * kk);
+                }
 #else
-                vload_x4(a_cur[mm], nbase, 0u * (nvoff + kk));
+                vload_x4(a_cur[mm], nbase, 0u * (nvoff + min(kh4 + 8u * mm, (uint32_t)nkmax)));
 #endif
             }
         }
@@ -433,7 +461,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                 if (q < a.nq) {
                     const char* src = reinterpret_cast<const char*>(a.piece[p].Bq + (size_t)q * a.piece[p].qstride) + lane * 16;
                     float* dst = lds + a.piece[p].lds_off + j * klen * 32;
-                    for (int c = (wave - dealt) & 7; c < kib; c += NT_WAVES) dma_1k(src + (c << 10), dst + (c << 8));
+                    for (int c = ((wave - dealt) % NT_WAVES + NT_WAVES) % NT_WAVES; c < kib; c += NT_WAVES) dma_1k(src + (c << 10), dst + (c << 8));
                     dealt += kib;
                 }
             }
@@ -449,10 +477,19 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         const float* bsrc = a.rowscale ? a.rowbias : a.bias;
         for (int i = tid; i < a.ldc; i += NT_THREADS) lds[a.bias_lds_off + i] = (bsrc && i < a.ncols) ? bsrc[i] : 0.f;
     }
+#ifdef PFN_EXP_DYN   /* tools/ubench experiment switch (run_gemm_nt_waves.sh): the waves of a block TAKE their row tiles (item i = tile i mod rw
+                        of block step i / rw) from a per-column-group counter in LDS instead of owning a fixed residue class -- measured,
+                        not kept */
+    int* wq = reinterpret_cast<int*>(lds + a.bias_lds_off + ((a.ldc + 3) & ~3));
+    if (tid < 8) wq[tid] = rw;
+#endif
     dma_wait();
     __syncthreads();   // the only barrier: from here on the waves run free
     NT_TS1;
     if (rt >= nrt || !(mfma_on || rem_on)) return;
+#ifdef PFN_EXP_HALF   /* tools/ubench experiment switch (wrong results: half the tiles are skipped): ONE wave per SIMD -- what a lone stream and an un-starved flush cost */
+    if (wave >= NT_WAVES / 2) return;
+#endif
     NT_T2_DECL;
 
     EpiCfg ep;
@@ -492,7 +529,14 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         int np = p + 1, nrt_ = rt;
         if (np == a.npiece) {
             np = 0;
+#ifdef PFN_EXP_DYN
+            int item = 0;
+            if (lane == 0) item = atomicAdd(&wq[cg], 1);
+            item = __builtin_amdgcn_readfirstlane(item);
+            nrt_ = blockIdx.x * rw + (item % rw) + (item / rw) * rt_step;
+#else
             nrt_ = rt + rt_step;
+#endif
         }
         const bool more = nrt_ < nrt;
         const int group = a.piece[p].group;
@@ -504,6 +548,27 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         // ---- per-row epilogue operands of the flush that follows this piece: requested NOW (hidden loads), so they are
         // older than the 17 refills issued inside the multiply; the flush waits for them with vmcnt(17)
         const int rbase = rt * 32;
+        // Addresses of the flush (these loads and the stores): lane (u = r32 >> 2, j = r32 & 3, kh) holds, after the quad transpose,
+        // row rbase + j + 4 kh + 8 g and the four columns 32 q + 4 u .. of quarter q for register group g -- the lane's part of the
+        // address does not depend on the tile, the group or the quarter, so it is ONE 32-bit offset per tensor and everything else
+        // goes into a wave-uniform base (scalar unit).  Was: a 64-bit row x stride product, a clamp and an add per load / store on
+        // the vector unit -- which an fp32 MFMA stream does not overlap with (profiles/r04_gemm_nt_cycle_accounting.txt).  Rows
+        // past M (the last tile) and columns past the row (a partial last quarter) are masked out instead of clamped.
+        const int jrow = (r32 & 3) + 4 * kh, uc4 = r32 & ~3;
+        const bool tile_full = rbase + 32 <= a.M;
+        auto rowok = [&](int g) { return rbase + jrow + 8 * g < a.M; };
+        auto colok = [&](int q) { return 32 * q + uc4 < a.ldc; };
+        auto qfull = [&](int q) { return 32 * q + 32 <= a.ldc; };
+        // float offset of (row rbase + 8 g, column 32 q) of a tensor with row stride ld / chunk-major with cm rows per plane
+        auto ubase = [&](int q, int g, int ld, int cm) -> size_t {
+            return cm > 0 ? ((size_t)8 * q * cm + rbase + 8 * g) * 4 : (size_t)(rbase + 8 * g) * ld + 32 * q;
+        };
+        auto lane_off = [&](int ld, int cm) -> uint32_t {   // bytes
+            return cm > 0 ? ((uint32_t)(uc4 >> 2) * (uint32_t)cm + jrow) * 16u : ((uint32_t)jrow * (uint32_t)ld + uc4) * 4u;
+        };
+        // (cleared as whole vectors of independent components, every round: defined by an empty asm instead -- no instruction -- the
+        //  component-wise loads below no longer coalesce into them and the copy into place runs before the hidden load has landed;
+        //  cleared only under has_aux, one register of the CT = 2 kernels spills)
         f32x4 aux[CTE][4], raux;
 #pragma unroll
         for (int ct = 0; ct < CTE; ++ct)
@@ -513,30 +578,28 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         const bool has_aux = flush_after && (a.rowscale || extra);
         if (has_aux) {
             if (a.rowscale) {
+                // (one dword per row, loaded straight into its component of `aux` -- unconditionally, from a clamped row: a masked load
+                //  would go through a temporary, and the copy out of it would run before the hidden load has landed)
+                const char* rb = reinterpret_cast<const char*>(a.rowscale + rbase);
+                const int rlast = a.M - 1 - rbase;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
-                    aux[0][g][0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
-                }
-                if (rem_on) {
-                    const int row = rbase + r32;
-                    raux[0] = vload_x1_addr(a.rowscale + (row < a.M ? row : a.M - 1));
-                }
+                for (int g = 0; g < 4; ++g) aux[0][g][0] = vload_x1_sv(rb, (uint32_t)min(jrow + 8 * g, rlast) * 4u);
+                if (rem_on) raux[0] = vload_x1_sv(rb, (uint32_t)min(r32, rlast) * 4u);
             } else {
+                const uint32_t vx = lane_off(ldx, a.aux_cm_rows);
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) {
-                    const int col0 = 32 * (tile0 + ct) + (r32 & ~3);
-                    const int colc = col0 < a.ldc ? col0 : 0;       // lanes past the row read column 0 (never stored)
+                    const int q = tile0 + ct < a.nq ? tile0 + ct : 0;   // (a quarter past the last one: loads quarter 0, never stored)
+                    const bool cfull = qfull(q);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int row = rbase + (r32 & 3) + 8 * g + 4 * kh;
-                        aux[ct][g] = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, colc, ldx, a.aux_cm_rows));
-                    }
+                    for (int g = 0; g < 4; ++g)
+                        if ((tile_full || rowok(g)) && (cfull || colok(q)))
+                            vload_x4(aux[ct][g], reinterpret_cast<const char*>(extra + ubase(q, g, ldx, a.aux_cm_rows)), vx);
                 }
-                if (rem_on) {
-                    const int row = rbase + r32;
-                    raux = vload_x4_addr(extra + act_off(row < a.M ? row : a.M - 1, rem_col, ldx, a.aux_cm_rows));
-                }
+                if (rem_on && (tile_full || rbase + r32 < a.M))
+                    vload_x4(raux, reinterpret_cast<const char*>(extra + (a.aux_cm_rows > 0 ? ((size_t)(rem_col >> 2) * a.aux_cm_rows + rbase) * 4
+                                                                                         : (size_t)rbase * ldx + rem_col)),
+                             a.aux_cm_rows > 0 ? (uint32_t)r32 * 16u : (uint32_t)r32 * (uint32_t)ldx * 4u);
             }
         }
         // ---- multiply
@@ -662,13 +725,20 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                         }
                     }
                     NT_T2_P(1);   // transposes + epilogue arithmetic
+                    {   // uniform base + the lane's one offset (see the epilogue-operand loads); a full tile of a full quarter needs no mask
+                        const int q = tile0 + ct;
+                        const uint32_t vc = lane_off(a.ldc, a.c_cm_rows);
+                        const bool unmasked = tile_full && qfull(q);
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
+                        for (int g = 0; g < 4; ++g) {
+                            const char* cb = reinterpret_cast<const char*>(C + ubase(q, g, a.ldc, a.c_cm_rows));
 #ifndef PFN_EXP_NOSTORE   /* experiment switch */
-                        if (row_of(g) < a.M) vstore_x4<(CT < 2)>(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+                            if (unmasked || (rowok(g) && colok(q))) vstore_x4_sv<(CT < 2)>(cb, vc, f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
 #else
-                        if (row_of(g) < 0) vstore_x4<(CT < 2)>(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
+                            if (row_of(g) < 0) vstore_x4_sv<(CT < 2)>(cb, vc, f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
 #endif
+                        }
+                    }
                     NT_T2_P(2);   // store issue
                 }
             }
@@ -881,7 +951,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
         // ---- multiply out of buffer s & 1, refilling the fragment for the next piece / row tile
         {
             const int pi = last ? p : np, rti = last ? rt : nrt_;
-            nt_multiply<CT, REM ? 1 : 0, NCH, LS, WS_DMAS>(acc, racc, a_cur, lds + (s & 1) * WS_IMG, KP, 4, 0, kh4, r32, a_base(rti, pi),
+            nt_multiply<CT, REM ? 1 : 0, NCH, LS, WS_DMAS, REM>(acc, racc, a_cur, lds + (s & 1) * WS_IMG, KP, 4, 0, kh4, r32, a_base(rti, pi),
                                                            a_voff(rti, pi), a.piece[pi].kmax, (uint32_t)a.piece[pi].kscale);
         }
         if (flush_after) {
@@ -1137,8 +1207,10 @@ static int launch_variant(const NtArgs& k, dim3 grid, size_t lds_bytes, hipStrea
 // the multiply variant of one launch (see gemm_nt_kernel); -1: not expressible with this CT
 static int pick_variant(const NtArgs& k, int CT) {
     const int nr = k.remv > 0 ? (k.nrem > 1 ? 4 : 1) : 0;   // trailing columns the launch's last column group owns
-    if (k.kuni == KP && nr <= 1) return k.klast == 1 ? 0 : 1;
-    if (k.kuni == KP - 8 && nr == 0) return 2;
+    bool diet_ok = true;                                     // (see launch_gemm_nt_rows: the straight-line variants need it)
+    for (int i = 0; i < k.npiece; ++i) diet_ok = diet_ok && k.piece[i].kmax >= k.piece[i].klen - 12;
+    if (k.kuni == KP && nr <= 1 && diet_ok) return k.klast == 1 ? 0 : 1;
+    if (k.kuni == KP - 8 && nr == 0 && diet_ok) return 2;
     return CT < 2 ? 3 : -1;
 }
 
@@ -1200,7 +1272,11 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     // ---- how many 32-column quarters of every piece fit in LDS at once (tps), and where the launch has to be cut
     auto piece_bytes = [](const NtPiece& pc, int tps) { return (size_t)pc.klen * (32 * tps + 4) * sizeof(float); };
     const size_t bias_bytes = (size_t)round_up((int64_t)a.ldc * sizeof(float), 16);   // the bias image rides behind the pieces
+#ifdef PFN_EXP_DYN
+    const size_t lds_budget = (size_t)NT_LDS_BYTES - bias_bytes - 32;
+#else
     const size_t lds_budget = (size_t)NT_LDS_BYTES - bias_bytes;
+#endif
     int tps = 0;
     if (nq > 0) {
         const int tps_cap = 4;
@@ -1225,6 +1301,11 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     for (const NtPiece& pc : pieces) fast &= pc.klen == pieces[0].klen;
     const int nrem = std::max(0, std::min(remv, a.ncols - 32 * nq));
     fast = fast && ((pieces[0].klen == KP && nrem <= 1) || (pieces[0].klen == KP - 8 && remv == 0));
+    // the straight-line variants refill every chunk but a piece's last without a clamp (nt_multiply's DIET): only the last chunk may
+    // reach past the operand's row.  False for the later pieces of a piece-padded image (K > 136): those take the generic variant.
+    bool diet_ok = true;
+    for (const NtPiece& pc : pieces) diet_ok = diet_ok && pc.kmax >= pc.klen - 12;   // lane half 1 of chunk klen / 8 - 2 reads k = klen - 12 ..
+    fast = fast && diet_ok;
     if (fast && tps >= 2 && (long)nrt * nslices * (tps / 2) >= 2L * ncu * NT_WAVES) CT = 2;
     static const int force_ct = diag_env("PFN_NT_CT") ? atoi(diag_env("PFN_NT_CT")) : 0;   // tuning aid: 1 or 2
     if (force_ct > 0 && CT > 0) CT = std::min(force_ct, (fast && tps >= 2) ? 2 : 1);
@@ -1278,7 +1359,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
         // (profiles/r03_gemm_nt_streaming.txt).
         bool ws_ok = ws_min > 0 && nq == 4 && remv == 4 && nrem == 1 && nslices > 2 && pieces.size() <= (size_t)NT_MAX_PIECES &&
                      (long)nrt >= (long)ws_min * per_round;
-        for (size_t i = 0; i < pieces.size(); ++i) ws_ok = ws_ok && pieces[i].klen == KP && last_steps[i] == 1;
+        for (size_t i = 0; i < pieces.size(); ++i) ws_ok = ws_ok && pieces[i].klen == KP && last_steps[i] == 1 && pieces[i].kmax >= KP - 12;
         if (ws_ok) {
             const long nround = nrt / per_round;
             const long rows_ws = std::min<long>(a.M, nround * per_round * 32);
@@ -1358,7 +1439,11 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
         }
         int rc = PFN_EINVAL;
         const int var = pick_variant(k, CT);
+#ifdef PFN_EXP_DYN
+        const size_t lb = used + bias_bytes + 32;
+#else
         const size_t lb = used + bias_bytes;
+#endif
 #define PFN_NT_CASE(CT_, V_) if (CT == CT_ && var == V_) rc = launch_variant<CT_, V_>(k, grid, lb, s)
         PFN_NT_CASE(0, 0); PFN_NT_CASE(0, 1); PFN_NT_CASE(0, 2); PFN_NT_CASE(0, 3);
         PFN_NT_CASE(1, 0); PFN_NT_CASE(1, 1); PFN_NT_CASE(1, 2); PFN_NT_CASE(1, 3);
