@@ -106,6 +106,11 @@ int main(int argc, char** argv) {
         printf("    loop cycles per piece by XCD    :"); for (int x = 0; x < 8; ++x) printf(" %.0f", xn[x] ? cyc_pp[x] / xn[x] : 0.0); printf("\n");
         printf("    loop cycles by wave slot        :"); for (int x = 0; x < 8; ++x) printf(" %.0f", wn[x] ? ws[x] / wn[x] : 0.0); printf("\n");
         printf("    loop cycles by pieces per wave  :"); for (int x = 0; x < 64; ++x) if (pn[x]) printf(" [%d: %.0f waves, %.0f]", x, pn[x], ps[x] / pn[x]); printf("\n");
+        if (getenv("PFN_TS2_GX")) {   // loop cycles by slice (blockIdx.y) when the caller knows the grid's x extent
+            const int gx = atoi(getenv("PFN_TS2_GX")); double ys[16] = {0}, yn[16] = {0}, ymax[16] = {0};
+            for (int w = 0; w < 4096; ++w) { if (ts[w * 8 + 4] == 0) continue; const int y = (w / 8) / gx; if (y < 16) { ys[y] += (double)ts[w * 8 + 4]; yn[y] += 1; if ((double)ts[w * 8 + 4] > ymax[y]) ymax[y] = (double)ts[w * 8 + 4]; } }
+            printf("    loop cycles by slice (mean / max):"); for (int y = 0; y < 16; ++y) if (yn[y]) printf(" [%d: %.0f / %.0f]", y, ys[y] / yn[y], ymax[y]); printf("\n");
+        }
         // the ten slowest waves
         std::vector<std::pair<double, int>> v; for (int w = 0; w < 4096; ++w) if (ts[w * 8 + 4]) v.push_back({(double)ts[w * 8 + 4], w});
         std::sort(v.begin(), v.end());
