@@ -24,6 +24,7 @@
 //         straight from registers.  The stores of one wave overlap the MFMAs of the other wave on its SIMD.
 //         A launch whose weights do not fit in LDS even for 32-column slices (hidden_dim >> 129) is split into several
 //         launches that accumulate into C (raw partial sums; the epilogue runs in the last one).
+#include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -152,17 +153,23 @@ struct EpiCfg {
     DropKey dk;
 };
 struct NtPiece {
+    // -- the eight dwords the stationary kernel's round loop reads of the NEXT piece, contiguous: one scalar load per round (they were
+    //    fetched field by field, the current, the next and the refill piece each indexed at run time: three dependent scalar round
+    //    trips between two multiplies, ~1 k cycles of the ~2 k a round spends outside nt_multiply -- with both waves of a SIMD in step
+    //    at small M that is matrix-pipe idle time)
     const float* A;      // operand rows, advanced to this piece's first k
-    const float* Bq;     // image of quarter 0 at this piece's first k group; quarter q lies q * qstride floats further
-    const float* Brem;   // trailing-column image at this piece's first k group
     int lda;             // floats between consecutive rows of A: its row stride -- or 4 when the operand is CHUNK-MAJOR
                          // ([ld / 4 planes][rows][float4]: what the big-graph hop kernel writes, edge.hip)
     int kscale;          // bytes between consecutive k's of one row: 4 -- or 4 * rows for a chunk-major operand (k a multiple of 4)
     int kmax;            // last legal 16-byte read position inside a row, relative to A
     int klen;            // k's of the piece: a multiple of 8, <= KP (the image is zero beyond the real K)
+    int gl;              // group | 256 when the piece is the LAST of its group inside the launch (the flush follows it)
+    int lds_off;         // float offset of the piece's slice image in LDS
+    // -- prologue only
+    const float* Bq;     // image of quarter 0 at this piece's first k group; quarter q lies q * qstride floats further
+    const float* Brem;   // trailing-column image at this piece's first k group
     int qstride;         // floats between quarters of the image
     int group;           // output group
-    int lds_off;         // float offset of the piece's slice image in LDS
 };
 struct NtArgs {
     int M, ncols, ldc, npiece;
@@ -523,6 +530,11 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     auto rounds = [&](auto nfast_c, auto nr_c, auto ls_c) {
     constexpr int NFAST = decltype(nfast_c)::value, NR = decltype(nr_c)::value, LS = decltype(ls_c)::value;
     int p = 0;
+    // (the piece table read through the kernel-argument segment's own address: indexed as `a.piece[pi]` with all eight fields wanted
+    //  at once, hipcc loads the WHOLE table into SGPRs up front and spills it -- 108-164 SGPR spills, a v_readlane per use)
+    typedef const NtPiece __attribute__((address_space(4)))* NtPieceK;
+    const NtPieceK pk = (NtPieceK)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(NtArgs, piece));
+    int cur_gl = pk[0].gl, cur_lds = pk[0].lds_off, cur_klen = pk[0].klen;
     while (true) {
         asm volatile("" : "+v"(kh4));   // opaque per round: keeps the 17 refill offsets from being hoisted into 17 VGPRs
         // ---- the piece after this one: same row tile, next piece -- or the wave's next row tile, first piece
@@ -539,12 +551,17 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #endif
         }
         const bool more = nrt_ < nrt;
-        const int group = a.piece[p].group;
-        const bool flush_after = !more || np == 0 || a.piece[np].group != group;
+        const int group = cur_gl & 255;
+        const bool flush_after = !more || (cur_gl >> 8) != 0;
         const int pi = more ? np : p;                        // no next piece: refill from the current one (harmless)
-        const char* nbase = a_base(more ? nrt_ : rt, pi);
-        const uint32_t nvoff = a_voff(more ? nrt_ : rt, pi);
-        const int nkmax = a.piece[pi].kmax;
+        // the next piece's eight dwords: one load, nothing of it is needed before the refills inside the multiply (the current
+        // piece's group / LDS offset / length came with the load of the round before)
+        const NtPieceK nx = pk + pi;
+        const float* nxA = nx->A;
+        const int nx_lda = nx->lda, nx_kscale = nx->kscale, nkmax = nx->kmax, nx_klen = nx->klen, nx_gl = nx->gl, nx_lds = nx->lds_off;
+        const int nrt2 = more ? nrt_ : rt;
+        const char* nbase = reinterpret_cast<const char*>(nxA + (size_t)nrt2 * 32 * nx_lda);
+        const uint32_t nvoff = (uint32_t)(min(r32, a.M - 1 - nrt2 * 32) * nx_lda) * 4u;
         // ---- per-row epilogue operands of the flush that follows this piece: requested NOW (hidden loads), so they are
         // older than the 17 refills issued inside the multiply; the flush waits for them with vmcnt(17)
         const int rbase = rt * 32;
@@ -604,11 +621,11 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         }
         // ---- multiply
         {
-            const float* S = lds + a.piece[p].lds_off;
-            const int klen = a.piece[p].klen, tsel = cg * CT;
+            const float* S = lds + cur_lds;
+            const int klen = cur_klen, tsel = cg * CT;
             NT_T2_A;
             nt_multiply<CT, NR, NFAST, LS>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax,
-                                           (uint32_t)a.piece[pi].kscale);
+                                           (uint32_t)nx_kscale);
             NT_T2_B;
         }
         if (flush_after) {
@@ -789,6 +806,9 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         if (!more) break;
         p = np;
         rt = nrt_;
+        cur_gl = nx_gl;
+        cur_lds = nx_lds;
+        cur_klen = nx_klen;
     }
     };
     using std::integral_constant;
@@ -1261,6 +1281,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
             pc.klen = std::min(KP, K8 - k0);
             pc.qstride = qstride;
             pc.group = tm.group;
+            pc.gl = tm.group;
             pc.lds_off = 0;
             pieces.push_back(pc);
             {
@@ -1429,6 +1450,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
         bool here[8] = {false, false, false, false, false, false, false, false};
         for (size_t i = i0; i < i1; ++i) {
             k.piece[i - i0] = pieces[i];
+            k.piece[i - i0].gl = pieces[i].group | ((i + 1 == i1 || pieces[i + 1].group != pieces[i].group) ? 256 : 0);
             here[pieces[i].group] = true;
         }
         for (int g = 0; g < 8; ++g) {
