@@ -140,8 +140,13 @@ __device__ __forceinline__ void t3_emit(const TnPair& pr, const T3Task& tk, int 
 // filled, loop done, row groups summed, end -- with the wall clock beside them (tools/ubench/run_gemm_tn_ts.sh)
 #ifdef T3_EXP_TS
 __device__ unsigned long long t3_ts[4096 * 8];
-#define T3_TS(i) do { if (lane == 0) { const int w_ = blockIdx.x * T3_WAVES + wave; if (w_ < 4096) t3_ts[w_ * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
-#define T3_TSW(i) do { if (lane == 0) { const int w_ = blockIdx.x * T3_WAVES + wave; if (w_ < 4096) t3_ts[w_ * 8 + (i)] = wall_clock64(); } } while (0)
+#ifdef T3_EXP_TS_RUNS   /* stamps of the runs-of-four form only (a step with chunk-major operands launches both forms) */
+#define T3_TS_ON RUNS
+#else
+#define T3_TS_ON true
+#endif
+#define T3_TS(i) do { if (T3_TS_ON && lane == 0) { const int w_ = blockIdx.x * T3_WAVES + wave; if (w_ < 4096) t3_ts[w_ * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#define T3_TSW(i) do { if (T3_TS_ON && lane == 0) { const int w_ = blockIdx.x * T3_WAVES + wave; if (w_ < 4096) t3_ts[w_ * 8 + (i)] = wall_clock64(); } } while (0)
 #else
 #define T3_TS(i)
 #define T3_TSW(i)
@@ -157,7 +162,7 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     const int c = lane & 31, kh = lane >> 5;
     T3_TS(0); T3_TSW(5);
 #ifdef T3_EXP_TS
-    if (lane == 0) { const int w_ = blockIdx.x * T3_WAVES + wave; if (w_ < 4096) t3_ts[w_ * 8 + 7] = (unsigned long long)(TA * 10 + TB) * 1000000ull + tk.nsplit; }
+    if (T3_TS_ON && lane == 0) { const int w_ = blockIdx.x * T3_WAVES + wave; if (w_ < 4096) t3_ts[w_ * 8 + 7] = (unsigned long long)(TA * 10 + TB) * 1000000ull + tk.nsplit; }
 #endif
     const TnPair& pr = a.pair[tk.pair];
     const int M = a.M;
