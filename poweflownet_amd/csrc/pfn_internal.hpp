@@ -569,8 +569,11 @@ __host__ __device__ __forceinline__ DropKey drop_key(uint64_t seed, uint64_t off
     return k;
 }
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#ifndef PFN_EXP_PHILOX_ROUNDS   /* tools experiment switch (a DIFFERENT, weaker generator): what do the ten rounds cost a step? */
+#define PFN_EXP_PHILOX_ROUNDS 10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < PFN_EXP_PHILOX_ROUNDS; ++r) {
         // (one 64-bit product per multiplier -- v_mad_u64_u32 -- instead of v_mul_hi_u32 + v_mul_lo_u32: 32-bit integer multiplies
         //  are quarter rate, and the ten rounds are most of a dropout epilogue's instruction time)
         const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];
