@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--config", default="standard", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="train", choices=["train", "infer"])
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--dp-mode", default=None, choices=["graph", "split", "eager"],
+                    help="launch form of the (data-parallel) training step: one hipGraph incl. the RCCL all-reduce (default), "
+                         "graph / eager all-reduce / graph, or eager launches; ranks always agree on it (dp.GraphedStep)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -412,8 +415,8 @@ def main():
                 # ONE hipGraph per step: forward, loss, backward, (DP: the RCCL all-reduce of the flat gradient buffer, captured
                 # between backward and optimizer like any other node; a backend that cannot be captured -- gloo in the one-GPU
                 # plumbing tests -- gets graph / eager all-reduce / graph), AdamW
-                gs = dp.GraphedStep(fb, opt.step, model).capture()
-                step, launch_mode = gs.replay, "hipGraph replay: " + gs.mode
+                gs = dp.GraphedStep(fb, opt.step, model, mode=args.dp_mode).capture()
+                step, launch_mode = gs.replay, ("hipGraph replay: " if gs.form != "eager" else "") + gs.mode
             else:
                 g_inf = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g_inf):

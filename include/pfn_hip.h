@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 5
+#define PFN_ABI_VERSION 6
 
 enum {
     PFN_OK = 0,
@@ -224,7 +224,9 @@ int pfn_adamw_step_dev(float* param, const float* grad, float* exp_avg, float* e
 /* ... and skipped ON THE DEVICE (nothing updated, the step not counted) when the device scalar `guard` -- normally the step's
  * loss -- is not finite: for a captured training step whose batch could not be validated on the host (a topology per batch: a
  * bad batch arrives as a NaN loss, pfn_graph_poison_if_bad; the reference's train loop, utils/training.py:55-77, would have
- * raised in the forward pass instead of stepping).  New layer, no reference counterpart.                                  */
+ * raised in the forward pass instead of stepping).  `step` is a device int64[3] here: {completed steps, arrival scratch,
+ * SKIPPED updates} -- the caller's loop reads step[2] to tell a poisoned / diverged batch from a healthy one (ABI 6).
+ * New layer, no reference counterpart.                                                                                   */
 int pfn_adamw_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t count,
                            const float* hyper, int64_t* step, const float* guard, void* stream);
 

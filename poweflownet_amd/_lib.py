@@ -34,7 +34,7 @@ class MpnConfig(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def load() -> C.CDLL:

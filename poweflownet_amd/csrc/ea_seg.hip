@@ -25,21 +25,6 @@
 
 namespace pfn {
 
-// tools/ubench experiment switch (never defined in the product build): wall-clock (100 MHz) timestamps of the backward kernel's
-// phases, one record per workgroup of the LAST launch, read back with pfn_debug_seg_ts()
-#ifdef SG_EXP_TS
-__device__ unsigned long long sg_ts[4096 * 8];
-#define SG_TS(slot)                                                                                                   \
-    do {                                                                                                              \
-        if (threadIdx.x == 0) {                                                                                       \
-            const int b_ = blockIdx.y * gridDim.x + blockIdx.x;                                                       \
-            if (b_ < 4096) sg_ts[b_ * 8 + (slot)] = wall_clock64();                                                   \
-        }                                                                                                             \
-    } while (0)
-#else
-#define SG_TS(slot) do { } while (0)
-#endif
-
 struct SegCsr {      // one adjacency slice in LDS: rp[rows + 1] (relative), nb[cap] (row index inside the block), ea[cap] (a_e)
     int* rp;
     int* nb;
@@ -71,10 +56,6 @@ __device__ __forceinline__ void csr_issue2(SegCsr& c, CsrRegs& r, int cap, const
     }
 }
 __device__ __forceinline__ void csr_commit(const SegCsr& c, const CsrRegs& r, int r0, int rows) {
-#ifdef SG_EXP_NOSTAGE
-    if ((int)threadIdx.x <= rows) c.rp[threadIdx.x] = 0;
-    return;
-#endif
     if ((int)threadIdx.x <= rows) c.rp[threadIdx.x] = r.rp - c.e0;
     if (c.in_lds && (int)threadIdx.x < c.ne) {
         c.nb[threadIdx.x] = r.nb - r0;
@@ -227,7 +208,6 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     // ---- P | Q tiles: wave w < 4 owns row tile w and multiplies its ONE A fragment with both weight quarters (P, then Q); as two
     // waves per row tile every fragment was fetched twice, and the prologue is bound by the bytes it pulls through L2 -> L1.
     // (rows <= SG_MAX_ROWS = 128: waves 4..7 carry no tile)
-    SG_TS(0);
     const int nrt = (rows + 31) >> 5;
     const bool mfma_on = wave < nrt;
     const int K8 = (a.K + 7) & ~7;
@@ -250,7 +230,6 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     }
     seg_dma_wait();
     __syncthreads();
-    SG_TS(1);
     if (mfma_on) {
         const f32x16 accp = seg_mma(ta, l.B0, K8, lane);
         seg_store_tile(accp, sc.q, a.b1, a.h, l.P, 32 * wave, lane);
@@ -258,24 +237,17 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         seg_store_tile(accq, sc.q, nullptr, a.h, l.Q, 32 * wave, lane);
     }
     __syncthreads();
-    SG_TS(2);
     // ---- P, Q out (the backward pass recomputes the pre-activation from them), and the walk
     for (int it = threadIdx.x; it < rows * sc.cw; it += SG_THREADS) {
         const int lr = it / sc.cw, lc = it - lr * sc.cw;
         const int tc = seg_tcol(sc, lc), gc = seg_gcol(sc, lc);
         const float4 p4 = sg_ld4(l.P + (size_t)lr * SG_TW + tc);
         const size_t o = (size_t)(r0 + lr) * a.ld + gc;
-#ifndef SG_EXP_NOSTORE
         sg_st4_wt(a.P + o, p4);
         sg_st4_wt(a.Q + o, sg_ld4(l.Q + (size_t)lr * SG_TW + tc));
-#endif
         const float4 w0 = sg_ld4(l.we + tc), w1 = sg_ld4(l.we + SG_TW + tc);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef SG_EXP_NOWALK
         const int beg = cin.rp[lr], end = cin.rp[lr + 1];
-#else
-        const int beg = 0, end = 0;
-#endif
         if (cin.in_lds) {   // four slots per trip (slots past the row's end re-read its last edge and are not added): the walk is a
             const int last = end - 1;   // chain of dependent LDS reads (index -> tile), four independent chains at a time
             for (int p = beg; p < end; p += 4) {
@@ -314,14 +286,8 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
                 acc = sg_add4(acc, sg_relu4(v));
             }
         }
-#ifndef SG_EXP_NOSTORE
         sg_st4_wt(a.S + o, acc);
-#else
-        if (acc.x == 123.456f) sg_st4_wt(a.S + o, acc);
-#endif
     }
-    SG_TS(3);
-    SG_TS(4);
 }
 
 
@@ -753,7 +719,6 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0);
     const SegCols sc = seg_cols(a.ld);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    SG_TS(0);
     // ---- dS slice: the MFMA waves request their operands first (the staging below is several dependent loads deep)
     const int nrt = (rows + 31) >> 5;
     const bool mfma_on = !DSG && wave < nrt;
@@ -772,14 +737,12 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     for (int j = 0; j < 3; ++j) {
         const int it = threadIdx.x + j * SG_THREADS;
         pv[j] = qv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#ifndef SG_EXP_NOPQ
         if (it < rows * sc.cw) {
             const int lr = it / sc.cw, lc = it - lr * sc.cw;
             const size_t o = (size_t)(r0 + lr) * a.ld + seg_gcol(sc, lc);
             pv[j] = sg_ld4(a.P + o);
             qv[j] = sg_ld4(a.Q + o);
         }
-#endif
     }
     csr_issue2(cin, cri, cap, in_src, a.ea_in);
     csr_issue2(cout, cro, cap, out_dst, a.ea_out);
@@ -836,7 +799,6 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         // (the W2 quarter sits where the dS tile goes: every wave is done reading it before the first one writes)
         seg_dma_wait();
         __syncthreads();
-        SG_TS(1);
         f32x16 acc;
         if (mfma_on) acc = seg_mma(ta, l.B0, K8, lane);
         __syncthreads();
@@ -844,7 +806,6 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         else if (rem_helper) seg_rem_store<false, 1>(threadIdx.x - 256, rows, sc.nq, nreal, nullptr, v1, v2, l.D, nullptr);
     }
     __syncthreads();
-    SG_TS(2);
     // ---- walks.  Thread = (chunk lane lc = tid & 7, row lane ty = tid >> 3): a thread keeps ONE column chunk for all its rows, so
     // the dWe partial sums stay in registers and the block emits one ordered partial per column.  The block that also owns the
     // trailing columns walks that ninth chunk in a second, short pass (two threads per row, one per direction): as a ninth lane it halved the row lanes and
@@ -857,19 +818,13 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
                 seg_bwd_row(l, cin, cout, lr, tc, w0, w1, accP, accQ, dwe0, dwe1);
             else
                 seg_bwd_row_slow(l, cin, cout, lr, tc, r0, in_src, out_dst, a.ea_in, a.ea_out, w0, w1, accP, accQ, dwe0, dwe1);
-#ifndef SG_EXP_NOSTORE
             sg_st4_wt(a.dP + (size_t)(r0 + lr) * a.ld + gc, accP);
             sg_st4_wt(a.dQ + (size_t)(r0 + lr) * a.ld + gc, accQ);
-#else
-            if (accP.x == 123.456f) sg_st4_wt(a.dP + (size_t)(r0 + lr) * a.ld + gc, accP);
-            if (accQ.x == 123.456f) sg_st4_wt(a.dQ + (size_t)(r0 + lr) * a.ld + gc, accQ);
-#endif
         }
     };
     const int cwm = sc.cw - (sc.rem ? 1 : 0);             // chunks of the 32-column quarter itself (<= 8)
     const int lc = threadIdx.x & 7, ty = threadIdx.x >> 3;
     float4 dwe0 = make_float4(0.f, 0.f, 0.f, 0.f), dwe1 = dwe0, rwe0 = dwe0, rwe1 = dwe0;
-#ifndef SG_EXP_NOWALK
     if (lc < cwm) walk_rows(ty, SG_THREADS / 8, 4 * lc, sc.col0 + 4 * lc, dwe0, dwe1);
     if (sc.rem) {   // the trailing chunk: a row's two walks go to two threads (t >> 1 = row, t & 1 = direction)
         const int lr = threadIdx.x >> 1, gc = 32 * sc.nq;
@@ -889,8 +844,6 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             }
         }
     }
-#endif
-    SG_TS(3);
     // ordered reduction of the dWe partials over the row lanes: inside a wave by a fixed xor tree (over the lanes that share a chunk:
     // lane bits 3..5; all six bits for the trailing chunk), then over the 8 waves in wave order -> the block's partial [2][ld]
     auto xor_sum = [&](float4& v, int off) {
@@ -915,7 +868,6 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             sg_st4_wt(a.dWe_partial + ((size_t)blockIdx.x * 2 + f) * a.ld + seg_gcol(sc, c2), s);
         }
     }
-    SG_TS(4);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -1040,8 +992,3 @@ int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStr
 
 }  // namespace pfn
 
-#ifdef SG_EXP_TS
-extern "C" int pfn_debug_seg_ts(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::sg_ts), (size_t)n * sizeof(unsigned long long));
-}
-#endif

@@ -34,14 +34,7 @@ __device__ __forceinline__ float4 mask4(unsigned m, float4 g) {   // g where the
 __device__ __forceinline__ float4 sel4(bool k, float4 a, float4 b) { return make_float4(k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z, k ? a.w : b.w); }
 __device__ __forceinline__ float4 relu4(float4 v) { return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)); }
 
-#ifdef PFN_EXP_XCD   /* tools experiment switch (never defined in the product build): XCD k walks the k-th eighth of the rows */
-__device__ __forceinline__ int exp_block(int b, int nb) {
-    const int x = b & 7, q = nb >> 3, r = nb & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
-#else
 __device__ __forceinline__ int exp_block(int b, int) { return b; }
-#endif
 // ------------------------------------------------------------------------------------------- hop
 template <bool NORM>
 __global__ __launch_bounds__(256) void hop_kernel(int n, int nchunk, const int* __restrict__ rowptr,
@@ -471,24 +464,16 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
         rpv[r] = 0;
         if (row < seg) {
             di[r] = dinv[r0 + row];
-#ifndef BH_EXP_NOLOADX
             // (the producing GEMM writes the layer input chunk-major when this kernel will read it: one contiguous run instead
             //  of 16 bytes per 528-byte row -- 100 of the kernel's 330 us)
             z[r] = x0_cm ? ld4(x0 + ((size_t)c * n_total + r0 + row) * 4) : ld4(x0 + (size_t)(r0 + row) * ld + 4 * c);
-#else
-            z[r] = ld4(x0 + (size_t)(r0 + (row & 63)) * 4 + 0 * c);
-#endif
             rpv[r] = rowptr[r0 + row];
         }
     }
 #pragma unroll
     for (int jn = 0; jn < BH_NBPT; ++jn) {
         const int i = t + jn * BH_THREADS;
-#ifndef BH_EXP_NOCSR
         nbv[jn] = (nb_in_lds && i < ne) ? nbr[e0 + i] : 0;
-#else
-        nbv[jn] = r0 + (i % seg);
-#endif
     }
 #pragma unroll
     for (int r = 0; r < BH_RPT; ++r) {
@@ -550,12 +535,7 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
             if (hubslot[r] >= 0) {
                 acc = s_hub_y[hubslot[r]];
             } else
-#ifdef BH_EXP_NOGATHER   /* tools/ubench experiment switches: never defined in the product build */
-            acc = bh_tile[row];
-            if (false) {
-#else
             if (nb_in_lds) {   // four slots per trip: index -> tile row is a chain of dependent LDS reads (see hop_kernel)
-#endif
                 const int beg = s_rp[row], end = s_rp[row + 1], last = end - 1;
                 for (int p = beg; p < end; p += 4) {
                     int s_[4];
@@ -570,20 +550,14 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
                     acc = sel4(p + 3 < end, add4(acc, v_[3]), acc);
                 }
             } else {           // a graph with more edges than the staged list holds: indices from global memory
-#ifndef BH_EXP_NOGATHER
                 for (int p = rowptr[r0 + row]; p < rowptr[r0 + row + 1]; ++p) acc = add4(acc, bh_tile[nbr[p] - r0]);
-#endif
             }
             const float4 y = mul4(di[r], acc);
             // the hop outputs are written CHUNK-MAJOR ([chunk][row][float4]): this block's 6470 x 16 bytes are one contiguous
             // run.  Row-major they were 16 bytes per 528-byte row -- 41 M partial-line writes per direction at 6470rte x 64, and
             // the kernel was no faster than the three gather passes it replaces (422 vs 3 x 142 us).  The consumers read the
             // layout through GemmTerm::cm_rows (gemm_nt A operand) and TnPair::b_cm_rows (gemm_tn B operand).
-#ifndef BH_EXP_NOSTORE
             st4(outk + ((size_t)c * n_total + r0 + row) * 4, y);
-#else
-            if (y.x == 123.456f) st4(outk + ((size_t)c * n_total + r0 + row) * 4, y);
-#endif
             z[r] = mul4(di[r], y);
         }
         if (k == K) break;
@@ -713,14 +687,9 @@ __device__ __forceinline__ float4 edge_sum_chunk(int row, int col, int e_stored,
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int q = min(p + u, last);
-#ifndef PFN_EXP_EDGE_NOL2   /* tools experiment switch (never defined in the product build): neighbour / edge ids WITHOUT the index loads */
                 s_[u] = nbr[q];
                 const int id = eid[q];
                 id_[u] = id >= e_stored ? id - e_stored : id;
-#else
-                s_[u] = max(row - u, 0);
-                id_[u] = min(q, e_stored - 1);
-#endif
             }
             float4 q_[4];
             float2 a_[4];
@@ -1505,18 +1474,20 @@ int launch_edge_bwd(const GraphView& g, const EdgeBwdArgs& a, const int64_t*, hi
 
 // dWe partial [nblocks][fe][ld]  ->  grad_w1[k][col0 + f]  (ordered: 4 interleaved lanes, then a fixed tree), for up to
 // DWE_MAX_JOBS EdgeAggregation layers in one launch (blockIdx.y = layer)
-__global__ __launch_bounds__(1024) void dwe_reduce_kernel(const DweJobs jobs, int fe, int ld, int h) {
+// stamp / stamp_want: the workspace guard of pfn_mpn_backward (model.hip WS_STAMP_TRAIN): on a mismatch the gradients are NaN
+__global__ __launch_bounds__(1024) void dwe_reduce_kernel(const DweJobs jobs, int fe, int ld, int h, const int* __restrict__ stamp,
+                                                          int stamp_want) {
     __shared__ float red[64][17];
-    dwe_reduce_body<64>(jobs.job[blockIdx.y], blockIdx.x, fe, ld, h, red);
+    dwe_reduce_body<64>(jobs.job[blockIdx.y], blockIdx.x, fe, ld, h, red, stamp != nullptr && *stamp != stamp_want);
 }
 
-int launch_dwe_reduce_multi(const DweJob* jobs, int njobs, int fe, int ld, int h, hipStream_t s) {
+int launch_dwe_reduce_multi(const DweJob* jobs, int njobs, int fe, int ld, int h, hipStream_t s, const int* stamp, int stamp_want) {
     for (int j0 = 0; j0 < njobs; j0 += DWE_MAX_JOBS) {
         DweJobs a;
         const int nj = njobs - j0 < DWE_MAX_JOBS ? njobs - j0 : DWE_MAX_JOBS;
         for (int j = 0; j < nj; ++j) a.job[j] = jobs[j0 + j];
         ProfScope ps("dwe_reduce", 0.0, 0.0, s);
-        dwe_reduce_kernel<<<dim3((fe * h + 15) / 16, nj), 1024, 0, s>>>(a, fe, ld, h);
+        dwe_reduce_kernel<<<dim3((fe * h + 15) / 16, nj), 1024, 0, s>>>(a, fe, ld, h, stamp, stamp_want);
         PFN_CHECK_LAUNCH();
     }
     return PFN_OK;

@@ -821,7 +821,8 @@ __global__ __launch_bounds__(256) void front_bwd_wg_kernel(int n, int h, int ld,
 // single chain, 41 us with sixteen), then the 64 sub-sums are added in j order
 __global__ __launch_bounds__(256) void front_wgrad_reduce_kernel(int nblk, int h, int ld, const float* __restrict__ partial,
                                                                  float* __restrict__ gwa, float* __restrict__ gba,
-                                                                 float* __restrict__ gwb, float* __restrict__ gbb) {
+                                                                 float* __restrict__ gwb, float* __restrict__ gbb,
+                                                                 const int* __restrict__ stamp, int stamp_want) {
     __shared__ float sub[64][5];
     const int el = threadIdx.x & 3, j = threadIdx.x >> 2;
     const int e = blockIdx.x * 4 + el, stride = fwg_stride(ld);
@@ -833,6 +834,7 @@ __global__ __launch_bounds__(256) void front_wgrad_reduce_kernel(int nblk, int h
     if (j != 0 || e >= stride) return;
     float t = sub[0][el];
     for (int k = 1; k < 64; ++k) t += sub[k][el];
+    if (stamp && *stamp != stamp_want) t = __builtin_nanf("");   // (pfn_mpn_backward's workspace guard, model.hip WS_STAMP_TRAIN)
     const int slot = e / ld, u = e - slot * ld;
     if (slot >= FWG_SLOTS) gbb[u] = t;                        // (u < 4: the four floats behind the slots)
     else if (u >= h) return;
@@ -848,7 +850,7 @@ size_t front_bwd_wg_scratch_floats(int n, int h) {
 }
 int launch_front_bwd_wg(int n, int h, int ldw1, const float* dP, const float* dQ, const float* maskf, const float* w1, const float* wa,
                         const float* ba, const float* wb, float* g0, float* scratch, float* gwa, float* gba, float* gwb, float* gbb,
-                        hipStream_t s) {
+                        hipStream_t s, const int* stamp, int stamp_want) {
     if (n == 0) return PFN_OK;
     int ld, nchunk, rows_pb;
     size_t lds;
@@ -860,7 +862,7 @@ int launch_front_bwd_wg(int n, int h, int ldw1, const float* dP, const float* dQ
         PFN_CHECK_LAUNCH();
     }
     ProfScope ps("front_wgrad_reduce", 0.0, 0.0, s);
-    front_wgrad_reduce_kernel<<<(fwg_stride(ld) + 3) / 4, 256, 0, s>>>(nblk, h, ld, scratch, gwa, gba, gwb, gbb);
+    front_wgrad_reduce_kernel<<<(fwg_stride(ld) + 3) / 4, 256, 0, s>>>(nblk, h, ld, scratch, gwa, gba, gwb, gbb, stamp, stamp_want);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }

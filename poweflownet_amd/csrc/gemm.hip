@@ -136,21 +136,6 @@ __device__ __forceinline__ void t3_emit(const TnPair& pr, const T3Task& tk, int 
 
 // RUNS: the launch has a chunk-major operand -> steps are dealt to the row groups in runs of four and refilled per run (see below);
 // otherwise step by step with immediate refills (a prefetch distance of the full ring: what small batches need)
-// tools experiment switch (never defined in the product build): per-wave shader-cycle stamps of the LAST launch -- start, ring
-// filled, loop done, row groups summed, end -- with the wall clock beside them (tools/ubench/run_gemm_tn_ts.sh)
-#ifdef T3_EXP_TS
-__device__ unsigned long long t3_ts[4096 * 8];
-#ifdef T3_EXP_TS_RUNS   /* stamps of the runs-of-four form only (a step with chunk-major operands launches both forms) */
-#define T3_TS_ON RUNS
-#else
-#define T3_TS_ON true
-#endif
-#define T3_TS(i) do { if (T3_TS_ON && lane == 0) { const int w_ = blockIdx.x * T3_WAVES + wave; if (w_ < 4096) t3_ts[w_ * 8 + (i)] = __builtin_amdgcn_s_memtime(); } } while (0)
-#define T3_TSW(i) do { if (T3_TS_ON && lane == 0) { const int w_ = blockIdx.x * T3_WAVES + wave; if (w_ < 4096) t3_ts[w_ * 8 + (i)] = wall_clock64(); } } while (0)
-#else
-#define T3_TS(i)
-#define T3_TSW(i)
-#endif
 template <int TA, int TB, bool RUNS>
 __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int bx, float4* lds) {
     constexpr int NQ = t3_quads(TA, TB);
@@ -160,10 +145,6 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = NH == 2 ? (wave & 1) : 0, wr = NH == 2 ? (wave >> 1) : wave;
     const int c = lane & 31, kh = lane >> 5;
-    T3_TS(0); T3_TSW(5);
-#ifdef T3_EXP_TS
-    if (T3_TS_ON && lane == 0) { const int w_ = blockIdx.x * T3_WAVES + wave; if (w_ < 4096) t3_ts[w_ * 8 + 7] = (unsigned long long)(TA * 10 + TB) * 1000000ull + tk.nsplit; }
-#endif
     const TnPair& pr = a.pair[tk.pair];
     const int M = a.M;
     // the block's row range: nsplit contiguous ranges whose length is a multiple of 8 x 8 rows (the last one is ragged)
@@ -303,7 +284,6 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
             ring[r].xv = ring[r].yv = ring[r].rs = 0.f;
             issue(ring[r], r);
         }
-        T3_TS(1);
         for (int t0 = 0; t0 < count; t0 += T3_R) {
 #pragma unroll
             for (int r = 0; r < T3_R; ++r) {
@@ -325,7 +305,6 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
             if (TWO_LEVEL && ((t0 / T3_R) & (T3_FLUSH - 1)) == T3_FLUSH - 1) flush();
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the over-fetched slots: nothing of the ring is in flight past here
-        T3_TS(2);
     }
     // ragged tail: an odd row count leaves ONE row (kh = 0 only) for the row group whose turn it is -- compiler-visible
     // loads, the upper lane half contributes zeros
@@ -397,7 +376,6 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
         }
         __syncthreads();
     }
-    T3_TS(3);
     if (wr != 0) return;
     // ---- one block: write the gradient; several: publish the partial for tn_combine_kernel
     if (tk.nsplit == 1) {
@@ -410,7 +388,6 @@ __device__ __forceinline__ void t3_body(const T3Args& a, const T3Task& tk, int b
 #pragma unroll
     for (int Q = 0; Q < NQ; ++Q) st4_wt(reinterpret_cast<float*>(mine + Q * 64 + lane), v[Q]);   // (write-through: ~9 MB of partials
                                                                                                   //  that the combine launch would wait for)
-    T3_TS(4); T3_TSW(6);
 }
 
 template <bool RUNS>
@@ -661,9 +638,3 @@ static int launch_weight_grads_uniform(const TnPair* pairs, int npairs, int64_t 
 
 }  // namespace pfn
 
-#ifdef T3_EXP_TS
-extern "C" int pfn_debug_t3_ts(unsigned long long* out, int n) {
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::t3_ts), (size_t)n * sizeof(unsigned long long));
-}
-#endif

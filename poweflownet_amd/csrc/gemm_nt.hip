@@ -39,11 +39,7 @@ namespace pfn {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#ifndef PFN_EXP_NT_THREADS   /* tools/ubench experiment switch (run_gemm_nt_waves.sh): 768 = three waves per SIMD; the stationary kernel only
-                                (the streaming kernel's DMA deal assumes 8 waves) */
-#define PFN_EXP_NT_THREADS 512
-#endif
-constexpr int NT_THREADS = PFN_EXP_NT_THREADS;
+constexpr int NT_THREADS = 512;                 // (the streaming kernel's DMA deal assumes 8 waves)
 constexpr int NT_WAVES = NT_THREADS / 64;
 constexpr int NCH = 17;                         // eight-wide k chunks per piece
 constexpr int KP = 8 * NCH;                     // 136 k's per piece: H = 129 is ONE piece
@@ -282,23 +278,17 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
             for (int c = 0; c < NR; ++c) r[c] = r_nxt[c];
             if (m + 1 < NCH && (FAST ? m + 1 < NFAST : 8 * (m + 1) < klen)) {
 #pragma unroll
-#ifndef PFN_EXP_NOLDS   /* tools/ubench experiment switch: never defined in the product build */
                 for (int ct = 0; ct < CT; ++ct) b_nxt[ct] = *reinterpret_cast<const f32x4*>(Bt + ct * tile_floats + (m + 1) * 256);
-#else
-                for (int ct = 0; ct < CT; ++ct) asm volatile("" : "+v"(b_nxt[ct]));
-#endif
 #pragma unroll
                 for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + (m + 1) * 32 + c * 4);
             }
             // (refills are issued per GROUP of four chunks, below: chunk m has 16 - (m & 3) younger loads)
-#ifndef PFN_EXP_NOWAIT   /* experiment switch */
             switch (m & 3) {
                 case 0: wait_a<NCH - 1 + XW>(a_cur[m]); break;
                 case 1: wait_a<NCH - 2 + XW>(a_cur[m]); break;
                 case 2: wait_a<NCH - 3 + XW>(a_cur[m]); break;
                 default: wait_a<NCH - 4 + XW>(a_cur[m]); break;
             }
-#endif
             const f32x4 av = a_cur[m];
 #pragma unroll
             for (int i = 0; i < ((FAST && m == NFAST - 1) ? LS : 4); ++i) {
@@ -317,7 +307,6 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
         if ((m & 3) == 3 || m == NCH - 1) {
 #pragma unroll
             for (int mm = m & ~3; mm <= m; ++mm) {
-#ifndef PFN_EXP_NOREFILL   /* experiment switch: every refill re-reads ONE cache line (the wave's first row) */
                 // VALU diet (round 4: an fp32 MFMA stream and the VALU do not overlap on a SIMD -- every vector instruction between
                 // MFMAs is matrix-pipe time, profiles/r04_gemm_nt_cycle_accounting.txt): when only the LAST chunk of a piece can
                 // reach past the operand's row (DIET: the launcher / caller guarantees it -- true for K <= 136; NOT for the last
@@ -332,78 +321,11 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
                     const uint32_t kk = min(kh4 + 8u * mm, (uint32_t)nkmax);
                     vload_x4(a_cur[mm], nbase, nvoff + nkscale * kk);
                 }
-#else
-                vload_x4(a_cur[mm], nbase, 0u * (nvoff + min(kh4 + 8u * mm, (uint32_t)nkmax)));
-#endif
             }
         }
-#ifndef PFN_EXP_NOSCHEDBAR   /* experiment switch */
         __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 }
-
-// tools/ubench experiment switch (never defined in the product build): wall-clock (100 MHz) timestamps of one workgroup's phases
-// -- kernel start, first barrier passed, first flush begins, end -- of the LAST launch, read back with pfn_debug_nt_ts()
-#ifdef NT_EXP_TS
-__device__ unsigned long long nt_ts[4096 * 4];
-#define NT_TS_DECL unsigned long long ts0_ = wall_clock64(), ts1_ = 0, ts2_ = 0
-#define NT_TS1 ts1_ = wall_clock64()
-#define NT_TS2 do { if (ts2_ == 0) ts2_ = wall_clock64(); } while (0)
-#define NT_TS_END                                                                                                   \
-    do {                                                                                                            \
-        const int b_ = blockIdx.y * gridDim.x + blockIdx.x;                                                         \
-        if (tid == 0 && b_ < 4096) {                                                                                \
-            nt_ts[b_ * 4] = ts0_; nt_ts[b_ * 4 + 1] = ts1_; nt_ts[b_ * 4 + 2] = ts2_; nt_ts[b_ * 4 + 3] = wall_clock64(); \
-        }                                                                                                           \
-    } while (0)
-#else
-#define NT_TS_DECL
-#define NT_TS1
-#define NT_TS2
-#define NT_TS_END
-#endif
-// tools/ubench experiment switch (never defined in the product build): per-WAVE shader-cycle accounting of the round loop
-// (s_memtime = shader cycles, tools/ubench/mfma_clock.hip) -- cycles inside nt_multiply, inside the flush (four sub-phases),
-// elsewhere; pieces, flushes; the wall clock beside it (-> the shader clock the loop ran at) -- per wave for the LAST launch
-// (pfn_debug_nt_ts2) and summed per launch class over a sample of the SIMD pairs of every launch (pfn_debug_nt_ts2_dump;
-// tools/ubench/run_gemm_nt_ts2.sh, run_gemm_nt_ts2_step.sh)
-#ifdef NT_EXP_TS2
-__device__ unsigned long long nt_ts2[4096 * 8];
-__device__ unsigned long long nt_ts2_sum[8 * 8];   // per launch class (pieces per tile): sums over the sampled waves of every launch since load
-__device__ unsigned long long nt_ts2_fp[8 * 4];    // per class: flush sub-phases
-#define NT_T2_DECL unsigned long long c_mul_ = 0, c_fl_ = 0, c_np_ = 0, c_nf_ = 0, c_beg_ = __builtin_amdgcn_s_memtime(), c_a_ = 0, c_b_ = 0, c_w0_ = wall_clock64(), c_pp_ = 0, c_fp_[4] = {0, 0, 0, 0}
-#define NT_T2_A c_a_ = __builtin_amdgcn_s_memtime()
-#define NT_T2_B do { c_b_ = __builtin_amdgcn_s_memtime(); c_mul_ += c_b_ - c_a_; ++c_np_; } while (0)
-#define NT_T2_C do { c_fl_ += __builtin_amdgcn_s_memtime() - c_b_; ++c_nf_; } while (0)
-#define NT_T2_P(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); c_fp_[i] += t_ - c_pp_; c_pp_ = t_; } while (0)
-#define NT_T2_P0 c_pp_ = __builtin_amdgcn_s_memtime()
-#define NT_T2_END                                                                                                        \
-    do {                                                                                                                 \
-        unsigned long long tot_ = __builtin_amdgcn_s_memtime() - c_beg_, wtot_ = wall_clock64() - c_w0_;                 \
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(tot_), "+s"(wtot_));   /* both clocks read BEFORE the contended atomics below */ \
-        const int w_ = (blockIdx.y * gridDim.x + blockIdx.x) * NT_WAVES + wave;                                          \
-        if (lane == 0 && w_ < 4096) {                                                                                    \
-            nt_ts2[w_ * 8] = c_mul_; nt_ts2[w_ * 8 + 1] = c_fl_; nt_ts2[w_ * 8 + 2] = c_np_; nt_ts2[w_ * 8 + 3] = c_nf_; \
-            nt_ts2[w_ * 8 + 4] = tot_;                                                                                   \
-        }                                                                                                                \
-        if (lane == 0 && (wave & 3) == 0 && (blockIdx.x & 3) == 0) {   /* a sample of the SIMD pairs: the atomics serialise */ \
-            unsigned long long* s_ = nt_ts2_sum + 8 * (a.npiece < 8 ? a.npiece : 7);                                     \
-            atomicAdd(s_, c_mul_); atomicAdd(s_ + 1, c_fl_); atomicAdd(s_ + 2, c_np_); atomicAdd(s_ + 3, c_nf_);         \
-            atomicAdd(s_ + 4, tot_); atomicAdd(s_ + 5, wtot_);                                                           \
-            atomicAdd(s_ + 6, 1ull);                                                                                     \
-            for (int i_ = 0; i_ < 4; ++i_) atomicAdd(nt_ts2_fp + 4 * (a.npiece < 8 ? a.npiece : 7) + i_, c_fp_[i_]);     \
-        }                                                                                                                \
-    } while (0)
-#else
-#define NT_T2_DECL
-#define NT_T2_P(i)
-#define NT_T2_P0
-#define NT_T2_A
-#define NT_T2_B
-#define NT_T2_C
-#define NT_T2_END
-#endif
 
 // VAR = the multiply variant of the launch (all pieces of a launch share it; chosen on the host, so that a kernel holds at most
 // TWO instantiations of the round loop -- with / without the trailing VALU column, a per-wave property; with more of them in one
@@ -413,7 +335,6 @@ __device__ unsigned long long nt_ts2_fp[8 * 4];    // per class: flush sub-phase
 template <int CT, int VAR>
 __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    NT_TS_DECL;
     constexpr int CTE = CT > 0 ? CT : 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -452,11 +373,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         for (int m = 0; m < NCH; ++m) {
             const uint32_t kk = min((uint32_t)(8 * m + 4 * kh), (uint32_t)kmax0);
             a_cur[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifndef PFN_EXP_COALFIRST   /* experiment switch (wrong results): the first fragment from CONTIGUOUS addresses, 1 KiB per instruction */
             vload_x4(a_cur[m], b0, v0 + ks0 * kk);
-#else
-            vload_x4(a_cur[m], b0, (uint32_t)(m * 1024 + lane * 16) + 0u * (v0 + ks0 * kk));
-#endif
         }
     }
     // ---- weights of every piece -> LDS, once: 1 KiB DMA pieces dealt round-robin to the 8 waves
@@ -485,20 +402,9 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         const float* bsrc = a.rowscale ? a.rowbias : a.bias;
         for (int i = tid; i < a.ldc; i += NT_THREADS) lds[a.bias_lds_off + i] = (bsrc && i < a.ncols) ? bsrc[i] : 0.f;
     }
-#ifdef PFN_EXP_DYN   /* tools/ubench experiment switch (run_gemm_nt_waves.sh): the waves of a block TAKE their row tiles (item i = tile i mod rw
-                        of block step i / rw) from a per-column-group counter in LDS instead of owning a fixed residue class -- measured,
-                        not kept */
-    int* wq = reinterpret_cast<int*>(lds + a.bias_lds_off + ((a.ldc + 3) & ~3));
-    if (tid < 8) wq[tid] = rw;
-#endif
     dma_wait();
     __syncthreads();   // the only barrier: from here on the waves run free
-    NT_TS1;
     if (rt >= nrt || !(mfma_on || rem_on)) return;
-#ifdef PFN_EXP_HALF   /* tools/ubench experiment switch (wrong results: half the tiles are skipped): ONE wave per SIMD -- what a lone stream and an un-starved flush cost */
-    if (wave >= NT_WAVES / 2) return;
-#endif
-    NT_T2_DECL;
 
     EpiCfg ep;
     ep.ncols = a.ncols;
@@ -542,14 +448,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         int np = p + 1, nrt_ = rt;
         if (np == a.npiece) {
             np = 0;
-#ifdef PFN_EXP_DYN
-            int item = 0;
-            if (lane == 0) item = atomicAdd(&wq[cg], 1);
-            item = __builtin_amdgcn_readfirstlane(item);
-            nrt_ = blockIdx.x * rw + (item % rw) + (item / rw) * rt_step;
-#else
             nrt_ = rt + rt_step;
-#endif
         }
         const bool more = nrt_ < nrt;
         const int group = cur_gl & 255;
@@ -624,14 +523,10 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         {
             const float* S = lds + cur_lds;
             const int klen = cur_klen, tsel = cg * CT;
-            NT_T2_A;
             nt_multiply<CT, NR, NFAST, LS>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax,
                                            (uint32_t)nx_kscale);
-            NT_T2_B;
         }
         if (flush_after) {
-            NT_TS2;
-            NT_T2_P0;
             // ---- flush straight from registers: acc[q] of lane (r32, kh) is D[row (q&3) + 8 (q>>2) + 4 kh][col r32];
             // after the quad transpose lane (u = r32 >> 2, j = r32 & 3) holds, for register group g, row
             // rbase + j + 8 g + 4 kh and the four columns col0 .. col0 + 3
@@ -661,7 +556,6 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                     raux = f32x4{raux[0], raux[0], raux[0], raux[0]};
                 }
             }
-            NT_T2_P(0);   // the accumulator hazard wait + the epilogue operands
             // Every epilogue stage is ONE kernel-uniform branch around straight-line code for all 16 values of a tile (a
             // per-element `switch` cost 7 us per flush).  Columns past ncols need no masking: packed weights, bias and
             // rowbias are zero there and the pad columns of resid / gate are zero by the layout invariant, so every stage
@@ -742,7 +636,6 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                                 for (int e = 0; e < 4; ++e) v[g][e] = aux[ct][g][e] > 0.f ? v[g][e] * ep.gate_scale : 0.f;
                         }
                     }
-                    NT_T2_P(1);   // transposes + epilogue arithmetic
                     {   // uniform base + the lane's one offset (see the epilogue-operand loads); a full tile of a full quarter needs no mask
                         const int q = tile0 + ct;
                         const uint32_t vc = lane_off(a.ldc, a.c_cm_rows);
@@ -750,14 +643,9 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
                         for (int g = 0; g < 4; ++g) {
                             const char* cb = reinterpret_cast<const char*>(C + ubase(q, g, a.ldc, a.c_cm_rows));
-#ifndef PFN_EXP_NOSTORE   /* experiment switch */
                             if (unmasked || (rowok(g) && colok(q))) vstore_x4_sv<(CT < 2)>(cb, vc, f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
-#else
-                            if (row_of(g) < 0) vstore_x4_sv<(CT < 2)>(cb, vc, f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
-#endif
                         }
                     }
-                    NT_T2_P(2);   // store issue
                 }
             }
             if (rem_on) {
@@ -801,8 +689,6 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
             racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
-            NT_T2_P(3);   // trailing column + clearing the accumulators
-            NT_T2_C;
         }
         if (!more) break;
         p = np;
@@ -827,8 +713,6 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     } else {
         rounds(I0{}, I4{}, I4{});
     }
-    NT_TS_END;
-    NT_T2_END;
     // CT == 2 exists only for the straight-line variants (the launcher never pairs it with the generic one: two tiles plus
     // four trailing columns plus per-chunk guards do not fit the register file without spills)
 }
@@ -963,12 +847,8 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
         // 17 refills of the previous multiply are younger), every wave is done reading the other buffer: one barrier says both
         if (s == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
-#ifndef PFN_EXP_WS_NOBARRIER   /* tools/ubench experiment switches: never defined in the product build */
         asm volatile("s_barrier" ::: "memory");
-#endif
-#ifndef PFN_EXP_WS_NODMA
         issue_dma(last ? p : np, (s + 1) & 1);              // (nothing follows the last piece: a harmless copy keeps the counts)
-#endif
         // ---- multiply out of buffer s & 1, refilling the fragment for the next piece / row tile
         {
             const int pi = last ? p : np, rti = last ? rt : nrt_;
@@ -1086,11 +966,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
-#ifndef PFN_EXP_NOSTORE   /* experiment switch */
                     if (live && row_of(g) < a.M) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
-#else
-                    if (live && row_of(g) < 0) vstore_x4(dst_of(g), f32x4{v[g][0], v[g][1], v[g][2], v[g][3]});
-#endif
             }
             if (REM) {   // the trailing column (129th): the two k halves, lane half 0 stores
                 float v0 = racc[0] + __shfl_xor(racc[0], 32);
@@ -1294,11 +1170,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     // ---- how many 32-column quarters of every piece fit in LDS at once (tps), and where the launch has to be cut
     auto piece_bytes = [](const NtPiece& pc, int tps) { return (size_t)pc.klen * (32 * tps + 4) * sizeof(float); };
     const size_t bias_bytes = (size_t)round_up((int64_t)a.ldc * sizeof(float), 16);   // the bias image rides behind the pieces
-#ifdef PFN_EXP_DYN
-    const size_t lds_budget = (size_t)NT_LDS_BYTES - bias_bytes - 32;
-#else
     const size_t lds_budget = (size_t)NT_LDS_BYTES - bias_bytes;
-#endif
     int tps = 0;
     if (nq > 0) {
         const int tps_cap = 4;
@@ -1462,11 +1334,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
         }
         int rc = PFN_EINVAL;
         const int var = pick_variant(k, CT);
-#ifdef PFN_EXP_DYN
-        const size_t lb = used + bias_bytes + 32;
-#else
         const size_t lb = used + bias_bytes;
-#endif
 #define PFN_NT_CASE(CT_, V_) if (CT == CT_ && var == V_) rc = launch_variant<CT_, V_>(k, grid, lb, s)
         PFN_NT_CASE(0, 0); PFN_NT_CASE(0, 1); PFN_NT_CASE(0, 2); PFN_NT_CASE(0, 3);
         PFN_NT_CASE(1, 0); PFN_NT_CASE(1, 1); PFN_NT_CASE(1, 2); PFN_NT_CASE(1, 3);
@@ -1481,30 +1349,3 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
 
 }  // namespace pfn
 
-#ifdef NT_EXP_TS2
-extern "C" int pfn_debug_nt_ts2(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::nt_ts2), (size_t)n * sizeof(unsigned long long));
-}
-extern "C" int pfn_debug_nt_ts2_dump() {   // per launch class, over the sampled waves of every launch so far
-    unsigned long long h[64], fp[32];
-    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(pfn::nt_ts2_sum), sizeof(h)) != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(fp, HIP_SYMBOL(pfn::nt_ts2_fp), sizeof(fp)) != hipSuccess) return -1;
-    for (int c = 0; c < 8; ++c) {
-        const unsigned long long* s = h + 8 * c;
-        if (s[6] == 0) continue;
-        const double np = (double)s[2], nf = (double)s[3], nw = (double)s[6];
-        printf("    flush of class %d: hazard wait + operands %.0f | transposes + epilogue %.0f | store issue %.0f | trailing column + clear %.0f cycles\n", c,
-               fp[4 * c] / nf, fp[4 * c + 1] / nf, fp[4 * c + 2] / nf, fp[4 * c + 3] / nf);
-        printf("gemm_nt class %d pieces/tile: %.0f waves | per piece: multiply %.0f cycles, elsewhere %.0f | per flush %.0f | loop cycles per wave %.0f | "
-               "shader clock over the loop %.3f GHz | matrix-pipe cycles needed per piece and SIMD-pair / spent = %.3f\n", c, nw, s[0] / np,
-               ((double)s[4] - s[0] - s[1]) / np, s[1] / nf, s[4] / nw, (double)s[4] / ((double)s[5] * 10.0),
-               (np * 65 * 2 * 64 * 2) / (double)s[4]);
-    }
-    return 0;
-}
-#endif
-#ifdef NT_EXP_TS
-extern "C" int pfn_debug_nt_ts(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::nt_ts), (size_t)n * sizeof(unsigned long long));
-}
-#endif

@@ -609,7 +609,10 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     const bool l0_fly = first_layer_fly(c, lo, seg, fused_front);
     const int ws_stamp = c.need_backward ? WS_STAMP_TRAIN : WS_STAMP_INFER;
     // batches of small graphs: the front AND layer 0's edge stage in one graph-resident launch (ea_seg.hip front_seg_fwd_kernel)
-    const bool seg_front = fused_front && seg_ea && !l0_fly && lo.nlayers > 1 && front_seg_fit(seg, lo.n, lo.h, lo.fe);
+    // (front_seg_fwd_kernel writes no ReLU masks: never where the backward pass of layer 0 would read them -- today the two fit
+    //  predicates exclude that by a grid bound only)
+    const bool seg_front = fused_front && seg_ea && !l0_fly && lo.nlayers > 1 && front_seg_fit(seg, lo.n, lo.h, lo.fe) &&
+                           !(c.need_backward && lo.fe == 2 && !ea_seg_fit(seg, lo.n, lo.fe, lo.ld, true));
     // ... and every layer between that launch and the last layer's 129 -> 4 Linear in ONE persistent launch (seg_chain.hip)
     const bool chain = seg_front && forward_chain_ok(lo, g, seg);
     if (fused_front) {
@@ -788,7 +791,8 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
     const bool meh_rc = front_recomputes_meh(c, lo, seg, fused_front);
     if (meh_rc) {        // ... and mask_embd's weight gradients too, me_h recomputed (front_bwd_wg_kernel; partials in the me_h buffer)
         PFN_TRY(launch_front_bwd_wg(lo.n, lo.h, 2 * lo.f0 + lo.fe, lo.dP[0], lo.dQ[0], lo.maskf, params[0], params[nparams - 4],
-                                    params[nparams - 3], params[nparams - 2], lo.gin[0], lo.me_h, gme[0], gme[1], gme[2], gme[3], s));
+                                    params[nparams - 3], params[nparams - 2], lo.gin[0], lo.me_h, gme[0], gme[1], gme[2], gme[3], s, lo.stamp,
+                                    WS_STAMP_TRAIN));
     } else if (fused_front) {   // g0 = dP0 W1i + dQ0 W1j and dh = (g0 Wb) [me_h > 0] in one launch (front.hip)
         PFN_TRY(launch_front_bwd(lo.n, lo.h, 2 * lo.f0 + lo.fe, lo.dP[0], lo.dQ[0], lo.me_h, params[0], params[nparams - 2],
                                  lo.gin[0], lo.dh, s));
@@ -813,7 +817,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
         ride.fe = lo.fe; ride.ld = lo.ld; ride.h = lo.h;
         PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s, &ride, lo.stamp, WS_STAMP_TRAIN));
     } else {
-        PFN_TRY(launch_dwe_reduce_multi(pairs.dwe.data(), (int)pairs.dwe.size(), lo.fe, lo.ld, lo.h, s));
+        PFN_TRY(launch_dwe_reduce_multi(pairs.dwe.data(), (int)pairs.dwe.size(), lo.fe, lo.ld, lo.h, s, lo.stamp, WS_STAMP_TRAIN));
         PFN_TRY(launch_weight_grads(pairs.pairs.data(), (int)pairs.pairs.size(), lo.n, lo.eas.red, s, nullptr, lo.stamp, WS_STAMP_TRAIN));
     }
     if (gx) PFN_CHECK_HIP(hipMemcpyAsync(gx, gcur, (size_t)lo.n * lo.ld0 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -959,7 +963,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     // (pfn_graph_poison_if_bad): every block sees the same value and leaves, nothing is updated, the step is not counted
     if (guard) {
         const float gv = *guard;
-        if (!(fabsf(gv) <= 3.402823466e+38f)) return;
+        if (!(fabsf(gv) <= 3.402823466e+38f)) {
+            if (blockIdx.x == 0 && threadIdx.x == 0) step[2] += 1;   // skipped updates: visible to the host loop (train_epoch warns)
+            return;
+        }
     }
     // 16 bytes per lane and array when the four flat buffers allow it (they are whole allocations: 256-byte aligned); the
     // update is a chain of dependent loads per element otherwise (10 us for 355 k parameters, 2x its memory time).  A thread's

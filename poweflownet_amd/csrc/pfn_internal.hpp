@@ -526,7 +526,8 @@ struct DweRide {
     DweJobs jobs;
     int njobs = 0, fe = 0, ld = 0, h = 0;
 };
-int launch_dwe_reduce_multi(const DweJob* jobs, int njobs, int fe, int ld, int h, hipStream_t s);
+int launch_dwe_reduce_multi(const DweJob* jobs, int njobs, int fe, int ld, int h, hipStream_t s, const int* stamp = nullptr,
+                            int stamp_want = 0);
 // sums dWe partials [nblocks][fe][ld] into grad_w1[:, 2Fi + f]
 int launch_dwe_reduce(const float* partial, int nblocks, int fe, int ld, int h, float* grad_w1, int ldw, int col0,
                       hipStream_t s);
@@ -559,7 +560,7 @@ int launch_front_bwd(int n, int h, int ldw1, const float* dP, const float* dQ, c
 size_t front_bwd_wg_scratch_floats(int n, int h);
 int launch_front_bwd_wg(int n, int h, int ldw1, const float* dP, const float* dQ, const float* maskf, const float* w1, const float* wa,
                         const float* ba, const float* wb, float* g0, float* scratch, float* gwa, float* gba, float* gwb, float* gbb,
-                        hipStream_t s);
+                        hipStream_t s, const int* stamp = nullptr, int stamp_want = 0);
 // mask_embd's hidden layer written from the float mask rows after the fact (the gate export), bit-identical to the front's
 int launch_front_meh(int n, int h, const void* mask, int mask_dtype, const float* wa, const float* ba, float* me_h, hipStream_t s);
 // P | Q of the first layer written from x0 after the fact (FrontFwdArgs::P null in the forward pass), bit-identical to the front's
@@ -576,11 +577,7 @@ int launch_pad_rows(const float* src, int64_t ld_src, float* dst, int64_t ld_dst
 __device__ __forceinline__ void st4_wt(float* p, float4 v) {
     typedef float f4wt_ __attribute__((ext_vector_type(4)));
     const f4wt_ d = {v.x, v.y, v.z, v.w};
-#ifdef PFN_EXP_ST_PLAIN      /* experiment switch: the plain store */
-    *reinterpret_cast<float4*>(p) = v;
-#else
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(d) : "memory");
-#endif
 }
 
 // ---------------------------------------------------------------------------------------- dropout RNG
@@ -599,11 +596,8 @@ __host__ __device__ __forceinline__ DropKey drop_key(uint64_t seed, uint64_t off
     return k;
 }
 __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-#ifndef PFN_EXP_PHILOX_ROUNDS   /* tools experiment switch (a DIFFERENT, weaker generator): what do the ten rounds cost a step? */
-#define PFN_EXP_PHILOX_ROUNDS 10
-#endif
 #pragma unroll
-    for (int r = 0; r < PFN_EXP_PHILOX_ROUNDS; ++r) {
+    for (int r = 0; r < 10; ++r) {
         // (one 64-bit product per multiplier -- v_mad_u64_u32 -- instead of v_mul_hi_u32 + v_mul_lo_u32: 32-bit integer multiplies
         //  are quarter rate, and the ten rounds are most of a dropout epilogue's instruction time)
         const uint64_t p0 = (uint64_t)0xD2511F53u * c[0], p1 = (uint64_t)0xCD9E8D57u * c[2];

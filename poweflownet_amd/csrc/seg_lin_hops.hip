@@ -27,22 +27,6 @@ __device__ __forceinline__ float4 slh_sel4(bool k, float4 a, float4 b) {   // (e
     return make_float4(k ? a.x : b.x, k ? a.y : b.y, k ? a.z : b.z, k ? a.w : b.w);
 }
 
-// tools/ubench experiment switches (never defined in the product build): SLH_EXP_TS = wall-clock (100 MHz) timestamps of the phases,
-// one record per workgroup of the LAST launch, read back with pfn_debug_slh_ts(); SLH_EXP_COAL = the A fragments loaded from
-// CONTIGUOUS addresses (same instruction and byte count, wrong results): what the row-per-lane gather costs
-#ifdef SLH_EXP_TS
-__device__ unsigned long long slh_ts[4096 * 8];
-#define SLH_TS(slot)                                                                                                  \
-    do {                                                                                                              \
-        if (threadIdx.x == 0) {                                                                                       \
-            const int b_ = blockIdx.y * gridDim.x + blockIdx.x;                                                       \
-            if (b_ < 4096) slh_ts[b_ * 8 + (slot)] = wall_clock64();                                                  \
-        }                                                                                                             \
-    } while (0)
-#else
-#define SLH_TS(slot) do { } while (0)
-#endif
-
 constexpr int SLH_REM_FLOATS = SG_NCH * 32;   // trailing-column image of one term: 34 k groups x [4 columns][4 k's]
 
 struct SlhLds {
@@ -137,25 +121,9 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
     const int K8 = 8 * SG_NCH;                       // (the launcher admits K8 == 136 only: straight-line multiply)
     // ---- prologue: EVERY global load is requested before the first LDS store (cf. ea_seg.hip)
     SegA ta;
-    SLH_TS(0);
-#ifdef SLH_EXP_NOA
-    if (mfma_on) {
-#pragma unroll
-        for (int m = 0; m < SG_NCH; ++m) ta.av[m] = f32x4{1.f * m, 2.f, 3.f, 1.f * lane};
-    }
-#elif !defined(SLH_EXP_COAL)
     if (mfma_on) seg_load_a(ta, (NTERM > 1 && mterm) ? a.A1 : a.A0, a.lda, K8, r0 + 32 * mtile, r0 + rows - 1, lane);
-#else
-    if (mfma_on) {
-        const float* base = ((NTERM > 1 && mterm) ? a.A1 : a.A0) + (size_t)(r0 + 24 * mtile) * a.lda;
-#pragma unroll
-        for (int m = 0; m < SG_NCH; ++m) ta.av[m] = *reinterpret_cast<const f32x4*>(base + m * 256 + lane * 4);
-    }
-#endif
-#ifndef SLH_EXP_NOB
     seg_copy_b(l.B[0], a.B0, sc.q, K8, wave, lane);
     if (NTERM > 1) seg_copy_b(l.B[1], a.B1, sc.q, K8, wave, lane);
-#endif
     const int e0 = rowptr[r0], ne = rowptr[r0 + rows] - e0;
     const bool nb_in_lds = ne <= cap;
     const int rpv = tid <= rows ? rowptr[r0 + tid] : 0;
@@ -202,7 +170,6 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
         gbits |= ((gv[j].x > 0.f ? 1u : 0u) | (gv[j].y > 0.f ? 2u : 0u) | (gv[j].z > 0.f ? 4u : 0u) | (gv[j].w > 0.f ? 8u : 0u)) << (4 * j);
     seg_dma_wait();
     __syncthreads();
-    SLH_TS(1);
     // ---- the Linear's tiles.  The terms of a tile go into ONE accumulator chain in term order (gemm_nt's order: bit-identical
     // sums): the wave that owns (tile, term 1) takes over the accumulators -- and the trailing column's two half-chains -- that
     // the wave of (tile, term 0) leaves in LDS.  (One wave running both terms needs the second fragment refilled in place under
@@ -232,7 +199,6 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
         }
         __syncthreads();
     }
-    SLH_TS(2);
     // ---- epilogue, item = (row, float4 chunk): gemm_nt's expressions element for element; result -> y and back into the tile
     DropKey dk = DropKey{0u, 0u, 0u, 0u};
     float keep_scale = 1.f;
@@ -274,7 +240,6 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
         }
     }
     seg_lds_barrier();   // (not __syncthreads(): the y stores drain while the hops run)
-    SLH_TS(3);
     // ---- K hops, ping-pong between the two tiles (fused_hops_kernel's walk: four slots per trip, edge-id order).  A row's first
     // four slots -- all of most rows of a power grid -- are planned ONCE for the K hops: tile offsets of the neighbour rows and the
     // edge weights dinv[src] * dinv[dst] in registers, so a hop is four independent tile reads and four fmas per item instead of
@@ -384,7 +349,6 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
             nxt = t;
         }
     }
-    SLH_TS(4);
 }
 
 // ------------------------------------------------------------------------------------------------ host
@@ -441,8 +405,3 @@ int launch_seg_lin_hops(const GraphView& g, const SegLinHopsArgs& a, int seg, hi
 
 }  // namespace pfn
 
-#ifdef SLH_EXP_TS
-extern "C" int pfn_debug_slh_ts(unsigned long long* out, int n) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pfn::slh_ts), (size_t)n * sizeof(unsigned long long));
-}
-#endif

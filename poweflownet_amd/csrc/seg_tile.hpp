@@ -26,11 +26,7 @@ __device__ __forceinline__ void seg_load_a(SegA& t, const float* __restrict__ A,
 #pragma unroll
     for (int m = 0; m < SG_NCH; ++m) {
         const int mc = min(m, (K8 >> 3) - 1);                        // clamped: chunks past K8 are loaded but not multiplied
-#ifndef SG_EXP_NOLOAD   /* tools/ubench experiment switches (results wrong by design): never defined in the product build */
         t.av[m] = *reinterpret_cast<const f32x4*>(arow + min(8 * mc + 4 * kh, kmax));
-#else
-        t.av[m] = f32x4{1.f * mc, 2.f, 3.f, 4.f};
-#endif
     }
 }
 // One 1 KiB LDS-DMA (64 lanes x 16 bytes; LDS destination = wave-uniform base + lane * 16); inline asm as in gemm_nt.hip: hidden
@@ -77,11 +73,7 @@ __device__ __forceinline__ f32x16 seg_mma_t(const SegA& t, const float* bl, int 
             f32x4 bn = b;
             if (FULL ? m + 1 < SG_NCH : 8 * (m + 1) < K8) bn = *reinterpret_cast<const f32x4*>(bp + (m + 1) * 256);
 #pragma unroll
-#ifndef SG_EXP_NOMFMA
             for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.av[m][i], b[i], acc, 0, 0, 0);
-#else
-            for (int i = 0; i < 4; ++i) acc[i] += t.av[m][i] * b[i];
-#endif
             b = bn;
         }
     }

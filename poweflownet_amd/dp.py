@@ -131,27 +131,65 @@ def allreduce_gradients(model: torch.nn.Module, ordered_params=None) -> None:
             off += g.numel()
 
 
-class GraphedStep:
-    """`fwd_bwd()` -> gradient all-reduce -> `opt_step()` replayed from hipGraphs.
+DP_MODES = ("graph", "split", "eager")
 
-    Without a process group: ONE graph.  With RCCL (`backend == "nccl"`): still ONE graph -- `ncclAllReduce` is captured
-    between the backward pass and the optimizer kernel like any other node (RCCL supports stream capture; the process group's
-    watchdog thread queries events, hence thread-local capture mode), so a data-parallel step costs one graph launch and the
-    collective starts the moment the last gradient kernel retires.  With any other backend (gloo in the one-GPU plumbing
-    tests: its all-reduce goes through the host and cannot be captured), or when the one-graph capture fails: graph(fwd+bwd),
-    an eager all-reduce, graph(optimizer).  `mode` says which of the three was built.
+
+def dp_mode_from_env(default: str = "graph") -> str:
+    """PFN_DP_MODE = graph | split | eager: the launch form of a data-parallel step (see GraphedStep)."""
+    mode = os.environ.get("PFN_DP_MODE", default)
+    if mode not in DP_MODES:
+        raise ValueError(f"PFN_DP_MODE={mode!r}: expected one of {DP_MODES}")
+    return mode
+
+
+def all_ranks_agree(ok: bool, device=None) -> bool:
+    """True iff EVERY rank passes True (one tiny MIN all-reduce, outside any stream capture): the ranks of a data-parallel job
+    must never end up in different launch forms -- one would wait in a collective the other never enters."""
+    if not active():
+        return bool(ok)
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if (torch.cuda.is_available() and dist.get_backend() == "nccl") else torch.device("cpu")
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return bool(flag.item())
+
+
+class GraphedStep:
+    """`fwd_bwd()` -> gradient all-reduce -> `opt_step()`, replayed.  Three launch forms (`mode`, default PFN_DP_MODE or "graph"):
+
+    * "graph": ONE hipGraph.  Without a process group that is all there is.  With RCCL (`backend == "nccl"`) `ncclAllReduce` is
+      captured between the backward pass and the optimizer kernel like any other node (RCCL supports stream capture; the process
+      group's watchdog thread queries events, hence thread-local capture mode): one graph launch per step, the collective starts
+      the moment the last gradient kernel retires.  A backend that cannot be captured (gloo in the one-GPU plumbing tests: its
+      all-reduce goes through the host) takes "split".
+    * "split": graph(fwd+bwd) -> an eager all-reduce -> graph(optimizer).
+    * "eager": no graph at all -- the three calls, every step (the fallback of last resort, and the form to bring up a new
+      multi-GPU box with).
+
+    A capture that fails on ANY rank demotes EVERY rank to the next form (the success flag is MIN-all-reduced before a form is
+    chosen; `form` says which one was built): ranks never disagree on how a step is launched.  `extra` are device tensors
+    SUM-all-reduced next to the gradients (the optimizer's guard scalar: a NaN loss on one rank must skip the update on all).
 
     `fwd_bwd` must write its loss into tensors it returns (kept as `self.out`); capture happens on the current stream after the
     caller's own warm-up (the process group's communicator must already exist: run at least one eager all-reduce first)."""
 
-    def __init__(self, fwd_bwd, opt_step, model=None, allreduce: Optional[bool] = None):
+    def __init__(self, fwd_bwd, opt_step, model=None, allreduce: Optional[bool] = None, mode: Optional[str] = None, extra=()):
         self.fwd_bwd, self.opt_step, self.model = fwd_bwd, opt_step, model
         self.allreduce = active() if allreduce is None else (allreduce and active())
-        self.graphs, self.mode, self.out = [], None, None
+        self.requested = dp_mode_from_env() if mode is None else mode
+        if self.requested not in DP_MODES:
+            raise ValueError(f"GraphedStep mode {self.requested!r}: expected one of {DP_MODES}")
+        self.extra = list(extra)
+        self.graphs, self.mode, self.form, self.out = [], None, None, None
         self._flat, self._grads = None, None       # split form: the gradient tensors the CAPTURED backward writes
+
+    def _reduce_extra(self):
+        for t in self.extra:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     def _reduce(self):
         allreduce_gradients(self.model)
+        self._reduce_extra()
 
     def _remember_captured_grads(self):
         """Split form only: the eager all-reduce between the two graphs must reduce the buffers the captured backward writes and
@@ -168,44 +206,80 @@ class GraphedStep:
     def _reduce_captured(self):
         if self._flat is not None:
             allreduce_flat(self._flat)
-            return
-        flat = torch.cat([g.reshape(-1) for g in self._grads])
-        allreduce_flat(flat)
-        off = 0
-        for g in self._grads:
-            g.copy_(flat[off:off + g.numel()].view_as(g))
-            off += g.numel()
+        else:
+            flat = torch.cat([g.reshape(-1) for g in self._grads])
+            allreduce_flat(flat)
+            off = 0
+            for g in self._grads:
+                g.copy_(flat[off:off + g.numel()].view_as(g))
+                off += g.numel()
+        self._reduce_extra()
+
+    def _try(self, build) -> bool:
+        """Run one capture attempt; True iff it succeeded on EVERY rank."""
+        err = None
+        try:
+            build()
+        except Exception as exc:                   # noqa: BLE001
+            err = exc
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        if not self.allreduce:
+            if err is not None:
+                raise err
+            return True
+        if all_ranks_agree(err is None):
+            return True
+        self.graphs = []
+        self._last_error = err
+        return False
 
     def capture(self):
         kw = {"capture_error_mode": "thread_local"} if self.allreduce else {}
-        if not self.allreduce or dist.get_backend() == "nccl":
-            g = torch.cuda.CUDAGraph()
-            try:
+        want = self.requested
+        if want == "graph" and self.allreduce and dist.get_backend() != "nccl":
+            want = "split"                         # (decided from the backend: the same on every rank)
+        if want == "graph":
+            def one():
+                g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, **kw):
                     self.out = self.fwd_bwd()
                     if self.allreduce:
                         self._reduce()
                     self.opt_step()
-                self.graphs, self.mode = [g], ("one graph incl. RCCL all-reduce" if self.allreduce else "one graph")
+                self.graphs = [g]
+            if self._try(one):
+                self.form = "graph"
+                self.mode = "one graph incl. RCCL all-reduce" if self.allreduce else "one graph"
                 return self
-            except Exception:                      # noqa: BLE001
-                if not self.allreduce:
-                    raise
-                torch.cuda.synchronize()           # a collective that would not capture: fall through to the split form
-        g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_fb, **kw):
-            self.out = self.fwd_bwd()
-        self._remember_captured_grads()
-        with torch.cuda.graph(g_opt, **kw):
-            self.opt_step()
-        self.graphs, self.mode = [g_fb, g_opt], "graph(fwd+bwd) -> eager all-reduce -> graph(optimizer)"
+            want = "split"
+        if want == "split":
+            def two():
+                g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_fb, **kw):
+                    self.out = self.fwd_bwd()
+                self._remember_captured_grads()
+                with torch.cuda.graph(g_opt, **kw):
+                    self.opt_step()
+                self.graphs = [g_fb, g_opt]
+            if self._try(two):
+                self.form = "split"
+                self.mode = "graph(fwd+bwd) -> eager all-reduce -> graph(optimizer)"
+                return self
+        self.graphs, self.form, self.mode = [], "eager", "eager launches (no graph)"
         return self
 
     def replay(self):
-        if len(self.graphs) == 1:
+        if self.form == "eager":
+            self.out = self.fwd_bwd()
+            if self.allreduce:
+                self._reduce()
+            self.opt_step()
+        elif len(self.graphs) == 1:
             self.graphs[0].replay()
         else:
             self.graphs[0].replay()
-            self._reduce_captured()
+            if self.allreduce:
+                self._reduce_captured()
             self.graphs[1].replay()
         return self.out

@@ -30,7 +30,7 @@ class FlatAdamW(torch.optim.Optimizer):
         self.flat_param = flat
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self.step_count = torch.zeros(2, dtype=torch.int64, device=flat.device)   # {steps done, arrival scratch}
+        self.step_count = torch.zeros(3, dtype=torch.int64, device=flat.device)   # {steps done, arrival scratch, skipped (guard)}
         self._gather = None
         # optional device scalar (a loss): the update is SKIPPED on the device when it is not finite -- set by a caller whose
         # step may be fed a batch it could not validate on the host (GraphedTrainStep with per-batch topologies)
@@ -71,6 +71,10 @@ class FlatAdamW(torch.optim.Optimizer):
                 self._gather[off:off + n].copy_(p.grad.reshape(-1))
             off += n
         return self._gather
+
+    def skipped_steps(self) -> int:
+        """Updates the device-side guard has skipped so far (a host read: call it once per epoch, not per step)."""
+        return int(self.step_count[2].item())
 
     @torch.no_grad()
     def step(self, closure=None):

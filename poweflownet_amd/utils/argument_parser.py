@@ -41,6 +41,9 @@ def argument_parser(argv=None):
     p.add_argument("--save", default=True, action=argparse.BooleanOptionalAction)
     # additions of this build (not in the reference): synthetic data size
     p.add_argument("--synthetic-samples", type=int, default=512)
+    # ... and the launch form of the training step (poweflownet_amd.dp.GraphedStep): one hipGraph incl. the gradient all-reduce,
+    # graph / eager all-reduce / graph, or eager launches.  Default: PFN_DP_MODE or "graph"; ranks always agree on the form.
+    p.add_argument("--dp-mode", type=str, default=None, choices=["graph", "split", "eager"])
     args, left = cfg.parse_known_args(argv)
     if args.cfg_json is not None:
         path = args.cfg_json

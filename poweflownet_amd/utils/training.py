@@ -57,8 +57,10 @@ class GraphedTrainStep:
     edge_index buffer, checks left on the device -- a bad batch gives a NaN loss, see GraphCSR.unverified), so per-batch
     topologies replay too, with no host sync per step (the reference syncs in every forward, networks/MPN.py:498-504)."""
 
-    def __init__(self, model, loss_fn, optimizer, allreduce: Optional[bool] = None):
+    def __init__(self, model, loss_fn, optimizer, allreduce: Optional[bool] = None, dp_mode: Optional[str] = None):
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
+        self.dp_mode = dp_mode     # graph | split | eager (dp.GraphedStep; None: PFN_DP_MODE or "graph")
+        self._guard_buf = None     # data parallel + guarded update: the loss, SUM-all-reduced, so that every rank skips together
         # data parallel (dp.py): the gradient all-reduce is part of the replayed step -- ONE hipGraph with the RCCL collective
         # captured between backward and optimizer, or graph / eager all-reduce / graph for a backend that cannot be captured
         self.allreduce = (dp.world_size() > 1) if allreduce is None else bool(allreduce)
@@ -167,6 +169,12 @@ class GraphedTrainStep:
         if self.dynamic:
             self._set_dynamic_topology(True)
         guarded = self.dynamic and hasattr(self.opt, "guard")
+        # a guarded update under data parallelism must be decided on a value EVERY rank sees: one rank's bad batch reaches the
+        # others only as NaN gradients through the all-reduce -- their own losses are finite -- so the losses are summed across
+        # ranks (NaN / inf survive a sum) next to the gradients and every rank skips, or none does
+        shared_guard = guarded and self.allreduce and dp.active()
+        if shared_guard and self._guard_buf is None:
+            self._guard_buf = torch.zeros((), dtype=torch.float32, device=data.x.device)
         try:
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                          # warm-up off the capture stream (allocator, adjacency cache)
@@ -183,9 +191,14 @@ class GraphedTrainStep:
                     # unverified batches: a bad one (ids out of range, edges across the claimed graph boundaries) reaches the
                     # step as a NaN loss (pfn_graph_poison_if_bad); the captured update then SKIPS instead of turning every
                     # parameter NaN for good (the reference would have raised before the step)
-                    self.opt.guard = box["loss"]
+                    if shared_guard:
+                        self._guard_buf.copy_(box["loss"])
+                        self.opt.guard = self._guard_buf
+                    else:
+                        self.opt.guard = box["loss"]
                 return box["loss"]
-            self.graph = dp.GraphedStep(fwd_bwd, self.opt.step, self.model, self.allreduce).capture()
+            self.graph = dp.GraphedStep(fwd_bwd, self.opt.step, self.model, self.allreduce, mode=self.dp_mode,
+                                        extra=[self._guard_buf] if shared_guard else ()).capture()
         finally:
             if guarded:
                 self.opt.guard = None
@@ -243,7 +256,7 @@ class GraphedTrainStep:
             self.opt.sync_hyper()                                  # a scheduler moved lr / betas: 20 bytes to the device
         for k in ("x", "y", "pred_mask", "edge_attr") + (("edge_index",) if self.dynamic else ()):
             getattr(self.static, k).copy_(getattr(data, k))
-        self.graph.replay()
+        self.loss = self.graph.replay()            # (graph forms: the captured loss tensor; the eager form: this step's)
         return self.loss
 
 
@@ -279,4 +292,14 @@ def train_epoch(model: nn.Module, loader, loss_fn: Callable, optimizer, device, 
         num_samples += len(data)
         term = loss.detach().double() * len(data)
         total = term if total is None else total + term
+    skipped = getattr(optimizer, "skipped_steps", None)
+    if skipped is not None and graph is not None and graph.dynamic:
+        # the guarded update (FlatAdamW.guard) skips on a non-finite loss without telling the host: say so once per epoch, so a
+        # poisoned batch -- or a run that has diverged for good -- does not replay silently (the reference would have raised)
+        n_skipped = skipped()
+        if n_skipped > getattr(graph, "_skipped_seen", 0):
+            import warnings
+            warnings.warn(f"train_epoch: {n_skipped - getattr(graph, '_skipped_seen', 0)} optimizer update(s) skipped this epoch "
+                          f"(non-finite loss: a batch flagged bad on the device, or a diverged run)")
+            graph._skipped_seen = n_skipped
     return float(total.item()) / max(num_samples, 1) if total is not None else 0.0

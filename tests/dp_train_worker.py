@@ -34,29 +34,36 @@ def main():
     ds = PowerFlowData(root=root, case=case, split=[.5, .25, .25], task="train", device=dev)
     shard = (rank, world) if world > 1 else None
 
-    def run(graphed):
+    def run(graphed, dp_mode=None):
         torch.manual_seed(1234)
         model = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).to(dev).train()
         opt = FlatAdamW(model, lr=1e-3)
         loader = DataLoader(ds, batch_size=gb * world, shard=shard)      # one topology tensor per batch size -> replays
-        g = GraphedTrainStep(model, MSELoss(), opt, allreduce=True) if graphed else None
+        g = GraphedTrainStep(model, MSELoss(), opt, allreduce=True, dp_mode=dp_mode) if graphed else None
         losses = [train_epoch(model, loader, MSELoss(), opt, dev, allreduce=True, graph=g) for _ in range(2)]
         torch.cuda.synchronize()
         mode = None
         if g is not None:
             assert g.graph is not None and not g.disabled, "the data-parallel step was not captured"
             mode = g.graph.mode
+            if dp_mode is not None:
+                mode = g.graph.form
         return opt.flat_param.detach().clone(), losses, mode
 
     p_graph, l_graph, mode = run(True)
     p_eager, l_eager, _ = run(False)
+    # the three launch forms of dp.GraphedStep, asked for by name: the same kernels in the same order -> the same bits
+    forms = {}
+    for want in ("graph", "split", "eager"):
+        p_m, l_m, form = run(True, want)
+        forms[want] = {"form": form, "max_abs_diff": float((p_m - p_eager).abs().max()), "losses_equal": l_m == l_eager}
     gathered = [torch.zeros_like(p_graph) for _ in range(world)]
     torch.distributed.all_gather(gathered, p_graph)
     assert all(torch.equal(t, gathered[0]) for t in gathered), "replicas diverged"
     if rank == 0:
         with open(out_path, "w") as f:
             json.dump({"mode": mode, "max_abs_diff": float((p_graph - p_eager).abs().max()), "scale": float(p_eager.abs().max()),
-                       "losses_graph": l_graph, "losses_eager": l_eager, "world": world,
+                       "losses_graph": l_graph, "losses_eager": l_eager, "world": world, "forms": forms,
                        "backend": torch.distributed.get_backend()}, f)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

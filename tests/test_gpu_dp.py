@@ -166,6 +166,26 @@ def test_graphed_train_step_under_dp_equals_eager_dp(tmp_path, world):
     assert got["mode"] == want_mode and got["world"] == world, got
     assert got["max_abs_diff"] == 0.0, got
     assert got["losses_graph"] == got["losses_eager"], got
+    # --dp-mode / PFN_DP_MODE: every form asked for by name lands where it should (a backend that cannot be captured turns
+    # "graph" into "split" on every rank alike) and all of them give the eager loop's parameters bit for bit
+    want_forms = {"graph": "graph" if world == 1 else "split", "split": "split", "eager": "eager"}
+    for name, rec in got["forms"].items():
+        assert rec["form"] == want_forms[name] and rec["max_abs_diff"] == 0.0 and rec["losses_equal"], (name, rec)
+
+
+def test_guarded_update_is_rank_consistent_under_dp(tmp_path):
+    """with per-batch topologies the captured step guards its AdamW update on the loss; under data parallelism a bad
+    batch on ONE rank reaches the others only as NaN gradients through the all-reduce.  The guard is therefore the rank-SUMMED
+    loss (all-reduced next to the gradients): every rank skips that update, replicas stay bit-identical and finite, and the skip
+    is counted in step_count[2] on every rank.  Two ranks on the one GPU (gloo), the last rank poisons its batch at step 2."""
+    out_path = str(tmp_path / "dp_guard.json")
+    script = [os.path.join(ROOT, "tests", "dp_guard_worker.py"), out_path, "2", "5"]
+    cmd, env = _torchrun(2, script, {"PFN_SINGLE_DEVICE": "1", "PFN_DIST_BACKEND": "gloo"})
+    _run(cmd, env, 420)
+    got = json.load(open(out_path))
+    assert got["replicas_equal"] and got["finite"], got
+    assert got["step_counts"] == [[4, 0, 1], [4, 0, 1]], got          # four updates applied, one skipped -- on BOTH ranks
+    assert all(l == l for l in got["losses_rank0"]), got               # rank 0's own losses were finite all along
 
 
 def test_bench_rccl_collective_path_world1():

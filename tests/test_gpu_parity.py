@@ -9,7 +9,7 @@ import torch
 from oracle import ref_cpu
 from poweflownet_amd.networks.MPN import EdgeAggregation, GraphCSR, MaskEmbdMultiMPN, TAGConv
 from poweflownet_amd.synth import make_batch
-from tests.util import RTOL, assert_close, data_from, load, params_from, record, rel_err
+from tests.util import RTOL, assert_close, data_from, load, params_from, record, record_elementwise, rel_err
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -228,7 +228,7 @@ def test_g6_flat_adamw_matches_reference_steps():
         loss.backward()
         opt.step()
         assert_close(loss, fx[f"loss.{step}"], RTOL, f"loss.{step}")
-    assert opt.step_count.tolist() == [3, 0]
+    assert opt.step_count.tolist() == [3, 0, 0]
     for k, p in m.named_parameters():
         ref, g = fx[f"param_after3.{k}"], g4[f"grad.{k}"]
         err = (p.detach().cpu() - ref).abs()
@@ -1242,7 +1242,7 @@ def _assert_grads_on_hip_gates(m, ref, data, what, out=None, gates=None):
         assert_close(p.grad, t.grad, RTOL, f"{what}: grad.{k} vs fp64 oracle on the HIP gates")
 
 
-def _check_full_size(m, ref, data, what, max_flips_per_site=64):
+def _check_full_size(m, ref, data, what, max_flips_per_site=64, ungated=False):
     """Forward + every parameter gradient of the HIP model `m` (eval mode, parameters == `ref`'s) at a BASELINE.json size.
     Forward: north_star's 1e-5 against the fp32 oracle AND the float64 oracle (each on its own ReLU decisions).  Gradients:
     1e-5 against the float64 oracle held to the HIP forward's ReLU decisions (_assert_grads_on_hip_gates); the number of
@@ -1256,6 +1256,13 @@ def _check_full_size(m, ref, data, what, max_flips_per_site=64):
     out = m(dd)
     assert_close(out, out_ref, RTOL, f"{what}: out vs fp32 oracle")
     assert_close(out, out64.float(), RTOL, f"{what}: out vs fp64 oracle")
+    # ... and the elementwise reading of the same tolerance (entries far below the tensor's maximum get a relative bound too):
+    # |a - b| <= 1e-5 |b| + 1e-6 max|b|.  RECORDED for both the HIP path and the fp32 oracle (gpurun_out/parity_report.json; round 5:
+    # 0 entries exceed it at configs 3 and 4, 1 of 60,416 at config 2 at 1.2 x the bound, 17 of 60,416 for hidden 512 at 2.0 x --
+    # the MFMA k order against the oracle's); asserted only as far as that justifies: <= 0.1 % of the entries, none beyond 4 x.
+    bad, total, worst = record_elementwise(out, out64, f"{what}: out vs fp64 oracle")
+    record_elementwise(out_ref, out64, f"{what}: fp32 ORACLE out vs fp64 oracle")
+    assert bad <= 1e-3 * total and worst <= 4.0, (what, bad, total, worst)
     loss = torch.nn.MSELoss()(out, dd.y)
     loss.backward()
     gates = _cpu_gates(m)
@@ -1265,6 +1272,19 @@ def _check_full_size(m, ref, data, what, max_flips_per_site=64):
     assert max(flips.values()) <= max_flips_per_site, flips
     del own64
     _assert_grads_on_hip_gates(m, ref, data, what, out, gates)
+    if ungated:
+        # the UNMODIFIED reference dataflow: the fp32 oracle on its own ReLU decisions.  A handful of flipped gates moves single
+        # weight gradients by 1e-5..2e-4 of their largest entry (see _assert_grads_on_hip_gates), so this is RECORDED, and
+        # bounded only by what two fp32 arithmetic orders of the same function can differ by
+        ref.zero_grad(set_to_none=True)
+        torch.nn.MSELoss()(ref(data), data.y).backward()
+        worst = 0.0
+        for (k, p), t in zip(m.named_parameters(), ref.parameters()):
+            err, scale = rel_err(p.grad, t.grad)
+            record(f"{what}: grad.{k} vs the UNGATED fp32 oracle", err, scale, 5e-4)
+            worst = max(worst, err / max(scale, 1e-300))
+        ref.zero_grad(set_to_none=True)
+        assert worst <= 5e-4, (what, worst)
 
 
 def test_config2_full_size_vs_oracle():
@@ -1275,7 +1295,53 @@ def test_config2_full_size_vs_oracle():
     m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0)
     m.load_state_dict(ref.state_dict())
     m = m.to(DEV).eval()
-    _check_full_size(m, ref, make_batch("118v2", 128, seed=0), "config 2")
+    _check_full_size(m, ref, make_batch("118v2", 128, seed=0), "config 2", ungated=True)
+
+
+def _as_real_dataset(data, seed):
+    """Give a synthetic batch the masked-entry statistics of the reference's datasets (datasets/PowerFlowData.py:126-139): x and y are
+    z-scored with per-feature statistics AFTER x = y * (1 - mask), so a masked entry of x is the per-feature CONSTANT -mean/std,
+    not 0, and y keeps a per-feature offset and scale."""
+    g = torch.Generator().manual_seed(seed)
+    mean = torch.tensor([1.0, 0.0, 0.3, 0.1]) + 0.2 * torch.randn(4, generator=g)
+    std = torch.tensor([0.05, 8.0, 1.2, 0.6]) * (1.0 + 0.2 * torch.rand(4, generator=g))
+    raw_y = data.y * std + mean                                 # "physical" values whose z-score is data.y
+    raw_x = raw_y * (1.0 - data.pred_mask.float())
+    data.x = (raw_x - mean) / std                               # masked entries: -mean / std, per feature
+    data.y = (raw_y - mean) / std
+    return data
+
+
+def test_config2_with_real_dataset_masked_entry_statistics():
+    """The metric configuration with inputs shaped like the reference's normalised datasets (masked entries of x = the constant
+    -mean/std per feature, datasets/PowerFlowData.py:126-139) instead of synth's zeros: forward and all gradients at 1e-5."""
+    torch.manual_seed(1234)
+    ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).eval()
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0)
+    m.load_state_dict(ref.state_dict())
+    m = m.to(DEV).eval()
+    data = _as_real_dataset(make_batch("118v2", 128, seed=3), seed=11)
+    assert (data.x[data.pred_mask.bool()].abs() > 1e-3).any()
+    _check_full_size(m, ref, data, "config 2, real-dataset masked-entry statistics")
+
+
+@pytest.mark.parametrize("dtype", [torch.int32, torch.bool, torch.uint8, torch.float32, torch.float64, torch.int16])
+def test_pred_mask_dtypes_go_through_float(dtype):
+    """`pred_mask` may arrive in any int / float dtype: the reference applies `.float()` (networks/MPN.py:533).  int64 takes the
+    kernel's own conversion, everything else `.float()` first -- the output and every gradient carry the int64 run's bits."""
+    torch.manual_seed(3)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).to(DEV).eval()
+    d = make_batch("14", 9, seed=2).to(DEV)
+    assert d.pred_mask.dtype == torch.int64
+    out0 = m(d)
+    torch.nn.MSELoss()(out0, d.y).backward()
+    g0 = m.flat_grad().clone()
+    m.zero_grad(set_to_none=True)
+    d2 = d.clone()
+    d2.pred_mask = d.pred_mask.to(dtype)
+    out1 = m(d2)
+    torch.nn.MSELoss()(out1, d2.y).backward()
+    assert torch.equal(out0, out1) and torch.equal(g0, m.flat_grad())
 
 
 def test_large_json_h512_case118_batch128_vs_oracle():

@@ -107,6 +107,41 @@ def test_dp_world2_gloo_equals_single_process_global_batch():
     assert (got - want).abs().max().item() <= 1e-6 * want.abs().max().item() + 1e-9
 
 
+def _agree_worker(rank, w, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=w)
+    from poweflownet_amd import dp
+    calls = []
+    gs = dp.GraphedStep(lambda: calls.append("fb") or torch.zeros(()), lambda: calls.append("opt"), model=None, allreduce=True, mode="graph")
+    gs._reduce = lambda: calls.append("reduce")
+    gs._reduce_captured = gs._reduce
+    # a capture attempt that fails on rank 1 ONLY: every rank must report failure (and then agree on the next form)
+    def build():
+        if rank == 1:
+            raise RuntimeError("capture failed here")
+        gs.graphs = ["a graph"]
+    ok_mixed = gs._try(build)
+    ok_all = gs._try(lambda: None)
+    # no GPU in this process: both graph forms fail on every rank -> everybody lands in "eager", whose replay is the three calls
+    gs.capture()
+    gs.replay()
+    ret[rank] = (ok_mixed, ok_all, gs.form, list(gs.graphs), calls[-3:])
+    dist.destroy_process_group()
+
+
+def test_dp_ranks_agree_on_the_launch_form():
+    """dp.GraphedStep: a capture that fails on ONE rank demotes EVERY rank (the success flag is MIN-all-reduced before a form is
+    chosen), so ranks never disagree on how a step is launched; world 2 over gloo, no GPU: both graph forms fail everywhere and
+    the step runs as eager launches (fwd_bwd, all-reduce, optimizer)."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_agree_worker, args=(2, port, ret), nprocs=2, join=True)
+    for rank in (0, 1):
+        ok_mixed, ok_all, form, graphs, calls = ret[rank]
+        assert ok_mixed is False and ok_all is True and form == "eager" and graphs == [] and calls == ["fb", "reduce", "opt"], (rank, ret[rank])
+
+
 def test_evaluation_metrics_and_evaluate_epoch_v2():
     """MaskedL2V2 / MaskedL1 (reference utils/custom_loss_functions.py:48-97) by their definitions, and evaluate_epoch_v2's
     accumulation rule (utils/evaluation.py:158-165: first batch unweighted, the rest weighted by len(data))."""

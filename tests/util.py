@@ -58,3 +58,19 @@ def assert_close(a, b, rtol=RTOL, what=""):
     record(what, err, scale, rtol)
     assert err <= rtol * scale + 1e-30, \
         f"{what}: max err {err:.3e} = {err / max(scale, 1e-300):.2e} of the largest entry {scale:.3e}, bound {rtol:g}"
+
+
+def record_elementwise(a, b, what, rtol=1e-5, atol_of_max=1e-6):
+    """The ELEMENTWISE reading of "1e-5 relative" next to the normwise one of assert_close: how many entries violate
+    |a - b| <= rtol * |b| + atol_of_max * max|b|, and by how much at worst.  Recorded (gpurun_out/parity_report.json), returned as
+    (violations, entries, worst ratio err / bound)."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    if b.numel() == 0:
+        return 0, 0, 0.0
+    bound = rtol * b.abs() + atol_of_max * b.abs().max()
+    ratio = ((a - b).abs() / bound.clamp_min(1e-300))
+    bad, worst = int((ratio > 1.0).sum()), float(ratio.max())
+    record(f"{what}: elementwise |a-b| <= {rtol:g}|b| + {atol_of_max:g} max|b|: {bad} of {b.numel()} entries exceed it, worst {worst:.3f} x the bound",
+           float((a - b).abs().max()), float(b.abs().max()), None)
+    return bad, b.numel(), worst

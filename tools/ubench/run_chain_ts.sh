@@ -2,8 +2,8 @@
 # phase timestamps of seg_chain_fwd_kernel (the instrumented build -- tools/ubench/seg_chain_timestamps.patch.txt, -DCH_EXP_TS -- in /tmp; per workgroup and stage, wall clock 100 MHz)
 R=$GRAFT_REPO_ROOT
 export PFN_SEG_CHAIN=1
-d=/tmp/exp_chain_ts; rm -rf $d; mkdir -p $d; cp -r $R/poweflownet_amd $R/bench.py $R/oracle $R/include $R/BASELINE.json $d/
-( cd $d/poweflownet_amd/csrc && patch -p0 seg_chain.hip < $R/tools/ubench/seg_chain_timestamps.patch.txt && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DCH_EXP_TS $CH_DEFS -c seg_chain.hip -o seg_chain.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC graph.o edge.o gemm.o gemm_nt.o front.o ea_seg.o seg_lin_hops.o seg_chain.o model.o physics.o prof.o -o libpfn_hip.so ) || exit 1
+d=/tmp/exp_chain_ts; rm -rf $d; mkdir -p $d; cp -r $R/poweflownet_amd $R/bench.py $R/oracle $R/include $R/BASELINE.json $d/; bash $R/tools/ubench/apply_experiments.sh $d/poweflownet_amd/csrc
+( cd $d/poweflownet_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DCH_EXP_TS $CH_DEFS -c seg_chain.hip -o seg_chain.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC graph.o edge.o gemm.o gemm_nt.o front.o ea_seg.o seg_lin_hops.o seg_chain.o model.o physics.o prof.o -o libpfn_hip.so ) || exit 1
 cd $d && python - <<'PY'
 import ctypes as C, torch, numpy as np, sys
 sys.path.insert(0, ".")

@@ -1,10 +1,10 @@
 #!/bin/bash
 # gemm_nt at large M with one ingredient removed at a time (compile-time switches in gemm_nt.hip; results are WRONG by design,
 # only the timings mean something): what bounds the multiply phase?
-R=$GRAFT_REPO_ROOT; C=$R/poweflownet_amd/csrc; cd $C
+R=$GRAFT_REPO_ROOT; S=/tmp/exp_src; rm -rf $S; mkdir -p $S; cp -r $R/poweflownet_amd $R/include $S/; C=$S/poweflownet_amd/csrc; bash $R/tools/ubench/apply_experiments.sh $C; cd $C   # (the switches live in tools/ubench/*.patch.txt)
 for v in BASE NOREFILL NOLDS NOSTORE "NOREFILL -DPFN_EXP_NOLDS" "NOREFILL -DPFN_EXP_NOLDS -DPFN_EXP_NOSTORE"; do
   d=/tmp/exp_$(echo $v | tr -d ' -' ); mkdir -p $d
-  for f in graph edge gemm gemm_nt front model physics prof; do
+  for f in $(ls *.hip | sed "s/.hip//"); do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DPFN_EXP_$v -c $f.hip -o $d/$f.o &
   done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $d/*.o -o $d/libpfn_hip.so

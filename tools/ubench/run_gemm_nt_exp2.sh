@@ -1,10 +1,10 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; C=$R/poweflownet_amd/csrc; cd $C
+R=$GRAFT_REPO_ROOT; S=/tmp/exp_src; rm -rf $S; mkdir -p $S; cp -r $R/poweflownet_amd $R/include $S/; C=$S/poweflownet_amd/csrc; bash $R/tools/ubench/apply_experiments.sh $C; cd $C   # (the switches live in tools/ubench/*.patch.txt)
 ALL="-DPFN_EXP_NOREFILL -DPFN_EXP_NOLDS -DPFN_EXP_NOSTORE"
 i=0
 for v in "" "$ALL" "$ALL -DPFN_EXP_NOWAIT" "$ALL -DPFN_EXP_NOSCHEDBAR" "$ALL -DPFN_EXP_NOWAIT -DPFN_EXP_NOSCHEDBAR"; do
   i=$((i+1)); d=/tmp/exp2_$i; mkdir -p $d
-  for f in graph edge gemm gemm_nt front model physics prof; do
+  for f in $(ls *.hip | sed "s/.hip//"); do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w $v -c $f.hip -o $d/$f.o &
   done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $d/*.o -o $d/libpfn_hip.so

@@ -1,10 +1,10 @@
 #!/bin/bash
 # gemm_nt at the metric's M = 15,104 (one row tile per wave) with the A refills re-reading ONE cache line (NOREFILL: wrong results,
 # timing only): how much of a 4-term launch is the row-per-lane gather of the operand fragments?
-R=$GRAFT_REPO_ROOT; C=$R/poweflownet_amd/csrc; cd $C
+R=$GRAFT_REPO_ROOT; S=/tmp/exp_src; rm -rf $S; mkdir -p $S; cp -r $R/poweflownet_amd $R/include $S/; C=$S/poweflownet_amd/csrc; bash $R/tools/ubench/apply_experiments.sh $C; cd $C   # (the switches live in tools/ubench/*.patch.txt)
 for v in ${NT_VARIANTS:-BASE NOREFILL}; do
   d=/tmp/exp_$(echo $v | tr -d ' -' ); mkdir -p $d
-  for f in graph edge gemm gemm_nt front ea_seg seg_lin_hops model physics prof; do
+  for f in $(ls *.hip | sed "s/.hip//"); do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DPFN_EXP_$v -c $f.hip -o $d/$f.o &
   done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $d/*.o -o $d/libpfn_hip.so

@@ -2,7 +2,7 @@
 # gemm_nt's per-wave cycle accounting (NT_EXP_TS2 build in /tmp) INSIDE the replayed step of configs 3 and 4, and back to back in
 # the harness: pipe occupancy in shader cycles and the shader clock (s_memtime / wall_clock64) the launches actually ran at
 R=$GRAFT_REPO_ROOT; d=/tmp/exp_ts2r; rm -rf $d; mkdir -p $d
-cp -r $R/poweflownet_amd $R/include $R/bench.py $R/configs $R/oracle $R/BASELINE.json $d/ 2>/dev/null
+cp -r $R/poweflownet_amd $R/include $R/bench.py $R/configs $R/oracle $R/BASELINE.json $d/ 2>/dev/null; bash $R/tools/ubench/apply_experiments.sh $d/poweflownet_amd/csrc
 ( cd $d/poweflownet_amd/csrc && rm -f *.o libpfn_hip.so && make -j16 CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DNT_EXP_TS2" > /dev/null ) || exit 1
 cd $d
 for cfgargs in "--case 118v2 --batch 2048 --mode infer --steps 30 --warmup 5" "--case 6470rte --batch 64 --mode train --steps 12 --warmup 3"; do

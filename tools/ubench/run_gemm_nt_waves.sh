@@ -4,7 +4,7 @@
 # pipe cycles a SIMD needs: 12940 tiles x 4 quarters x terms x 64 MFMAs x 64 / 1024 = 207,040 x terms
 R=$GRAFT_REPO_ROOT
 for T in 512 768; do
-  d=/tmp/exp_w$T; rm -rf $d; mkdir -p $d; cp -r $R/poweflownet_amd $R/include $d/
+  d=/tmp/exp_w$T; rm -rf $d; mkdir -p $d; cp -r $R/poweflownet_amd $R/include $d/; bash $R/tools/ubench/apply_experiments.sh $d/poweflownet_amd/csrc
   ( cd $d/poweflownet_amd/csrc && rm -f *.o libpfn_hip.so && make -j16 CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DNT_EXP_TS2 -DPFN_EXP_NT_THREADS=$T $NT_EXTRA" > /dev/null ) || exit 1
   cd $R/tools/ubench
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -DNT_EXP_TS2 gemm_nt_bench.hip -L$d/poweflownet_amd/csrc -lpfn_hip -Wl,-rpath,$d/poweflownet_amd/csrc -o $d/bench || exit 1

@@ -1,10 +1,10 @@
 #!/bin/bash
 # The weight-streaming gemm_nt with one ingredient removed at a time (compile-time switches; results are WRONG by design, only the
 # timings mean something): what bounds it at M = 414,080?
-R=$GRAFT_REPO_ROOT; C=$R/poweflownet_amd/csrc; cd $C
+R=$GRAFT_REPO_ROOT; S=/tmp/exp_src; rm -rf $S; mkdir -p $S; cp -r $R/poweflownet_amd $R/include $S/; C=$S/poweflownet_amd/csrc; bash $R/tools/ubench/apply_experiments.sh $C; cd $C   # (the switches live in tools/ubench/*.patch.txt)
 for v in BASE NOREFILL NOSTORE NOLDS NOWAIT NOSCHEDBAR WS_NOBARRIER WS_NODMA "NOREFILL -DPFN_EXP_NOSTORE -DPFN_EXP_WS_NODMA -DPFN_EXP_WS_NOBARRIER" "NOREFILL -DPFN_EXP_NOSTORE -DPFN_EXP_WS_NODMA -DPFN_EXP_WS_NOBARRIER -DPFN_EXP_NOWAIT -DPFN_EXP_NOSCHEDBAR"; do
   d=/tmp/exp_$(echo $v | tr -d ' -' | cut -c1-40); mkdir -p $d
-  for f in graph edge gemm gemm_nt front ea_seg model physics prof; do
+  for f in $(ls *.hip | sed "s/.hip//"); do
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DPFN_EXP_$v -c $f.hip -o $d/$f.o &
   done; wait
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $d/*.o -o $d/libpfn_hip.so

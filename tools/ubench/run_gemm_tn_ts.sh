@@ -2,7 +2,7 @@
 # gemm_tn's per-wave cycle stamps (T3_EXP_TS build in /tmp) for the LAST launch of an eager training step: where do the cycles
 # between "kernel start" and "partials published" go?  tools/ubench/run_gemm_tn_ts.sh ["bench args"]
 R=$GRAFT_REPO_ROOT; d=/tmp/exp_t3ts; rm -rf $d; mkdir -p $d
-cp -r $R/poweflownet_amd $R/include $R/bench.py $R/configs $R/oracle $R/BASELINE.json $d/ 2>/dev/null
+cp -r $R/poweflownet_amd $R/include $R/bench.py $R/configs $R/oracle $R/BASELINE.json $d/ 2>/dev/null; bash $R/tools/ubench/apply_experiments.sh $d/poweflownet_amd/csrc
 ( cd $d/poweflownet_amd/csrc && rm -f *.o libpfn_hip.so && make -j16 CXXFLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DT3_EXP_TS $T3_EXTRA" > /dev/null ) || exit 1
 cd $d
 for cfgargs in "${1:---case 118v2 --batch 128 --mode train --steps 20 --warmup 5}"; do

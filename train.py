@@ -89,7 +89,7 @@ def main():
                     for k in ("xymean", "xystd", "edgemean", "edgestd")},
                    os.path.join(args.data_dir, "params", f"data_params_{run_id}.pt"))
     best_val = float("inf")
-    graphed = GraphedTrainStep(model, loss_fn, optimizer)   # one hipGraph launch per batch; under DP it contains the all-reduce
+    graphed = GraphedTrainStep(model, loss_fn, optimizer, dp_mode=getattr(args, "dp_mode", None))   # one hipGraph launch per batch; under DP it contains the all-reduce
     for epoch in range(args.num_epochs):
         t0 = time.time()
         train_loss = train_epoch(model, train_loader, loss_fn, optimizer, device, graph=graphed)
