@@ -132,7 +132,8 @@ class DataLoader:
     def __len__(self):
         return self._num_batches()
 
-    def __iter__(self) -> Iterable[Batch]:
+    def _index_lists(self):
+        """The epoch's batches as lists of sample indices (one draw of the permutation, the shard rule applied)."""
         n = len(self.dataset)
         order = torch.randperm(n, generator=self.generator).tolist() if self.shuffle else list(range(n))
         for b in range(self._num_batches()):
@@ -140,6 +141,21 @@ class DataLoader:
             if self.shard is not None:
                 r, w = self.shard
                 idx = idx[:len(idx) // w * w][r::w]            # equal shards: len(idx) // w graphs on every rank
+            yield idx
+
+    def index_batches(self, device):
+        """The same batches as `__iter__` would collate -- same permutation, same shard rule -- as DEVICE int64 index tensors:
+        ONE host->device copy per epoch (the whole permutation), every batch a view of it.  For a consumer that gathers the
+        samples itself (utils.training.GraphedTrainStep.step_indexed with a device-resident dataset)."""
+        lists = list(self._index_lists())
+        flat = torch.tensor([i for l in lists for i in l], dtype=torch.long).to(device, non_blocking=True)
+        off = 0
+        for l in lists:
+            yield flat[off:off + len(l)]
+            off += len(l)
+
+    def __iter__(self) -> Iterable[Batch]:
+        for idx in self._index_lists():
             if hasattr(self.dataset, "collate_indices"):       # device-resident dataset: one gather per field, no host loop
                 yield self.dataset.collate_indices(idx)
             else:

@@ -187,6 +187,25 @@ class PowerFlowData:
         return self
 
     # ---------------------------------------------------------------------------------------------- batches
+    def can_gather(self) -> bool:
+        """One dense device-resident block, one topology for every sample, no per-sample transform: a batch is then five row
+        gathers INTO tensors that already exist (`gather_into`) -- what lets a captured training step pull its own batch."""
+        return (self._list is None and len(self._blocks) == 1 and self.transform is None and self._blocks[0].static_topology
+                and self._blocks[0].x.is_cuda)
+
+    def gather_into(self, batch: Batch, idx: torch.Tensor) -> None:
+        """Overwrite the sample-dependent fields of `batch` (built earlier by `collate_indices` for the same number of samples)
+        with the samples `idx` (a device int64 tensor): index_select(out=...) per field, no allocation, no host work -- hipGraph-
+        capturable, so `GraphedTrainStep` replays "gather the batch + train on it" as ONE graph launch (zero per-batch
+        host work).  edge_index / batch / ptr do not depend on the samples (static topology) and stay as they are."""
+        b = self._blocks[0]
+        B, n, e = int(idx.numel()), int(b.x.shape[1]), int(b.edge_index.shape[2])
+        torch.index_select(b.x, 0, idx, out=batch.x.view(B, n, -1))
+        torch.index_select(b.y, 0, idx, out=batch.y.view(B, n, -1))
+        torch.index_select(b.bus_type, 0, idx, out=batch.bus_type.view(B, n))
+        torch.index_select(b.pred_mask, 0, idx, out=batch.pred_mask.view(B, n, -1))
+        torch.index_select(b.edge_attr, 0, idx, out=batch.edge_attr.view(B, e, -1))
+
     def collate_indices(self, indices: Sequence[int]) -> Batch:
         """The batch PyG's collate would build from samples `indices` (cat along dim 0, edge_index offset by the cumulative
         node count, `batch`, `ptr`) -- assembled on the dataset's device with one gather per field.  Falls back to the

@@ -60,6 +60,10 @@ class GraphedTrainStep:
     def __init__(self, model, loss_fn, optimizer, allreduce: Optional[bool] = None, dp_mode: Optional[str] = None):
         self.model, self.loss_fn, self.opt = model, loss_fn, optimizer
         self.dp_mode = dp_mode     # graph | split | eager (dp.GraphedStep; None: PFN_DP_MODE or "graph")
+        # indexed mode (step_indexed): one child step per batch SIZE (the epoch's short last batch gets a graph of its own), each
+        # gathering its samples from the device-resident dataset INSIDE its captured graph
+        self._children = {}
+        self._source = None        # (dataset, captured index buffer) of a child
         self._guard_buf = None     # data parallel + guarded update: the loss, SUM-all-reduced, so that every rank skips together
         # data parallel (dp.py): the gradient all-reduce is part of the replayed step -- ONE hipGraph with the RCCL collective
         # captured between backward and optimizer, or graph / eager all-reduce / graph for a backend that cannot be captured
@@ -102,6 +106,8 @@ class GraphedTrainStep:
         return (float(g["lr"]), betas, float(g.get("eps", 0.0)), float(g.get("weight_decay", 0.0)))
 
     def _fwd_bwd(self, data):
+        if self._source is not None:                               # indexed mode: pull the batch named by the index buffer
+            self._source[0].gather_into(data, self._source[1])
         self.opt.zero_grad()
         loss = _dispatch_loss(self.loss_fn, self.model(data), data)
         _backward(self.loss_fn, loss)
@@ -223,6 +229,39 @@ class GraphedTrainStep:
     def _compatible(self, data):
         return self._same_shapes(data) and (self.dynamic or data.edge_index is self.static.edge_index)
 
+    def step_indexed(self, dataset, idx):
+        """One training step on the samples `idx` (a device int64 tensor) of a device-resident dataset (`dataset.can_gather()`).
+        The captured graph contains the five row gathers that assemble the batch, so a step costs the host ONE 1-KiB device copy
+        (the indices) and ONE graph launch -- no collate, no per-field copies; every batch size met gets its own
+        captured step (the short last batch of an epoch no longer runs eager).  Returns (loss, len(batch)) like the loop needs."""
+        B = int(idx.numel())
+        child = self._children.get(B)
+        if child is None:
+            child = GraphedTrainStep(self.model, self.loss_fn, self.opt, self.allreduce, self.dp_mode)
+            child._source = (dataset, idx.clone())
+            child._template = dataset.collate_indices(idx.tolist())   # shapes, edge_index / batch / ptr of this batch size
+            self._children[B] = child
+        child.allreduce = self.allreduce
+        child._source[1].copy_(idx)
+        return child(child._template), len(child._template)
+
+    def captured(self):
+        """The dp.GraphedStep this step (or, in indexed mode, one of its per-size children) replays; None before the first capture."""
+        if self.graph is not None:
+            return self.graph
+        for ch in self._children.values():
+            if ch.graph is not None:
+                return ch.graph
+        return None
+
+    def any_disabled(self) -> bool:
+        return self.disabled or any(ch.disabled for ch in self._children.values())
+
+    def _drop_all(self):
+        self._drop_graph()
+        for ch in self._children.values():
+            ch._drop_graph()
+
     def __call__(self, data):
         if self.disabled or not data.x.is_cuda:
             return self._eager(data)
@@ -254,8 +293,9 @@ class GraphedTrainStep:
             return self._eager(data)                               # e.g. the short last batch of an epoch
         if hasattr(self.opt, "sync_hyper"):
             self.opt.sync_hyper()                                  # a scheduler moved lr / betas: 20 bytes to the device
-        for k in ("x", "y", "pred_mask", "edge_attr") + (("edge_index",) if self.dynamic else ()):
-            getattr(self.static, k).copy_(getattr(data, k))
+        if self._source is None:
+            for k in ("x", "y", "pred_mask", "edge_attr") + (("edge_index",) if self.dynamic else ()):
+                getattr(self.static, k).copy_(getattr(data, k))
         self.loss = self.graph.replay()            # (graph forms: the captured loss tensor; the eager form: this step's)
         return self.loss
 
@@ -276,8 +316,18 @@ def train_epoch(model: nn.Module, loader, loss_fn: Callable, optimizer, device, 
         from tqdm import tqdm
         it = tqdm(loader, total=len(loader), desc="Training")
     if graph is not None and graph.allreduce != bool(allreduce):
-        graph._drop_graph()                     # the replayed step contains (or not) the collective: capture again
+        graph._drop_all()                       # the replayed step contains (or not) the collective: capture again
         graph.allreduce = bool(allreduce)
+    ds = getattr(loader, "dataset", None)
+    if (graph is not None and not progress and hasattr(loader, "index_batches") and hasattr(ds, "can_gather") and ds.can_gather()
+            and ds.device == torch.device(device)):
+        # device-resident dataset: the captured step gathers its own batch -- per batch one index copy and one graph launch
+        for idx in loader.index_batches(device):
+            loss, n_keys = graph.step_indexed(ds, idx)
+            num_samples += n_keys
+            term = loss.detach().double() * n_keys
+            total = term if total is None else total + term
+        it = ()
     for data in it:
         data = data.to(device)
         if graph is not None:

@@ -44,10 +44,11 @@ def main():
         torch.cuda.synchronize()
         mode = None
         if g is not None:
-            assert g.graph is not None and not g.disabled, "the data-parallel step was not captured"
-            mode = g.graph.mode
+            assert g.captured() is not None and not g.any_disabled(), "the data-parallel step was not captured"
+            assert g._children, "the device-resident dataset did not take the indexed path (the step gathers its own batch)"
+            mode = g.captured().mode
             if dp_mode is not None:
-                mode = g.graph.form
+                mode = g.captured().form
         return opt.flat_param.detach().clone(), losses, mode
 
     p_graph, l_graph, mode = run(True)

@@ -339,8 +339,9 @@ def test_powerflowdata_on_device_feeds_the_model(tmp_path):
 
 
 def test_graphed_train_step_equals_eager_training(tmp_path):
-    """train_epoch with a GraphedTrainStep (one hipGraph replay per batch, eager for the short last batch, re-capture
-    after a learning-rate change) leaves the same parameters and returns the same epoch loss as the eager loop."""
+    """train_epoch with a GraphedTrainStep (one hipGraph replay per batch -- the batch gathered from the device-resident dataset
+    INSIDE the graph, a graph of its own for the short last batch, re-capture after a learning-rate change) leaves the same
+    parameters and returns the same epoch loss as the eager loop."""
     import numpy as np
     from poweflownet_amd.data import DataLoader
     from poweflownet_amd.datasets import PowerFlowData
@@ -374,6 +375,10 @@ def test_graphed_train_step_equals_eager_training(tmp_path):
             losses.append(train_epoch(m, loader, loss_fn, opt, DEV, graph=g))
             if epoch == 1:
                 opt.param_groups[0]["lr"] = 5e-4                                   # what a scheduler does between epochs
+        if g is not None:
+            # device-resident dataset: every batch SIZE has its own captured step, which gathers its samples inside the graph
+            # (utils/training.py step_indexed) -- also the epoch's short last batch
+            assert sorted(g._children) == [6, 8] and all(ch.graph is not None and not ch.disabled for ch in g._children.values())
         return losses, [p.detach().clone() for p in m.parameters()]
 
     l_e, p_e = run(False)
