@@ -1330,6 +1330,35 @@ def test_config2_with_real_dataset_masked_entry_statistics():
     _check_full_size(m, ref, data, "config 2, real-dataset masked-entry statistics")
 
 
+def test_new_edge_index_tensor_with_the_same_content_keeps_the_cached_adjacency():
+    """A PyG-style loader hands out a NEW `edge_index` tensor per batch (train.py:90-92) although every sample of a case shares one
+    topology.  The adjacency cache compares a new tensor of the cached shape with a private copy of the list it was built from
+    (device-side elementwise equal, one byte read back) and keeps the cached, validated build when the content is the same; a
+    tensor with OTHER content of the same shape is built and validated anew.  Results carry the same bits either way."""
+    torch.manual_seed(9)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).to(DEV).eval()
+    d = make_batch("118v2", 16, seed=4).to(DEV)
+    with torch.no_grad():
+        out0 = m(d)
+        g0 = m._graphs._graph
+        d2 = d.clone()                                       # every tensor new, the same values
+        out1 = m(d2)
+        assert m._graphs.content_hits == 1 and m._graphs._graph is g0 and torch.equal(out0, out1)
+        out1b = m(d2)                                        # ... and from then on the identity path
+        assert m._graphs.content_hits == 1 and torch.equal(out0, out1b)
+        d3 = d.clone()
+        d3.edge_index = d.edge_index.flip(0).contiguous()    # every edge reversed: other content, same shape
+        out2 = m(d3)
+        assert m._graphs.content_hits == 1 and m._graphs._graph is not g0
+        ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.0).eval()
+        ref.load_state_dict(m.state_dict())
+        assert_close(out2, ref(d3.to("cpu")), RTOL, "reversed edge list: out vs oracle")
+        d4 = d.clone()
+        d4.edge_index[0, 0] = d4.x.shape[0] + 3              # a bad id in a new tensor: still raises (the compare misses, the build validates)
+        with pytest.raises(RuntimeError):
+            m(d4)
+
+
 @pytest.mark.parametrize("dtype", [torch.int32, torch.bool, torch.uint8, torch.float32, torch.float64, torch.int16])
 def test_pred_mask_dtypes_go_through_float(dtype):
     """`pred_mask` may arrive in any int / float dtype: the reference applies `.float()` (networks/MPN.py:533).  int64 takes the
