@@ -245,7 +245,7 @@ int pfn_adamw_step_guarded(float* param, const float* grad, float* exp_avg, floa
  *                           launch that does both (ea_seg.hip front_seg_fwd_kernel; bit-identical results)
  *   PFN_NO_FUSED_BACK=1     the last layer's Linear / dS outside the edge walks (generic GEMMs)
  *   PFN_FRONT_BLOCK_ROWS=1  front.hip: the block-per-row-group kernels instead of one row per wave
- *   PFN_NO_BIG_HOPS=1       TAGConv hops of large graphs (one LDS tile + registers per graph and column chunk): K generic hop launches instead
+ *   PFN_NO_BIG_HOPS=1       TAGConv hops of large graphs (one LDS tile + registers per graph and column chunk, workgroups persistent over a graph's chunks): K generic hop launches instead
  *   PFN_NO_ROW_HOPS=1       TAGConv hops of big batches of small graphs: the two-tile column-slice kernel instead of whole rows per block
  *   PFN_NO_EDGE_ROWS=1      the edge stage of big inference batches of small graphs: the generic gather kernel instead of the LDS-resident one
  *   PFN_NO_L0_FLY=1         the front writes the first layer's P | Q and the edge walk gathers them (default: the walk forms them from x0)

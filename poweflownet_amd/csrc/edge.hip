@@ -10,10 +10,16 @@
 // order -> no atomics, deterministic, same summation order as the reference's sequential scatter.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pfn_internal.hpp"
 
 namespace pfn {
 
+// Barrier that publishes LDS traffic only: __syncthreads() also waits (vmcnt(0)) until every global STORE of the wave is
+// acknowledged -- a round trip of 1-2 us under load at every barrier that follows output stores (seg_tile.hpp seg_lds_barrier).
+// Only where no thread reads another thread's GLOBAL writes behind the barrier: the hop kernels' tiles live in LDS.
+__device__ __forceinline__ void bh_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 fma4(float a, float4 x, float4 acc) {
@@ -320,11 +326,11 @@ __global__ __launch_bounds__(RH_THREADS, 4) void row_hops_kernel(int n, int rows
             __builtin_amdgcn_sched_barrier(0);   // (left alone the scheduler interleaves all eight items' gathers and spills)
         }
         if (k == K) break;
-        __syncthreads();
+        bh_lds_barrier();          // (not __syncthreads(): the hop's output stores drain under the next hop)
 #pragma unroll
         for (int r = 0; r < RH_IPT; ++r)
             if (t + r * RH_THREADS < items) rh_tile[t + r * RH_THREADS] = z[r];
-        __syncthreads();
+        bh_lds_barrier();
     }
 }
 // whole graphs per block: rows x chunks <= 4,096 items, rows <= 1,024, tile + offsets in HALF of the LDS (two blocks per CU)
@@ -414,16 +420,14 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
 // The K hops of one TAGConv direction for graphs too large for fused_hops_kernel's two ping-pong tiles (6470 buses: one float4
 // column of a whole graph is 103 KB).  ONE tile is enough: a hop reads its neighbours' values from the LDS tile and keeps its
 // rows' results in REGISTERS (a thread owns rows tid, tid + 1024, ...: <= 8 float4), a barrier, the registers go back into the
-// tile.  Block = one graph x ONE float4 column chunk, 1024 threads; the graph's adjacency is staged once as 16-bit local ids and
+// tile.  Work item = one graph x ONE float4 column chunk, 1024 threads; the graph's adjacency is staged as 16-bit local ids and
 // offsets (6470 nodes / 18,010 directed edges: 36 + 13 KB beside the 103 KB tile).  The tile holds z = D^-1/2 x, so a hop is
 // y_i = d_i sum_j z_j and the next tile is d_i y_i: no per-edge weight, no D^-1/2 table in LDS.  Global traffic per direction: x
-// read once, K outputs written, the adjacency once per block (L2) -- instead of K full gather passes (3 x 852 MB at 6470rte x 64).
-// The 16-byte-per-row accesses of a chunk only make sense because the 33 chunk-blocks of a graph run TOGETHER on ONE XCD (block
-// b -> XCD b mod 8; graph = (b / (8 nchunk)) * 8 + b mod 8, chunk = (b / 8) mod nchunk): a row's cache line is fetched from HBM
-// once and serves the other chunks out of that XCD's L2, and their partial-line stores merge there.
+// read once, K outputs written, the adjacency once per workgroup (L2) -- instead of K full gather passes (3 x 852 MB at 6470rte x 64).
+// Inputs and outputs are chunk-major, so a chunk's rows are one contiguous run; the workgroups of a graph sit on ONE XCD
+// (workgroup b -> XCD b mod 8) and share its adjacency in that L2.
 constexpr int BH_THREADS = 1024;
 constexpr int BH_RPT = 8;                       // rows per thread at most: graphs up to 8,192 nodes
-constexpr int BH_NBPT = 20;                     // staged neighbour ids per thread at most: 20,480 directed edges per graph
 // High-degree buses (a "hub" substation: 100+ lines) are NOT walked by their owner thread -- a 170-edge row was one thread's
 // 43 serial trips per hop while the block's other 1,023 threads waited at the barrier (hub grid: 343 vs 268 us per launch).
 // Rows above BH_HUB_DEG edges are listed once, and in every hop a WAVE sums such a row: lane l adds the edges l, l + 64, ... in
@@ -432,7 +436,44 @@ constexpr int BH_NBPT = 20;                     // staged neighbour ids per thre
 constexpr int BH_HUB_DEG = 32;
 constexpr int BH_HUB_CAP = 128;                 // listed hub rows per graph (more: the rest stay with their owners)
 __host__ __device__ constexpr size_t bh_hub_bytes() { return (size_t)BH_HUB_CAP * 16 + (size_t)BH_HUB_CAP * 2 + 16; }
-__global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int nchunk, int ngraphs, int nb_cap,
+// A workgroup is PERSISTENT over column chunks of ONE graph (chunk w, w + wpg, ...; the launcher picks wpg = workgroups per graph
+// so that the grid is one round of the chip): the adjacency is staged ONCE per workgroup instead of once per (graph, chunk) --
+// it is as many bytes as the tile itself -- and every row is PLANNED once for all chunks and hops: first slot | degree | hub slot
+// in one register, so a hop's first trip of four slots (all of most rows of a power grid: mean degree 2.8) is four independent
+// id reads and four independent tile reads instead of the chain row pointer -> neighbour id -> tile row inside a loop (cf.
+// seg_lin_hops.hip).  The next chunk's rows are requested at the start of the LAST hop of the current one (the registers that
+// hold them are dead from that hop's tile write on) and arrive under its gathers and stores.  Barriers publish LDS only
+// (lgkmcnt): no thread reads another thread's global writes, so nothing waits for the output stores to be acknowledged.
+// Same sums in the same order as the one-(graph, chunk)-per-workgroup form of rounds 3-4: bit-identical outputs (checked on the
+// GPU against that kernel before it was removed); 6470rte x 64: 284 / 273 -> 245 / 239 us per launch, step 12.37 -> 12.15 ms.
+// What the compiler needed (1024 threads = 128 registers): the last hop PEELED out of the hop loop (z written in one branch and
+// loaded in another doubled its 32 registers: 114-214 spills), and the plan / row offsets made opaque per hop (their unpacked
+// fields, 64-bit offsets and lane masks are loop-invariant and were hoisted into 70-180 SGPRs and as many spills).
+// A graph with more edges than the staged neighbour list holds (the list is sized for an equal share of the batch's edges plus
+// slack): indices from global memory, nothing planned, no register arrays -- a thread re-reads its own hop output to refill the tile.
+__device__ __noinline__ void bh_unstaged_graph(float4* bh_tile, int seg, int nchunk, int w, int wpg, int r0, const int* __restrict__ rowptr,
+                                               const int* __restrict__ nbr, const float* __restrict__ dinv, const float* __restrict__ xb,
+                                               size_t xrow, size_t xchunk, float* __restrict__ xk, size_t stride, int K, int n_total) {
+    const int t = threadIdx.x;
+    for (int c = w; c < nchunk; c += wpg) {
+        __syncthreads();
+        for (int row = t; row < seg; row += BH_THREADS) bh_tile[row] = mul4(dinv[r0 + row], ld4(xb + (size_t)c * xchunk + (size_t)row * xrow));
+        __syncthreads();
+        for (int k = 1; k <= K; ++k) {
+            float* outc = xk + (size_t)(k - 1) * stride + ((size_t)c * n_total + r0) * 4;
+            for (int row = t; row < seg; row += BH_THREADS) {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int p = rowptr[r0 + row]; p < rowptr[r0 + row + 1]; ++p) acc = add4(acc, bh_tile[nbr[p] - r0]);
+                st4(outc + (size_t)row * 4, mul4(dinv[r0 + row], acc));
+            }
+            __syncthreads();                    // every read of the tile is done (and this thread's stores are acknowledged)
+            if (k == K) break;
+            for (int row = t; row < seg; row += BH_THREADS) bh_tile[row] = mul4(dinv[r0 + row], ld4(outc + (size_t)row * 4));
+            __syncthreads();
+        }
+    }
+}
+__global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int nchunk, int ngraphs, int wpg, int nb_cap,
                                                                     const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                                     const float* __restrict__ dinv, const float* __restrict__ x0,
                                                                     float* __restrict__ xk, size_t stride, int ld, int K, int n_total,
@@ -444,73 +485,63 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
     unsigned short* s_rp = reinterpret_cast<unsigned short*>(s_hub_n + 4);
     unsigned short* s_nb = s_rp + ((seg + 2 + 7) & ~7);
     const int b = blockIdx.x, xcd = b & 7, j = b >> 3;
-    const int c = j % nchunk, gi = (j / nchunk) * 8 + xcd;
-    if (gi >= ngraphs) return;
+    const int w = j % wpg, gi = (j / wpg) * 8 + xcd;      // the wpg workgroups of a graph sit on ONE XCD (they share its adjacency in L2)
+    if (gi >= ngraphs || w >= nchunk) return;
     const int r0 = gi * seg, t = threadIdx.x;
     const int e0 = rowptr[r0], ne = rowptr[r0 + seg] - e0;
-    const bool nb_in_lds = ne <= nb_cap && ne < 65536 && ne <= BH_NBPT * BH_THREADS;
-    // EVERYTHING the prologue needs from global memory is requested before the first LDS store (two round trips in all: e0, then
-    // the rest).  As load -> LDS-store loops every iteration waited for its own load: ~25 serial L2 round trips per thread, 40 of
-    // the block's 43 us.
+    // the layer input: row `row` of chunk c at xb + c * xchunk + row * xrow floats.  (The producing GEMM writes it chunk-major when
+    // this kernel will read it: one contiguous run per chunk instead of 16 bytes per 528-byte row.)
+    const float* xb = x0_cm ? x0 + (size_t)r0 * 4 : x0 + (size_t)r0 * ld;
+    const size_t xrow = x0_cm ? 4 : (size_t)ld, xchunk = x0_cm ? (size_t)n_total * 4 : 4;
+    if (!(ne <= nb_cap && ne < 65536)) {
+        bh_unstaged_graph(bh_tile, seg, nchunk, w, wpg, r0, rowptr, nbr, dinv, xb, xrow, xchunk, xk, stride, K, n_total);
+        return;
+    }
+    // ---- staging, amortised over the workgroup's chunks.  Rows past the graph's end are clamped to its last row (loaded, planned
+    // and summed like it, never stored): straight-line code, no per-row branches around the register arrays.
     float di[BH_RPT];
     float4 z[BH_RPT];
-    int rpv[BH_RPT + 1], nbv[BH_NBPT];
     if (t == 0) s_hub_n[0] = 0;
 #pragma unroll
     for (int r = 0; r < BH_RPT; ++r) {
-        const int row = t + r * BH_THREADS;
-        di[r] = 0.f;
-        z[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        rpv[r] = 0;
-        if (row < seg) {
-            di[r] = dinv[r0 + row];
-            // (the producing GEMM writes the layer input chunk-major when this kernel will read it: one contiguous run instead
-            //  of 16 bytes per 528-byte row -- 100 of the kernel's 330 us)
-            z[r] = x0_cm ? ld4(x0 + ((size_t)c * n_total + r0 + row) * 4) : ld4(x0 + (size_t)(r0 + row) * ld + 4 * c);
-            rpv[r] = rowptr[r0 + row];
-        }
+        const int row = min(t + r * BH_THREADS, seg - 1);
+        di[r] = dinv[r0 + row];
+        z[r] = ld4(xb + (size_t)w * xchunk + (size_t)row * xrow);
     }
-#pragma unroll
-    for (int jn = 0; jn < BH_NBPT; ++jn) {
-        const int i = t + jn * BH_THREADS;
-        nbv[jn] = (nb_in_lds && i < ne) ? nbr[e0 + i] : 0;
-    }
-#pragma unroll
-    for (int r = 0; r < BH_RPT; ++r) {
-        const int row = t + r * BH_THREADS;
-        if (row < seg) {
-            s_rp[row] = (unsigned short)(rpv[r] - e0);
-            bh_tile[row] = mul4(di[r], z[r]);
-        }
-    }
-    if (t == 0) s_rp[seg] = (unsigned short)ne;
-    if (nb_in_lds) {
-#pragma unroll
-        for (int jn = 0; jn < BH_NBPT; ++jn) {
-            const int i = t + jn * BH_THREADS;
-            if (i < ne) s_nb[i] = (unsigned short)(nbv[jn] - r0);
-        }
-    }
+    for (int row = t; row <= seg; row += BH_THREADS) s_rp[row] = (unsigned short)(rowptr[r0 + row] - e0);
+    for (int i = t; i < ne; i += BH_THREADS) s_nb[i] = (unsigned short)(nbr[e0 + i] - r0);
     __syncthreads();                            // (also publishes the zeroed hub counter)
-    // hub rows: listed once (the slot order is arrival order -- it decides which wave sums a row, not what the sum is)
-    int hubslot[BH_RPT];
+    // ---- per-row plan, once for every chunk and hop: plan = first slot of the row in the staged list | min(degree, 255) << 16 |
+    // (hub slot + 1) << 24 -- a hop's first trip of four slots (all of most rows of a power grid: mean degree 2.8) is then four
+    // independent id reads and four independent tile reads, without the row-pointer level and without a loop around it.  Hub rows
+    // are listed once (the slot order is arrival order -- it decides which wave sums a row, not what the sum is).
+    uint32_t plan[BH_RPT];
 #pragma unroll
     for (int r = 0; r < BH_RPT; ++r) {
-        hubslot[r] = -1;
-        const int row = t + r * BH_THREADS;
-        if (nb_in_lds && row < seg && (int)s_rp[row + 1] - (int)s_rp[row] > BH_HUB_DEG) {
+        const int rowu = t + r * BH_THREADS, row = min(rowu, seg - 1);
+        const int beg = s_rp[row], cnt = (int)s_rp[row + 1] - beg;
+        uint32_t hub = 0u;
+        if (cnt > BH_HUB_DEG && rowu < seg) {
             const int sl = atomicAdd(s_hub_n, 1);
             if (sl < BH_HUB_CAP) {
-                hubslot[r] = sl;
+                hub = (uint32_t)sl + 1u;
                 s_hub_row[sl] = (unsigned short)row;
             }
         }
+        plan[r] = (uint32_t)beg | ((uint32_t)min(cnt, 255) << 16) | (hub << 24);
     }
     __syncthreads();
     const int nhub = min(s_hub_n[0], BH_HUB_CAP);
     const int wave_ = t >> 6, lane_ = t & 63;
-    for (int k = 1; k <= K; ++k) {
-        float* outk = xk + (size_t)(k - 1) * stride;
+    // one hop over the tile: hub rows by waves, then every thread its rows; KEEP: the rows' next tile values d_i y_i go to z
+    auto hop = [&](auto keep_c, float* outc) {
+        constexpr bool KEEP = decltype(keep_c)::value;
+        // opaque per hop: what is derived from them -- the rows' global offsets (64-bit), their lane masks (degree > 0..4, hub,
+        // row < seg: SGPR pairs) and the unpacked plan fields -- is loop-invariant, gets hoisted out of both loops and spilled
+        int to = t;
+        asm volatile("" : "+v"(to));
+#pragma unroll
+        for (int r = 0; r < BH_RPT; ++r) asm volatile("" : "+v"(plan[r]));
         // ---- hub rows first: one wave per row, lanes stride over its edges, fixed xor tree
         for (int hs = wave_; hs < nhub; hs += BH_THREADS / 64) {
             const int row = s_hub_row[hs];
@@ -526,48 +557,77 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
             }
             if (lane_ == 0) s_hub_y[hs] = part;
         }
-        if (nhub > 0) __syncthreads();
+        if (nhub > 0) bh_lds_barrier();
 #pragma unroll
         for (int r = 0; r < BH_RPT; ++r) {
-            const int row = t + r * BH_THREADS;
-            if (row >= seg) continue;
+            const int row = to + r * BH_THREADS;
+            const int beg = (int)(plan[r] & 0xffffu), cnt = (int)((plan[r] >> 16) & 255u), hub = (int)(plan[r] >> 24);
+            const int l = max(cnt - 1, 0);
+            const int i0 = s_nb[beg], i1 = s_nb[beg + min(1, l)], i2 = s_nb[beg + min(2, l)], i3 = s_nb[beg + min(3, l)];
+            const float4 v0 = bh_tile[i0], v1 = bh_tile[i1], v2 = bh_tile[i2], v3 = bh_tile[i3];
+            // (reading only the slots that exist -- lanes masked off per slot, a third fewer tile reads -- measured SLOWER: 250 vs 244 us
+            //  per launch at 6470rte x 64: the hop is bound by LDS round trips and instruction issue, not by LDS bandwidth)
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (hubslot[r] >= 0) {
-                acc = s_hub_y[hubslot[r]];
-            } else
-            if (nb_in_lds) {   // four slots per trip: index -> tile row is a chain of dependent LDS reads (see hop_kernel)
-                const int beg = s_rp[row], end = s_rp[row + 1], last = end - 1;
-                for (int p = beg; p < end; p += 4) {
+            acc = sel4(cnt > 0, add4(acc, v0), acc);
+            acc = sel4(cnt > 1, add4(acc, v1), acc);
+            acc = sel4(cnt > 2, add4(acc, v2), acc);
+            acc = sel4(cnt > 3, add4(acc, v3), acc);
+            if (hub) {
+                acc = s_hub_y[hub - 1];
+            } else if (cnt > 4) {   // the rest of a longer row: four slots per trip, dependent index -> tile row reads
+                const int rc = min(row, seg - 1);
+                const int end = s_rp[rc + 1], last = end - 1;
+                for (int p = beg + 4; p < end; p += 4) {
                     int s_[4];
 #pragma unroll
                     for (int u = 0; u < 4; ++u) s_[u] = s_nb[min(p + u, last)];
-                    float4 v_[4];
+                    float4 x_[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) v_[u] = bh_tile[s_[u]];
-                    acc = add4(acc, v_[0]);
-                    acc = sel4(p + 1 < end, add4(acc, v_[1]), acc);
-                    acc = sel4(p + 2 < end, add4(acc, v_[2]), acc);
-                    acc = sel4(p + 3 < end, add4(acc, v_[3]), acc);
+                    for (int u = 0; u < 4; ++u) x_[u] = bh_tile[s_[u]];
+                    acc = add4(acc, x_[0]);
+                    acc = sel4(p + 1 < end, add4(acc, x_[1]), acc);
+                    acc = sel4(p + 2 < end, add4(acc, x_[2]), acc);
+                    acc = sel4(p + 3 < end, add4(acc, x_[3]), acc);
                 }
-            } else {           // a graph with more edges than the staged list holds: indices from global memory
-                for (int p = rowptr[r0 + row]; p < rowptr[r0 + row + 1]; ++p) acc = add4(acc, bh_tile[nbr[p] - r0]);
             }
             const float4 y = mul4(di[r], acc);
-            // the hop outputs are written CHUNK-MAJOR ([chunk][row][float4]): this block's 6470 x 16 bytes are one contiguous
-            // run.  Row-major they were 16 bytes per 528-byte row -- 41 M partial-line writes per direction at 6470rte x 64, and
-            // the kernel was no faster than the three gather passes it replaces (422 vs 3 x 142 us).  The consumers read the
-            // layout through GemmTerm::cm_rows (gemm_nt A operand) and TnPair::b_cm_rows (gemm_tn B operand).
-            st4(outk + ((size_t)c * n_total + r0 + row) * 4, y);
-            z[r] = mul4(di[r], y);
+            // the hop outputs are written CHUNK-MAJOR ([chunk][row][float4]): this chunk's 6470 x 16 bytes are one contiguous
+            // run.  Row-major they were 16 bytes per 528-byte row -- 41 M partial-line writes per direction at 6470rte x 64.
+            // The consumers read the layout through GemmTerm::cm_rows (gemm_nt A operand) and TnPair::b_cm_rows (gemm_tn).
+            if (row < seg) st4(outc + (size_t)row * 4, y);
+            if (KEEP) z[r] = mul4(di[r], y);
         }
-        if (k == K) break;
-        __syncthreads();                        // every read of the tile is done
+        bh_lds_barrier();                       // every read of the tile is done
+    };
+    for (int c = w; c < nchunk; c += wpg) {
+        // ---- the tile of chunk c: z = D^-1/2 x  (every read of the previous chunk's tile is behind the barrier of its last hop)
 #pragma unroll
         for (int r = 0; r < BH_RPT; ++r) {
             const int row = t + r * BH_THREADS;
-            if (row < seg) bh_tile[row] = z[r];
+            if (row < seg) bh_tile[row] = mul4(di[r], z[r]);
         }
-        __syncthreads();
+        bh_lds_barrier();
+        float* outc = xk + ((size_t)c * n_total + r0) * 4;
+        for (int k = 1; k < K; ++k) {
+            hop(std::true_type{}, outc);
+#pragma unroll
+            for (int r = 0; r < BH_RPT; ++r) {
+                const int row = t + r * BH_THREADS;
+                if (row < seg) bh_tile[row] = z[r];
+            }
+            bh_lds_barrier();
+            outc += stride;
+        }
+        // the next chunk's rows are requested now (z is dead until that chunk's tile write) and arrive under the last hop; after
+        // the workgroup's last chunk the same load re-reads the current one (unused)
+        {
+            const int cn = c + wpg < nchunk ? c + wpg : c;
+            int to = t;
+            asm volatile("" : "+v"(to));
+#pragma unroll
+            for (int r = 0; r < BH_RPT; ++r) z[r] = ld4(xb + (size_t)cn * xchunk + (size_t)min(to + r * BH_THREADS, seg - 1) * xrow);
+        }
+        hop(std::false_type{}, outc);
     }
 }
 
@@ -603,8 +663,12 @@ int launch_big_graph_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_
     PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(big_graph_hops_kernel), 160 * 1024, lds_raised));
     const bool adjt = a.adjt < 0 ? false : a.adjt != 0;
     ProfScope ps(adjt ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
-    const int blocks = ((ngraphs + 7) / 8) * 8 * nchunk;
-    big_graph_hops_kernel<<<blocks, BH_THREADS, lds_total, s>>>(a.seg, nchunk, ngraphs, nb_cap, adjt ? g.rowptr_out : g.rowptr_in,
+    // workgroups per graph: one round of the chip (one 1024-thread workgroup per CU; four at 6470rte x 64 -- 3 and 8 measured:
+    // 284 and 281 us per launch against 245), at least one, at most one per chunk
+    const int g8 = ((ngraphs + 7) / 8) * 8;
+    const int wpg = std::max(1, std::min(nchunk, device_cus() / std::max(1, g8)));
+    const int blocks = g8 * wpg;
+    big_graph_hops_kernel<<<blocks, BH_THREADS, lds_total, s>>>(a.seg, nchunk, ngraphs, wpg, nb_cap, adjt ? g.rowptr_out : g.rowptr_in,
                                                                adjt ? g.out_dst : g.in_src, g.dinv, a.x0, a.xk, a.stride, a.ld, a.K, g.n, a.x0_cm);
     PFN_CHECK_LAUNCH();
     return PFN_OK;

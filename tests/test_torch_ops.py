@@ -1,0 +1,138 @@
+"""TORCH_LIBRARY(pfn, ...) (poweflownet_amd/csrc/torch_ops.cpp): the operator surface above the C ABI.  CPU: the
+library loads, every operator is registered with the documented schema, a CPU tensor is refused.  GPU: every operator gives the
+SAME BITS as the ctypes binding the nn.Module classes use (both call the one C ABI)."""
+import pytest
+import torch
+
+from poweflownet_amd import torch_ops
+from poweflownet_amd import _lib as L
+
+
+def test_library_loads_and_registers_every_operator():
+    ops = torch_ops.load()
+    assert int(ops.abi_version()) == L.ABI_VERSION
+    for name in torch_ops.OPS:
+        assert hasattr(ops, name), name
+    s = str(torch.ops.pfn.mpn_forward.default._schema)
+    assert "Tensor graph_ws" in s and "int[] dims" in s and "Tensor? rng_state" in s and "-> (Tensor, Tensor)" in s
+    s = str(torch.ops.pfn.adamw_step_.default._schema)
+    assert "Tensor(a!) param" in s and "Tensor(d!) step" in s
+
+
+def test_cpu_tensors_are_refused():
+    ops = torch_ops.load()
+    with pytest.raises(RuntimeError):          # (NotImplementedError is a RuntimeError: no CPU kernel is registered)
+        ops.scatter_add(torch.zeros(8, dtype=torch.uint8), 1, torch.zeros(3, 4))
+    with pytest.raises(RuntimeError):
+        ops.graph_build(torch.zeros(2, 3, dtype=torch.int64), 3, -1)
+
+
+# ------------------------------------------------------------------------------------------------------------ GPU
+def _setup(case="14", B=5, train=False, seed=3):
+    from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+    from poweflownet_amd.synth import make_batch
+    torch.manual_seed(seed)
+    m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 2, 0.2 if train else 0.0).to("cuda:0")
+    m.train() if train else m.eval()
+    d = make_batch(case, B, seed=seed + 1).to("cuda:0")
+    return m, d
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train", [False, True])
+def test_model_ops_match_the_module_bit_for_bit(train):
+    ops = torch_ops.load()
+    m, d = _setup(train=train)
+    if train:
+        m.seed_dropout(77)
+    out = m(d)
+    torch.nn.MSELoss()(out, d.y).backward()
+    flat = m.flat_grad().clone()
+    g = m._graphs._graph
+    params = [p.detach() for p in m._ordered_params()]
+    dims = torch_ops.model_dims(m)
+    rng = torch.tensor([77, 0], dtype=torch.int64, device="cuda:0") if train else None
+    gws = ops.graph_build(d.edge_index, d.x.shape[0], -1)
+    out2, ws = ops.mpn_forward(gws, d.edge_index.shape[1], g.seg_nodes, dims, m.dropout_rate, train, True, params, d.x, d.pred_mask,
+                               d.edge_attr, rng)
+    assert torch.equal(out2, out.detach())
+    gout = (2.0 / out2.numel()) * (out2 - d.y)
+    flat2, gx, gea = ops.mpn_backward(gws, d.edge_index.shape[1], g.seg_nodes, dims, m.dropout_rate, train, params, d.x, d.pred_mask,
+                                      d.edge_attr, gout, ws, True, True)
+    assert gx.shape == d.x.shape and gea.shape == d.edge_attr.shape and torch.isfinite(gx).all() and torch.isfinite(gea).all()
+    # (the module's loss gradient comes from pfn_mse_loss: 2 (out - y) / n, the same expression in fp32)
+    lo, gr = ops.mse_loss(out2, d.y, torch.zeros(264, device="cuda:0"))
+    flat3, _, _ = ops.mpn_backward(gws, d.edge_index.shape[1], g.seg_nodes, dims, m.dropout_rate, train, params, d.x, d.pred_mask,
+                                   d.edge_attr, gr, ws, False, False)
+    assert torch.equal(flat3, flat)
+    assert torch.allclose(flat2, flat, rtol=1e-5, atol=1e-7 * flat.abs().max().item())
+    assert abs(lo.item() - torch.nn.functional.mse_loss(out2, d.y).item()) <= 1e-6 * abs(lo.item())
+
+
+@pytest.mark.gpu
+def test_layer_ops_match_the_modules_bit_for_bit():
+    from poweflownet_amd.networks.MPN import EdgeAggregation, TAGConv
+    ops = torch_ops.load()
+    _, d = _setup(case="118", B=3)
+    torch.manual_seed(5)
+    n, e = d.x.shape[0], d.edge_index.shape[1]
+    gws = ops.graph_build(d.edge_index, n, 1)
+    x = torch.randn(n, 7, device="cuda:0", requires_grad=True)
+    ea = EdgeAggregation(7, 2, 33, 5).to("cuda:0")
+    ei2 = torch.cat([d.edge_index, d.edge_index.flip(0)], 1)
+    at2 = torch.cat([d.edge_attr, d.edge_attr], 0)
+    y = ea(x, ei2, at2)                          # the module is given the undirected list (networks/MPN.py:538-541)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    l1, l2 = ea.edge_aggr[0], ea.edge_aggr[2]
+    gws0 = ops.graph_build(ei2, n, 0)
+    y2, ws = ops.edge_aggr_forward(gws0, ei2.shape[1], x.detach(), at2, l1.weight.detach(), l1.bias.detach(), l2.weight.detach(), l2.bias.detach())
+    assert torch.equal(y2, y.detach())
+    gx, gea, gw1, gb1, gw2, gb2 = ops.edge_aggr_backward(gws0, ei2.shape[1], x.detach(), at2, l1.weight.detach(), l1.bias.detach(),
+                                                         l2.weight.detach(), l2.bias.detach(), w, ws)
+    assert torch.equal(gx, x.grad) and torch.equal(gw1, l1.weight.grad) and torch.equal(gb1, l1.bias.grad)
+    assert torch.equal(gw2, l2.weight.grad) and torch.equal(gb2, l2.bias.grad)
+    # TAGConv
+    x.grad = None
+    tg = TAGConv(7, 6, K=3).to("cuda:0")
+    with torch.no_grad():
+        tg.bias.normal_()
+    y = tg(x, ei2)
+    w = torch.randn_like(y)
+    (y * w).sum().backward()
+    ws_ = [l.weight.detach() for l in tg.lins]
+    y2, ws = ops.tag_conv_forward(gws0, ei2.shape[1], 0, x.detach(), ws_, tg.bias.detach())
+    assert torch.equal(y2, y.detach())
+    gx, gb, gws_ = ops.tag_conv_backward(gws0, ei2.shape[1], 0, x.detach(), ws_, w, ws, True)
+    assert torch.equal(gx, x.grad) and torch.equal(gb, tg.bias.grad)
+    for a, l in zip(gws_, tg.lins):
+        assert torch.equal(a, l.weight.grad)
+    # scatter_add == index_add_ in stored edge order
+    xs = torch.randn(n, 129, device="cuda:0")
+    ref = torch.zeros_like(xs).index_add_(0, ei2[1], xs[ei2[0]])
+    assert torch.equal(ops.scatter_add(gws0, ei2.shape[1], xs), ref)
+    del gws
+
+
+@pytest.mark.gpu
+def test_adamw_op_matches_flat_adamw_and_bad_inputs_raise():
+    from poweflownet_amd.optim import FlatAdamW
+    ops = torch_ops.load()
+    m, d = _setup()
+    out = m(d)
+    torch.nn.MSELoss()(out, d.y).backward()
+    flat_g = m.flat_grad().clone()
+    p0 = torch.cat([p.detach().reshape(-1) for p in m._ordered_params()]).clone()
+    opt = FlatAdamW(m, lr=1e-3)
+    opt.step()
+    p_mod = torch.cat([p.detach().reshape(-1) for p in m._ordered_params()])
+    p, ea, es = p0.clone(), torch.zeros_like(p0), torch.zeros_like(p0)
+    step = torch.zeros(2, dtype=torch.int64, device="cuda:0")
+    ops.adamw_step_(p, flat_g, ea, es, 1e-3, 0.9, 0.999, 1e-8, 0.01, step)
+    assert int(step[0].item()) == 1 and torch.equal(p, p_mod)
+    with pytest.raises(RuntimeError):
+        ops.scatter_add(torch.zeros(8, dtype=torch.uint8, device="cuda:0"), 1, torch.zeros(3, 4, device="cuda:0", dtype=torch.float64))
+    with pytest.raises(RuntimeError):
+        ops.graph_build(torch.zeros(3, 3, dtype=torch.int64, device="cuda:0"), 3, -1)
+    with pytest.raises(RuntimeError):          # an out-of-range mode
+        ops.graph_build(torch.zeros(2, 3, dtype=torch.int64, device="cuda:0"), 3, 7)
