@@ -1734,6 +1734,31 @@ def test_big_graph_hops_with_unequal_edge_counts():
     _assert_grads_on_hip_gates(m, ref, data, "big-graph hops, unequal edge counts", out)
 
 
+def test_big_graph_hops_one_workgroup_per_graph_walks_every_chunk():
+    """big_graph_hops_kernel's workgroups are persistent over the column chunks of ONE graph; the launcher deals `CUs / graphs`
+    workgroups to a graph.  With more graphs than a third of the CUs a single workgroup walks ALL chunks of its graph (H = 20: five
+    chunks, the last one partly padding), in more than one round of the chip -- and 139 graphs leave 5 idle workgroups in the last
+    group of eight.  Forward and all gradients against the oracle (K = 2 and the K = 1 edge case: no tile refill at all)."""
+    from poweflownet_amd.data import Batch
+    from poweflownet_amd.synth import make_graph, make_topology
+    n, e = 2500, 3400
+    topo = make_topology(n, e, seed=11)
+    data = Batch.from_data_list([make_graph(n, e, seed=60 + i, edge_index=topo) for i in range(139)])
+    for K in (2, 1):
+        torch.manual_seed(9 + K)
+        ref = ref_cpu.MaskEmbdMultiMPN(4, 2, 4, 20, 2, K, 0.0).eval()
+        m = MaskEmbdMultiMPN(4, 2, 4, 20, 2, K, 0.0)
+        m.load_state_dict(ref.state_dict())
+        m = m.to(DEV).eval()
+        dd = data.to(DEV)
+        out = m(dd)
+        assert m._graphs._graph.seg_nodes == n
+        torch.nn.MSELoss()(out, dd.y).backward()
+        with torch.no_grad():
+            assert_close(out, ref(data), RTOL, f"big-graph hops, 139 graphs, K={K}: out vs fp32 oracle")
+        _assert_grads_on_hip_gates(m, ref, data, f"big-graph hops, one workgroup per graph, K={K}", out)
+
+
 def test_rows_kernels_with_unequal_edge_counts(tmp_path):
     """Big inference batches of small graphs take the whole-rows LDS kernels (row_hops_kernel, edge_rows_fwd_kernel -- the first
     layer's launch forming P | Q from x0).  Their staged adjacency / attribute lists are sized for an EQUAL share of the edges per
