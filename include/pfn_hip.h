@@ -236,8 +236,6 @@ int pfn_adamw_step_guarded(float* param, const float* grad, float* exp_avg, floa
  * replaces, the tuning scripts under tools/ to sweep a launch parameter -- and none of them is needed in production: unset, the
  * library behaves as DESIGN.md describes.  There is no switch that routes work off the GPU or through another backend.
  *   PFN_NO_SEG_EA=1         EdgeAggregation of small-graph batches: generic gemm_nt + edge walks instead of the graph-resident kernels
- *   PFN_NO_NT_SEQ=1         gemm_nt at large M: the two quarters of a wave's tile interleaved step by step, the whole flush behind the multiply
- *                           (instead of quarter by quarter with the first quarter's flush inside the second's multiply; bit-identical)
  *   PFN_NO_SEG_LIN_HOPS=1   small-graph batches: the Linear in front of a TAGConv's hops and the hops as two launches (gemm_nt + fused hops)
  *                           instead of one graph-resident launch (seg_lin_hops.hip; bit-identical results)
  *   PFN_NO_FUSED_FRONT=1    mask_embd + first P|Q as generic GEMMs instead of front.hip's one launch

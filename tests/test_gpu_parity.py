@@ -832,50 +832,6 @@ torch.save({{"out": out.detach().cpu(), "gx": d.x.grad.cpu(), "g": m.flat_grad()
         assert_close(res[tag]["g"], res["generic"]["g"], RTOL, f"{tag}: flat parameter gradient")
 
 
-def test_quarter_by_quarter_gemm_nt_is_bit_identical_to_the_interleaved_form(tmp_path):
-    """gemm_nt at large M (two 32-column quarters per wave): launches whose every K = 129 piece is flushed -- S W2^T (ReLU, inference),
-    P | Q, the four dY W_k of a TAGConv backward -- run quarter BY quarter, quarter 0's flush sliced into quarter 1's MFMA stream
-    (nt_multiply_seq; the nn.Linear products of networks/MPN.py:17-21 and PyG TAGConv's lins).  Same k order per accumulator, same
-    epilogue expressions: outputs and all gradients carry the SAME BITS as the step-by-step interleaved kernel (PFN_NO_NT_SEQ=1;
-    read once per process -> child processes).  case118v2 x 600 = 70,800 rows (a ragged last row tile, row-major operands) and
-    6470rte x 11 = 71,170 rows (chunk-major TAGConv operands and outputs), inference (ReLU epilogues) and training with dropout."""
-    import os
-    import subprocess
-    import sys
-    script = f"""
-import sys, torch
-sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
-from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
-from poweflownet_amd.synth import make_batch
-case, B, train = sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
-torch.manual_seed(3)
-m = MaskEmbdMultiMPN(4, 2, 4, 129, 3, 3, 0.2).to("cuda:0")
-d = make_batch(case, B, seed=4).to("cuda:0")
-if train:
-    m.train()
-    m.seed_dropout(5)
-    out = m(d)
-    torch.nn.MSELoss()(out, d.y).backward()
-    torch.save({{"out": out.detach().cpu(), "g": m.flat_grad().cpu()}}, sys.argv[1])
-else:
-    m.eval()
-    with torch.no_grad():
-        out = m(d)
-    torch.save({{"out": out.cpu()}}, sys.argv[1])
-"""
-    for case, B in (("118v2", 600), ("6470rte", 11)):
-        for train in (0, 1):
-            res = {}
-            for tag, env in (("seq", {}), ("interleaved", {"PFN_NO_NT_SEQ": "1"})):
-                path = str(tmp_path / f"{tag}.pt")
-                subprocess.run([sys.executable, "-c", script, path, case, str(B), str(train)], check=True, env=dict(os.environ, **env),
-                               timeout=600)
-                res[tag] = torch.load(path)
-            assert torch.isfinite(res["seq"]["out"]).all()
-            for key in res["seq"]:
-                assert torch.equal(res["seq"][key], res["interleaved"][key]), f"case{case} x {B} train={train}: {key} differs"
-
-
 def test_chain_kernels_are_bit_identical_to_the_launch_per_phase_path(tmp_path):
     """seg_chain.hip: for batches of small graphs everything between the front launch and the last layer's 129 -> 4 Linear --
     `act(S W2^T + deg b2)` + K hops, the TAGConv product, the next EdgeAggregation's P | Q product + edge walk, times L - 1
