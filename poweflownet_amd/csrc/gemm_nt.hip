@@ -218,20 +218,6 @@ __device__ __forceinline__ void vstore_x4_sv(const char* sbase, uint32_t voff, f
     if (WT) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
-// ... under a lane mask (a wave-uniform 64-bit ballot) WITHOUT a branch: the store stays inside its basic block, so the scheduler can
-// keep the code around it between the MFMAs of a chunk (nt_multiply_seq's flush slices)
-__device__ __forceinline__ void vstore_x4_sv_masked(const char* sbase, uint32_t voff, f32x4 v, uint64_t lanes) {
-    uint64_t keep;
-    asm volatile(
-        "s_mov_b64 %0, exec\n\t"
-        "s_and_b64 exec, exec, %4\n\t"
-        "global_store_dwordx4 %1, %2, %3\n\t"
-        "s_nop 1\n\t"
-        "s_mov_b64 exec, %0"
-        : "=&s"(keep)
-        : "v"(voff), "v"(v), "s"(sbase), "s"(lanes)
-        : "memory");
-}
 template <bool WT = false>
 __device__ __forceinline__ void vstore_x4(float* p, f32x4 v) {
     // the s_nop is the ISA's "VMEM store wider than 64 bits -> VALU overwrites its data registers" hazard (2 wait states),
@@ -341,117 +327,12 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
     }
 }
 
-// ---- SEQ: the two quarters of a CT = 2 tile multiplied ONE AFTER THE OTHER off the same A fragment, for launches whose every
-// piece is followed by a flush (one K = 129 piece per tile: S W2^T, P | Q, dS W2, dY W_k -- 57 % of the large-M gemm_nt flops of
-// a training step, at 0.66-0.70 of the loop's matrix-pipe time against 0.90 for the 4-piece TAGConv product, because a wave's
-// flush runs with its matrix pipe idle and crawls while its SIMD partner multiplies).  Pass 1: quarter 0 (and the trailing
-// column), waiting for the fragment chunk by chunk, no refills.  Pass 2: quarter 1, the refills for the next tile -- and quarter
-// 0's FLUSH cut into four slices (one register group each: transpose, epilogue, one store) that sit between pass 2's MFMAs, where
-// a wave's own vector instructions cost almost nothing (profiles/r05_mfma_valu_interleave.txt).  Quarter 1 is flushed behind
-// the multiply as before.  Same MFMA k order per accumulator, same epilogue expressions: bit-identical to the interleaved form.
-// vmcnt: in pass 1 no refill of THIS round has been issued, so R_m has the 16 - m later refills of the previous round younger
-// than itself -- plus that round's output stores and this round's epilogue-operand loads, which only make the wait early
-// (it then also covers a few more of the old refills; the operand loads stay among the 16 - m youngest except at the last
-// chunks, 16 chunks after they were requested).
-template <int M_>
-__device__ __forceinline__ void wait_a_seq(f32x4& v) {
-    asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(NCH - 1 - M_));
-}
-template <int NR, int NFAST, int LS, typename SLICE>
-__device__ __forceinline__ void nt_multiply_seq(f32x16 (&acc)[2], float (&racc)[4], f32x4 (&a_cur)[NCH], const float* S, int tps,
-                                                int tsel, uint32_t kh4, int r32, const char* nbase, uint32_t nvoff, int nkmax,
-                                                uint32_t nkscale, float (&rsv)[4], float& rrem, bool has_aux, SLICE&& slice) {
-    static_assert(NFAST == NCH, "SEQ: K = 129 .. 136 pieces only");
-    constexpr int NRE = NR > 0 ? NR : 1;
-    constexpr int tile_floats = NFAST * 8 * 32;
-    const float* Bt = S + tsel * tile_floats + (kh4 * 8 + r32) * 4;
-    const float* Rt = S + tps * tile_floats + kh4 * 4;
-    const uint32_t vlane0 = nvoff + nkscale * kh4;
-    // ---- pass 1: quarter 0 + the trailing column
-    {
-        f32x4 b_nxt = *reinterpret_cast<const f32x4*>(Bt), r_nxt[NRE];
-#pragma unroll
-        for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + c * 4);
-#pragma unroll
-        for (int m = 0; m < NCH; ++m) {
-            const f32x4 b = b_nxt;
-            f32x4 r[NRE];
-#pragma unroll
-            for (int c = 0; c < NR; ++c) r[c] = r_nxt[c];
-            if (m + 1 < NCH) {
-                b_nxt = *reinterpret_cast<const f32x4*>(Bt + (m + 1) * 256);
-#pragma unroll
-                for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + (m + 1) * 32 + c * 4);
-            }
-            switch (m) {
-                case 0: wait_a_seq<0>(a_cur[m]); break;   case 1: wait_a_seq<1>(a_cur[m]); break;
-                case 2: wait_a_seq<2>(a_cur[m]); break;   case 3: wait_a_seq<3>(a_cur[m]); break;
-                case 4: wait_a_seq<4>(a_cur[m]); break;   case 5: wait_a_seq<5>(a_cur[m]); break;
-                case 6: wait_a_seq<6>(a_cur[m]); break;   case 7: wait_a_seq<7>(a_cur[m]); break;
-                case 8: wait_a_seq<8>(a_cur[m]); break;   case 9: wait_a_seq<9>(a_cur[m]); break;
-                case 10: wait_a_seq<10>(a_cur[m]); break; case 11: wait_a_seq<11>(a_cur[m]); break;
-                case 12: wait_a_seq<12>(a_cur[m]); break; case 13: wait_a_seq<13>(a_cur[m]); break;
-                case 14: wait_a_seq<14>(a_cur[m]); break; case 15: wait_a_seq<15>(a_cur[m]); break;
-                default: wait_a_seq<16>(a_cur[m]); break;
-            }
-            const f32x4 av = a_cur[m];
-#pragma unroll
-            for (int i = 0; i < (m == NFAST - 1 ? LS : 4); ++i) {
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b[i], acc[0], 0, 0, 0);
-#pragma unroll
-                for (int c = 0; c < NR; ++c) racc[c] = fmaf(av[i], r[c][i], racc[c]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-    // the epilogue operands of this tile's flush were requested before pass 1 (~17 chunks ago); nothing younger is in flight
-    if (has_aux) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rsv[0]), "+v"(rsv[1]), "+v"(rsv[2]), "+v"(rsv[3]), "+v"(rrem));
-    // ---- pass 2: quarter 1, the refills, quarter 0's flush in slices
-    {
-        const float* Bt1 = Bt + tile_floats;
-        f32x4 b_nxt = *reinterpret_cast<const f32x4*>(Bt1);
-#pragma unroll
-        for (int m = 0; m < NCH; ++m) {
-            const f32x4 b = b_nxt;
-            if (m + 1 < NCH) b_nxt = *reinterpret_cast<const f32x4*>(Bt1 + (m + 1) * 256);
-            const f32x4 av = a_cur[m];
-#pragma unroll
-            for (int i = 0; i < (m == NFAST - 1 ? LS : 4); ++i) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b[i], acc[1], 0, 0, 0);
-            if ((m & 3) == 3 || m == NCH - 1) {
-#pragma unroll
-                for (int mm = m & ~3; mm <= m; ++mm) {
-                    if (mm < NFAST - 1) {
-                        vload_x4(a_cur[mm], nbase + (size_t)mm * 8u * nkscale, vlane0);
-                    } else {
-                        const uint32_t kk = min(kh4 + 8u * mm, (uint32_t)nkmax);
-                        vload_x4(a_cur[mm], nbase, nvoff + nkscale * kk);
-                    }
-                }
-            }
-            slice(m);
-            if (m < 16 && (m & 3) == 1) {
-                // the slice's vector instructions dealt between the chunk's four MFMAs (left alone the scheduler puts 75-95 of them
-                // behind the fourth: ~300 cycles against the 64 an MFMA covers)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // one MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x002, 11, 0);   // ~a quarter of the slice: what one MFMA's 64 cycles cover
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
 // VAR = the multiply variant of the launch (all pieces of a launch share it; chosen on the host, so that a kernel holds at most
 // TWO instantiations of the round loop -- with / without the trailing VALU column, a per-wave property; with more of them in one
 // kernel the CT = 2 build had no registers left for the one-step tail):
 //   0: 17 chunks, the last chunk is ONE MFMA step (K = 129)     1: 17 chunks, last chunk 4 steps
 //   2: 16 chunks (K = 128), no trailing column                  3: generic (per-chunk guards, 4 trailing columns; CT < 2 only)
-// SEQ: 0 = the quarters of a CT = 2 tile interleaved step by step; 1 / 2 / 3 = quarter by quarter (nt_multiply_seq) with the
-// activation fixed at compile time (none / ReLU / dropout + ReLU): the flush slices are straight-line code the scheduler can lay
-// between the MFMAs of a chunk
-template <int CT, int VAR, int SEQ = 0>
+template <int CT, int VAR>
 __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CTE = CT > 0 ? CT : 1;
@@ -612,18 +493,6 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
             for (int g = 0; g < 4; ++g) aux[ct][g] = f32x4{0.f, 0.f, 0.f, 0.f};
         raux = f32x4{0.f, 0.f, 0.f, 0.f};
         const bool has_aux = flush_after && (a.rowscale || extra);
-        // SEQ launches take no gate / residual operand (the launcher sees to it): their only epilogue operand is the row scale, one
-        // dword per row -- five registers where the interleaved form's 2 x 4 x float4 operand block holds 36
-        float rsv[4] = {0.f, 0.f, 0.f, 0.f}, rrem = 0.f;
-        if (SEQ != 0 && CT == 2) {
-            if (has_aux) {
-                const char* rb = reinterpret_cast<const char*>(a.rowscale + rbase);
-                const int rlast = a.M - 1 - rbase;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) rsv[g] = vload_x1_sv(rb, (uint32_t)min(jrow + 8 * g, rlast) * 4u);
-                if (rem_on) rrem = vload_x1_sv(rb, (uint32_t)min(r32, rlast) * 4u);
-            }
-        } else
         if (has_aux) {
             if (a.rowscale) {
                 // (one dword per row, loaded straight into its component of `aux` -- unconditionally, from a clamped row: a masked load
@@ -650,107 +519,6 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                              a.aux_cm_rows > 0 ? (uint32_t)r32 * 16u : (uint32_t)r32 * (uint32_t)ldx * 4u);
             }
         }
-        // ---- SEQ launches (every piece flushes; CT = 2): quarter by quarter, quarter 0's flush inside quarter 1's multiply
-        if constexpr (SEQ != 0 && CT == 2 && NFAST == NCH) {
-            constexpr int ACT_ = SEQ - 1;                   // ACT_NONE / ACT_RELU / ACT_DROPOUT_RELU, fixed per kernel
-            float* C = a.C[group];
-            const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
-            const int row_base = rbase + (r32 & 3) + 4 * kh;
-            // the bias stage without a branch: v = fma(mul, cb, v) with mul = the row scale, or 1 (plain bias: fma(1, cb, v) is v + cb
-            // exactly), or 0 (no bias: v + 0)
-            const float bmul = use_bias && !ep.has_rowscale ? 1.f : 0.f;
-            const uint32_t vc = lane_off(a.ldc, a.c_cm_rows);
-            // everything with a branch in it is settled here, per tile: the slices must stay ONE basic block with the MFMAs around
-            // them.  Float offset of register group 0 of each quarter + a uniform stride per group; the lanes' store masks by
-            // bitwise logic (&& / || and ?: on these compile to scalar branches)
-            size_t qb[2];
-            bool qon[2], qfl[2], qcl[2];
-#pragma unroll
-            for (int ct = 0; ct < 2; ++ct) {
-                const int q = min(tile0 + ct, a.nq - 1);    // (a quarter past the last one: computed like the last, stored nowhere)
-                qb[ct] = ubase(q, 0, a.ldc, a.c_cm_rows);
-                qon[ct] = (tile0 + ct < a.nq) & (32 * q + (r32 & ~3) < a.ldc);
-                qfl[ct] = tile_full & qfull(q);
-                qcl[ct] = colok(q);
-            }
-            const size_t gstride = a.c_cm_rows > 0 ? (size_t)32 : (size_t)8 * a.ldc;
-            // One register group of one quarter in two straight-line parts -- `draw`: the group's four dropout uniforms (Philox, ~100
-            // vector instructions); `emit`: transpose, epilogue, store -- the flush's expressions, element for element.
-            float ud[4] = {1.f, 1.f, 1.f, 1.f};
-            auto draw = [&](int ct, int g) {
-                if constexpr (ACT_ == ACT_DROPOUT_RELU) {
-                    uint32_t cgv = (uint32_t)((32 * (tile0 + ct) + (r32 & ~3)) >> 2);
-                    asm volatile("" : "+v"(cgv));
-                    dropout_uniform4(ep.dk, (uint32_t)(row_base + 8 * g + a.row0), cgv, ud);
-                }
-            };
-            auto emit = [&](int ct, int g) {
-                const int q = min(tile0 + ct, a.nq - 1);
-                const int col0 = 32 * q + (r32 & ~3);
-                float t[4] = {acc[ct][4 * g], acc[ct][4 * g + 1], acc[ct][4 * g + 2], acc[ct][4 * g + 3]};
-                quad_transpose(t, lane);
-                const f32x4 cb4 = *reinterpret_cast<const f32x4*>(lds + a.bias_lds_off + min(col0, a.ldc - 4));
-                const float mul = ep.has_rowscale ? rsv[g] : bmul;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) t[e] = fmaf(mul, cb4[e], t[e]);
-                if constexpr (ACT_ == ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
-                } else if constexpr (ACT_ == ACT_DROPOUT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) t[e] = (ud[e] >= ep.p_drop && t[e] > 0.f) ? t[e] * ep.keep_scale : 0.f;
-                }
-                const bool on = qon[ct] & (qfl[ct] | (rowok(g) & qcl[ct]));
-                const char* cbp = reinterpret_cast<const char*>(C + qb[ct] + (size_t)g * gstride);
-                vstore_x4_sv_masked(cbp, vc, f32x4{t[0], t[1], t[2], t[3]}, __builtin_amdgcn_ballot_w64(on));
-            };
-            nt_multiply_seq<NR, NFAST, LS>(acc, racc, a_cur, lds + cur_lds, a.tps, cg * CT, kh4, r32, nbase, nvoff, nkmax, (uint32_t)nx_kscale,
-                                           rsv, rrem, has_aux, [&](int m) {
-                // group g = m / 4 of quarter 0: its uniforms in chunk 4 g, its transpose / epilogue / store in chunk 4 g + 1
-                if (m < 16 && (m & 3) == 0) draw(0, m >> 2);
-                if (m < 16 && (m & 3) == 1) emit(0, m >> 2);
-            });
-            // quarter 1 and the trailing column behind the multiply, as in the interleaved form
-            asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[1]));
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                draw(1, g);
-                emit(1, g);
-            }
-            if (rem_on) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = racc[e] + __shfl_xor(racc[e], 32);   // the two k halves
-                const int row = rbase + r32;
-                if (kh == 0 && row < a.M) {
-                    float* dst = C + act_off(row, rem_col, a.ldc, a.c_cm_rows);
-                    const f32x4 rcb = *reinterpret_cast<const f32x4*>(lds + a.bias_lds_off + rem_col);
-                    float ud[4] = {1.f, 1.f, 1.f, 1.f};
-                    if (ACT_ == ACT_DROPOUT_RELU) {
-                        uint32_t cgv = (uint32_t)(rem_col >> 2);
-                        asm volatile("" : "+v"(cgv));
-                        dropout_uniform4(ep.dk, (uint32_t)(row + a.row0), cgv, ud);
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float x = v[e] + ((use_bias && !ep.has_rowscale) ? rcb[e] : 0.f);
-                        if (ep.has_rowscale) x = fmaf(rrem, rcb[e], x);
-                        if (ACT_ == ACT_RELU) {
-                            x = fmaxf(x, 0.f);
-                        } else if (ACT_ == ACT_DROPOUT_RELU) {
-                            x = (ud[e] >= ep.p_drop && x > 0.f) ? x * ep.keep_scale : 0.f;
-                        }
-                        v[e] = rem_col + e < ep.ncols ? x : 0.f;
-                    }
-                    vstore_x4<false>(dst, f32x4{v[0], v[1], v[2], v[3]});
-                }
-            }
-#pragma unroll
-            for (int ct = 0; ct < CTE; ++ct)
-#pragma unroll
-                for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
-            racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
-        } else {
         // ---- multiply
         {
             const float* S = lds + cur_lds;
@@ -922,7 +690,6 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
                 for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
             racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
         }
-        }   // (!SEQ)
         if (!more) break;
         p = np;
         rt = nrt_;
@@ -1326,11 +1093,11 @@ __global__ __launch_bounds__(64 * TINY_MAX_PIECES) void gemm_nt_tiny_kernel(cons
     }
 }
 
-template <int CT, int VAR, int SEQ = 0>
+template <int CT, int VAR>
 static int launch_variant(const NtArgs& k, dim3 grid, size_t lds_bytes, hipStream_t s) {
     static std::atomic<uint64_t> lds_raised{0};
-    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<CT, VAR, SEQ>), NT_LDS_BYTES, lds_raised));
-    gemm_nt_kernel<CT, VAR, SEQ><<<grid, NT_THREADS, lds_bytes, s>>>(k);
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<CT, VAR>), NT_LDS_BYTES, lds_raised));
+    gemm_nt_kernel<CT, VAR><<<grid, NT_THREADS, lds_bytes, s>>>(k);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
@@ -1571,18 +1338,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
 #define PFN_NT_CASE(CT_, V_) if (CT == CT_ && var == V_) rc = launch_variant<CT_, V_>(k, grid, lb, s)
         PFN_NT_CASE(0, 0); PFN_NT_CASE(0, 1); PFN_NT_CASE(0, 2); PFN_NT_CASE(0, 3);
         PFN_NT_CASE(1, 0); PFN_NT_CASE(1, 1); PFN_NT_CASE(1, 2); PFN_NT_CASE(1, 3);
-        // every piece of the launch is flushed (one K = 129 piece per tile), nothing accumulates or stays raw: the quarter-by-quarter
-        // kernel, whose first quarter's flush runs inside the second quarter's multiply (nt_multiply_seq)
-        static const bool no_seq = diag_env("PFN_NO_NT_SEQ") != nullptr;   // A/B switch: the interleaved-quarters kernel (bit-identical)
-        bool seq = !no_seq && CT == 2 && var == 0 && i0 == 0 && i1 == pieces.size() && !a.gate && !a.resid;
-        for (size_t i = i0; i < i1 && seq; ++i) seq = (k.piece[i - i0].gl >> 8) != 0;
-        for (int g = 0; g < 8 && seq; ++g) seq = k.gflags[g] == 0;
-        if (seq && k.act == ACT_NONE) rc = launch_variant<2, 0, 1>(k, grid, lb, s);
-        else if (seq && k.act == ACT_RELU) rc = launch_variant<2, 0, 2>(k, grid, lb, s);
-        // (dropout + ReLU: the Philox draws next to a second quarter's multiply do not fit the register file -- 25 spills, i.e. a
-        //  drained prefetch per reload: those launches keep the interleaved form)
-        else { PFN_NT_CASE(2, 0); }
-        PFN_NT_CASE(2, 1); PFN_NT_CASE(2, 2);
+        PFN_NT_CASE(2, 0); PFN_NT_CASE(2, 1); PFN_NT_CASE(2, 2);
 #undef PFN_NT_CASE
         if (var < 0) set_error("gemm_nt: no CT = %d kernel for this launch (kuni %d, nrem %d)", CT, k.kuni, k.nrem);
         if (rc != PFN_OK) return rc;
