@@ -518,7 +518,7 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
     // (hub slot + 1) << 24 -- a hop's first trip of four slots (all of most rows of a power grid: mean degree 2.8) is then four
     // independent id reads and four independent tile reads, without the row-pointer level and without a loop around it.  Hub rows
     // are listed once (the slot order is arrival order -- it decides which wave sums a row, not what the sum is).
-    uint32_t plan[BH_RPT];
+    uint32_t plan[BH_RPT], id01[BH_RPT], id23[BH_RPT];
 #pragma unroll
     for (int r = 0; r < BH_RPT; ++r) {
         const int rowu = t + r * BH_THREADS, row = min(rowu, seg - 1);
@@ -532,6 +532,11 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
             }
         }
         plan[r] = (uint32_t)beg | ((uint32_t)min(cnt, 255) << 16) | (hub << 24);
+        // ... and the first trip's four tile rows themselves, 16 bits each; a slot past the row's end points at the ZERO row
+        const unsigned short* nbp = s_nb + beg;
+        const uint32_t i0 = cnt > 0 ? nbp[0] : seg, i1 = cnt > 1 ? nbp[1] : seg, i2 = cnt > 2 ? nbp[2] : seg, i3 = cnt > 3 ? nbp[3] : seg;
+        id01[r] = i0 | (i1 << 16);
+        id23[r] = i2 | (i3 << 16);
     }
     __syncthreads();
     const int nhub = min(s_hub_n[0], BH_HUB_CAP);
@@ -544,7 +549,7 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
         int to = t;
         asm volatile("" : "+v"(to));
 #pragma unroll
-        for (int r = 0; r < BH_RPT; ++r) asm volatile("" : "+v"(plan[r]));
+        for (int r = 0; r < BH_RPT; ++r) asm volatile("" : "+v"(plan[r]), "+v"(id01[r]), "+v"(id23[r]));
         // ---- hub rows first: one wave per row, lanes stride over its edges, fixed xor tree
         for (int hs = wave_; hs < nhub; hs += BH_THREADS / 64) {
             const int row = s_hub_row[hs];
@@ -565,16 +570,11 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
         for (int r = 0; r < BH_RPT; ++r) {
             const int row = to + r * BH_THREADS;
             const int beg = (int)(plan[r] & 0xffffu), cnt = (int)((plan[r] >> 16) & 255u), hub = (int)(plan[r] >> 24);
-            // the first trip: four ids from ONE address (slots past the row's end read whatever follows in the list and are redirected
-            // to the tile's ZERO row), four tile reads, three adds.  Adding the zero row is exact -- the running sum starts as
-            // +0 + v0 and is never -0 -- so the sum carries the bits of the select chain it replaces; that chain (16 v_cndmask per
-            // row and hop, plus a clamp per slot) made the hop vector-ALU bound: ~100 vector instructions per row and hop
-            const unsigned short* nbp = s_nb + beg;
-            int i0 = nbp[0], i1 = nbp[1], i2 = nbp[2], i3 = nbp[3];
-            i0 = cnt > 0 ? i0 : seg;
-            i1 = cnt > 1 ? i1 : seg;
-            i2 = cnt > 2 ? i2 : seg;
-            i3 = cnt > 3 ? i3 : seg;
+            // the first trip: the four tile rows come out of the plan (a slot past the row's end points at the tile's ZERO row): four
+            // independent tile reads, three adds.  Adding the zero row is exact -- the running sum starts as +0 + v0 and is never
+            // -0 -- so the sum carries the bits of the select chain it replaces; that chain (16 v_cndmask per row and hop, a
+            // clamp per slot) had made the hop vector-ALU bound: ~100 vector instructions per row and hop
+            const uint32_t i0 = id01[r] & 0xffffu, i1 = id01[r] >> 16, i2 = id23[r] & 0xffffu, i3 = id23[r] >> 16;
             const float4 v0 = bh_tile[i0], v1 = bh_tile[i1], v2 = bh_tile[i2], v3 = bh_tile[i3];
             float4 acc = add4(add4(add4(add4(make_float4(0.f, 0.f, 0.f, 0.f), v0), v1), v2), v3);
             if (hub) {
