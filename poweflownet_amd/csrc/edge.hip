@@ -438,14 +438,17 @@ constexpr int BH_HUB_CAP = 128;                 // listed hub rows per graph (mo
 __host__ __device__ constexpr size_t bh_hub_bytes() { return (size_t)BH_HUB_CAP * 16 + (size_t)BH_HUB_CAP * 2 + 16; }
 // A workgroup is PERSISTENT over column chunks of ONE graph (chunk w, w + wpg, ...; the launcher picks wpg = workgroups per graph
 // so that the grid is one round of the chip): the adjacency is staged ONCE per workgroup instead of once per (graph, chunk) --
-// it is as many bytes as the tile itself -- and every row is PLANNED once for all chunks and hops: first slot | degree | hub slot
-// in one register, so a hop's first trip of four slots (all of most rows of a power grid: mean degree 2.8) is four independent
-// id reads and four independent tile reads instead of the chain row pointer -> neighbour id -> tile row inside a loop (cf.
-// seg_lin_hops.hip).  The next chunk's rows are requested at the start of the LAST hop of the current one (the registers that
-// hold them are dead from that hop's tile write on) and arrive under its gathers and stores.  Barriers publish LDS only
-// (lgkmcnt): no thread reads another thread's global writes, so nothing waits for the output stores to be acknowledged.
+// it is as many bytes as the tile itself -- and every row is PLANNED once for all chunks and hops: the tile rows of its first four
+// slots (all of most rows of a power grid: mean degree 2.8) as 16-bit ids in two registers, a slot past the row's end pointing
+// at a ZERO row behind the tile, plus first slot | degree | hub slot in a third for the rare longer rows.  A hop's first trip
+// is then four independent tile reads and three adds: no row-pointer / id reads, no loop, no clamps, no select chain (adding the
+// zero row is exact -- the running sum starts as +0 + v0 and is never -0 -- so the bits are those of `slot exists ? acc + v : acc`).
+// The next chunk's rows are requested at the start of the LAST hop of the current one (the registers that hold them are dead
+// from that hop's tile write on) and arrive under its gathers and stores.  Barriers publish LDS only (lgkmcnt): no thread reads
+// another thread's global writes, so nothing waits for the output stores to be acknowledged.
 // Same sums in the same order as the one-(graph, chunk)-per-workgroup form of rounds 3-4: bit-identical outputs (checked on the
-// GPU against that kernel before it was removed); 6470rte x 64: 284 / 273 -> 245 / 239 us per launch, step 12.37 -> 12.15 ms.
+// GPU against that kernel before it was removed, and build against build for every later step); 6470rte x 64: 284 / 273 ->
+// 221 / 218 us per launch (profiles/r05_big_graph_hops_persistent.txt).
 // What the compiler needed (1024 threads = 128 registers): the last hop PEELED out of the hop loop (z written in one branch and
 // loaded in another doubled its 32 registers: 114-214 spills), and the plan / row offsets made opaque per hop (their unpacked
 // fields, 64-bit offsets and lane masks are loop-invariant and were hoisted into 70-180 SGPRs and as many spills).
@@ -515,9 +518,8 @@ __global__ __launch_bounds__(BH_THREADS) void big_graph_hops_kernel(int seg, int
     for (int i = t; i < ne; i += BH_THREADS) s_nb[i] = (unsigned short)(nbr[e0 + i] - r0);
     __syncthreads();                            // (also publishes the zeroed hub counter)
     // ---- per-row plan, once for every chunk and hop: plan = first slot of the row in the staged list | min(degree, 255) << 16 |
-    // (hub slot + 1) << 24 -- a hop's first trip of four slots (all of most rows of a power grid: mean degree 2.8) is then four
-    // independent id reads and four independent tile reads, without the row-pointer level and without a loop around it.  Hub rows
-    // are listed once (the slot order is arrival order -- it decides which wave sums a row, not what the sum is).
+    // (hub slot + 1) << 24 (what the longer rows' later trips and the hub rows need), id01 / id23 = the first trip's tile rows.
+    // Hub rows are listed once (the slot order is arrival order -- it decides which wave sums a row, not what the sum is).
     uint32_t plan[BH_RPT], id01[BH_RPT], id23[BH_RPT];
 #pragma unroll
     for (int r = 0; r < BH_RPT; ++r) {
