@@ -8,7 +8,8 @@
 // arithmetic and no state lives in this file; libpfn_hip.so stays free of torch types and is what the tests grade.
 //
 //   callers this serves                                     operator
-//   utils/training.py:58 / utils/evaluation.py:79  model(data)              pfn::mpn_forward / pfn::mpn_backward
+//   utils/training.py:58 / utils/evaluation.py:79  model(data)              pfn::mpn (differentiable: one C++ autograd node),
+//                                                                          pfn::mpn_forward / pfn::mpn_backward (its two halves)
 //   networks/MPN.py:498-523 is_directed + undirect_graph                   pfn::graph_build
 //   networks/MPN.py:30-56   EdgeAggregation.forward (+ autograd)           pfn::edge_aggr_forward / _backward
 //   networks/MPN.py:477-484 PyG TAGConv.forward (+ autograd)               pfn::tag_conv_forward / _backward
@@ -21,6 +22,7 @@
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>   // (torch-ROCm tensors carry DeviceType::CUDA: the plain HIPGuard refuses them)
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/csrc/autograd/custom_function.h>
 #include <torch/library.h>
 
 #include <tuple>
@@ -319,6 +321,78 @@ void adamw_step_(Tensor param, const Tensor& grad, Tensor exp_avg, Tensor exp_av
            "pfn_adamw_step");
 }
 
+// ---- the differentiable form: `pfn::mpn` = MaskEmbdMultiMPN.forward with its autograd edge (what utils/training.py:58 + :74 use
+// as model(data) ... loss.backward()).  One autograd node for the whole network, like the Python mirror's `_MpnFn`: forward =
+// mpn_forward (need_backward iff anything differentiable asks for it), backward = mpn_backward; the parameter gradients are views
+// of ONE flat buffer (the data-parallel all-reduce unit).
+struct MpnFunction : public torch::autograd::Function<MpnFunction> {
+    // (a C++ autograd node differentiates its TENSOR arguments only -- not the members of a Tensor[] -- so the parameters arrive as
+    //  ONE flat tensor, concatenated by the caller below with a differentiable cat, and are handed to the C ABI as views of it)
+    static std::vector<Tensor> views_of(const Tensor& flat, const std::vector<int64_t>& numels) {
+        std::vector<Tensor> v;
+        int64_t off = 0;
+        for (int64_t n : numels) {
+            v.push_back(flat.narrow(0, off, n));
+            off += n;
+        }
+        return v;
+    }
+    static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes,
+                          std::vector<int64_t> dims, double dropout, bool training, const Tensor& flat_params, std::vector<int64_t> numels,
+                          const Tensor& x, const Tensor& pred_mask, const Tensor& edge_attr, const c10::optional<Tensor>& rng_state,
+                          bool need) {
+        // (need: decided by the caller -- inside `apply` grad mode is off and says nothing)
+        at::AutoDispatchBelowADInplaceOrView guard;
+        const std::vector<Tensor> params = views_of(flat_params, numels);
+        auto res = mpn_forward(graph_ws, e_stored, seg_nodes, dims, dropout, training, need, params, x, pred_mask, edge_attr, rng_state);
+        if (need) {
+            ctx->save_for_backward({graph_ws, x, pred_mask, edge_attr, std::get<1>(res), flat_params});
+            ctx->saved_data["e_stored"] = e_stored;
+            ctx->saved_data["seg_nodes"] = seg_nodes;
+            ctx->saved_data["dims"] = dims;
+            ctx->saved_data["numels"] = numels;
+            ctx->saved_data["dropout"] = dropout;
+            ctx->saved_data["training"] = training;
+            ctx->saved_data["need_gx"] = x.requires_grad();
+            ctx->saved_data["need_gea"] = edge_attr.requires_grad();
+        }
+        return std::get<0>(res);
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list grad_outputs) {
+        const auto saved = ctx->get_saved_variables();
+        TORCH_CHECK(saved.size() == 6, "pfn::mpn: backward through a forward that recorded nothing");
+        const Tensor &graph_ws = saved[0], &x = saved[1], &pred_mask = saved[2], &edge_attr = saved[3], &ws = saved[4];
+        const std::vector<Tensor> params = views_of(saved[5], ctx->saved_data["numels"].toIntVector());
+        const bool need_gx = ctx->saved_data["need_gx"].toBool(), need_gea = ctx->saved_data["need_gea"].toBool();
+        const std::vector<int64_t> dims = ctx->saved_data["dims"].toIntVector();
+        auto res = mpn_backward(graph_ws, ctx->saved_data["e_stored"].toInt(), ctx->saved_data["seg_nodes"].toInt(), dims,
+                                ctx->saved_data["dropout"].toDouble(), ctx->saved_data["training"].toBool(), params, x, pred_mask, edge_attr,
+                                grad_outputs[0].contiguous(), ws, need_gx, need_gea);
+        // inputs in order: graph_ws, e_stored, seg_nodes, dims, dropout, training, flat_params, numels, x, pred_mask, edge_attr,
+        // rng_state, need
+        torch::autograd::variable_list grads(13, Tensor());
+        grads[6] = std::get<0>(res);            // the flat gradient of every parameter (the cat's backward hands out its slices)
+        grads[8] = std::get<1>(res);            // x
+        grads[10] = std::get<2>(res);           // edge_attr
+        return grads;
+    }
+};
+Tensor mpn_autograd(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, at::IntArrayRef dims, double dropout, bool training,
+                    at::TensorList params, const Tensor& x, const Tensor& pred_mask, const Tensor& edge_attr,
+                    const c10::optional<Tensor>& rng_state) {
+    bool need = x.requires_grad() || edge_attr.requires_grad();
+    std::vector<Tensor> flats;
+    std::vector<int64_t> numels;
+    for (const Tensor& p : params) {
+        need = need || p.requires_grad();
+        flats.push_back(p.reshape({-1}));
+        numels.push_back(p.numel());
+    }
+    need = need && at::GradMode::is_enabled();
+    return MpnFunction::apply(graph_ws, e_stored, seg_nodes, dims.vec(), dropout, training, at::cat(flats), numels, x, pred_mask, edge_attr,
+                              rng_state, need);
+}
+
 int64_t abi_version() { return pfn_abi_version(); }
 
 }  // namespace
@@ -338,6 +412,8 @@ TORCH_LIBRARY(pfn, m) {
     m.def("tag_conv_backward(Tensor graph_ws, int e_stored, int seg_nodes, Tensor x, Tensor[] weights, Tensor grad_out, Tensor ws, "
           "bool has_bias=True) -> (Tensor, Tensor, Tensor[])");
     m.def("scatter_add(Tensor graph_ws, int e_stored, Tensor x) -> Tensor");
+    m.def("mpn(Tensor graph_ws, int e_stored, int seg_nodes, int[] dims, float dropout, bool training, Tensor[] params, Tensor x, "
+          "Tensor pred_mask, Tensor edge_attr, Tensor? rng_state=None) -> Tensor");
     m.def("mse_loss(Tensor out, Tensor y, Tensor(a!) ws) -> (Tensor, Tensor)");
     m.def("adamw_step_(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, float beta2, float eps, "
           "float weight_decay, Tensor(d!) step) -> ()");
@@ -355,4 +431,14 @@ TORCH_LIBRARY_IMPL(pfn, CUDA, m) {
     m.impl("scatter_add", &scatter_add);
     m.impl("mse_loss", &mse_loss);
     m.impl("adamw_step_", &adamw_step_);
+}
+
+// `pfn::mpn` carries its own autograd node (MpnFunction); with nothing differentiable in sight it is a plain inference forward
+TORCH_LIBRARY_IMPL(pfn, Autograd, m) { m.impl("mpn", &mpn_autograd); }
+TORCH_LIBRARY_IMPL(pfn, CUDA, m) {
+    m.impl("mpn", [](const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, at::IntArrayRef dims, double dropout, bool training,
+                     at::TensorList params, const Tensor& x, const Tensor& pred_mask, const Tensor& edge_attr,
+                     const c10::optional<Tensor>& rng_state) {
+        return std::get<0>(mpn_forward(graph_ws, e_stored, seg_nodes, dims, dropout, training, false, params, x, pred_mask, edge_attr, rng_state));
+    });
 }

@@ -4,6 +4,7 @@ include/pfn_hip.h -- what a C++ / TorchScript / `torch.ops` caller of utils/trai
     from poweflownet_amd import torch_ops
     ops = torch_ops.load()                       # == torch.ops.pfn
     g = ops.graph_build(edge_index, num_nodes, -1)
+    out = ops.mpn(g, E, 0, [4, 2, 4, 129, 4, 3], 0.2, False, params, x, pred_mask, edge_attr, None)      # differentiable
     out, ws = ops.mpn_forward(g, E, 0, [4, 2, 4, 129, 4, 3], 0.2, False, False, params, x, pred_mask, edge_attr, None)
 
 The operators validate with TORCH_CHECK (RuntimeError), allocate through ATen, run on torch's current stream and call exactly
@@ -20,7 +21,7 @@ from . import _lib as L
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpfn_torch.so")
 
-OPS = ("abi_version", "graph_build", "mpn_forward", "mpn_backward", "edge_aggr_forward", "edge_aggr_backward",
+OPS = ("abi_version", "graph_build", "mpn", "mpn_forward", "mpn_backward", "edge_aggr_forward", "edge_aggr_backward",
        "tag_conv_forward", "tag_conv_backward", "scatter_add", "mse_loss", "adamw_step_")
 
 _loaded = False

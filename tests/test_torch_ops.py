@@ -70,6 +70,40 @@ def test_model_ops_match_the_module_bit_for_bit(train):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("train", [False, True])
+def test_differentiable_model_op_matches_the_module(train):
+    """`pfn::mpn` carries its own autograd node (csrc/torch_ops.cpp MpnFunction): model(data) ... loss.backward() of
+    utils/training.py:58,:74 through torch.ops alone -- same output, same parameter / input gradients, bit for bit, as the module."""
+    ops = torch_ops.load()
+    m, d = _setup(train=train)
+    if train:
+        m.seed_dropout(77)
+    x = d.x.clone().requires_grad_(True)
+    d.x = x
+    out = m(d)
+    w = torch.randn_like(out)
+    (out * w).sum().backward()
+    ref_grads = [p.grad.clone() for p in m._ordered_params()]
+    ref_gx = x.grad.clone()
+    g = m._graphs._graph
+    params = [p.detach().clone().requires_grad_(True) for p in m._ordered_params()]
+    x2 = d.x.detach().clone().requires_grad_(True)
+    rng = torch.tensor([77, 0], dtype=torch.int64, device="cuda:0") if train else None
+    gws = ops.graph_build(d.edge_index, x2.shape[0], -1)
+    out2 = ops.mpn(gws, d.edge_index.shape[1], g.seg_nodes, torch_ops.model_dims(m), m.dropout_rate, train, params, x2, d.pred_mask,
+                   d.edge_attr, rng)
+    assert out2.requires_grad and torch.equal(out2.detach(), out.detach())
+    (out2 * w).sum().backward()
+    assert torch.equal(x2.grad, ref_gx)
+    for p, gr in zip(params, ref_grads):
+        assert p.grad is not None and torch.equal(p.grad, gr)
+    with torch.no_grad():      # nothing differentiable in sight: a plain inference forward
+        out3 = ops.mpn(gws, d.edge_index.shape[1], g.seg_nodes, torch_ops.model_dims(m), m.dropout_rate, False, [p.detach() for p in params],
+                       x2.detach(), d.pred_mask, d.edge_attr, None)
+    assert not out3.requires_grad and torch.isfinite(out3).all()
+
+
+@pytest.mark.gpu
 def test_layer_ops_match_the_modules_bit_for_bit():
     from poweflownet_amd.networks.MPN import EdgeAggregation, TAGConv
     ops = torch_ops.load()
