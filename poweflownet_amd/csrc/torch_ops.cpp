@@ -11,8 +11,8 @@
 //   utils/training.py:58 / utils/evaluation.py:79  model(data)              pfn::mpn (differentiable: one C++ autograd node),
 //                                                                          pfn::mpn_forward / pfn::mpn_backward (its two halves)
 //   networks/MPN.py:498-523 is_directed + undirect_graph                   pfn::graph_build
-//   networks/MPN.py:30-56   EdgeAggregation.forward (+ autograd)           pfn::edge_aggr_forward / _backward
-//   networks/MPN.py:477-484 PyG TAGConv.forward (+ autograd)               pfn::tag_conv_forward / _backward
+//   networks/MPN.py:30-56   EdgeAggregation.forward (+ autograd)           pfn::edge_aggr (differentiable), pfn::edge_aggr_forward / _backward
+//   networks/MPN.py:477-484 PyG TAGConv.forward (+ autograd)               pfn::tag_conv (differentiable), pfn::tag_conv_forward / _backward
 //   PyG propagate(aggr='add') in isolation (the roofline run)              pfn::scatter_add
 //   train.py:103 MSELoss, utils/training.py:72-74                          pfn::mse_loss
 //   train.py:123 AdamW.step                                                pfn::adamw_step_
@@ -393,6 +393,65 @@ Tensor mpn_autograd(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes,
                               rng_state, need);
 }
 
+// ---- the two layers as differentiable operators (what the reference's other model classes compose, networks/MPN.py:143-453)
+struct EdgeAggrFunction : public torch::autograd::Function<EdgeAggrFunction> {
+    static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& graph_ws, int64_t e_stored, const Tensor& x,
+                          const Tensor& edge_attr, const Tensor& w1, const Tensor& b1, const Tensor& w2, const Tensor& b2) {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        auto res = edge_aggr_forward(graph_ws, e_stored, x, edge_attr, w1, b1, w2, b2);
+        ctx->save_for_backward({graph_ws, x, edge_attr, w1, b1, w2, b2, std::get<1>(res)});
+        ctx->saved_data["e_stored"] = e_stored;
+        return std::get<0>(res);
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list go) {
+        const auto sv = ctx->get_saved_variables();
+        auto r = edge_aggr_backward(sv[0], ctx->saved_data["e_stored"].toInt(), sv[1], sv[2], sv[3], sv[4], sv[5], sv[6], go[0].contiguous(), sv[7]);
+        // inputs: graph_ws, e_stored, x, edge_attr, w1, b1, w2, b2
+        return {Tensor(), Tensor(), std::get<0>(r), std::get<1>(r), std::get<2>(r), std::get<3>(r), std::get<4>(r), std::get<5>(r)};
+    }
+};
+Tensor edge_aggr_autograd(const Tensor& graph_ws, int64_t e_stored, const Tensor& x, const Tensor& edge_attr, const Tensor& w1, const Tensor& b1,
+                          const Tensor& w2, const Tensor& b2) {
+    return EdgeAggrFunction::apply(graph_ws, e_stored, x, edge_attr, w1, b1, w2, b2);
+}
+struct TagConvFunction : public torch::autograd::Function<TagConvFunction> {
+    // (the K + 1 weights as ONE flat tensor: see MpnFunction)
+    static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, const Tensor& x,
+                          const Tensor& flat_w, int64_t nw, const c10::optional<Tensor>& bias) {
+        at::AutoDispatchBelowADInplaceOrView guard;
+        const int64_t cin = x.size(1), cout = flat_w.numel() / (nw * cin);
+        std::vector<Tensor> ws_;
+        for (int64_t k = 0; k < nw; ++k) ws_.push_back(flat_w.narrow(0, k * cout * cin, cout * cin).view({cout, cin}));
+        auto res = tag_conv_forward(graph_ws, e_stored, seg_nodes, x, ws_, bias);
+        const bool has_bias = bias.has_value() && bias->defined();
+        ctx->save_for_backward({graph_ws, x, flat_w, std::get<1>(res)});
+        ctx->saved_data["e_stored"] = e_stored;
+        ctx->saved_data["seg_nodes"] = seg_nodes;
+        ctx->saved_data["nw"] = nw;
+        ctx->saved_data["has_bias"] = has_bias;
+        return std::get<0>(res);
+    }
+    static torch::autograd::variable_list backward(torch::autograd::AutogradContext* ctx, torch::autograd::variable_list go) {
+        const auto sv = ctx->get_saved_variables();
+        const int64_t nw = ctx->saved_data["nw"].toInt(), cin = sv[1].size(1), cout = sv[2].numel() / (nw * cin);
+        std::vector<Tensor> ws_;
+        for (int64_t k = 0; k < nw; ++k) ws_.push_back(sv[2].narrow(0, k * cout * cin, cout * cin).view({cout, cin}));
+        auto r = tag_conv_backward(sv[0], ctx->saved_data["e_stored"].toInt(), ctx->saved_data["seg_nodes"].toInt(), sv[1], ws_, go[0].contiguous(),
+                                   sv[3], ctx->saved_data["has_bias"].toBool());
+        std::vector<Tensor> gflat;
+        for (const Tensor& g : std::get<2>(r)) gflat.push_back(g.reshape({-1}));
+        // inputs: graph_ws, e_stored, seg_nodes, x, flat_w, nw, bias
+        return {Tensor(), Tensor(), Tensor(), std::get<0>(r), at::cat(gflat), Tensor(), std::get<1>(r)};
+    }
+};
+Tensor tag_conv_autograd(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, const Tensor& x, at::TensorList weights,
+                         const c10::optional<Tensor>& bias) {
+    TORCH_CHECK(!weights.empty(), "weights must be non-empty");
+    std::vector<Tensor> flats;
+    for (const Tensor& w : weights) flats.push_back(w.reshape({-1}));
+    return TagConvFunction::apply(graph_ws, e_stored, seg_nodes, x, at::cat(flats), (int64_t)weights.size(), bias);
+}
+
 int64_t abi_version() { return pfn_abi_version(); }
 
 }  // namespace
@@ -412,6 +471,8 @@ TORCH_LIBRARY(pfn, m) {
     m.def("tag_conv_backward(Tensor graph_ws, int e_stored, int seg_nodes, Tensor x, Tensor[] weights, Tensor grad_out, Tensor ws, "
           "bool has_bias=True) -> (Tensor, Tensor, Tensor[])");
     m.def("scatter_add(Tensor graph_ws, int e_stored, Tensor x) -> Tensor");
+    m.def("edge_aggr(Tensor graph_ws, int e_stored, Tensor x, Tensor edge_attr, Tensor w1, Tensor b1, Tensor w2, Tensor b2) -> Tensor");
+    m.def("tag_conv(Tensor graph_ws, int e_stored, int seg_nodes, Tensor x, Tensor[] weights, Tensor? bias=None) -> Tensor");
     m.def("mpn(Tensor graph_ws, int e_stored, int seg_nodes, int[] dims, float dropout, bool training, Tensor[] params, Tensor x, "
           "Tensor pred_mask, Tensor edge_attr, Tensor? rng_state=None) -> Tensor");
     m.def("mse_loss(Tensor out, Tensor y, Tensor(a!) ws) -> (Tensor, Tensor)");
@@ -434,11 +495,19 @@ TORCH_LIBRARY_IMPL(pfn, CUDA, m) {
 }
 
 // `pfn::mpn` carries its own autograd node (MpnFunction); with nothing differentiable in sight it is a plain inference forward
-TORCH_LIBRARY_IMPL(pfn, Autograd, m) { m.impl("mpn", &mpn_autograd); }
+TORCH_LIBRARY_IMPL(pfn, Autograd, m) {
+    m.impl("mpn", &mpn_autograd);
+    m.impl("edge_aggr", &edge_aggr_autograd);
+    m.impl("tag_conv", &tag_conv_autograd);
+}
 TORCH_LIBRARY_IMPL(pfn, CUDA, m) {
     m.impl("mpn", [](const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, at::IntArrayRef dims, double dropout, bool training,
                      at::TensorList params, const Tensor& x, const Tensor& pred_mask, const Tensor& edge_attr,
                      const c10::optional<Tensor>& rng_state) {
         return std::get<0>(mpn_forward(graph_ws, e_stored, seg_nodes, dims, dropout, training, false, params, x, pred_mask, edge_attr, rng_state));
     });
+    m.impl("edge_aggr", [](const Tensor& graph_ws, int64_t e_stored, const Tensor& x, const Tensor& edge_attr, const Tensor& w1, const Tensor& b1,
+                           const Tensor& w2, const Tensor& b2) { return std::get<0>(edge_aggr_forward(graph_ws, e_stored, x, edge_attr, w1, b1, w2, b2)); });
+    m.impl("tag_conv", [](const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, const Tensor& x, at::TensorList weights,
+                          const c10::optional<Tensor>& bias) { return std::get<0>(tag_conv_forward(graph_ws, e_stored, seg_nodes, x, weights, bias)); });
 }

@@ -141,6 +141,30 @@ def test_layer_ops_match_the_modules_bit_for_bit():
     assert torch.equal(gx, x.grad) and torch.equal(gb, tg.bias.grad)
     for a, l in zip(gws_, tg.lins):
         assert torch.equal(a, l.weight.grad)
+    # ... and the differentiable forms: autograd through torch.ops alone gives the modules' gradients, bit for bit
+    xa = x.detach().clone().requires_grad_(True)
+    pa = [p.detach().clone().requires_grad_(True) for p in (l1.weight, l1.bias, l2.weight, l2.bias)]
+    ya = ops.edge_aggr(gws0, ei2.shape[1], xa, at2, *pa)
+    wy = torch.randn_like(ya)
+    xr = x.detach().clone().requires_grad_(True)
+    ea.zero_grad()
+    (ea(xr, ei2, at2) * wy).sum().backward()
+    (ya * wy).sum().backward()
+    assert torch.equal(xa.grad, xr.grad)
+    for a, b in zip(pa, (l1.weight, l1.bias, l2.weight, l2.bias)):
+        assert torch.equal(a.grad, b.grad)
+    xt = x.detach().clone().requires_grad_(True)
+    wt = [l.weight.detach().clone().requires_grad_(True) for l in tg.lins]
+    bt = tg.bias.detach().clone().requires_grad_(True)
+    yt = ops.tag_conv(gws0, ei2.shape[1], 0, xt, wt, bt)
+    wz = torch.randn_like(yt)
+    xr = x.detach().clone().requires_grad_(True)
+    tg.zero_grad()
+    (tg(xr, ei2) * wz).sum().backward()
+    (yt * wz).sum().backward()
+    assert torch.equal(xt.grad, xr.grad) and torch.equal(bt.grad, tg.bias.grad)
+    for a, l in zip(wt, tg.lins):
+        assert torch.equal(a.grad, l.weight.grad)
     # scatter_add == index_add_ in stored edge order
     xs = torch.randn(n, 129, device="cuda:0")
     ref = torch.zeros(n, 129).index_add_(0, ei2[1].cpu(), xs.cpu()[ei2[0].cpu()])     # (CPU: sequential, the stored edge order)
