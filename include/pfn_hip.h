@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 6
+#define PFN_ABI_VERSION 7
 
 enum {
     PFN_OK = 0,
@@ -111,7 +111,8 @@ size_t pfn_mpn_workspace_bytes(const pfn_mpn_config* cfg, int64_t n_nodes, int64
  * (:23-56) and TAGConv.forward.  x [N, F0] f32, pred_mask [N, F0] (mask_dtype 0: int64, the dataset
  * layout of datasets/PowerFlowData.py:193; 1: float32), edge_attr [e_stored, Fe] f32, out [N, output_dim] f32.  `ws` receives the activations backward needs.  `rng_state`: device
  * uint64[2] {seed, offset}; when training && dropout_rate > 0 the offset is advanced by one at the start of the call
- * and then read by the dropout epilogues.                                                          */
+ * and then read by the dropout epilogues.  `out` may be NULL where pfn_mpn_mse_tail_ok answers 1 and
+ * pfn_mpn_backward_mse follows (which then writes the rows).                                        */
 int pfn_mpn_forward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
                     const float* const* params, const float* x, const void* pred_mask,
                     int mask_dtype, const float* edge_attr, float* out, void* ws, size_t ws_bytes,
@@ -124,6 +125,24 @@ int pfn_mpn_backward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_
                      const float* const* params, float* const* grads, const float* x,
                      const void* pred_mask, int mask_dtype, const float* edge_attr, const float* grad_out,
                      float* grad_x, float* grad_edge_attr, void* ws, size_t ws_bytes, int64_t seg_nodes, void* stream);
+
+/* `loss = torch.nn.MSELoss()(out, y); loss.backward()` (train.py:103; the else-branch of train_epoch, utils/training.py:70-74)
+ * together with the autograd pass above, for batches of small graphs: the first backward launch -- the graph-resident
+ * EdgeAggregation backward of the LAST layer -- forms the output rows `out = S W2^T + deg b2` (networks/MPN.py:559 hands them to
+ * the loss), the loss and `grad_out = 2 (out - y) / (4 N)` itself, so the output Linear's launch and the loss launch leave the
+ * step (three launches -> one).  Call pfn_mpn_forward on the same workspace first; its `out` may then be NULL (the rows are only
+ * written here).  Results: `out` bit-identical to pfn_mpn_forward's, `grad_out` and every entry of `grads` bit-identical to
+ * pfn_mpn_forward -> pfn_mse_loss -> pfn_mpn_backward; loss[0] = mean((out - y)^2) summed per row block, the blocks in block
+ * order (deterministic; not pfn_mse_loss's partition, so equal to its value up to the rounding of a different summation order).
+ * y, out, grad_out: [N, 4] f32, no padding (output_dim must be 4).  `loss_ws`: >= 4100 bytes -- 1024 float partials + one int32
+ * arrival counter at byte 4096 that must be ZERO before the first call and is left zero by every call.  grad_x optional.
+ * Available where pfn_mpn_mse_tail_ok returns 1 (seg_nodes from pfn_graph_segments, Fe = 2, output_dim 4, the batch in the
+ * graph-resident regime); PFN_EINVAL elsewhere -- the caller then runs the three calls above.                              */
+int pfn_mpn_mse_tail_ok(const pfn_mpn_config* cfg, int64_t n_nodes, int64_t e_stored, int64_t seg_nodes);
+int pfn_mpn_backward_mse(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
+                         const float* const* params, float* const* grads, const float* x, const float* edge_attr,
+                         const float* y, float* out, float* loss, float* grad_out, float* grad_x, void* ws, size_t ws_bytes,
+                         void* loss_ws, size_t loss_ws_bytes, int64_t seg_nodes, void* stream);
 
 /* Verification aid for the autograd above (what loss.backward() differentiates, utils/training.py:74; the ReLUs are
  * networks/MPN.py:19 (edge MLP), :547 (layer outputs) and :493 (mask_embd)): the ReLU gate decisions of the forward pass that
@@ -244,6 +263,7 @@ int pfn_adamw_step_guarded(float* param, const float* grad, float* exp_avg, floa
  *   PFN_NO_SEG_FRONT=1      small-graph batches: front.hip's launch + the generic first edge walk instead of the one graph-resident
  *                           launch that does both (ea_seg.hip front_seg_fwd_kernel; bit-identical results)
  *   PFN_NO_FUSED_BACK=1     the last layer's Linear / dS outside the edge walks (generic GEMMs)
+ *   PFN_NO_MSE_TAIL=1       pfn_mpn_mse_tail_ok answers 0: the output Linear, MSELoss and the backward pass as three calls
  *   PFN_FRONT_BLOCK_ROWS=1  front.hip: the block-per-row-group kernels instead of one row per wave
  *   PFN_NO_BIG_HOPS=1       TAGConv hops of large graphs (one LDS tile + registers per graph and column chunk, workgroups persistent over a graph's chunks): K generic hop launches instead
  *   PFN_NO_ROW_HOPS=1       TAGConv hops of big batches of small graphs: the two-tile column-slice kernel instead of whole rows per block

@@ -159,12 +159,14 @@ __device__ __forceinline__ void we_commit(float* s_we, float v) {
 }
 
 // LDS carve-up (floats): tiles first (16-byte aligned), then the CSR slices
+constexpr int SG_W2A_CH = 34;        // float4 chunks per W2 row kept for the MSELoss tail (ld <= 8 * SG_NCH = 136 floats)
 struct SegLds {
     float* P;
     float* Q;
     float* D;      // backward only: dS
     float* we;     // [2][SG_TW]
     float* w2s;    // backward, last layer only: W2 slice [4][SG_TW]
+    float4* w2a;   // backward, last layer with the MSELoss tail: all of W2 as [4][SG_W2A_CH] float4 chunks
     float* B0;     // forward: the quarter of W1i^T | W1j^T (2 x 34 x 128 floats); backward: the quarter of W2 -- ALIASES the dS tile
     float* B1;
     float4* part;  // backward only: dWe partials [8 waves][16 chunk lanes][2]
@@ -180,6 +182,7 @@ __device__ __forceinline__ SegLds seg_lds(float* base, int trows, int rows_pb, i
     l.B1 = p; if (!bwd) p += SG_NCH * 256;
     l.we = p; p += 2 * SG_TW;
     l.w2s = p; if (bwd) p += 4 * SG_TW;
+    l.w2a = reinterpret_cast<float4*>(p); if (bwd) p += 4 * SG_W2A_CH * 4;
     l.part = reinterpret_cast<float4*>(p); if (bwd) p += 8 * 16 * 2 * 4;
     l.in.ea = reinterpret_cast<float2*>(p); p += 2 * cap;
     l.out.ea = reinterpret_cast<float2*>(p); if (bwd) p += 2 * cap;
@@ -191,7 +194,7 @@ __device__ __forceinline__ SegLds seg_lds(float* base, int trows, int rows_pb, i
     return l;
 }
 static size_t seg_lds_bytes(int trows, int rows_pb, int cap, bool bwd) {
-    size_t f = (size_t)(bwd ? 3 : 2) * trows * SG_TW + (bwd ? 0 : 2 * SG_NCH * 256) + 2 * SG_TW + (bwd ? 4 * SG_TW + 8 * 16 * 2 * 4 : 0) + (size_t)(bwd ? 2 : 1) * 2 * cap;
+    size_t f = (size_t)(bwd ? 3 : 2) * trows * SG_TW + (bwd ? 0 : 2 * SG_NCH * 256) + 2 * SG_TW + (bwd ? 4 * SG_TW + 4 * SG_W2A_CH * 4 + 8 * 16 * 2 * 4 : 0) + (size_t)(bwd ? 2 : 1) * 2 * cap;
     size_t i = (size_t)(bwd ? 2 : 1) * (rows_pb + 1 + cap);
     return (f + i) * 4 + 16;
 }
@@ -710,7 +713,7 @@ __device__ __forceinline__ void seg_bwd_row_slow(const SegLds& l, const SegCsr& 
     }
 }
 
-template <bool DSG>
+template <bool DSG, bool LOSS = false>   // LOSS (with DSG): the MSELoss tail -- out, loss and grad_out formed here (MseTail)
 __global__ __launch_bounds__(SG_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4)))
 void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __restrict__ rp_in, const int* __restrict__ in_src,
                        const int* __restrict__ rp_out, const int* __restrict__ out_dst, const EaSegBwdArgs a) {
@@ -768,11 +771,37 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     if (DSG) {   // last layer: dS[row][u] = sum_o gout[row][o] W2[o][u] from the 16-byte gout rows (edge.hip ds_row)
         // (the gout rows are requested BEFORE the barrier that publishes the W2 slice: behind it they were one more exposed round trip)
         float4 gv[3];
+        // MSELoss tail: thread (row lr = t >> 2, part pq = t & 3) requests the S chunks c = pq + 4 k of its row (nine at most)
+        const int nch = a.ld >> 2;
+        const int mlr = threadIdx.x >> 2, mpq = threadIdx.x & 3;
+        const int mrow = r0 + min(mlr, rows - 1);
+        float4 sv[9], yv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float dgv = 0.f;
+        if (LOSS) {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int it = threadIdx.x + j * SG_THREADS;
-            gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (it < rows * sc.cw) gv[j] = sg_ld4(a.gout + (size_t)(r0 + it / sc.cw) * 4);
+            for (int k = 0; k < 9; ++k) sv[k] = sg_ld4(a.mse.S + (size_t)mrow * a.ld + 4 * min(mpq + 4 * k, nch - 1));
+            if (mpq == 0) {
+                yv = sg_ld4(a.mse.y + (size_t)mrow * 4);
+                dgv = a.mse.deg[mrow];
+            }
+            for (int i = threadIdx.x; i < 4 * SG_W2A_CH; i += SG_THREADS) {
+                const int o = i / SG_W2A_CH, c = i - o * SG_W2A_CH;
+                float w[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int u = 4 * c + j;
+                    const float v = a.w2[(size_t)min(o, a.fo - 1) * a.h + min(u, a.h - 1)];
+                    w[j] = (o < a.fo && u < a.h) ? v : 0.f;
+                }
+                l.w2a[i] = make_float4(w[0], w[1], w[2], w[3]);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int it = threadIdx.x + j * SG_THREADS;
+                gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (it < rows * sc.cw) gv[j] = sg_ld4(a.gout + (size_t)(r0 + it / sc.cw) * 4);
+            }
         }
         for (int i = threadIdx.x; i < 4 * SG_TW; i += SG_THREADS) {
             const int o = i / SG_TW, t = i - o * SG_TW;
@@ -780,6 +809,75 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             l.w2s[i] = (o < a.fo && col >= 0 && col < a.h) ? a.w2[(size_t)o * a.h + col] : 0.f;
         }
         __syncthreads();
+        if (LOSS) {
+            // out[row][o] = sum_u S[row][u] W2[o][u] + deg b2[o] with lin_out4_wave_kernel's bits: chunk products as its fma chain, the
+            // chunk sums added in the order of its xor butterfly (lane 0's tree: a[c] + a[c + 32], + 16, + 8, + 4 inside a part --
+            // slots k, k + 8 | + 4 | + 2 | + 1 --, then the parts by two quad shuffles); see front_seg_fwd_kernel's x0 phase
+            float4* gs = l.part;                                   // [SG_MAX_ROWS] grad_out rows (the dWe partials come last)
+            float* sq = reinterpret_cast<float*>(l.part + SG_MAX_ROWS);   // [SG_MAX_ROWS] squared errors per row
+            auto slot = [&](int k) -> float4 {
+                const int c = mpq + 4 * k;
+                if (k >= 9 || c >= nch) return make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 s4 = sv[k < 9 ? k : 0];
+                const float4 r0_ = l.w2a[c], r1_ = l.w2a[SG_W2A_CH + c], r2_ = l.w2a[2 * SG_W2A_CH + c], r3_ = l.w2a[3 * SG_W2A_CH + c];
+                float4 acc;
+                acc.x = fmaf(s4.w, r0_.w, fmaf(s4.z, r0_.z, fmaf(s4.y, r0_.y, s4.x * r0_.x)));
+                acc.y = fmaf(s4.w, r1_.w, fmaf(s4.z, r1_.z, fmaf(s4.y, r1_.y, s4.x * r1_.x)));
+                acc.z = fmaf(s4.w, r2_.w, fmaf(s4.z, r2_.z, fmaf(s4.y, r2_.y, s4.x * r2_.x)));
+                acc.w = fmaf(s4.w, r3_.w, fmaf(s4.z, r3_.z, fmaf(s4.y, r3_.y, s4.x * r3_.x)));
+                return acc;
+            };
+            float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), vp = u0;
+#pragma unroll
+            for (int k1 = 0; k1 < 2; ++k1) {
+                float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), tt = t0;
+#pragma unroll
+                for (int k2 = 0; k2 < 2; ++k2) {
+                    const int k = k1 + 2 * k2;
+                    const float4 sa = sg_add4(slot(k), slot(k + 8)), sb = sg_add4(slot(k + 4), slot(k + 12));
+                    const float4 t = sg_add4(sa, sb);
+                    if (k2 == 0) t0 = t; else tt = sg_add4(t0, t);
+                }
+                if (k1 == 0) u0 = tt; else vp = sg_add4(u0, tt);
+            }
+            float4 vo;
+            vo.x = __shfl_xor(vp.x, 2); vo.y = __shfl_xor(vp.y, 2); vo.z = __shfl_xor(vp.z, 2); vo.w = __shfl_xor(vp.w, 2);
+            const float4 wp = (mpq & 2) ? sg_add4(vo, vp) : sg_add4(vp, vo);
+            float4 wo;
+            wo.x = __shfl_xor(wp.x, 1); wo.y = __shfl_xor(wp.y, 1); wo.z = __shfl_xor(wp.z, 1); wo.w = __shfl_xor(wp.w, 1);
+            const float4 t4 = (mpq & 1) ? sg_add4(wo, wp) : sg_add4(wp, wo);
+            if (mpq == 0) {
+                const float b0 = a.mse.b2[0], b1_ = a.fo > 1 ? a.mse.b2[1] : 0.f, b2_ = a.fo > 2 ? a.mse.b2[2] : 0.f, b3_ = a.fo > 3 ? a.mse.b2[3] : 0.f;
+                const float4 o4 = make_float4(fmaf(dgv, b0, t4.x), a.fo > 1 ? fmaf(dgv, b1_, t4.y) : 0.f,
+                                              a.fo > 2 ? fmaf(dgv, b2_, t4.z) : 0.f, a.fo > 3 ? fmaf(dgv, b3_, t4.w) : 0.f);
+                const bool on = mlr < rows;
+                const float4 d4 = make_float4(o4.x - yv.x, o4.y - yv.y, o4.z - yv.z, o4.w - yv.w);
+                const float4 g4 = on ? make_float4(2.f * d4.x * a.mse.inv_n, 2.f * d4.y * a.mse.inv_n, 2.f * d4.z * a.mse.inv_n,
+                                                   2.f * d4.w * a.mse.inv_n)
+                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (mlr < SG_MAX_ROWS) {
+                    gs[mlr] = g4;
+                    sq[mlr] = on ? fmaf(d4.w, d4.w, fmaf(d4.z, d4.z, fmaf(d4.y, d4.y, d4.x * d4.x))) : 0.f;
+                }
+                if (on && sc.q == max(0, sc.nq - 2)) {   // ONE quarter per graph stores the 4-wide tensors (an early, light one)
+                    sg_st4_wt(a.mse.out + (size_t)mrow * 4, o4);
+                    sg_st4_wt(a.mse.gout + (size_t)mrow * 4, g4);
+                }
+            }
+            seg_lds_barrier();
+            // the block's loss partial: rows l and l + 64, then a fixed xor tree (wave 0; once per block)
+            if (wave == 0 && sc.q == max(0, sc.nq - 2)) {
+                float v = sq[lane] + sq[lane + 64];
+                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+                if (lane == 0) __hip_atomic_store(a.mse.partial + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int it = threadIdx.x + j * SG_THREADS;
+                gv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (it < rows * sc.cw) gv[j] = gs[it / sc.cw];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int it = threadIdx.x + j * SG_THREADS;
@@ -866,6 +964,28 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
             for (int w = 0; w < SG_WAVES; ++w) s = sg_add4(s, l.part[(w * 16 + c2) * 2 + f]);
             sg_st4_wt(a.dWe_partial + ((size_t)blockIdx.x * 2 + f) * a.ld + seg_gcol(sc, c2), s);
+        }
+    }
+    if (LOSS && wave == 0 && sc.q == max(0, sc.nq - 2)) {
+        // the loss: the last of the partial-owning blocks to get here sums the partials in BLOCK order (deterministic).  Same
+        // hand-off as mse_kernel (model.hip): write-through partial, drained, then the ticket; agent-scope loads on the consumer
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "the loss hand-off relies on gfx950 semantics (sc1 write-through stores drained by s_waitcnt vmcnt(0))"
+#endif
+        int last = 0;
+        if (lane == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            last = __hip_atomic_fetch_add(a.mse.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        }
+        last = __shfl(last, 0);
+        if (last) {
+            float v = 0.f;
+            for (int i = lane; i < (int)gridDim.x; i += 64) v += __hip_atomic_load(a.mse.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) {
+                a.mse.loss[0] = v * a.mse.inv_n;
+                *a.mse.counter = 0;
+            }
         }
     }
 }
@@ -975,9 +1095,18 @@ int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStr
     }
     const size_t lds = seg_lds_bytes(p.trows, p.rows_pb, p.cap, true);
     const bool dsg = a.Bd == nullptr;
-    static std::atomic<uint64_t> raised0{0}, raised1{0};
-    ProfScope ps("ea_seg_bwd", 0.0, a.Bd ? 2.0 * g.n * (double)a.fo * a.h : 0.0, s);
-    if (dsg) {
+    static std::atomic<uint64_t> raised0{0}, raised1{0}, raised2{0};
+    if (a.mse.y && !(dsg && a.ld / 4 <= SG_W2A_CH && a.mse.S && a.mse.b2 && a.mse.deg && a.mse.out && a.mse.gout && a.mse.partial &&
+                     a.mse.counter && a.mse.loss)) {
+        set_error("ea_seg_bwd: the MSELoss tail needs the last layer's form and every MseTail pointer (internal)");
+        return PFN_EINVAL;
+    }
+    ProfScope ps(a.mse.y ? "ea_seg_bwd+out+mse" : "ea_seg_bwd", 0.0, a.Bd ? 2.0 * g.n * (double)a.fo * a.h : 0.0, s);
+    if (a.mse.y) {
+        PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(ea_seg_bwd_kernel<true, true>), SG_LDS_BYTES, raised2));
+        ea_seg_bwd_kernel<true, true><<<dim3(p.nblocks, p.ny), SG_THREADS, lds, s>>>(g.n, p.rows_pb, p.trows, p.cap, g.rowptr_in, g.in_src,
+                                                                                   g.rowptr_out, g.out_dst, a);
+    } else if (dsg) {
         PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(ea_seg_bwd_kernel<true>), SG_LDS_BYTES, raised1));
         ea_seg_bwd_kernel<true><<<dim3(p.nblocks, p.ny), SG_THREADS, lds, s>>>(g.n, p.rows_pb, p.trows, p.cap, g.rowptr_in, g.in_src,
                                                                              g.rowptr_out, g.out_dst, a);

@@ -158,7 +158,9 @@ static int ea_forward(const GraphView& g, int fi, int fe, int h, int fo, const f
         PFN_TRY(launch_edge_fwd(g, e, s));
     }
     if (!out_in_walk && w2 && act.act == ACT_NONE && lin_out4_ok(h, fo, ldo, g.n)) {
-        PFN_TRY(launch_lin_out4(g.n, h, fo, sv.S, w2, b2, g.deg, out, s));   // the last layer at small batches: one row per wave
+        // the last layer at small batches: one row per wave.  out == nullptr: deferred -- pfn_mpn_backward_mse forms the rows in its
+        // first launch (mse_tail_ok was asked by the caller)
+        if (out) PFN_TRY(launch_lin_out4(g.n, h, fo, sv.S, w2, b2, g.deg, out, s));
     } else if (!out_in_walk && hop_xk) {   // out = act(S W2^T + deg * b2) and the next TAGConv's K hops over it, one launch
         SegLinHopsArgs f;
         memset(&f, 0, sizeof(f));
@@ -191,7 +193,8 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
                        int ldgx, float* gw1, float* gb1, float* gw2, float* gb2, float* gea, const EaSaved& sv,
                        const EaScratch& sc, hipStream_t s, PairList* defer, int seg = 0, const float* ea_in = nullptr,
                        const float* ea_out = nullptr, const unsigned* relu_mask = nullptr, int gx_cm = 0, float* hop_out = nullptr,
-                       int hop_K = 0) {
+                       int hop_K = 0, const MseTail* mse = nullptr) {
+    // mse: `gout` is not written yet -- the graph-resident backward launch forms out, the loss and gout itself (MseTail)
     // hop_out / hop_K: gx is the output gradient of a TAGConv whose backward hops it K times over A_hat^T first: the dx Linear and
     // those hops in one launch (seg_lin_hops.hip; the caller has asked seg_lin_hops_fit)
     const int ld = ld_of(h), ldw1 = 2 * fi + fe;
@@ -200,7 +203,11 @@ static int ea_backward(const GraphView& g, int fi, int fe, int h, int fo, const 
     if (seg_walk) {
         const bool last = fo <= 4 && ldgo == 4;
         EaSegBwdArgs e{gout, last ? nullptr : pw.w2_d, w2, sv.P, sv.Q, ea_in, ea_out, w1, sc.dP, sc.dQ, sc.dWe, ldgo, fo, ld, h, fi};
+        if (mse) e.mse = *mse;
         PFN_TRY(launch_ea_seg_bwd(g, e, seg, s));
+    } else if (mse) {
+        set_error("EdgeAggregation backward: the MSELoss tail without the graph-resident launch (internal)");
+        return PFN_EINVAL;
     }
     // the network's last layer (Fo <= 4): the walks form dS rows from the 16-byte gout rows themselves (edge.hip ds_row), so
     // the K = 4 GEMM that would write N x H (and the walks' re-read of it) goes away
@@ -724,7 +731,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
 
 static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
                           float* const* grads, const float* x, const float* edge_attr, const float* gout, float* gx,
-                          float* gea, int seg, hipStream_t s) {
+                          float* gea, int seg, hipStream_t s, const MseTail* mse = nullptr) {
     (void)x;
     const bool drop = c.training && c.dropout_rate > 0.f;
     const float gscale = drop ? 1.f / (1.f - c.dropout_rate) : 1.f;
@@ -777,7 +784,7 @@ static int model_backward(const pfn_mpn_config& c, const GraphView& g, const Lay
                                 (fused_front && i == 0) ? nullptr : gnext, ldi, grads[p0], grads[p0 + 1], grads[p0 + 2],
                                 grads[p0 + 3], gea, lo.ea[i], sc, s, &pairs, seg, lo.ea_in, lo.ea_out,
                                 ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr, gx_cm,
-                                hops_fused ? lo.tags.G : nullptr, lo.K));
+                                hops_fused ? lo.tags.G : nullptr, lo.K, last ? mse : nullptr));
         } else {
             PFN_TRY(tag_backward(g, lo.h, lo.h, lo.K, inp, ldi, mp.tag[i], gcur, ldg, gate, gnext, ldi, grads + p0,
                                  grads[p0 + lo.K + 1], lo.xk[i], lo.tags, s, &pairs, seg, big_cm, gout_cm, hops_fused));
@@ -1108,22 +1115,74 @@ static int check_common(const pfn_mpn_config* c, const void* gws, int64_t n, int
     return PFN_OK;
 }
 
+// The MSELoss tail (pfn_mpn_backward_mse): the last layer's backward must be the graph-resident launch in its last-layer form,
+// and the out rows those of lin_out4_wave_kernel
+static bool mse_tail_ok(const pfn_mpn_config& c, const Layout& lo, int seg) {
+    static const bool off = diag_env("PFN_NO_MSE_TAIL") != nullptr;   // A/B switch: lin_out4 + mse_kernel + the plain backward
+    return !off && c.need_backward != 0 && lo.n > 0 && lo.nlayers > 1 && lo.fe == 2 && lo.fo == 4 && lo.ldo == 4 &&
+           lin_out4_ok(lo.h, lo.fo, lo.ldo, lo.n) && back_fused_ok() && ea_seg_fit(seg, lo.n, lo.fe, lo.ld, false) &&
+           ea_seg_fit(seg, lo.n, lo.fe, lo.ld, true) && lo.ld / 4 <= 34;
+}
+
 int pfn_mpn_forward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
                     const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr, float* out, void* ws,
                     size_t ws_bytes, uint64_t* rng, int64_t seg_nodes, void* stream) {
     PFN_TRY(check_common(c, gws, n, e, ws));
-    PFN_CHECK_ARG(params && (n == 0 || (x && pred_mask && out)) && (e == 0 || edge_attr), "pfn_mpn_forward: null tensor");
+    PFN_CHECK_ARG(params && (n == 0 || (x && pred_mask)) && (e == 0 || edge_attr), "pfn_mpn_forward: null tensor");
     Layout lo;
     PFN_TRY(make_layout(*c, n, e, ws, lo));
     if (ws_bytes < lo.bytes) {
         set_error("pfn_mpn_forward: workspace %zu < %zu bytes", ws_bytes, lo.bytes);
         return PFN_ENOSPACE;
     }
+    // out == NULL: the output rows are left to pfn_mpn_backward_mse -- only where that entry point is available
+    PFN_CHECK_ARG(n == 0 || out || (seg_nodes > 0 && n % seg_nodes == 0 && mse_tail_ok(*c, lo, (int)seg_nodes)),
+                  "pfn_mpn_forward: out may be NULL only where pfn_mpn_mse_tail_ok says so");
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
     PFN_CHECK_ARG(c->nfeature_dim % 4 == 0, "nfeature_dim must be a multiple of 4 (the reference asserts 4, networks/MPN.py:528)");
     PFN_CHECK_ARG(seg_nodes >= 0 && (seg_nodes == 0 || n % seg_nodes == 0), "seg_nodes must be 0 or divide n_nodes");
     return model_forward(*c, g, lo, params, x, pred_mask, mask_dtype, edge_attr, out, rng, (int)seg_nodes,
                          static_cast<hipStream_t>(stream));
+}
+
+int pfn_mpn_mse_tail_ok(const pfn_mpn_config* c, int64_t n, int64_t e, int64_t seg_nodes) {
+    if (!c || n <= 0 || e < 0 || n >= (1ll << 30) || e >= (1ll << 29) || seg_nodes <= 0 || n % seg_nodes != 0) return 0;
+    Layout lo;
+    if (make_layout(*c, n, e, nullptr, lo) != PFN_OK) return 0;
+    return mse_tail_ok(*c, lo, (int)seg_nodes) ? 1 : 0;
+}
+
+int pfn_mpn_backward_mse(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
+                         float* const* grads, const float* x, const float* edge_attr, const float* y, float* out, float* loss,
+                         float* grad_out, float* gx, void* ws, size_t ws_bytes, void* loss_ws, size_t loss_ws_bytes,
+                         int64_t seg_nodes, void* stream) {
+    PFN_TRY(check_common(c, gws, n, e, ws));
+    PFN_CHECK_ARG(params && grads && x && y && out && loss && grad_out && loss_ws, "pfn_mpn_backward_mse: null tensor");
+    PFN_CHECK_ARG(c->need_backward != 0, "pfn_mpn_backward_mse: the forward ran with need_backward = 0");
+    PFN_CHECK_ARG(loss_ws_bytes >= 4100, "pfn_mpn_backward_mse: loss workspace must hold 4100 bytes");
+    Layout lo;
+    PFN_TRY(make_layout(*c, n, e, ws, lo));
+    if (ws_bytes < lo.bytes) {
+        set_error("pfn_mpn_backward_mse: workspace %zu < %zu bytes", ws_bytes, lo.bytes);
+        return PFN_ENOSPACE;
+    }
+    PFN_CHECK_ARG(seg_nodes > 0 && n % seg_nodes == 0, "seg_nodes must divide n_nodes");
+    if (!mse_tail_ok(*c, lo, (int)seg_nodes)) {
+        set_error("pfn_mpn_backward_mse: not available for this model / batch (ask pfn_mpn_mse_tail_ok)");
+        return PFN_EINVAL;
+    }
+    GraphView g = graph_view(const_cast<void*>(gws), n, e);
+    const int nparams = pfn_mpn_num_params(c);
+    MseTail t;
+    t.S = lo.ea[lo.nlayers - 1].S;
+    t.b2 = params[nparams - 4 - 1];   // the last EdgeAggregation's b2 (its four tensors end in front of mask_embd's)
+    t.deg = g.deg;
+    t.y = y; t.out = out; t.gout = grad_out;
+    t.partial = static_cast<float*>(loss_ws);
+    t.counter = reinterpret_cast<int*>(static_cast<char*>(loss_ws) + 4096);
+    t.loss = loss;
+    t.inv_n = 1.f / (float)(n * 4);
+    return model_backward(*c, g, lo, params, grads, x, edge_attr, grad_out, gx, nullptr, (int)seg_nodes, static_cast<hipStream_t>(stream), &t);
 }
 
 int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,

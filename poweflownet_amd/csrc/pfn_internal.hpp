@@ -364,6 +364,22 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s);
 // EdgeAggregation for batches of small graphs, graph-resident in LDS (ea_seg.hip): the node GEMM of one 32-column quarter and
 // the edge walk over it in ONE launch per direction.  `seg` = nodes per graph (pfn_graph_segments); ea_seg_fit() says whether
 // the rows of whole graphs fit (else: gemm_nt + edge_fwd / edge_bwd).  Fe = 2 only.
+// `loss = MSELoss()(out, y); loss.backward()` riding in the last layer's graph-resident backward launch (pfn_mpn_backward_mse):
+// the out Linear (lin_out4_wave_kernel's summation tree, bit for bit), the loss and its gradient need the S rows of a graph only, so
+// every (graph, quarter) workgroup recomputes its graph's 16-byte out rows; ONE quarter per graph stores out / grad_out and
+// contributes the graph's loss partial; the last of those to finish sums the partials in block order.
+struct MseTail {
+    const float* S = nullptr;      // N x ld, the forward edge stage's sums
+    const float* b2 = nullptr;
+    const float* deg = nullptr;
+    const float* y = nullptr;      // N x 4 targets; null: no tail
+    float* out = nullptr;          // N x 4
+    float* gout = nullptr;         // N x 4: grad_out, read by the weight-gradient launch
+    float* partial = nullptr;      // [row blocks] loss partials
+    int* counter = nullptr;        // arrival counter, zero between launches
+    float* loss = nullptr;
+    float inv_n = 0.f;             // 1 / (4 N)
+};
 struct EaSegFwdArgs {
     const float* x;        // layer input, N x ldx, K = Fi real columns
     const float* Bi;       // packed images (ld_out = ld) of W1[:, :Fi]^T and W1[:, Fi:2Fi]^T
@@ -389,6 +405,9 @@ struct EaSegBwdArgs {
     float* dQ;
     float* dWe_partial;    // [ea_seg_blocks][2][ld]
     int ldgo, fo, ld, h, fi;
+    // MSELoss tail (last layer only; `mse.y` set): the launch forms out = S W2^T + deg b2 (lin_out4's bits), the loss partials and
+    // grad_out = 2 (out - y) / (4 N) itself instead of reading `gout` -- see MseTail
+    struct MseTail mse;
 };
 bool ea_seg_fit(int seg, int n, int fe, int ld, bool bwd);
 // mask_embd + residual AND the first EdgeAggregation's edge stage in one graph-resident launch (ea_seg.hip front_seg_fwd_kernel),

@@ -66,14 +66,60 @@ class _MseFn(torch.autograd.Function):
         return ctx.grad * gloss, None, None
 
 
+class MseTail:
+    """What `MSELoss.attach` arranged for ONE forward/backward pair of a model (pfn_mpn_backward_mse): the model left its output
+    rows unwritten; its backward pass writes `out`, `loss` and `grad_out` in its first launch."""
+    __slots__ = ("target", "target_version", "loss", "grad_out", "ws")
+
+    def __init__(self, target, loss, grad_out, ws):
+        self.target, self.target_version, self.loss, self.grad_out, self.ws = target, target._version, loss, grad_out, ws
+
+
+class _MseTailFn(torch.autograd.Function):
+    """The loss node of an attached pair: nothing is launched here.  forward hands out the tensor the model's backward pass will
+    write the loss into; backward hands the model the (still unwritten) grad_out buffer as the token that says "form it yourself"."""
+
+    @staticmethod
+    def forward(ctx, out, tail):
+        ctx.tail = tail
+        return tail.loss.detach()      # (an alias: returning tail.loss itself would tie loss -> grad_fn -> tail -> loss into a cycle)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        tail = ctx.tail
+        if gloss.data_ptr() != _one(tail.grad_out.device).data_ptr():
+            raise RuntimeError("MSELoss.attach(): the attached loss must be differentiated with loss.backward(MSELoss.unit_grad(loss)) "
+                               "(a scaled loss needs the plain path: do not call attach)")
+        return tail.grad_out, None
+
+
 class MSELoss(nn.Module):
     """Drop-in for `torch.nn.MSELoss()` (reduction='mean') on HIP tensors."""
 
     def __init__(self):
         super().__init__()
         self._ws = _Workspace(264)
+        self._tail_ws = _Workspace(1028)     # pfn_mpn_backward_mse: 1024 partials + the arrival counter
+
+    def attach(self, model, target):
+        """Promise of the training loop, made right before `out = model(data)`: the next three statements are
+        `loss = self(out, target)`, `loss.backward(self.unit_grad(loss))`, and nobody reads `out` or `loss` before that backward
+        has run.  A model that can (`MaskEmbdMultiMPN` on a batch of small graphs, output_dim 4: pfn_mpn_mse_tail_ok) then leaves
+        its output Linear to its backward pass, whose first launch forms `out`, the loss and its gradient -- two launches fewer
+        per step (train_epoch's per-batch body, utils/training.py:55-77, is exactly this sequence).  One-shot: consumed by the
+        next forward whether it could use it or not; where it could not, nothing changes.  Results: `out` and every gradient bit
+        for bit those of the plain path, the loss to the rounding of another summation order."""
+        if hasattr(model, "_mse_attach"):
+            model._mse_attach = (target, self._tail_ws)
 
     def forward(self, input, target):
+        tail = getattr(input, "_pfn_mse_tail", None)
+        if tail is not None:
+            if not (torch.is_tensor(target) and tail.target is target and tail.target_version == target._version
+                    and input.shape == target.shape):
+                raise RuntimeError("MSELoss.attach(): the loss was called with another target (or a modified one) than the one "
+                                   "attached -- the model's output rows are not written on this path")
+            return _MseTailFn.apply(input, tail)
         return _MseFn.apply(input, target, self._ws)
 
     @staticmethod

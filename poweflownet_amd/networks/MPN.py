@@ -307,10 +307,27 @@ class _MpnFn(torch.autograd.Function):
         nbytes = lib.pfn_mpn_workspace_bytes(C.byref(cfg), n, graph.e_stored)
         ws = torch.empty(nbytes, dtype=torch.uint8, device=x.device)
         mask_dtype = 0 if pred_mask.dtype == torch.int64 else 1
+        # MSELoss announced for this very forward (loss.MSELoss.attach, the training loop's promise): the output rows, the loss and
+        # its gradient are left to the backward pass's first launch (pfn_mpn_backward_mse).  Not with checks left on the device
+        # (the poison below must reach the loss through `out`).
+        attach, model._mse_attach = getattr(model, "_mse_attach", None), None
+        tail = None
+        if (attach is not None and cfg.need_backward and fo == 4 and not graph.unverified and graph.seg_nodes > 0
+                and not ctx.needs_input_grad[4] and torch.is_tensor(attach[0]) and attach[0].is_cuda
+                and attach[0].device == x.device and attach[0].dtype == torch.float32 and tuple(attach[0].shape) == (n, 4)
+                and attach[0].is_contiguous()
+                and lib.pfn_mpn_mse_tail_ok(C.byref(cfg), n, graph.e_stored, graph.seg_nodes) == 1):
+            from ..loss import MseTail
+            tail = MseTail(attach[0], torch.empty((), dtype=torch.float32, device=x.device),
+                           torch.empty(n, 4, dtype=torch.float32, device=x.device), attach[1].on(x.device))
         L.check(lib.pfn_mpn_forward(C.byref(cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params), x.data_ptr(),
-                                    pred_mask.data_ptr(), mask_dtype, edge_attr.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                                    nbytes, L.ptr(model._rng_state_on(x.device)), graph.seg_nodes, L.stream_ptr()),
+                                    pred_mask.data_ptr(), mask_dtype, edge_attr.data_ptr(), None if tail is not None else out.data_ptr(),
+                                    ws.data_ptr(), nbytes, L.ptr(model._rng_state_on(x.device)), graph.seg_nodes, L.stream_ptr()),
                 "pfn_mpn_forward")
+        # (an alias, not `out` itself: the returned tensor gets this node as grad_fn -- keeping IT here would be a reference cycle
+        #  that holds the whole workspace until the garbage collector runs)
+        ctx.tail, ctx.out = tail, (out.detach() if tail is not None else None)
+        model._mse_tail = tail        # picked up by MaskEmbdMultiMPN.forward, which hangs it on the tensor it returns
         if graph.unverified:     # checks not read back (changing topology / capture): a bad batch must not pass silently
             L.check(lib.pfn_graph_poison_if_bad(graph.ws.data_ptr(), n, graph.e_stored, out.data_ptr(), out.numel(),
                                                 L.stream_ptr()), "pfn_graph_poison_if_bad")
@@ -332,6 +349,18 @@ class _MpnFn(torch.autograd.Function):
         grads = [g if p.dim() == 1 else g.view(p.shape) for g, p in zip(flat.split_with_sizes(sizes), params)]
         gx = torch.empty_like(x) if ctx.needs_input_grad[2] else None
         gea = torch.empty_like(edge_attr) if ctx.needs_input_grad[4] else None
+        tail = ctx.tail
+        if tail is not None:         # the attached MSELoss: out, loss and grad_out are formed by the first backward launch
+            if gout.data_ptr() != tail.grad_out.data_ptr():
+                raise RuntimeError("MSELoss.attach(): the model output was used by something else than the attached loss "
+                                   "(its rows are only written by this backward pass)")
+            L.check(lib.pfn_mpn_backward_mse(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
+                                             L.ptr_table(grads), x.data_ptr(), edge_attr.data_ptr(), tail.target.data_ptr(),
+                                             ctx.out.data_ptr(), tail.loss.data_ptr(), tail.grad_out.data_ptr(), L.ptr(gx),
+                                             ctx.ws.data_ptr(), ctx.ws.numel(), tail.ws.data_ptr(), tail.ws.numel() * 4,
+                                             graph.seg_nodes, L.stream_ptr()), "pfn_mpn_backward_mse")
+            model._last_flat_grad = flat
+            return (None, None, gx, None, gea, *grads)
         L.check(lib.pfn_mpn_backward(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
                                      L.ptr_table(grads), x.data_ptr(), pred_mask.data_ptr(), ctx.mask_dtype,
                                      edge_attr.data_ptr(), gp.data_ptr(), L.ptr(gx), L.ptr(gea), ctx.ws.data_ptr(),
@@ -369,6 +398,9 @@ class _UndirectHelpers:
 
 class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
     """networks/MPN.py:456-559: mask embedding + (EdgeAggregation, TAGConv) x (L-1) + EdgeAggregation."""
+
+    _mse_attach = None   # (target, workspace) announced by loss.MSELoss.attach for the NEXT forward, consumed by it (one-shot)
+    _mse_tail = None
 
     def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
         super().__init__()
@@ -519,7 +551,11 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
             seg_hint = x.shape[0] // nseg if nseg > 0 and x.shape[0] % nseg == 0 else 0
             graph = self._graphs.get(edge_index, x.shape[0], -1, seg_hint, rebuild=self.dynamic_topology)   # is_directed + undirect_graph (:539)
             self._grad_mode_at_apply = torch.is_grad_enabled()
-            return _MpnFn.apply(self, graph, x, mask, edge_features, *params)
+            self._mse_tail = None
+            out = _MpnFn.apply(self, graph, x, mask, edge_features, *params)
+            if self._mse_tail is not None:     # loss.MSELoss.forward finds the arrangement on the tensor it is handed
+                out._pfn_mse_tail, self._mse_tail = self._mse_tail, None
+            return out
 
 
 # ============================================================================================ MPN_simplenet
