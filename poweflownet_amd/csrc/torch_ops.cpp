@@ -107,7 +107,8 @@ Tensor graph_build(const Tensor& edge_index, int64_t num_nodes, int64_t mode) {
 // ---- MaskEmbdMultiMPN.forward, networks/MPN.py:525-559.  Returns (out [N, output_dim], ws: what mpn_backward needs)
 std::tuple<Tensor, Tensor> mpn_forward(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, at::IntArrayRef dims, double dropout,
                                        bool training, bool need_backward, at::TensorList params, const Tensor& x, const Tensor& pred_mask,
-                                       const Tensor& edge_attr, const c10::optional<Tensor>& rng_state) {
+                                       const Tensor& edge_attr, const c10::optional<Tensor>& rng_state, bool defer_out = false) {
+    // defer_out: the output rows are left to mpn_backward_mse (where mpn_mse_tail_ok says so); `out` comes back unwritten
     TORCH_CHECK(x.defined() && x.dim() == 2, "x must be [N, nfeature_dim]");
     const pfn_mpn_config c = config_of(dims, dropout, training, need_backward);
     TORCH_CHECK(x.size(1) == c.nfeature_dim, "x must be [N, ", c.nfeature_dim, "], got [", x.size(0), ", ", x.size(1), "]");
@@ -132,9 +133,60 @@ std::tuple<Tensor, Tensor> mpn_forward(const Tensor& graph_ws, int64_t e_stored,
     const size_t bytes = pfn_mpn_workspace_bytes(&c, n, e_stored);
     Tensor ws = at::empty({(int64_t)bytes}, x.options().dtype(at::kByte));
     pfn_ok(pfn_mpn_forward(&c, graph_ws.data_ptr(), n, e_stored, pp.data(), x.data_ptr<float>(), pred_mask.data_ptr(), mask_dtype_of(pred_mask),
-                           edge_attr.data_ptr<float>(), out.data_ptr<float>(), ws.data_ptr(), bytes, rng, seg_nodes, cur_stream(x)),
+                           edge_attr.data_ptr<float>(), defer_out ? nullptr : out.data_ptr<float>(), ws.data_ptr(), bytes, rng, seg_nodes,
+                           cur_stream(x)),
            "pfn_mpn_forward");
     return {unpad_rows(out, c.output_dim), ws};
+}
+
+// ---- is the MSELoss tail (mpn_backward_mse) available for this model and batch?  (pfn_mpn_mse_tail_ok)
+bool mpn_mse_tail_ok(int64_t num_nodes, int64_t e_stored, int64_t seg_nodes, at::IntArrayRef dims, double dropout, bool training) {
+    const pfn_mpn_config c = config_of(dims, dropout, training, true);
+    return pfn_mpn_mse_tail_ok(&c, num_nodes, e_stored, seg_nodes) == 1;
+}
+
+// ---- loss = MSELoss()(out, y); loss.backward() -- train.py:103, utils/training.py:70-74 -- riding in the backward pass's first
+// launch (pfn_mpn_backward_mse).  `out`: the tensor mpn_forward returned (with defer_out it is written HERE).  `loss_ws`: float32
+// [>= 1025], zero before the first call.  Returns (flat gradient of every parameter, loss, grad_out, grad_x?)
+std::tuple<Tensor, Tensor, Tensor, Tensor> mpn_backward_mse(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, at::IntArrayRef dims,
+                                                            double dropout, bool training, at::TensorList params, const Tensor& x,
+                                                            const Tensor& edge_attr, const Tensor& y, Tensor out, const Tensor& ws,
+                                                            Tensor loss_ws, bool need_grad_x) {
+    const pfn_mpn_config c = config_of(dims, dropout, training, true);
+    want_f32(x, "x", x);
+    want_graph(graph_ws, x);
+    want(ws, "ws", at::kByte, x);
+    want_f32(edge_attr, "edge_attr", x);
+    want_f32(y, "y", x);
+    want_f32(out, "out", x);
+    want_f32(loss_ws, "loss_ws", x);
+    const int64_t n = x.size(0);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == c.nfeature_dim, "x must be [N, nfeature_dim]");
+    TORCH_CHECK(c.output_dim == 4 && y.dim() == 2 && y.size(0) == n && y.size(1) == 4 && out.sizes() == y.sizes(), "y and out must be [N, 4]");
+    TORCH_CHECK(loss_ws.numel() >= 1025, "loss_ws must hold 1025 floats");
+    TORCH_CHECK((int64_t)params.size() == pfn_mpn_num_params(&c), "expected ", pfn_mpn_num_params(&c), " parameter tensors, got ", params.size());
+    const std::vector<const float*> pp = ptrs(params, "parameter", x);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    TORCH_CHECK((size_t)ws.numel() == pfn_mpn_workspace_bytes(&c, n, e_stored), "ws is not the buffer mpn_forward(need_backward=True) returned");
+    int64_t total = 0;
+    for (const Tensor& p : params) total += p.numel();
+    Tensor flat = at::empty({total}, x.options());
+    std::vector<float*> gp;
+    gp.reserve(params.size());
+    int64_t off = 0;
+    for (const Tensor& p : params) {
+        gp.push_back(flat.data_ptr<float>() + off);
+        off += p.numel();
+    }
+    Tensor loss = at::empty({}, x.options());
+    Tensor gout = at::empty_like(y);
+    Tensor gx = need_grad_x ? at::empty_like(x) : Tensor();
+    pfn_ok(pfn_mpn_backward_mse(&c, graph_ws.data_ptr(), n, e_stored, pp.data(), gp.data(), x.data_ptr<float>(), edge_attr.data_ptr<float>(),
+                                y.data_ptr<float>(), out.data_ptr<float>(), loss.data_ptr<float>(), gout.data_ptr<float>(),
+                                need_grad_x ? gx.data_ptr<float>() : nullptr, ws.data_ptr(), (size_t)ws.numel(), loss_ws.data_ptr(),
+                                (size_t)loss_ws.numel() * 4, seg_nodes, cur_stream(x)),
+           "pfn_mpn_backward_mse");
+    return {flat, loss, gout, gx};
 }
 
 // ---- what loss.backward() runs, utils/training.py:74.  Returns (flat gradient of every parameter in table order, grad_x?, grad_edge_attr?)
@@ -460,7 +512,10 @@ TORCH_LIBRARY(pfn, m) {
     m.def("abi_version() -> int", &abi_version);
     m.def("graph_build(Tensor edge_index, int num_nodes, int mode=-1) -> Tensor");
     m.def("mpn_forward(Tensor graph_ws, int e_stored, int seg_nodes, int[] dims, float dropout, bool training, bool need_backward, "
-          "Tensor[] params, Tensor x, Tensor pred_mask, Tensor edge_attr, Tensor? rng_state=None) -> (Tensor, Tensor)");
+          "Tensor[] params, Tensor x, Tensor pred_mask, Tensor edge_attr, Tensor? rng_state=None, bool defer_out=False) -> (Tensor, Tensor)");
+    m.def("mpn_mse_tail_ok(int num_nodes, int e_stored, int seg_nodes, int[] dims, float dropout, bool training) -> bool", &mpn_mse_tail_ok);
+    m.def("mpn_backward_mse(Tensor graph_ws, int e_stored, int seg_nodes, int[] dims, float dropout, bool training, Tensor[] params, Tensor x, "
+          "Tensor edge_attr, Tensor y, Tensor(a!) out, Tensor ws, Tensor(b!) loss_ws, bool need_grad_x=False) -> (Tensor, Tensor, Tensor, Tensor)");
     m.def("mpn_backward(Tensor graph_ws, int e_stored, int seg_nodes, int[] dims, float dropout, bool training, Tensor[] params, Tensor x, "
           "Tensor pred_mask, Tensor edge_attr, Tensor grad_out, Tensor ws, bool need_grad_x=False, bool need_grad_edge_attr=False) "
           "-> (Tensor, Tensor, Tensor)");
@@ -485,6 +540,7 @@ TORCH_LIBRARY_IMPL(pfn, CUDA, m) {
     m.impl("graph_build", &graph_build);
     m.impl("mpn_forward", &mpn_forward);
     m.impl("mpn_backward", &mpn_backward);
+    m.impl("mpn_backward_mse", &mpn_backward_mse);
     m.impl("edge_aggr_forward", &edge_aggr_forward);
     m.impl("edge_aggr_backward", &edge_aggr_backward);
     m.impl("tag_conv_forward", &tag_conv_forward);

@@ -71,6 +71,41 @@ def test_model_ops_match_the_module_bit_for_bit(train):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("train", [False, True])
+def test_mse_tail_ops_match_the_three_op_path_bit_for_bit(train):
+    """pfn::mpn_forward(defer_out) -> pfn::mpn_backward_mse (the output rows, MSELoss and its gradient in the backward pass's first
+    launch, pfn_mpn_backward_mse) against pfn::mpn_forward -> pfn::mse_loss -> pfn::mpn_backward: same out, same gradients."""
+    ops = torch_ops.load()
+    m, d = _setup(train=train)
+    g_seg = None
+    m(d)                                   # (builds the module's adjacency: seg_nodes comes from there)
+    g_seg = m._graphs._graph.seg_nodes
+    params = [p.detach() for p in m._ordered_params()]
+    dims = torch_ops.model_dims(m)
+    e, n = d.edge_index.shape[1], d.x.shape[0]
+    assert ops.mpn_mse_tail_ok(n, e, g_seg, dims, m.dropout_rate, train)
+    assert not ops.mpn_mse_tail_ok(n, e, 0, dims, m.dropout_rate, train)
+    gws = ops.graph_build(d.edge_index, n, -1)
+
+    def rng():
+        return torch.tensor([77, 0], dtype=torch.int64, device="cuda:0") if train else None
+    out, ws = ops.mpn_forward(gws, e, g_seg, dims, m.dropout_rate, train, True, params, d.x, d.pred_mask, d.edge_attr, rng())
+    lo, gr = ops.mse_loss(out, d.y, torch.zeros(264, device="cuda:0"))
+    flat, gx, _ = ops.mpn_backward(gws, e, g_seg, dims, m.dropout_rate, train, params, d.x, d.pred_mask, d.edge_attr, gr, ws, True, False)
+    out2, ws2 = ops.mpn_forward(gws, e, g_seg, dims, m.dropout_rate, train, True, params, d.x, d.pred_mask, d.edge_attr, rng(), True)
+    out2.fill_(float("nan"))               # deferred: whatever it holds now is not the output
+    loss_ws = torch.zeros(1028, device="cuda:0")
+    for _ in range(2):                     # (twice: the arrival counter in loss_ws is left zero)
+        flat2, lo2, gr2, gx2 = ops.mpn_backward_mse(gws, e, g_seg, dims, m.dropout_rate, train, params, d.x, d.edge_attr, d.y, out2, ws2,
+                                                    loss_ws, True)
+        assert torch.equal(out2, out) and torch.equal(gr2, gr) and torch.equal(flat2, flat) and torch.equal(gx2, gx)
+        assert abs(lo2.item() - lo.item()) <= 2e-6 * abs(lo.item())
+    assert loss_ws[1024].item() == 0.0
+    with pytest.raises(RuntimeError, match="1025"):
+        ops.mpn_backward_mse(gws, e, g_seg, dims, m.dropout_rate, train, params, d.x, d.edge_attr, d.y, out2, ws2, loss_ws[:8], False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train", [False, True])
 def test_differentiable_model_op_matches_the_module(train):
     """`pfn::mpn` carries its own autograd node (csrc/torch_ops.cpp MpnFunction): model(data) ... loss.backward() of
     utils/training.py:58,:74 through torch.ops alone -- same output, same parameter / input gradients, bit for bit, as the module."""
