@@ -382,8 +382,11 @@ def main():
 
         def fwd_bwd():
             opt.zero_grad(set_to_none=True)
-            if not masked:
-                loss_fn.attach(model, data.y)          # the loop body's promise (utils/training.py:59-74): loss, then its backward
+            # the loop body's promise (utils/training.py:59-74): the loss, then its backward
+            if masked:
+                loss_fn.attach(model, data.y, data.pred_mask)
+            else:
+                loss_fn.attach(model, data.y)
             loss = loss_fn(model(data), data.y, data.pred_mask) if masked else loss_fn(model(data), data.y)
             loss.backward(loss_fn.unit_grad(loss))     # == loss.backward(), minus autograd's ones_like + mul kernels
             loss_box[0] = loss

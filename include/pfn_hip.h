@@ -139,6 +139,16 @@ int pfn_mpn_backward(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_
  * Available where pfn_mpn_mse_tail_ok returns 1 (seg_nodes from pfn_graph_segments, Fe = 2, output_dim 4, the batch in the
  * graph-resident regime); PFN_EINVAL elsewhere -- the caller then runs the three calls above.                              */
 int pfn_mpn_mse_tail_ok(const pfn_mpn_config* cfg, int64_t n_nodes, int64_t e_stored, int64_t seg_nodes);
+/* The same with `Masked_L2_loss(regularize, regcoeff)(out, y, pred_mask)` (utils/custom_loss_functions.py:10-46, the default
+ * --train_loss_fn, dispatch utils/training.py:61-62) as the loss, `pred_mask` being THE mask the forward call was given (its
+ * first launch kept the float mask rows and the per-block counts of the two index sets in `ws`): loss and grad as
+ * pfn_masked_l2_loss defines them -- grad_out bit-identical to it, loss[0] to the rounding of another summation order.
+ * `loss_ws`: >= 8196 bytes (2048 float partials + the int32 arrival counter at byte 8192, zero between calls).         */
+int pfn_mpn_backward_masked_l2(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
+                               const float* const* params, float* const* grads, const float* x, const float* edge_attr,
+                               const float* y, int regularize, float regcoeff, float* out, float* loss, float* grad_out,
+                               float* grad_x, void* ws, size_t ws_bytes, void* loss_ws, size_t loss_ws_bytes,
+                               int64_t seg_nodes, void* stream);
 int pfn_mpn_backward_mse(const pfn_mpn_config* cfg, const void* graph_ws, int64_t n_nodes, int64_t e_stored,
                          const float* const* params, float* const* grads, const float* x, const float* edge_attr,
                          const float* y, float* out, float* loss, float* grad_out, float* grad_x, void* ws, size_t ws_bytes,

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libpfn_hip.so")
 SYMBOLS = (
     "pfn_abi_version", "pfn_last_error", "pfn_padded_ld",
     "pfn_graph_workspace_bytes", "pfn_graph_build", "pfn_graph_info", "pfn_graph_segments", "pfn_graph_segments_async", "pfn_graph_poison_if_bad", "pfn_graph_export_edges",
-    "pfn_mpn_num_params", "pfn_mpn_workspace_bytes", "pfn_mpn_forward", "pfn_mpn_backward", "pfn_mpn_mse_tail_ok", "pfn_mpn_backward_mse", "pfn_mpn_export_gates",
+    "pfn_mpn_num_params", "pfn_mpn_workspace_bytes", "pfn_mpn_forward", "pfn_mpn_backward", "pfn_mpn_mse_tail_ok", "pfn_mpn_backward_mse", "pfn_mpn_backward_masked_l2", "pfn_mpn_export_gates",
     "pfn_edge_aggr_workspace_bytes", "pfn_edge_aggr_forward", "pfn_edge_aggr_backward",
     "pfn_tag_conv_workspace_bytes", "pfn_tag_conv_forward", "pfn_tag_conv_backward",
     "pfn_scatter_add", "pfn_pad_rows", "pfn_mse_loss", "pfn_masked_l2_loss", "pfn_power_imbalance", "pfn_dropout_mask", "pfn_adamw_step", "pfn_adamw_step_dev", "pfn_adamw_step_guarded",
@@ -66,6 +66,7 @@ def load() -> C.CDLL:
         "pfn_mpn_backward": (C.c_int, [cfgp, p, i64, i64, p, p, p, p, i32, p, p, p, p, p, sz, i64, p]),
         "pfn_mpn_mse_tail_ok": (C.c_int, [cfgp, i64, i64, i64]),
         "pfn_mpn_backward_mse": (C.c_int, [cfgp, p, i64, i64, p, p, p, p, p, p, p, p, p, p, sz, p, sz, i64, p]),
+        "pfn_mpn_backward_masked_l2": (C.c_int, [cfgp, p, i64, i64, p, p, p, p, p, i32, f32, p, p, p, p, p, sz, p, sz, i64, p]),
         "pfn_mpn_export_gates": (C.c_int, [cfgp, p, i64, i64, p, p, p, sz, i64, C.c_int32, C.c_int32, p, p]),
         "pfn_edge_aggr_workspace_bytes": (sz, [i64, i64, i32, i32, i32, i32]),
         "pfn_edge_aggr_forward": (C.c_int, [p, i64, i64, i32, i32, i32, i32, p, i64, p, p, p, p, p, p, i64, p, sz, p]),

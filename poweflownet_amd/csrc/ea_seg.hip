@@ -388,6 +388,8 @@ void front_seg_fwd_kernel(const FrontFwdArgs f, const PackArgs pa, int nseg_x, i
     // mask_embd's weights as one 48-byte record per hidden unit: wa[4] | ba, wb[0..2] | wb[3], 0, 0, 0  (three 16-byte LDS reads
     // per unit; as scalar loads inside the per-row loop every unit waited ~300 cycles for its own loads: 40 us)
     float4* s_me = reinterpret_cast<float4*>(s_w + 9 * 56);      // [h][3]
+    int* s_cnt = reinterpret_cast<int*>(s_me + 3 * h);           // [2]: the block's mask census (FrontFwdArgs::mask_counts)
+    if (tid < 2) s_cnt[tid] = 0;
     if (tid < h) {
         const float4 a4 = sg_ld4(f.wa + (size_t)tid * 4);
         const float b0 = f.ba[tid], w0_ = f.wb[tid], w1_ = f.wb[h + tid], w2_ = f.wb[2 * h + tid], w3_ = f.wb[3 * h + tid];
@@ -460,8 +462,25 @@ void front_seg_fwd_kernel(const FrontFwdArgs f, const PackArgs pa, int nseg_x, i
                 sg_st4_wt(f.x0 + (size_t)row * 4, o);
             }
         }
+        // the block's mask census for a Masked_L2_loss riding in the backward pass (MseTail::counts): integer sums, any order
+        if (f.mask_counts && by == 0) {
+            int c1 = 0, c0 = 0;
+            if (on && pq == 0) {
+                c1 = (m.x != 0.f) + (m.y != 0.f) + (m.z != 0.f) + (m.w != 0.f);
+                c0 = (1.f - m.x != 0.f) + (1.f - m.y != 0.f) + (1.f - m.z != 0.f) + (1.f - m.w != 0.f);
+            }
+            for (int off = 32; off > 0; off >>= 1) {
+                c1 += __shfl_xor(c1, off);
+                c0 += __shfl_xor(c0, off);
+            }
+            if ((tid & 63) == 0) {
+                atomicAdd(&s_cnt[0], c1);
+                atomicAdd(&s_cnt[1], c0);
+            }
+        }
     }
     seg_lds_barrier();
+    if (f.mask_counts && by == 0 && tid < 2) f.mask_counts[2 * bx + tid] = s_cnt[tid];
     // ---- me_h, P | Q of the block's chunks: item = (row, chunk), the row-per-wave kernel's fma chains
     for (int it = tid; it < rows * sc.cw; it += SG_THREADS) {
         const int lr = it / sc.cw, lc = it - lr * sc.cw;
@@ -775,7 +794,7 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         const int nch = a.ld >> 2;
         const int mlr = threadIdx.x >> 2, mpq = threadIdx.x & 3;
         const int mrow = r0 + min(mlr, rows - 1);
-        float4 sv[9], yv = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 sv[9], yv = make_float4(0.f, 0.f, 0.f, 0.f), mkv = yv;
         float dgv = 0.f;
         if (LOSS) {
 #pragma unroll
@@ -783,6 +802,23 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             if (mpq == 0) {
                 yv = sg_ld4(a.mse.y + (size_t)mrow * 4);
                 dgv = a.mse.deg[mrow];
+                if (a.mse.maskf) mkv = sg_ld4(a.mse.maskf + (size_t)mrow * 4);
+            }
+            if (a.mse.maskf) {   // Masked_L2_loss: the batch's mask census = the sum of the row blocks' (integers: any order)
+                int c1 = 0, c0 = 0;
+                for (int i = threadIdx.x; i < a.mse.count_blocks; i += SG_THREADS) {
+                    c1 += a.mse.counts[2 * i];
+                    c0 += a.mse.counts[2 * i + 1];
+                }
+                for (int off = 32; off > 0; off >>= 1) {
+                    c1 += __shfl_xor(c1, off);
+                    c0 += __shfl_xor(c0, off);
+                }
+                if (lane == 0) {
+                    int* cw = reinterpret_cast<int*>(l.part) + 768 + 2 * wave;
+                    cw[0] = c1;
+                    cw[1] = c0;
+                }
             }
             for (int i = threadIdx.x; i < 4 * SG_W2A_CH; i += SG_THREADS) {
                 const int o = i / SG_W2A_CH, c = i - o * SG_W2A_CH;
@@ -852,12 +888,37 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
                                               a.fo > 2 ? fmaf(dgv, b2_, t4.z) : 0.f, a.fo > 3 ? fmaf(dgv, b3_, t4.w) : 0.f);
                 const bool on = mlr < rows;
                 const float4 d4 = make_float4(o4.x - yv.x, o4.y - yv.y, o4.z - yv.z, o4.w - yv.w);
-                const float4 g4 = on ? make_float4(2.f * d4.x * a.mse.inv_n, 2.f * d4.y * a.mse.inv_n, 2.f * d4.z * a.mse.inv_n,
-                                                   2.f * d4.w * a.mse.inv_n)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+                float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                float q1 = 0.f, q0 = 0.f;
+                if (a.mse.maskf) {
+                    // Masked_L2_loss: masked_l2_grad_kernel's expressions (model.hip) on the batch-wide counts
+                    const int* cw = reinterpret_cast<const int*>(l.part) + 768;
+                    int c1 = 0, c0 = 0;
+#pragma unroll
+                    for (int w = 0; w < SG_WAVES; ++w) { c1 += cw[2 * w]; c0 += cw[2 * w + 1]; }
+                    const float g1 = 2.f / (float)c1, g0 = a.mse.regularize ? 2.f * a.mse.regcoeff / (float)c0 : 0.f;
+                    const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, mv[4] = {mkv.x, mkv.y, mkv.z, mkv.w};
+                    float gv4[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = dv[j], m = mv[j];
+                        float g = 0.f;
+                        if (m != 0.f) { g += g1 * d; q1 = fmaf(d, d, q1); }
+                        if (1.f - m != 0.f) {
+                            if (a.mse.regularize) g += g0 * d;
+                            q0 = fmaf(d, d, q0);
+                        }
+                        gv4[j] = g;
+                    }
+                    if (on) g4 = make_float4(gv4[0], gv4[1], gv4[2], gv4[3]);
+                } else {
+                    if (on) g4 = make_float4(2.f * d4.x * a.mse.inv_n, 2.f * d4.y * a.mse.inv_n, 2.f * d4.z * a.mse.inv_n, 2.f * d4.w * a.mse.inv_n);
+                    q1 = fmaf(d4.w, d4.w, fmaf(d4.z, d4.z, fmaf(d4.y, d4.y, d4.x * d4.x)));
+                }
                 if (mlr < SG_MAX_ROWS) {
                     gs[mlr] = g4;
-                    sq[mlr] = on ? fmaf(d4.w, d4.w, fmaf(d4.z, d4.z, fmaf(d4.y, d4.y, d4.x * d4.x))) : 0.f;
+                    sq[mlr] = on ? q1 : 0.f;
+                    sq[SG_MAX_ROWS + mlr] = on ? q0 : 0.f;
                 }
                 if (on && sc.q == max(0, sc.nq - 2)) {   // ONE quarter per graph stores the 4-wide tensors (an early, light one)
                     sg_st4_wt(a.mse.out + (size_t)mrow * 4, o4);
@@ -867,9 +928,19 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             seg_lds_barrier();
             // the block's loss partial: rows l and l + 64, then a fixed xor tree (wave 0; once per block)
             if (wave == 0 && sc.q == max(0, sc.nq - 2)) {
-                float v = sq[lane] + sq[lane + 64];
-                for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-                if (lane == 0) __hip_atomic_store(a.mse.partial + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1: write-through
+                float v = sq[lane] + sq[lane + 64], v0 = sq[SG_MAX_ROWS + lane] + sq[SG_MAX_ROWS + lane + 64];
+                for (int off = 32; off > 0; off >>= 1) {
+                    v += __shfl_xor(v, off);
+                    v0 += __shfl_xor(v0, off);
+                }
+                if (lane == 0) {   // sc1: write-through
+                    if (a.mse.maskf) {
+                        __hip_atomic_store(a.mse.partial + 2 * blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(a.mse.partial + 2 * blockIdx.x + 1, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        __hip_atomic_store(a.mse.partial + blockIdx.x, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
             }
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
@@ -979,11 +1050,29 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         }
         last = __shfl(last, 0);
         if (last) {
-            float v = 0.f;
-            for (int i = lane; i < (int)gridDim.x; i += 64) v += __hip_atomic_load(a.mse.partial + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            const int stride = a.mse.maskf ? 2 : 1;
+            float v = 0.f, v0 = 0.f;
+            for (int i = lane; i < (int)gridDim.x; i += 64) {
+                v += __hip_atomic_load(a.mse.partial + stride * i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a.mse.maskf) v0 += __hip_atomic_load(a.mse.partial + 2 * i + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int c1 = 0, c0 = 0;
+            if (a.mse.maskf)
+                for (int i = lane; i < a.mse.count_blocks; i += 64) { c1 += a.mse.counts[2 * i]; c0 += a.mse.counts[2 * i + 1]; }
+            for (int off = 32; off > 0; off >>= 1) {
+                v += __shfl_xor(v, off);
+                v0 += __shfl_xor(v0, off);
+                c1 += __shfl_xor(c1, off);
+                c0 += __shfl_xor(c0, off);
+            }
             if (lane == 0) {
-                a.mse.loss[0] = v * a.mse.inv_n;
+                if (a.mse.maskf) {   // masked_l2_reduce_kernel's closing expressions (0 / 0 = NaN: torch's mean of an empty selection)
+                    float lv = v / (float)c1;
+                    if (a.mse.regularize) lv += a.mse.regcoeff * (v0 / (float)c0);
+                    a.mse.loss[0] = lv;
+                } else {
+                    a.mse.loss[0] = v * a.mse.inv_n;
+                }
                 *a.mse.counter = 0;
             }
         }
@@ -1097,11 +1186,11 @@ int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStr
     const bool dsg = a.Bd == nullptr;
     static std::atomic<uint64_t> raised0{0}, raised1{0}, raised2{0};
     if (a.mse.y && !(dsg && a.ld / 4 <= SG_W2A_CH && a.mse.S && a.mse.b2 && a.mse.deg && a.mse.out && a.mse.gout && a.mse.partial &&
-                     a.mse.counter && a.mse.loss)) {
+                     a.mse.counter && a.mse.loss && (!a.mse.maskf || (a.mse.counts && a.mse.count_blocks == p.nblocks)))) {
         set_error("ea_seg_bwd: the MSELoss tail needs the last layer's form and every MseTail pointer (internal)");
         return PFN_EINVAL;
     }
-    ProfScope ps(a.mse.y ? "ea_seg_bwd+out+mse" : "ea_seg_bwd", 0.0, a.Bd ? 2.0 * g.n * (double)a.fo * a.h : 0.0, s);
+    ProfScope ps(a.mse.y ? (a.mse.maskf ? "ea_seg_bwd+out+masked_l2" : "ea_seg_bwd+out+mse") : "ea_seg_bwd", 0.0, a.Bd ? 2.0 * g.n * (double)a.fo * a.h : 0.0, s);
     if (a.mse.y) {
         PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(ea_seg_bwd_kernel<true, true>), SG_LDS_BYTES, raised2));
         ea_seg_bwd_kernel<true, true><<<dim3(p.nblocks, p.ny), SG_THREADS, lds, s>>>(g.n, p.rows_pb, p.trows, p.cap, g.rowptr_in, g.in_src,

@@ -427,6 +427,7 @@ struct Layout {
     int n, e, f0, fe, fo, h, L, K, ld, ld0, ldo, nlayers;
     int* stamp;                  // guard word: WS_STAMP_TRAIN after a forward that saved what the backward pass reads
     int* sync;                   // CHAIN_SYNC_WORDS words of the chain launches (seg_chain.hip): per-graph arrival counters, status
+    int* mask_counts;            // [1024 row blocks][2]: front_seg_fwd_kernel's mask census (FrontFwdArgs::mask_counts; training only)
     // forward-saved
     float *maskf, *me_h, *x0, *packed;
     float *ea_in, *ea_out;       // edge attributes in CSR slot order (Fe = 2; SlotEa), filled once per forward
@@ -502,6 +503,7 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
     }
     lo.stamp = cv.take<int>(4);
     lo.sync = cv.take<int>(CHAIN_SYNC_WORDS);
+    lo.mask_counts = cv.take<int>(2048);
     lo.packed = cv.take<float>(lo.packed_floats);
     lo.maskf = cv.take<float>((size_t)n * lo.ld0);
     lo.ea_in = cv.take<float>((size_t)4 * e + 4);
@@ -593,6 +595,15 @@ static bool forward_chain_ok(const Layout& lo, const GraphView& g, int seg) {
            seg_chain_fit(seg, lo.n, lo.fe, lo.h, lo.K);
 }
 
+// batches of small graphs: the front AND layer 0's edge stage in one graph-resident launch (ea_seg.hip front_seg_fwd_kernel)
+// (front_seg_fwd_kernel writes no ReLU masks: never where the backward pass of layer 0 would read them -- today the two fit
+//  predicates exclude that by a grid bound only)
+static bool uses_seg_front(const pfn_mpn_config& c, const Layout& lo, int seg) {
+    const bool fused_front = front_fused_ok(lo.f0, lo.h);
+    return fused_front && ea_seg_fit(seg, lo.n, lo.fe, lo.ld, false) && !first_layer_fly(c, lo, seg, fused_front) && lo.nlayers > 1 &&
+           front_seg_fit(seg, lo.n, lo.h, lo.fe) && !(c.need_backward && lo.fe == 2 && !ea_seg_fit(seg, lo.n, lo.fe, lo.ld, true));
+}
+
 static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layout& lo, const float* const* params,
                          const float* x, const void* pred_mask, int mask_dtype, const float* edge_attr, float* out,
                          uint64_t* rng, int seg, hipStream_t s) {
@@ -615,11 +626,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     const bool fused_front = front_fused_ok(lo.f0, lo.h);
     const bool l0_fly = first_layer_fly(c, lo, seg, fused_front);
     const int ws_stamp = c.need_backward ? WS_STAMP_TRAIN : WS_STAMP_INFER;
-    // batches of small graphs: the front AND layer 0's edge stage in one graph-resident launch (ea_seg.hip front_seg_fwd_kernel)
-    // (front_seg_fwd_kernel writes no ReLU masks: never where the backward pass of layer 0 would read them -- today the two fit
-    //  predicates exclude that by a grid bound only)
-    const bool seg_front = fused_front && seg_ea && !l0_fly && lo.nlayers > 1 && front_seg_fit(seg, lo.n, lo.h, lo.fe) &&
-                           !(c.need_backward && lo.fe == 2 && !ea_seg_fit(seg, lo.n, lo.fe, lo.ld, true));
+    const bool seg_front = uses_seg_front(c, lo, seg);
     // ... and every layer between that launch and the last layer's 129 -> 4 Linear in ONE persistent launch (seg_chain.hip)
     const bool chain = seg_front && forward_chain_ok(lo, g, seg);
     if (fused_front) {
@@ -632,6 +639,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         f.maskf = lo.maskf; f.me_h = (c.need_backward && !front_recomputes_meh(c, lo, seg, fused_front)) ? lo.me_h : nullptr; f.x0 = lo.x0;
         f.P = l0_fly ? nullptr : lo.ea[0].P;
         f.Q = l0_fly ? nullptr : lo.ea[0].Q;
+        f.mask_counts = (seg_front && c.need_backward) ? lo.mask_counts : nullptr;   // (read by pfn_mpn_backward_masked_l2)
         if (seg_front)
             PFN_TRY(launch_front_seg_fwd(g, f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, &se, lo.stamp, ws_stamp, edge_attr,
                                          lo.ea[0].S, seg, s, chain ? lo.sync : nullptr));
@@ -1149,17 +1157,18 @@ int pfn_mpn_mse_tail_ok(const pfn_mpn_config* c, int64_t n, int64_t e, int64_t s
     if (!c || n <= 0 || e < 0 || n >= (1ll << 30) || e >= (1ll << 29) || seg_nodes <= 0 || n % seg_nodes != 0) return 0;
     Layout lo;
     if (make_layout(*c, n, e, nullptr, lo) != PFN_OK) return 0;
-    return mse_tail_ok(*c, lo, (int)seg_nodes) ? 1 : 0;
+    // (one answer for both losses: the masked one also needs the front launch that leaves the mask census behind)
+    return (mse_tail_ok(*c, lo, (int)seg_nodes) && uses_seg_front(*c, lo, (int)seg_nodes)) ? 1 : 0;
 }
 
-int pfn_mpn_backward_mse(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
-                         float* const* grads, const float* x, const float* edge_attr, const float* y, float* out, float* loss,
-                         float* grad_out, float* gx, void* ws, size_t ws_bytes, void* loss_ws, size_t loss_ws_bytes,
-                         int64_t seg_nodes, void* stream) {
+static int backward_with_loss_tail(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
+                                   float* const* grads, const float* x, const float* edge_attr, const float* y, float* out, float* loss,
+                                   float* grad_out, float* gx, void* ws, size_t ws_bytes, void* loss_ws, size_t loss_ws_bytes,
+                                   int64_t seg_nodes, void* stream, bool masked, int regularize, float regcoeff) {
     PFN_TRY(check_common(c, gws, n, e, ws));
-    PFN_CHECK_ARG(params && grads && x && y && out && loss && grad_out && loss_ws, "pfn_mpn_backward_mse: null tensor");
-    PFN_CHECK_ARG(c->need_backward != 0, "pfn_mpn_backward_mse: the forward ran with need_backward = 0");
-    PFN_CHECK_ARG(loss_ws_bytes >= 4100, "pfn_mpn_backward_mse: loss workspace must hold 4100 bytes");
+    PFN_CHECK_ARG(params && grads && x && y && out && loss && grad_out && loss_ws, "pfn_mpn_backward_mse / _masked_l2: null tensor");
+    PFN_CHECK_ARG(c->need_backward != 0, "pfn_mpn_backward_mse / _masked_l2: the forward ran with need_backward = 0");
+    PFN_CHECK_ARG(loss_ws_bytes >= (masked ? 8196u : 4100u), "pfn_mpn_backward_mse: loss workspace must hold 4100 bytes (_masked_l2: 8196)");
     Layout lo;
     PFN_TRY(make_layout(*c, n, e, ws, lo));
     if (ws_bytes < lo.bytes) {
@@ -1167,8 +1176,8 @@ int pfn_mpn_backward_mse(const pfn_mpn_config* c, const void* gws, int64_t n, in
         return PFN_ENOSPACE;
     }
     PFN_CHECK_ARG(seg_nodes > 0 && n % seg_nodes == 0, "seg_nodes must divide n_nodes");
-    if (!mse_tail_ok(*c, lo, (int)seg_nodes)) {
-        set_error("pfn_mpn_backward_mse: not available for this model / batch (ask pfn_mpn_mse_tail_ok)");
+    if (!mse_tail_ok(*c, lo, (int)seg_nodes) || (masked && !uses_seg_front(*c, lo, (int)seg_nodes))) {
+        set_error("pfn_mpn_backward_mse / _masked_l2: not available for this model / batch (ask pfn_mpn_mse_tail_ok)");
         return PFN_EINVAL;
     }
     GraphView g = graph_view(const_cast<void*>(gws), n, e);
@@ -1179,10 +1188,33 @@ int pfn_mpn_backward_mse(const pfn_mpn_config* c, const void* gws, int64_t n, in
     t.deg = g.deg;
     t.y = y; t.out = out; t.gout = grad_out;
     t.partial = static_cast<float*>(loss_ws);
-    t.counter = reinterpret_cast<int*>(static_cast<char*>(loss_ws) + 4096);
+    t.counter = reinterpret_cast<int*>(static_cast<char*>(loss_ws) + (masked ? 8192 : 4096));
     t.loss = loss;
     t.inv_n = 1.f / (float)(n * 4);
+    if (masked) {
+        t.maskf = lo.maskf;
+        t.counts = lo.mask_counts;
+        t.count_blocks = ea_seg_blocks((int)seg_nodes, lo.n, lo.ld);
+        t.regularize = regularize ? 1 : 0;
+        t.regcoeff = regcoeff;
+    }
     return model_backward(*c, g, lo, params, grads, x, edge_attr, grad_out, gx, nullptr, (int)seg_nodes, static_cast<hipStream_t>(stream), &t);
+}
+
+int pfn_mpn_backward_mse(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
+                         float* const* grads, const float* x, const float* edge_attr, const float* y, float* out, float* loss,
+                         float* grad_out, float* gx, void* ws, size_t ws_bytes, void* loss_ws, size_t loss_ws_bytes,
+                         int64_t seg_nodes, void* stream) {
+    return backward_with_loss_tail(c, gws, n, e, params, grads, x, edge_attr, y, out, loss, grad_out, gx, ws, ws_bytes, loss_ws,
+                                   loss_ws_bytes, seg_nodes, stream, false, 0, 0.f);
+}
+
+int pfn_mpn_backward_masked_l2(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,
+                               float* const* grads, const float* x, const float* edge_attr, const float* y, int regularize,
+                               float regcoeff, float* out, float* loss, float* grad_out, float* gx, void* ws, size_t ws_bytes,
+                               void* loss_ws, size_t loss_ws_bytes, int64_t seg_nodes, void* stream) {
+    return backward_with_loss_tail(c, gws, n, e, params, grads, x, edge_attr, y, out, loss, grad_out, gx, ws, ws_bytes, loss_ws,
+                                   loss_ws_bytes, seg_nodes, stream, true, regularize, regcoeff);
 }
 
 int pfn_mpn_backward(const pfn_mpn_config* c, const void* gws, int64_t n, int64_t e, const float* const* params,

@@ -379,6 +379,15 @@ struct MseTail {
     int* counter = nullptr;        // arrival counter, zero between launches
     float* loss = nullptr;
     float inv_n = 0.f;             // 1 / (4 N)
+    // Masked_L2_loss instead of MSELoss (utils/custom_loss_functions.py:10-46) when `maskf` is set: the float mask rows the
+    // forward's front kept (N x 4) and the per-row-block counts {#(m != 0), #(1 - m != 0)} its front_seg_fwd_kernel left behind
+    // (the two means' denominators are sums over the whole batch: every block adds up the `count_blocks` pairs itself);
+    // partial then holds TWO floats per block (the two squared-error sums)
+    const float* maskf = nullptr;
+    const int* counts = nullptr;   // [count_blocks][2]
+    int count_blocks = 0;
+    int regularize = 0;
+    float regcoeff = 0.f;
 };
 struct EaSegFwdArgs {
     const float* x;        // layer input, N x ldx, K = Fi real columns
@@ -567,6 +576,8 @@ struct FrontFwdArgs {
     const float *wa, *ba, *wb, *bb, *w1, *b1;
     float *maskf, *me_h, *x0, *P, *Q;      // maskf: pred_mask.float() (networks/MPN.py:533), kept for the weight gradients;
                                            // P, Q null: not written (the first edge stage forms them from x0, EdgeFwdArgs::x0)
+    int* mask_counts = nullptr;            // front_seg_fwd_kernel only, optional: [row blocks][2] = #(m != 0), #(1 - m != 0) of the
+                                           // block's mask entries (the denominators of Masked_L2_loss, MseTail::counts)
 };
 // the front AND the weight re-layout of a forward pass (independent of each other) in one launch; `rng_advance` as in launch_pack
 int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream_t s,

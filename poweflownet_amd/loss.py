@@ -69,10 +69,11 @@ class _MseFn(torch.autograd.Function):
 class MseTail:
     """What `MSELoss.attach` arranged for ONE forward/backward pair of a model (pfn_mpn_backward_mse): the model left its output
     rows unwritten; its backward pass writes `out`, `loss` and `grad_out` in its first launch."""
-    __slots__ = ("target", "target_version", "loss", "grad_out", "ws")
+    __slots__ = ("target", "target_version", "loss", "grad_out", "ws", "masked", "mask")
 
-    def __init__(self, target, loss, grad_out, ws):
+    def __init__(self, target, loss, grad_out, ws, masked=None, mask=None):
         self.target, self.target_version, self.loss, self.grad_out, self.ws = target, target._version, loss, grad_out, ws
+        self.masked, self.mask = masked, mask      # Masked_L2_loss: (regularize, regcoeff) and the mask tensor the model was given
 
 
 class _MseTailFn(torch.autograd.Function):
@@ -110,13 +111,13 @@ class MSELoss(nn.Module):
         next forward whether it could use it or not; where it could not, nothing changes.  Results: `out` and every gradient bit
         for bit those of the plain path, the loss to the rounding of another summation order."""
         if hasattr(model, "_mse_attach"):
-            model._mse_attach = (target, self._tail_ws)
+            model._mse_attach = (target, self._tail_ws, None, None)
 
     def forward(self, input, target):
         tail = getattr(input, "_pfn_mse_tail", None)
         if tail is not None:
             if not (torch.is_tensor(target) and tail.target is target and tail.target_version == target._version
-                    and input.shape == target.shape):
+                    and input.shape == target.shape and tail.masked is None):
                 raise RuntimeError("MSELoss.attach(): the loss was called with another target (or a modified one) than the one "
                                    "attached -- the model's output rows are not written on this path")
             return _MseTailFn.apply(input, tail)
@@ -164,10 +165,25 @@ MASKED_L2_WS_FLOATS = 1032
 POWER_IMBALANCE_WS_FLOATS = 320
 
 
+def masked_l2_attach(model, target, mask, regularize, regcoeff, tail_ws):
+    """`Masked_L2_loss.attach`: the promise of `MSELoss.attach` for the reference's default training loss
+    (utils/custom_loss_functions.py:10-46; dispatch utils/training.py:61-62).  `mask` must be the very tensor the model is about to
+    read as `data.pred_mask` (its first launch counts the two index sets of the loss while it converts the mask)."""
+    if hasattr(model, "_mse_attach"):
+        model._mse_attach = (target, tail_ws, (bool(regularize), float(regcoeff)), mask)
+
+
 def masked_l2_loss(output, target, mask, regularize=True, regcoeff=1, workspace=None):
     """Masked_L2_loss.forward (utils/custom_loss_functions.py:30-46) on HIP tensors: loss and its gradient in two launches
     instead of four `masked_select` compactions, two means and their autograd graph.  `workspace`: the calling loss
     object's `_Workspace(MASKED_L2_WS_FLOATS)` (a throw-away one is made when omitted)."""
+    tail = getattr(output, "_pfn_mse_tail", None)
+    if tail is not None:
+        if not (tail.masked == (bool(regularize), float(regcoeff)) and tail.target is target and tail.target_version == target._version
+                and tail.mask is mask and output.shape == target.shape):
+            raise RuntimeError("Masked_L2_loss.attach(): the loss was called with another target / mask / setting than the one "
+                               "attached -- the model's output rows are not written on this path")
+        return _MseTailFn.apply(output, tail)
     return _MaskedL2Fn.apply(output, target, mask, regularize, regcoeff, workspace or _Workspace(MASKED_L2_WS_FLOATS))
 
 

@@ -316,10 +316,11 @@ class _MpnFn(torch.autograd.Function):
                 and not ctx.needs_input_grad[4] and torch.is_tensor(attach[0]) and attach[0].is_cuda
                 and attach[0].device == x.device and attach[0].dtype == torch.float32 and tuple(attach[0].shape) == (n, 4)
                 and attach[0].is_contiguous()
+                and (attach[2] is None or attach[3] is model._mask_seen)      # Masked_L2_loss: its mask IS the model's pred_mask
                 and lib.pfn_mpn_mse_tail_ok(C.byref(cfg), n, graph.e_stored, graph.seg_nodes) == 1):
             from ..loss import MseTail
             tail = MseTail(attach[0], torch.empty((), dtype=torch.float32, device=x.device),
-                           torch.empty(n, 4, dtype=torch.float32, device=x.device), attach[1].on(x.device))
+                           torch.empty(n, 4, dtype=torch.float32, device=x.device), attach[1].on(x.device), attach[2], attach[3])
         L.check(lib.pfn_mpn_forward(C.byref(cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params), x.data_ptr(),
                                     pred_mask.data_ptr(), mask_dtype, edge_attr.data_ptr(), None if tail is not None else out.data_ptr(),
                                     ws.data_ptr(), nbytes, L.ptr(model._rng_state_on(x.device)), graph.seg_nodes, L.stream_ptr()),
@@ -354,11 +355,19 @@ class _MpnFn(torch.autograd.Function):
             if gout.data_ptr() != tail.grad_out.data_ptr():
                 raise RuntimeError("MSELoss.attach(): the model output was used by something else than the attached loss "
                                    "(its rows are only written by this backward pass)")
-            L.check(lib.pfn_mpn_backward_mse(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
-                                             L.ptr_table(grads), x.data_ptr(), edge_attr.data_ptr(), tail.target.data_ptr(),
-                                             ctx.out.data_ptr(), tail.loss.data_ptr(), tail.grad_out.data_ptr(), L.ptr(gx),
-                                             ctx.ws.data_ptr(), ctx.ws.numel(), tail.ws.data_ptr(), tail.ws.numel() * 4,
-                                             graph.seg_nodes, L.stream_ptr()), "pfn_mpn_backward_mse")
+            if tail.masked is not None:
+                L.check(lib.pfn_mpn_backward_masked_l2(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
+                                                       L.ptr_table(grads), x.data_ptr(), edge_attr.data_ptr(), tail.target.data_ptr(),
+                                                       int(tail.masked[0]), float(tail.masked[1]), ctx.out.data_ptr(),
+                                                       tail.loss.data_ptr(), tail.grad_out.data_ptr(), L.ptr(gx), ctx.ws.data_ptr(),
+                                                       ctx.ws.numel(), tail.ws.data_ptr(), tail.ws.numel() * 4, graph.seg_nodes,
+                                                       L.stream_ptr()), "pfn_mpn_backward_masked_l2")
+            else:
+                L.check(lib.pfn_mpn_backward_mse(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
+                                                 L.ptr_table(grads), x.data_ptr(), edge_attr.data_ptr(), tail.target.data_ptr(),
+                                                 ctx.out.data_ptr(), tail.loss.data_ptr(), tail.grad_out.data_ptr(), L.ptr(gx),
+                                                 ctx.ws.data_ptr(), ctx.ws.numel(), tail.ws.data_ptr(), tail.ws.numel() * 4,
+                                                 graph.seg_nodes, L.stream_ptr()), "pfn_mpn_backward_mse")
             model._last_flat_grad = flat
             return (None, None, gx, None, gea, *grads)
         L.check(lib.pfn_mpn_backward(C.byref(ctx.cfg), graph.ws.data_ptr(), n, graph.e_stored, L.ptr_table(params),
@@ -401,6 +410,7 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
 
     _mse_attach = None   # (target, workspace) announced by loss.MSELoss.attach for the NEXT forward, consumed by it (one-shot)
     _mse_tail = None
+    _mask_seen = None
 
     def __init__(self, nfeature_dim, efeature_dim, output_dim, hidden_dim, n_gnn_layers, K, dropout_rate):
         super().__init__()
@@ -533,6 +543,7 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
         if self.nfeature_dim != 4:
             raise RuntimeError("MaskEmbdMultiMPN.forward asserts 4 node features (networks/MPN.py:528); "
                                f"this model was built with nfeature_dim={self.nfeature_dim}")
+        self._mask_seen = mask                             # (identity of the tensor as the caller holds it: Masked_L2_loss.attach)
         params = self._ordered_params()
         L.require_device(x, mask, edge_index, edge_features, params[0], params[-1], what="MaskEmbdMultiMPN input")
         x, edge_features = L.f32c(x, "data.x"), L.f32c(edge_features, "data.edge_attr")
@@ -555,6 +566,7 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
             out = _MpnFn.apply(self, graph, x, mask, edge_features, *params)
             if self._mse_tail is not None:     # loss.MSELoss.forward finds the arrangement on the tensor it is handed
                 out._pfn_mse_tail, self._mse_tail = self._mse_tail, None
+            self._mask_seen = None
             return out
 
 

@@ -20,6 +20,13 @@ class Masked_L2_loss(nn.Module):
         self.regcoeff = regcoeff
         from ..loss import MASKED_L2_WS_FLOATS, _Workspace
         self._ws = _Workspace(MASKED_L2_WS_FLOATS)
+        self._tail_ws = _Workspace(2052)     # pfn_mpn_backward_masked_l2: 2048 partials + the arrival counter
+
+    def attach(self, model, target, mask):
+        """See loss.MSELoss.attach: the same promise for this loss -- the model's backward pass forms the output rows, the loss
+        and its gradient in its first launch (pfn_mpn_backward_masked_l2), three launches fewer per step."""
+        from ..loss import masked_l2_attach
+        masked_l2_attach(model, target, mask, self.regularize, self.regcoeff, self._tail_ws)
 
     def forward(self, output, target, mask):
         from ..loss import masked_l2_loss

@@ -32,6 +32,8 @@ def _announce_loss(loss_fn, model, data):
     backward pass (loss.MSELoss.attach -> pfn_mpn_backward_mse)."""
     if isinstance(loss_fn, MSELoss):
         loss_fn.attach(model, data.y)
+    elif isinstance(loss_fn, Masked_L2_loss):
+        loss_fn.attach(model, data.y, data.pred_mask)
 
 
 def _dispatch_loss(loss_fn, out, data):

@@ -176,3 +176,99 @@ def test_attached_pair_leaves_no_reference_cycle():
     finally:
         gc.enable()
     assert seen[-1] <= seen[1], seen
+
+
+# ------------------------------------------------------------------------------------------------ Masked_L2_loss
+def _run_masked(m, d, loss_fn, attach):
+    from poweflownet_amd import _lib as L
+    m.seed_dropout(78)
+    m.zero_grad(set_to_none=True)
+    L.profile_report(reset=True)
+    L.profile_enable(True)
+    if attach:
+        loss_fn.attach(m, d.y, d.pred_mask)
+    out = m(d)
+    loss = loss_fn(out, d.y, d.pred_mask)
+    loss.backward(loss_fn.unit_grad(loss))
+    torch.cuda.synchronize()
+    L.profile_enable(False)
+    rep = L.profile_report(reset=True)
+    return {"out": out.detach().clone(), "loss": loss.detach().clone(), "g": m.flat_grad().clone(),
+            "launches": {k: v["count"] for k, v in rep.items() if not k.startswith("__")}}
+
+
+@pytest.mark.parametrize("case,B,train,float_mask,reg,coeff", [("118v2", 128, True, False, True, 1), ("118v2", 16, False, True, True, 0.5),
+                                                                ("14", 37, True, False, False, 1), ("14", 300, True, True, True, 2.0)])
+def test_attached_masked_l2_is_bit_identical_to_the_plain_path(case, B, train, float_mask, reg, coeff):
+    """pfn_mpn_backward_masked_l2: the reference's default training loss (/root/reference/utils/custom_loss_functions.py:10-46)
+    riding in the backward pass's first launch, the two means' denominators counted by the forward pass's first launch."""
+    from poweflownet_amd.synth import make_batch
+    from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss
+    m = _models()
+    m.train(train)
+    d = make_batch(case, B, seed=1).to(DEV)
+    if float_mask:
+        d.pred_mask = d.pred_mask.float()
+    loss_fn = Masked_L2_loss(regularize=reg, regcoeff=coeff)
+    plain = _run_masked(m, d, loss_fn, attach=False)
+    assert "ea_seg_bwd+out+masked_l2" not in plain["launches"] and plain["launches"].get("lin_out4") == 1
+    for _ in range(3):
+        fused = _run_masked(m, d, loss_fn, attach=True)
+        assert fused["launches"].get("ea_seg_bwd+out+masked_l2") == 1 and "lin_out4" not in fused["launches"], fused["launches"]
+        assert torch.isfinite(fused["out"]).all() and fused["g"].abs().max() > 0
+        assert torch.equal(fused["out"], plain["out"])
+        assert torch.equal(fused["g"], plain["g"]), (fused["g"] - plain["g"]).abs().max().item()
+        a, b = fused["loss"].item(), plain["loss"].item()
+        assert abs(a - b) <= 2e-6 * abs(b), (a, b)
+
+
+def test_attached_masked_l2_against_torch_and_misuse():
+    """The attached loss value against the reference's formula in plain torch on the stored outputs; a mask that is not the model's
+    pred_mask falls back to the plain path; another mask at the loss call raises."""
+    from poweflownet_amd.synth import make_batch
+    from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss
+    m = _models(p=0.0).eval()
+    d = make_batch("118v2", 8, seed=7).to(DEV)
+    loss_fn = Masked_L2_loss(regularize=True, regcoeff=0.25)
+    r = _run_masked(m, d, loss_fn, attach=True)
+    mk = d.pred_mask.bool()
+    want = torch.nn.functional.mse_loss(r["out"][mk], d.y[mk]) + 0.25 * torch.nn.functional.mse_loss(r["out"][~mk], d.y[~mk])
+    assert abs(r["loss"].item() - want.item()) <= 5e-6 * abs(want.item())
+    # an all-zero mask: the first mean is over nothing -> NaN, as torch's
+    d0 = make_batch("118v2", 8, seed=7).to(DEV)
+    d0.pred_mask = torch.zeros_like(d0.pred_mask)
+    r0 = _run_masked(m, d0, Masked_L2_loss(), attach=True)
+    assert torch.isnan(r0["loss"])
+    other = d.pred_mask.clone()
+    loss_fn.attach(m, d.y, other)                  # not the tensor the model reads: consumed, plain path
+    out = m(d)
+    assert getattr(out, "_pfn_mse_tail", None) is None
+    loss_fn.attach(m, d.y, d.pred_mask)
+    out = m(d)
+    with pytest.raises(RuntimeError, match="another target"):
+        loss_fn(out, d.y, other)
+
+
+def test_graphed_train_step_with_masked_l2_matches_the_eager_loop():
+    from poweflownet_amd.optim import FlatAdamW
+    from poweflownet_amd.synth import make_batch
+    from poweflownet_amd.utils.custom_loss_functions import Masked_L2_loss
+    from poweflownet_amd.utils.training import GraphedTrainStep
+    d = make_batch("118v2", 32, seed=4).to(DEV)
+    finals = []
+    for graphed in (True, False):
+        m = _models(seed=11).train()
+        m.seed_dropout(5)
+        opt = FlatAdamW(m, lr=1e-3)
+        loss_fn = Masked_L2_loss()
+        step = GraphedTrainStep(m, loss_fn, opt) if graphed else None
+        for _ in range(3):
+            if graphed:
+                step(d)
+            else:
+                opt.zero_grad()
+                loss = loss_fn(m(d), d.y, d.pred_mask)
+                loss.backward(loss_fn.unit_grad(loss))
+                opt.step()
+        finals.append(opt.flat_param.detach().clone())
+    assert torch.equal(finals[0], finals[1]), (finals[0] - finals[1]).abs().max().item()
