@@ -389,6 +389,7 @@ void front_seg_fwd_kernel(const FrontFwdArgs f, const PackArgs pa, int nseg_x, i
     // per unit; as scalar loads inside the per-row loop every unit waited ~300 cycles for its own loads: 40 us)
     float4* s_me = reinterpret_cast<float4*>(s_w + 9 * 56);      // [h][3]
     int* s_cnt = reinterpret_cast<int*>(s_me + 3 * h);           // [2]: the block's mask census (FrontFwdArgs::mask_counts)
+    float4* s_tab = s_me + 3 * h + 1;                            // [16]: the residual term of the 16 binary mask patterns
     if (tid < 2) s_cnt[tid] = 0;
     if (tid < h) {
         const float4 a4 = sg_ld4(f.wa + (size_t)tid * 4);
@@ -403,8 +404,56 @@ void front_seg_fwd_kernel(const FrontFwdArgs f, const PackArgs pa, int nseg_x, i
     // s[c] = a[c] + a[c + 32]; t = s[c] + s[c + 16]; u = t[c] + t[c + 8]; v = u[c] + u[c + 4]; w = v[c] + v[c + 2]; w[0] + w[1]), so
     // x0 carries the bits that kernel stores: thread p of a row forms v[p], two quad shuffles finish the tree.  (As a butterfly
     // per row in every one of a graph's four blocks the LDS crossbar was the whole kernel: 24 ds_bpermute per row.)
+    // ... and a TABLE for binary masks: the residual term Wb relu(Wa m + ba) depends on the row's four mask entries only, and
+    // pred_mask is 0 / 1 (datasets/PowerFlowData.py:193: one pattern per bus type), so the first wave evaluates the tree ONCE for
+    // each of the 16 patterns and every row looks its sum up -- the same operands in the same order give the same bits as the
+    // per-row evaluation, which remains the path of a row whose mask holds anything else.  (Per row the phase was 36 hidden-unit
+    // records and ~800 vector instructions per thread, in every one of a graph's four blocks: 7.6-9.8 of the launch's 25 us.)
     {
-        const int lr = tid >> 2, pq = tid & 3;
+        const int pq = tid & 3;
+        // v[pq] of one row's tree, then the two quad shuffles: call with all four lanes of a quad
+        auto x0_tree = [&](const float4& m) -> float4 {
+            auto chunk_sum = [&](int c) -> float4 {
+                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < nchunk) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int u = 4 * c + i;
+                        if (u < h) {
+                            const float4 ra = s_me[3 * u], rb = s_me[3 * u + 1], rc = s_me[3 * u + 2];
+                            float v = rb.x;
+                            v = fmaf(ra.x, m.x, v); v = fmaf(ra.y, m.y, v); v = fmaf(ra.z, m.z, v); v = fmaf(ra.w, m.w, v);
+                            v = fmaxf(v, 0.f);
+                            acc.x = fmaf(rb.y, v, acc.x); acc.y = fmaf(rb.z, v, acc.y);
+                            acc.z = fmaf(rb.w, v, acc.z); acc.w = fmaf(rc.x, v, acc.w);
+                        }
+                    }
+                }
+                return acc;
+            };
+            float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), vp = u0;
+#pragma unroll
+            for (int c2 = 0; c2 < 2; ++c2) {
+                float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), tt = t0;
+#pragma unroll
+                for (int c3 = 0; c3 < 2; ++c3) {
+                    const int c = pq + 4 * c2 + 8 * c3;
+                    const float4 sa = sg_add4(chunk_sum(c), chunk_sum(c + 32)), sb = sg_add4(chunk_sum(c + 16), chunk_sum(c + 48));
+                    const float4 t = sg_add4(sa, sb);
+                    if (c3 == 0) t0 = t; else tt = sg_add4(t0, t);
+                }
+                if (c2 == 0) u0 = tt; else vp = sg_add4(u0, tt);
+            }
+            // w[p & 1] = v[p & 1] + v[(p & 1) + 2] (partner: lane ^ 2), then w[0] + w[1] (partner: lane ^ 1): lower index first
+            float4 vo;
+            vo.x = __shfl_xor(vp.x, 2); vo.y = __shfl_xor(vp.y, 2); vo.z = __shfl_xor(vp.z, 2); vo.w = __shfl_xor(vp.w, 2);
+            const float4 wp = (pq & 2) ? sg_add4(vo, vp) : sg_add4(vp, vo);
+            float4 wo;
+            wo.x = __shfl_xor(wp.x, 1); wo.y = __shfl_xor(wp.y, 1); wo.z = __shfl_xor(wp.z, 1); wo.w = __shfl_xor(wp.w, 1);
+            return (pq & 1) ? sg_add4(wo, wp) : sg_add4(wp, wo);
+        };
+        // the row's inputs are requested before the table is built
+        const int lr = tid >> 2;
         const bool on = lr < rows;
         const int row = r0 + min(lr, rows - 1);
         float4 m;
@@ -415,45 +464,19 @@ void front_seg_fwd_kernel(const FrontFwdArgs f, const PackArgs pa, int nseg_x, i
             m = sg_ld4(static_cast<const float*>(f.mask) + (size_t)row * 4);
         }
         const float4 xi = sg_ld4(f.x + (size_t)row * 4);
-        auto chunk_sum = [&](int c) -> float4 {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < nchunk) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int u = 4 * c + i;
-                    if (u < h) {
-                        const float4 ra = s_me[3 * u], rb = s_me[3 * u + 1], rc = s_me[3 * u + 2];
-                        float v = rb.x;
-                        v = fmaf(ra.x, m.x, v); v = fmaf(ra.y, m.y, v); v = fmaf(ra.z, m.z, v); v = fmaf(ra.w, m.w, v);
-                        v = fmaxf(v, 0.f);
-                        acc.x = fmaf(rb.y, v, acc.x); acc.y = fmaf(rb.z, v, acc.y);
-                        acc.z = fmaf(rb.w, v, acc.z); acc.w = fmaf(rc.x, v, acc.w);
-                    }
-                }
-            }
-            return acc;
-        };
-        float4 u0 = make_float4(0.f, 0.f, 0.f, 0.f), vp = u0;
-#pragma unroll
-        for (int c2 = 0; c2 < 2; ++c2) {
-            float4 t0 = make_float4(0.f, 0.f, 0.f, 0.f), tt = t0;
-#pragma unroll
-            for (int c3 = 0; c3 < 2; ++c3) {
-                const int c = pq + 4 * c2 + 8 * c3;
-                const float4 sa = sg_add4(chunk_sum(c), chunk_sum(c + 32)), sb = sg_add4(chunk_sum(c + 16), chunk_sum(c + 48));
-                const float4 t = sg_add4(sa, sb);
-                if (c3 == 0) t0 = t; else tt = sg_add4(t0, t);
-            }
-            if (c2 == 0) u0 = tt; else vp = sg_add4(u0, tt);
+        if (tid < 64) {   // pattern k = tid >> 2: bit j set = mask entry j is 1
+            const int k = tid >> 2;
+            const float4 mk = make_float4((k & 1) ? 1.f : 0.f, (k & 2) ? 1.f : 0.f, (k & 4) ? 1.f : 0.f, (k & 8) ? 1.f : 0.f);
+            const float4 sk = x0_tree(mk);
+            if (pq == 0) s_tab[k] = sk;
         }
-        // w[p & 1] = v[p & 1] + v[(p & 1) + 2] (partner: lane ^ 2), then w[0] + w[1] (partner: lane ^ 1): lower index first
-        float4 vo;
-        vo.x = __shfl_xor(vp.x, 2); vo.y = __shfl_xor(vp.y, 2); vo.z = __shfl_xor(vp.z, 2); vo.w = __shfl_xor(vp.w, 2);
-        const float4 wp = (pq & 2) ? sg_add4(vo, vp) : sg_add4(vp, vo);
-        float4 wo;
-        wo.x = __shfl_xor(wp.x, 1); wo.y = __shfl_xor(wp.y, 1); wo.z = __shfl_xor(wp.z, 1); wo.w = __shfl_xor(wp.w, 1);
-        const float4 s4 = (pq & 1) ? sg_add4(wo, wp) : sg_add4(wp, wo);
+        seg_lds_barrier();
+        const bool b0 = m.x == 0.f || m.x == 1.f, b1 = m.y == 0.f || m.y == 1.f, b2 = m.z == 0.f || m.z == 1.f, b3 = m.w == 0.f || m.w == 1.f;
+        float4 s4;
+        if (b0 && b1 && b2 && b3) s4 = s_tab[(m.x != 0.f ? 1 : 0) | (m.y != 0.f ? 2 : 0) | (m.z != 0.f ? 4 : 0) | (m.w != 0.f ? 8 : 0)];
+        else s4 = x0_tree(m);      // (the four threads of a row hold the same mask: the quad takes this branch together)
         const float4 o = make_float4(xi.x + (s4.x + bb4.x), xi.y + (s4.y + bb4.y), xi.z + (s4.z + bb4.z), xi.w + (s4.w + bb4.w));
+        int c1 = 0, c0 = 0;
         if (on && pq == 0) {
             s_x0[lr] = o;
             s_m[lr] = m;
@@ -461,14 +484,11 @@ void front_seg_fwd_kernel(const FrontFwdArgs f, const PackArgs pa, int nseg_x, i
                 sg_st4_wt(f.maskf + (size_t)row * 4, m);
                 sg_st4_wt(f.x0 + (size_t)row * 4, o);
             }
+            // the block's mask census for a Masked_L2_loss riding in the backward pass (MseTail::counts): integer sums, any order
+            c1 = (m.x != 0.f) + (m.y != 0.f) + (m.z != 0.f) + (m.w != 0.f);
+            c0 = (1.f - m.x != 0.f) + (1.f - m.y != 0.f) + (1.f - m.z != 0.f) + (1.f - m.w != 0.f);
         }
-        // the block's mask census for a Masked_L2_loss riding in the backward pass (MseTail::counts): integer sums, any order
         if (f.mask_counts && by == 0) {
-            int c1 = 0, c0 = 0;
-            if (on && pq == 0) {
-                c1 = (m.x != 0.f) + (m.y != 0.f) + (m.z != 0.f) + (m.w != 0.f);
-                c0 = (1.f - m.x != 0.f) + (1.f - m.y != 0.f) + (1.f - m.z != 0.f) + (1.f - m.w != 0.f);
-            }
             for (int off = 32; off > 0; off >>= 1) {
                 c1 += __shfl_xor(c1, off);
                 c0 += __shfl_xor(c0, off);

@@ -983,10 +983,14 @@ from poweflownet_amd.synth import make_batch, make_graph, make_topology
 from poweflownet_amd.data import Batch
 from poweflownet_amd import _lib as L
 res = {{}}
-def run(tag, m, d, float_mask=False):
+def run(tag, m, d, float_mask=False, frac=False):
     d = d.to("cuda:0")
     if float_mask:
         d.pred_mask = d.pred_mask.float()
+    if frac:     # entries that are neither 0 nor 1: the per-row evaluation behind the 16-pattern table of the fused launch
+        d.pred_mask[::7] *= 0.5
+        d.pred_mask[::5, 2] = 2.0
+        d.pred_mask[3::11, 0] = -0.0
     d.x.requires_grad_(True)
     L.profile_report(reset=True); L.profile_enable(True)
     out = m(d)
@@ -1006,6 +1010,7 @@ m.train()
 run("train118", m, make_batch("118v2", 128, seed=1))
 m.eval()
 run("eval118f", m, make_batch("118v2", 16, seed=2), float_mask=True)
+run("frac118", m, make_batch("118v2", 16, seed=4), float_mask=True, frac=True)
 run("eval14", m, make_batch("14", 37, seed=3))
 topo = make_topology(16, 100, 0)
 run("dense16", m, Batch.from_data_list([make_graph(16, 100, seed=50 + b, edge_index=topo) for b in range(21)]))
@@ -1016,7 +1021,7 @@ torch.save(res, sys.argv[1])
         path = str(tmp_path / f"{tag}.pt")
         subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=600)
         res[tag] = torch.load(path)
-    for case in ("train118", "eval118f", "eval14", "dense16"):
+    for case in ("train118", "eval118f", "frac118", "eval14", "dense16"):
         lf, lt = res["fused"][case + ".launches"], res["two"][case + ".launches"]
         assert lf.get("front_seg_fwd+pack") == 1 and "front_fwd+pack" not in lf and "edge_fwd" not in lf, lf
         assert lt.get("front_fwd+pack") == 1 and lt.get("edge_fwd") == 1 and "front_seg_fwd+pack" not in lt, lt
