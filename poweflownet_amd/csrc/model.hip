@@ -1001,9 +1001,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (hp) {
         lr = hp[0]; b1 = hp[1]; b2 = hp[2]; eps = hp[3]; wd = hp[4];
     }
-    // step[0] = completed steps, step[1] = arrival counter: the last block to finish bumps the step and re-arms the
-    // counter, so the whole update is ONE launch and stays hipGraph-replayable
-    const float t = (float)(step[0] + 1);
+    // step[0] = completed steps, step[1] = arrival counter: the last block to ARRIVE bumps the step and re-arms the counter, so the
+    // whole update is ONE launch and stays hipGraph-replayable.  The ticket is taken as soon as every wave of the block has READ
+    // step[0] (the barrier below waits for that scalar load only, not for the element loads in flight) -- the bump has to come after
+    // all blocks' reads, not after their updates; taken behind the update, the launch ended with stores drained -> atomic round
+    // trip -> store, ~1 us of nothing.
+    const int64_t step_now = step[0];
+    const float t = (float)(step_now + 1);
+    asm volatile("s_barrier" ::"s"((int)step_now) : "memory");   // (the operand: this wave's read of step[0] has returned)
+    if (threadIdx.x == 0) {
+        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(step + 1), 1ull);
+        if (prev == (unsigned long long)gridDim.x - 1) {
+            step[1] = 0;
+            step[0] = step_now + 1;
+        }
+    }
     const float bc1 = 1.f - powf(b1, t), bc2 = 1.f - powf(b2, t);
     const float step_size = lr / bc1, inv_sqrt_bc2 = 1.f / sqrtf(bc2);
     auto upd = [&](float& pi, float gi, float& mi, float& vi) {
@@ -1034,14 +1046,6 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         p[i] = pi;
         m[i] = mi;
         v[i] = vi;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned long long prev = atomicAdd(reinterpret_cast<unsigned long long*>(step + 1), 1ull);
-        if (prev == (unsigned long long)gridDim.x - 1) {
-            step[1] = 0;
-            step[0] += 1;
-        }
     }
 }
 
