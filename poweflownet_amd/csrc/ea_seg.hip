@@ -214,8 +214,10 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     const int nrt = (rows + 31) >> 5;
     const bool mfma_on = wave < nrt;
     const int K8 = (a.K + 7) & ~7;
+    // (K8 == 136, every hidden layer: the fragment goes out behind the staging and is consumed while it arrives, seg_tile.hpp)
+    const bool async_a = K8 == 8 * SG_NCH;
     SegA ta;
-    if (mfma_on) seg_load_a(ta, a.x, a.ldx, K8, r0 + 32 * wave, r0 + rows - 1, lane);
+    if (mfma_on && !async_a) seg_load_a(ta, a.x, a.ldx, K8, r0 + 32 * wave, r0 + rows - 1, lane);
     seg_copy_b(l.B0, a.Bi, sc.q, K8, wave, lane);
     seg_copy_b(l.B1, a.Bj, sc.q, K8, wave, lane);
     SegCsr cin = l.in;
@@ -231,13 +233,25 @@ void ea_seg_fwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         seg_rem_dots<true, 2, 3>(threadIdx.x, a.x, a.ldx, a.K, r0, rows, a.Bi, a.Bj, sc.nq, nreal, v1, v2);
         seg_rem_store<true, 2>(threadIdx.x, rows, sc.nq, nreal, a.b1, v1, v2, l.P, l.Q);
     }
-    seg_dma_wait();
-    __syncthreads();
-    if (mfma_on) {
-        const f32x16 accp = seg_mma(ta, l.B0, K8, lane);
-        seg_store_tile(accp, sc.q, a.b1, a.h, l.P, 32 * wave, lane);
-        const f32x16 accq = seg_mma(ta, l.B1, K8, lane);
-        seg_store_tile(accq, sc.q, nullptr, a.h, l.Q, 32 * wave, lane);
+    if (async_a) {
+        seg_drain_visible();
+        if (mfma_on) seg_load_a_async(ta, a.x, a.ldx, r0 + 32 * wave, r0 + rows - 1, lane);
+        seg_lds_barrier();
+        if (mfma_on) {
+            const f32x16 accp = seg_mma_async(ta, l.B0, lane);
+            seg_store_tile(accp, sc.q, a.b1, a.h, l.P, 32 * wave, lane);
+            const f32x16 accq = seg_mma_t<true>(ta, l.B1, K8, lane);
+            seg_store_tile(accq, sc.q, nullptr, a.h, l.Q, 32 * wave, lane);
+        }
+    } else {
+        seg_dma_wait();
+        __syncthreads();
+        if (mfma_on) {
+            const f32x16 accp = seg_mma(ta, l.B0, K8, lane);
+            seg_store_tile(accp, sc.q, a.b1, a.h, l.P, 32 * wave, lane);
+            const f32x16 accq = seg_mma(ta, l.B1, K8, lane);
+            seg_store_tile(accq, sc.q, nullptr, a.h, l.Q, 32 * wave, lane);
+        }
     }
     __syncthreads();
     // ---- P, Q out (the backward pass recomputes the pre-activation from them), and the walk
@@ -765,8 +779,9 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     const int nrt = (rows + 31) >> 5;
     const bool mfma_on = !DSG && wave < nrt;
     const int K8 = (a.fo + 7) & ~7;
+    const bool async_a = !DSG && K8 == 8 * SG_NCH;   // (the fragment behind the staging, consumed while it arrives: seg_tile.hpp)
     SegA ta;
-    if (mfma_on) seg_load_a(ta, a.gout, a.ldgo, K8, r0 + 32 * wave, r0 + rows - 1, lane);
+    if (mfma_on && !async_a) seg_load_a(ta, a.gout, a.ldgo, K8, r0 + 32 * wave, r0 + rows - 1, lane);
     if (!DSG) seg_copy_b(l.B0, a.Bd, sc.q, K8, wave, lane);
     SegCsr cin = l.in, cout = l.out;
     CsrRegs cri, cro;
@@ -986,10 +1001,17 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
         }
     } else {
         // (the W2 quarter sits where the dS tile goes: every wave is done reading it before the first one writes)
-        seg_dma_wait();
-        __syncthreads();
         f32x16 acc;
-        if (mfma_on) acc = seg_mma(ta, l.B0, K8, lane);
+        if (async_a) {
+            seg_drain_visible();
+            if (mfma_on) seg_load_a_async(ta, a.gout, a.ldgo, r0 + 32 * wave, r0 + rows - 1, lane);
+            seg_lds_barrier();
+            if (mfma_on) acc = seg_mma_async(ta, l.B0, lane);
+        } else {
+            seg_dma_wait();
+            __syncthreads();
+            if (mfma_on) acc = seg_mma(ta, l.B0, K8, lane);
+        }
         __syncthreads();
         if (mfma_on) seg_store_tile(acc, sc.q, nullptr, a.h, l.D, 32 * wave, lane);
         else if (rem_helper) seg_rem_store<false, 1>(threadIdx.x - 256, rows, sc.nq, nreal, nullptr, v1, v2, l.D, nullptr);

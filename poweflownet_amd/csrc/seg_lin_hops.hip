@@ -71,7 +71,14 @@ static size_t slh_lds_bytes(int trows, int rows_pb, int cap, int nterm) {
 // One term's 32 x 32 tile on top of `acc` (gemm_nt's chunk / step order: chunk m, step i, lane half kh supplies k = 8m + 4kh + i;
 // the last chunk of K = 129 carries ONE real step, LS = 1, like gemm_nt's variant 0), plus -- REM -- the trailing column's
 // chain off the same fragment (racc: this lane half's k's; the halves are added after the last term, as gemm_nt's flush does).
-template <int LS, bool REM>
+template <int M>
+__device__ __forceinline__ void slh_wait(const SegA& t, int m) {   // seg_wait_chunk<m> for the unrolled loop's constant m
+    if constexpr (M < SG_NCH) {
+        if (m == M) seg_wait_chunk<M>(t);
+        else slh_wait<M + 1>(t, m);
+    }
+}
+template <int LS, bool REM, bool ASYNC>   // ASYNC: the fragment was requested with seg_load_a_async (seg_tile.hpp): waited for chunk by chunk
 __device__ __forceinline__ void slh_mma(f32x16& acc, float& racc, const SegA& t, const float* bl, const float* rl, int lane) {
     const int r32 = lane & 31, kh = lane >> 5;
     const float* bp = bl + kh * 128 + r32 * 4;
@@ -86,6 +93,7 @@ __device__ __forceinline__ void slh_mma(f32x16& acc, float& racc, const SegA& t,
             bn = *reinterpret_cast<const f32x4*>(bp + (m + 1) * 256);
             if (REM) rn = *reinterpret_cast<const f32x4*>(rp + (m + 1) * 32);
         }
+        if (ASYNC) slh_wait<0>(t, m);
 #pragma unroll
         for (int i = 0; i < (m == SG_NCH - 1 ? LS : 4); ++i) {
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.av[m][i], b[i], acc, 0, 0, 0);
@@ -121,7 +129,7 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
     const int K8 = 8 * SG_NCH;                       // (the launcher admits K8 == 136 only: straight-line multiply)
     // ---- prologue: EVERY global load is requested before the first LDS store (cf. ea_seg.hip)
     SegA ta;
-    if (mfma_on) seg_load_a(ta, (NTERM > 1 && mterm) ? a.A1 : a.A0, a.lda, K8, r0 + 32 * mtile, r0 + rows - 1, lane);
+    // (the fragment: behind the staging, consumed while it arrives -- below)
     seg_copy_b(l.B[0], a.B0, sc.q, K8, wave, lane);
     if (NTERM > 1) seg_copy_b(l.B[1], a.B1, sc.q, K8, wave, lane);
     const int e0 = rowptr[r0], ne = rowptr[r0 + rows] - e0;
@@ -168,8 +176,11 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
 #pragma unroll
     for (int j = 0; j < 3; ++j)
         gbits |= ((gv[j].x > 0.f ? 1u : 0u) | (gv[j].y > 0.f ? 2u : 0u) | (gv[j].z > 0.f ? 4u : 0u) | (gv[j].w > 0.f ? 8u : 0u)) << (4 * j);
-    seg_dma_wait();
-    __syncthreads();
+    // the operand fragment goes out NOW -- staging consumed, weight DMAs landed -- and stays in flight across the barrier: the
+    // multiply runs while it arrives (protocol: seg_tile.hpp seg_load_a_async)
+    seg_drain_visible();
+    if (mfma_on) seg_load_a_async(ta, (NTERM > 1 && mterm) ? a.A1 : a.A0, a.lda, r0 + 32 * mtile, r0 + rows - 1, lane);
+    seg_lds_barrier();
     // ---- the Linear's tiles.  The terms of a tile go into ONE accumulator chain in term order (gemm_nt's order: bit-identical
     // sums): the wave that owns (tile, term 1) takes over the accumulators -- and the trailing column's two half-chains -- that
     // the wave of (tile, term 0) leaves in LDS.  (One wave running both terms needs the second fragment refilled in place under
@@ -185,8 +196,8 @@ void seg_lin_hops_kernel(int n, int rows_pb, int trows, int cap, const int* __re
                 slh_load_tile(acc, l.t0, 32 * mtile, lane);
                 if (sc.rem) racc = l.rq[mtile * 64 + lane];
             }
-            if (sc.rem) slh_mma<1, true>(acc, racc, ta, l.B[term], l.R[term], lane);
-            else slh_mma<1, false>(acc, racc, ta, l.B[term], l.R[term], lane);
+            if (sc.rem) slh_mma<1, true, true>(acc, racc, ta, l.B[term], l.R[term], lane);
+            else slh_mma<1, false, true>(acc, racc, ta, l.B[term], l.R[term], lane);
             seg_store_tile(acc, sc.q, nullptr, a.ncols, l.t0, 32 * mtile, lane);
             if (sc.rem) {
                 if (term + 1 < NTERM) {

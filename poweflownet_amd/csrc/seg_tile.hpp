@@ -29,6 +29,42 @@ __device__ __forceinline__ void seg_load_a(SegA& t, const float* __restrict__ A,
         t.av[m] = *reinterpret_cast<const f32x4*>(arow + min(8 * mc + 4 * kh, kmax));
     }
 }
+// The same fragment (K8 == 8 * SG_NCH) requested with loads HIDDEN from hipcc and consumed WHILE IT ARRIVES: chunk m is waited
+// for by hand right before its MFMAs (seg_wait_chunk<m>: vector-memory reads return in order, so "at most SG_NCH - 1 - m younger
+// operations outstanding" means chunk m has landed; any other younger operation only makes the wait stricter).  Protocol of the
+// calling kernel -- each step checked in the ISA of every kernel that uses it:
+//   1. every OTHER load of the prologue is consumed and a compiler-VISIBLE `s_waitcnt vmcnt(0)` (seg_drain_visible) has run before
+//      these loads go out: hipcc then knows of nothing pending and places no wait of its own behind them (with visible loads it
+//      cannot prove finished across the kernels' branches it puts a vmcnt(0) -- a full drain -- in front of the first MFMA);
+//   2. the barrier that follows waits for LDS only (seg_lds_barrier);
+//   3. nothing reads, copies or spills t.av[] before its chunk's wait (no "+v" ties: those made hipcc copy a fragment register
+//      BEFORE the wait); the waits are pinned between sched_barriers so no MFMA moves above its wait.
+// Why: the fragment -- 16 bytes per lane out of 32 different rows per instruction -- is the slowest thing a graph-resident
+// prologue asks for, and requested up front it held the barrier back until its LAST chunk was in; the multiply began only then.
+__device__ __forceinline__ void seg_drain_visible() { __builtin_amdgcn_s_waitcnt(0x0F70); }   // vmcnt(0), expcnt / lgkmcnt untouched
+__device__ __forceinline__ void seg_load_a_async(SegA& t, const float* __restrict__ A, int lda, int r_first, int r_last, int lane) {
+    const int r32 = lane & 31, kh = lane >> 5;
+    const float* arow = A + (size_t)min(r_first + r32, r_last) * lda;
+    const float* p0 = arow + 4 * kh;
+    const float* plast = arow + min(8 * (SG_NCH - 1) + 4 * kh, lda - 4);   // (the last chunk's upper half is clamped into the row)
+#define PFN_SEG_LD(m) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(t.av[m]) : "v"(p0), "n"(32 * (m)) : "memory")
+    PFN_SEG_LD(0); PFN_SEG_LD(1); PFN_SEG_LD(2); PFN_SEG_LD(3); PFN_SEG_LD(4); PFN_SEG_LD(5); PFN_SEG_LD(6); PFN_SEG_LD(7);
+    PFN_SEG_LD(8); PFN_SEG_LD(9); PFN_SEG_LD(10); PFN_SEG_LD(11); PFN_SEG_LD(12); PFN_SEG_LD(13); PFN_SEG_LD(14); PFN_SEG_LD(15);
+#undef PFN_SEG_LD
+    static_assert(SG_NCH == 17, "seg_load_a_async spells out SG_NCH loads");
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(t.av[SG_NCH - 1]) : "v"(plast) : "memory");
+}
+//   4. ALL FOUR registers of a chunk stay reserved until its wait, also where the multiply reads one of them (the last chunk of
+//      K = 129): hipcc had handed the three "dead" registers of that tuple to an LDS address and a loop counter while the load
+//      that overwrites them was in flight -- the empty asm behind the wait names the whole tuple.
+template <int M>
+__device__ __forceinline__ void seg_wait_chunk(const SegA& t) {
+    static_assert(M >= 0 && M < SG_NCH, "chunk index");
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SG_NCH - 1 - M) : "memory");
+    asm volatile("" ::"v"(t.av[M]));
+    __builtin_amdgcn_sched_barrier(0);
+}
 // One 1 KiB LDS-DMA (64 lanes x 16 bytes; LDS destination = wave-uniform base + lane * 16); inline asm as in gemm_nt.hip: hidden
 // from the compiler, waited for by hand (seg_dma_wait) before the barrier that publishes the copy
 __device__ __forceinline__ void seg_dma_1k(const char* g, float* lds_dst) {
@@ -81,6 +117,29 @@ __device__ __forceinline__ f32x16 seg_mma_t(const SegA& t, const float* bl, int 
 }
 __device__ __forceinline__ f32x16 seg_mma(const SegA& t, const float* bl, int K8, int lane) {
     return K8 == 8 * SG_NCH ? seg_mma_t<true>(t, bl, K8, lane) : seg_mma_t<false>(t, bl, K8, lane);
+}
+// the FULL multiply over a fragment requested with seg_load_a_async: every chunk is waited for right before its MFMAs
+template <int M>
+__device__ __forceinline__ void seg_mma_async_from(f32x16& acc, f32x4& b, const SegA& t, const float* bp) {
+    if constexpr (M < SG_NCH) {
+        f32x4 bn = b;
+        if (M + 1 < SG_NCH) bn = *reinterpret_cast<const f32x4*>(bp + (M + 1) * 256);
+        seg_wait_chunk<M>(t);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t.av[M][i], b[i], acc, 0, 0, 0);
+        b = bn;
+        seg_mma_async_from<M + 1>(acc, b, t, bp);
+    }
+}
+__device__ __forceinline__ f32x16 seg_mma_async(const SegA& t, const float* bl, int lane) {
+    const int r32 = lane & 31, kh = lane >> 5;
+    const float* bp = bl + kh * 128 + r32 * 4;
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    f32x4 b = *reinterpret_cast<const f32x4*>(bp);
+    seg_mma_async_from<0>(acc, b, t, bp);
+    return acc;
 }
 
 

@@ -128,3 +128,16 @@ def test_every_environment_switch_of_the_library_is_documented():
     header = open(os.path.join(ROOT, "include", "pfn_hip.h")).read()
     documented = set(re.findall(r"^ \*   (PFN_[A-Z0-9_]+)", header, flags=re.M))
     assert used == documented, (sorted(used - documented), sorted(documented - used))
+
+
+def test_isa_of_the_async_operand_fragments_is_hazard_free():
+    """seg_tile.hpp seg_load_a_async: 17 inline-asm loads whose registers hold garbage until a hand-placed wait.  The compiler does
+    not know; tools/check_async_fragments.py compiles the two sources (hipcc -S, no GPU needed) and reads the ISA: every fragment
+    has its wait sequence, and nothing names a fragment register between its load and its wait."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_fragments.py")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("2 async fragment(s) checked, 0 problem(s)") == 2, r.stdout     # ea_seg.hip: fwd + bwd; seg_lin_hops.hip: <1> + <2>
