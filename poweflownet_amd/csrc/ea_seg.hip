@@ -803,6 +803,21 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     }
     csr_issue2(cin, cri, cap, in_src, a.ea_in);
     csr_issue2(cout, cro, cap, out_dst, a.ea_out);
+    // MSELoss tail: thread (row lr = t >> 2, part pq = t & 3) requests the S chunks c = pq + 4 k of its row (nine at most)
+    const int nch = a.ld >> 2;
+    const int mlr = threadIdx.x >> 2, mpq = threadIdx.x & 3;
+    const int mrow = r0 + min(mlr, rows - 1);
+    float4 sv[9], yv = make_float4(0.f, 0.f, 0.f, 0.f), mkv = yv;
+    float dgv = 0.f;
+    if (LOSS) {   // (requested with the rest of the prologue: behind its commits they were one more exposed round trip)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) sv[k] = sg_ld4(a.mse.S + (size_t)mrow * a.ld + 4 * min(mpq + 4 * k, nch - 1));
+        if (mpq == 0) {
+            yv = sg_ld4(a.mse.y + (size_t)mrow * 4);
+            dgv = a.mse.deg[mrow];
+            if (a.mse.maskf) mkv = sg_ld4(a.mse.maskf + (size_t)mrow * 4);
+        }
+    }
     csr_commit(cin, cri, r0, rows);
     csr_commit(cout, cro, r0, rows);
     we_commit(l.we, wev);
@@ -825,20 +840,7 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     if (DSG) {   // last layer: dS[row][u] = sum_o gout[row][o] W2[o][u] from the 16-byte gout rows (edge.hip ds_row)
         // (the gout rows are requested BEFORE the barrier that publishes the W2 slice: behind it they were one more exposed round trip)
         float4 gv[3];
-        // MSELoss tail: thread (row lr = t >> 2, part pq = t & 3) requests the S chunks c = pq + 4 k of its row (nine at most)
-        const int nch = a.ld >> 2;
-        const int mlr = threadIdx.x >> 2, mpq = threadIdx.x & 3;
-        const int mrow = r0 + min(mlr, rows - 1);
-        float4 sv[9], yv = make_float4(0.f, 0.f, 0.f, 0.f), mkv = yv;
-        float dgv = 0.f;
         if (LOSS) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) sv[k] = sg_ld4(a.mse.S + (size_t)mrow * a.ld + 4 * min(mpq + 4 * k, nch - 1));
-            if (mpq == 0) {
-                yv = sg_ld4(a.mse.y + (size_t)mrow * 4);
-                dgv = a.mse.deg[mrow];
-                if (a.mse.maskf) mkv = sg_ld4(a.mse.maskf + (size_t)mrow * 4);
-            }
             if (a.mse.maskf) {   // Masked_L2_loss: the batch's mask census = the sum of the row blocks' (integers: any order)
                 int c1 = 0, c0 = 0;
                 for (int i = threadIdx.x; i < a.mse.count_blocks; i += SG_THREADS) {
