@@ -141,3 +141,17 @@ def test_isa_of_the_async_operand_fragments_is_hazard_free():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_async_fragments.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.count("2 async fragment(s) checked, 0 problem(s)") == 2, r.stdout     # ea_seg.hip: fwd + bwd; seg_lin_hops.hip: <1> + <2>
+
+
+def test_experiment_patches_still_apply_to_the_product_sources(tmp_path):
+    """tools/ubench/*.patch.txt hold the timestamp / ablation instrumentation that was taken out of the product kernels (the product
+    sources carry no experiment switches); every run_*_ts.sh / run_*_exp.sh applies them to a copy of csrc/ first.  A kernel change
+    that moves their context breaks those tools silently -- so: they must apply cleanly to a copy of the current sources."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dst = tmp_path / "csrc"
+    shutil.copytree(os.path.join(root, "poweflownet_amd", "csrc"), dst, ignore=shutil.ignore_patterns("*.o", "*.so"))
+    r = subprocess.run(["bash", os.path.join(root, "tools", "ubench", "apply_experiments.sh"), str(dst)], capture_output=True, text=True)
+    assert r.returncode == 0 and not list(dst.glob("*.rej")), r.stdout + r.stderr
