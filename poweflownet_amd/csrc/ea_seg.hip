@@ -836,7 +836,9 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
     float v1[4], v2[4];
     const int nreal = min(sc.remv, a.h - 32 * sc.nq);
     const bool rem_helper = !DSG && sc.rem && wave >= 4;
-    if (rem_helper) seg_rem_dots<false, 1, 5>(threadIdx.x - 256, a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, nreal, v1, v2);
+    // (where the multiply runs while its fragment arrives, these dot products run UNDER it, behind the publishing barrier: in the
+    //  prologue they held that barrier -- of the block that is the launch's critical path -- back by their ~4 us)
+    if (rem_helper && !async_a) seg_rem_dots<false, 1, 5>(threadIdx.x - 256, a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, nreal, v1, v2);
     if (DSG) {   // last layer: dS[row][u] = sum_o gout[row][o] W2[o][u] from the 16-byte gout rows (edge.hip ds_row)
         // (the gout rows are requested BEFORE the barrier that publishes the W2 slice: behind it they were one more exposed round trip)
         float4 gv[3];
@@ -1009,6 +1011,7 @@ void ea_seg_bwd_kernel(int n, int rows_pb, int trows, int cap, const int* __rest
             if (mfma_on) seg_load_a_async(ta, a.gout, a.ldgo, r0 + 32 * wave, r0 + rows - 1, lane);
             seg_lds_barrier();
             if (mfma_on) acc = seg_mma_async(ta, l.B0, lane);
+            else if (rem_helper) seg_rem_dots<false, 1, 5>(threadIdx.x - 256, a.gout, a.ldgo, a.fo, r0, rows, a.Bd, nullptr, sc.nq, nreal, v1, v2);
         } else {
             seg_dma_wait();
             __syncthreads();
