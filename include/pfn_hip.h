@@ -268,8 +268,6 @@ int pfn_adamw_step_guarded(float* param, const float* grad, float* exp_avg, floa
  *   PFN_NO_SEG_LIN_HOPS=1   small-graph batches: the Linear in front of a TAGConv's hops and the hops as two launches (gemm_nt + fused hops)
  *                           instead of one graph-resident launch (seg_lin_hops.hip; bit-identical results)
  *   PFN_NO_FUSED_FRONT=1    mask_embd + first P|Q as generic GEMMs instead of front.hip's one launch
- *   PFN_SEG_CHAIN=1         small-graph batches: the persistent chain launch with per-graph barriers (seg_chain.hip) instead of one launch
- *                           per phase (seg_lin_hops / gemm_nt / ea_seg); bit-identical results, measured slower: opt-in
  *   PFN_NO_SEG_FRONT=1      small-graph batches: front.hip's launch + the generic first edge walk instead of the one graph-resident
  *                           launch that does both (ea_seg.hip front_seg_fwd_kernel; bit-identical results)
  *   PFN_NO_FUSED_BACK=1     the last layer's Linear / dS outside the edge walks (generic GEMMs)

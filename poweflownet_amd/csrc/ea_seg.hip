@@ -340,11 +340,6 @@ void front_seg_fwd_kernel(const FrontFwdArgs f, const PackArgs pa, int nseg_x, i
     // riders of the forward pass's first launch (front.hip front_pack_kernel): dropout stream, workspace stamp, slot-ordered attributes
     if (pa.rng_advance && blockIdx.x == 0 && tid == 0) pa.rng_advance[1] += 1;
     if (pa.stamp && blockIdx.x == 0 && tid == 0) *pa.stamp = pa.stamp_value;
-    if (pa.zero_words) {   // the counters (and the status word) of the chain launch that follows this one (seg_chain.hip)
-        const int64_t gt = (int64_t)blockIdx.x * blockDim.x + tid;
-        if (gt < CHAIN_SYNC_CLEAR) pa.zero_words[gt] = 0;
-        else if (gt == CHAIN_SYNC_CLEAR) pa.zero_words[CHAIN_SYNC_STATUS] = 0;
-    }
     slot_ea_body(pa.slot_ea, (int64_t)blockIdx.x * blockDim.x + tid, (int64_t)gridDim.x * blockDim.x);
     // the weight re-layout jobs: ONE workgroup per job, FIRST in the grid (every workgroup of this launch holds half a CU's LDS:
     // behind the graph blocks the jobs would start when those retire; dealt to the graph blocks they cost every block a loop
@@ -1166,8 +1161,7 @@ bool front_seg_fit(int seg, int n, int h, int fe) {
     return !off && ld / 4 <= 64 && front_latency_regime(h, n) && ea_seg_fit(seg, n, fe, ld, false);
 }
 int launch_front_seg_fwd(const GraphView& g, const FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance,
-                         const SlotEa* slot_ea, int* stamp, int stamp_value, const float* ea, float* S, int seg, hipStream_t s,
-                         int* zero_words) {
+                         const SlotEa* slot_ea, int* stamp, int stamp_value, const float* ea, float* S, int seg, hipStream_t s) {
     const int ld = ld_of(f.h);
     SegPlan p;
     if (!seg_plan(seg, g.n, ld, p, false)) {
@@ -1184,7 +1178,6 @@ int launch_front_seg_fwd(const GraphView& g, const FrontFwdArgs& f, const PackJo
     pa.rng_advance = rng_advance;
     pa.stamp = stamp;
     pa.stamp_value = stamp_value;
-    pa.zero_words = zero_words;
     pa.mask = nullptr;
     pa.maskf = nullptr;
     pa.mask_count = 0;

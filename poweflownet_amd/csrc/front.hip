@@ -570,7 +570,6 @@ int launch_front_fwd_pack(const FrontFwdArgs& f, const PackJob* jobs, int njobs,
     pa.rng_advance = rng_advance;
     pa.stamp = stamp;
     pa.stamp_value = stamp_value;
-    pa.zero_words = nullptr;
     pa.mask = nullptr;
     pa.maskf = nullptr;
     pa.mask_count = 0;

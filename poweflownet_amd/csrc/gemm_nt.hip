@@ -77,7 +77,6 @@ int launch_pack(const PackJob* jobs, int njobs, uint64_t* rng_advance, hipStream
         a.rng_advance = j0 == 0 ? rng_advance : nullptr;
         a.stamp = j0 == 0 ? stamp : nullptr;
         a.stamp_value = stamp_value;
-        a.zero_words = nullptr;
         const bool rider = j0 == 0 && mask != nullptr && mask_count > 0;
         a.mask = rider ? mask : nullptr;
         a.maskf = maskf;

@@ -426,7 +426,6 @@ struct Layout {
     // dims
     int n, e, f0, fe, fo, h, L, K, ld, ld0, ldo, nlayers;
     int* stamp;                  // guard word: WS_STAMP_TRAIN after a forward that saved what the backward pass reads
-    int* sync;                   // CHAIN_SYNC_WORDS words of the chain launches (seg_chain.hip): per-graph arrival counters, status
     int* mask_counts;            // [1024 row blocks][2]: front_seg_fwd_kernel's mask census (FrontFwdArgs::mask_counts; training only)
     // forward-saved
     float *maskf, *me_h, *x0, *packed;
@@ -502,7 +501,6 @@ static int make_layout(const pfn_mpn_config& c, int64_t n, int64_t e, void* ws, 
         lo.packed_floats = measure.off;
     }
     lo.stamp = cv.take<int>(4);
-    lo.sync = cv.take<int>(CHAIN_SYNC_WORDS);
     lo.mask_counts = cv.take<int>(2048);
     lo.packed = cv.take<float>(lo.packed_floats);
     lo.maskf = cv.take<float>((size_t)n * lo.ld0);
@@ -588,13 +586,6 @@ static bool front_recomputes_meh(const pfn_mpn_config& c, const Layout& lo, int 
            front_bwd_wg_scratch_floats(lo.n, lo.h) <= (size_t)lo.n * lo.ld;   // (the partial sums live in the unused me_h buffer)
 }
 
-// The chain launch's precondition beyond seg_chain_fit: the standard E T E T .. E stack with at least one (E, T) pair, no
-// chunk-major tensors (those belong to the big-graph hop kernel), few enough stages for one argument block
-static bool forward_chain_ok(const Layout& lo, const GraphView& g, int seg) {
-    return lo.L >= 2 && lo.L - 1 <= 6 && lo.K == 3 && !tag_input_cm(seg, lo.ld, lo.n, g.e_stored, lo.K) &&
-           seg_chain_fit(seg, lo.n, lo.fe, lo.h, lo.K);
-}
-
 // batches of small graphs: the front AND layer 0's edge stage in one graph-resident launch (ea_seg.hip front_seg_fwd_kernel)
 // (front_seg_fwd_kernel writes no ReLU masks: never where the backward pass of layer 0 would read them -- today the two fit
 //  predicates exclude that by a grid bound only)
@@ -627,8 +618,6 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     const bool l0_fly = first_layer_fly(c, lo, seg, fused_front);
     const int ws_stamp = c.need_backward ? WS_STAMP_TRAIN : WS_STAMP_INFER;
     const bool seg_front = uses_seg_front(c, lo, seg);
-    // ... and every layer between that launch and the last layer's 129 -> 4 Linear in ONE persistent launch (seg_chain.hip)
-    const bool chain = seg_front && forward_chain_ok(lo, g, seg);
     if (fused_front) {
         // ONE launch: the weight re-layout (which also advances the dropout stream for this forward) next to the front --
         // pred_mask.float(), mask_embd, the residual add and the first EdgeAggregation's P | Q (front.hip)
@@ -642,7 +631,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
         f.mask_counts = (seg_front && c.need_backward) ? lo.mask_counts : nullptr;   // (read by pfn_mpn_backward_masked_l2)
         if (seg_front)
             PFN_TRY(launch_front_seg_fwd(g, f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, &se, lo.stamp, ws_stamp, edge_attr,
-                                         lo.ea[0].S, seg, s, chain ? lo.sync : nullptr));
+                                         lo.ea[0].S, seg, s));
         else
             PFN_TRY(launch_front_fwd_pack(f, pk.jobs.data(), (int)pk.jobs.size(), drop ? rng : nullptr, s, seg_ea ? &se : nullptr, lo.stamp,
                                           ws_stamp));
@@ -673,35 +662,7 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
     const float* cur = lo.x0;
     int ldc = lo.ld0, fcur = lo.f0, pi = 0;
     bool hops_fused = false;
-    int i0 = 0;
-    if (chain) {   // layers 0 (second Linear) .. nlayers - 1 (edge stage): stage s = (E_2s second half, T_2s+1, E_2s+2 first half)
-        SegChainFwd ch;
-        memset(&ch, 0, sizeof(ch));
-        ch.ld = lo.ld; ch.h = lo.h; ch.nhops = lo.K; ch.nstage = lo.L - 1;
-        ch.act = drop ? ACT_DROPOUT_RELU : ACT_RELU; ch.store_pq = c.need_backward ? 1 : 0; ch.p_drop = c.dropout_rate; ch.rng = rng;
-        ch.ea_in = lo.ea_in; ch.cnt = lo.sync; ch.zero_words = c.need_backward ? lo.sync + CHAIN_SYNC_BWD : nullptr;
-        ch.status = lo.sync + CHAIN_SYNC_STATUS;
-        int pj = 0;
-        for (int st = 0; st < ch.nstage; ++st) {
-            const int ie = 2 * st, it = ie + 1, in = ie + 2;
-            const int pe = pj, pt = pj + 4, pn = pt + lo.K + 2;
-            SegChainFwdStage& d = ch.st[st];
-            d.S_in = lo.ea[ie].S; d.w2_img = mp.ea[ie].w2_t; d.b2 = params[pe + 3]; d.y = lo.y[ie]; d.xk = lo.xk[it];
-            for (int k = 0; k <= lo.K; ++k) d.tag_img[k] = mp.tag[it].wt[k];
-            d.tag_bias = params[pt + lo.K + 1]; d.h = lo.y[it];
-            d.w1i_img = mp.ea[in].w1i_t; d.w1j_img = mp.ea[in].w1j_t; d.b1 = params[pn + 1]; d.w1 = params[pn];
-            d.P = lo.ea[in].P; d.Q = lo.ea[in].Q; d.S_out = lo.ea[in].S;
-            d.stream_y = (uint32_t)ie; d.stream_h = (uint32_t)it;
-            pj = pn;
-        }
-        PFN_TRY(launch_seg_chain_fwd(g, ch, seg, s));
-        i0 = lo.nlayers - 1;
-        pi = pj;
-        cur = lo.y[i0 - 1];
-        ldc = lo.ld;
-        fcur = lo.h;
-    }
-    for (int i = i0; i < lo.nlayers; ++i) {
+    for (int i = 0; i < lo.nlayers; ++i) {
         const bool last = i + 1 == lo.nlayers;
         Act act;
         if (!last) {
@@ -720,9 +681,9 @@ static int model_forward(const pfn_mpn_config& c, const GraphView& g, const Layo
             // batches of small graphs: this layer's second Linear also runs the K hops of the TAGConv behind it (seg_lin_hops.hip)
             hops_fused = !last && !big_cm && seg_lin_hops_fit(seg, lo.n, lo.ld, lo.h, lo.h, lo.K, 1);
             PFN_TRY(ea_forward(g, fcur, lo.fe, lo.h, fo, cur, ldc, edge_attr, params[pi], params[pi + 1], params[pi + 2],
-                               params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, (fused_front && i == 0) || (chain && i == i0), seg, seg_ea ? lo.ea_in : nullptr,
+                               params[pi + 3], mp.ea[i], y, ldy, act, lo.ea[i], s, fused_front && i == 0, seg, seg_ea ? lo.ea_in : nullptr,
                                ea_saves_mask(c, lo, seg, fused_front, i) ? lo.relu_mask[i] : nullptr, l0_fly && i == 0,
-                               hops_fused ? lo.xk[i + 1] : nullptr, lo.K, (seg_front && i == 0) || (chain && i == i0)));
+                               hops_fused ? lo.xk[i + 1] : nullptr, lo.K, seg_front && i == 0));
             pi += 4;
             fcur = fo;
         } else {

@@ -139,8 +139,6 @@ struct PackArgs {
     uint64_t* rng_advance;   // device {seed, offset}: offset += 1 (dropout stream), or null
     int* stamp;              // optional: *stamp = stamp_value (the forward pass marks its workspace: training / inference)
     int stamp_value;
-    int* zero_words;         // optional (front_seg_fwd_kernel only): CHAIN_SYNC_CLEAR words cleared for the chain launch behind it
-                             // (seg_chain.hip: per-graph arrival counters and the status word)
     // optional rider (one launch floor less per forward): pred_mask -> float32, spread over all blocks of the launch
     const void* mask;
     float* maskf;
@@ -423,8 +421,7 @@ bool ea_seg_fit(int seg, int n, int fe, int ld, bool bwd);
 // carrying the forward pass's weight re-layout jobs like launch_front_fwd_pack; writes maskf, me_h (when f.me_h), x0, P, Q, S
 bool front_seg_fit(int seg, int n, int h, int fe);
 int launch_front_seg_fwd(const GraphView& g, const struct FrontFwdArgs& f, const PackJob* jobs, int njobs, uint64_t* rng_advance,
-                         const SlotEa* slot_ea, int* stamp, int stamp_value, const float* ea, float* S, int seg, hipStream_t s,
-                         int* zero_words = nullptr);
+                         const SlotEa* slot_ea, int* stamp, int stamp_value, const float* ea, float* S, int seg, hipStream_t s);
 int ea_seg_blocks(int seg, int n, int ld);
 int launch_ea_seg_fwd(const GraphView& g, const EaSegFwdArgs& a, int seg, hipStream_t s);
 int launch_ea_seg_bwd(const GraphView& g, const EaSegBwdArgs& a, int seg, hipStream_t s);
@@ -452,32 +449,6 @@ struct SegLinHopsArgs {
 bool seg_lin_hops_fit(int seg, int n, int ld, int K, int ncols, int nhops, int nterm);
 int launch_seg_lin_hops(const GraphView& g, const SegLinHopsArgs& a, int seg, hipStream_t s);
 
-
-// The whole E -> act -> T -> act -> E chain of a batch of small graphs in ONE persistent launch (seg_chain.hip): per stage the
-// second Linear of an EdgeAggregation + the K hops (seg_lin_hops), the TAGConv product (gemm_nt) and the next EdgeAggregation's
-// P | Q product + edge walk (ea_seg_fwd), the launch boundaries replaced by per-graph barriers.  Bit-identical to those launches.
-struct SegChainFwdStage {
-    const float* S_in; const float* w2_img; const float* b2; float* y; float* xk;
-    const float* tag_img[4]; const float* tag_bias; float* h;
-    const float* w1i_img; const float* w1j_img; const float* b1; const float* w1;
-    float* P; float* Q; float* S_out;
-    uint32_t stream_y, stream_h;
-};
-struct SegChainFwd {
-    int ld, h, nhops, nstage, act, store_pq;
-    float p_drop;
-    const uint64_t* rng;
-    const float* ea_in;
-    int* cnt;          // [seg_chain_blocks] arrival counters, ZERO at launch (the forward pass's pack rider clears them)
-    int* zero_words;   // optional: seg_chain_blocks words this launch clears (the backward chain's counters)
-    int* status;       // [0] = 1 when a workgroup's bounded wait ran out (its output is NaN then)
-    SegChainFwdStage st[6];
-};
-// the chain launches' words in the model workspace: [0, 1024) forward counters, [1024, 2048) backward counters, [2048] status
-constexpr int CHAIN_SYNC_WORDS = 2048 + 64, CHAIN_SYNC_BWD = 1024, CHAIN_SYNC_STATUS = 2048, CHAIN_SYNC_CLEAR = 1024;
-bool seg_chain_fit(int seg, int n, int fe, int h, int K);
-int seg_chain_blocks(int seg, int n, int ld);
-int launch_seg_chain_fwd(const GraphView& g, const SegChainFwd& c, int seg, hipStream_t s);
 
 struct EdgeBwdArgs {
     const float* P;

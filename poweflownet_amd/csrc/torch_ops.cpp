@@ -46,7 +46,26 @@ void want(const Tensor& t, const char* name, at::ScalarType dt, const Tensor& li
     TORCH_CHECK(t.is_contiguous(), name, " must be contiguous");
 }
 void want_f32(const Tensor& t, const char* name, const Tensor& like) { want(t, name, at::kFloat, like); }
-void want_graph(const Tensor& g, const Tensor& like) { want(g, "graph_ws", at::kByte, like); }
+// a graph workspace is only ever what graph_build returned for THIS (num_nodes, e_stored): the kernels index it by those two
+// numbers, so a mismatch would read out of bounds on the device
+void want_graph(const Tensor& g, const Tensor& like, int64_t n, int64_t e_stored) {
+    want(g, "graph_ws", at::kByte, like);
+    TORCH_CHECK(n >= 0 && e_stored >= 0, "num_nodes and e_stored must be non-negative");
+    TORCH_CHECK((size_t)g.numel() == pfn_graph_workspace_bytes(n, e_stored), "graph_ws holds ", g.numel(), " bytes, but graph_build(edge_index [2, ",
+                e_stored, "], num_nodes = ", n, ") returns ", pfn_graph_workspace_bytes(n, e_stored), ": it was built for another batch");
+}
+// What keeps a bad graph from producing plausible numbers through torch.ops (the Python module raises, or poisons, in the same
+// cases): a caller that has NOT run graph_check / graph_segments (`validated` false) gets (i) the segment check of its
+// `seg_nodes` run on the device in front of the forward and (ii) `out` overwritten with NaN behind it when the workspace records
+// a node id outside [0, num_nodes) or an edge that crosses a segment boundary (pfn_graph_poison_if_bad).  No host sync.
+void graph_precheck(const Tensor& graph_ws, int64_t n, int64_t e_stored, int64_t seg_nodes, void* stream) {
+    if (seg_nodes <= 0) return;
+    TORCH_CHECK(n > 0 && n % seg_nodes == 0 && seg_nodes <= (1 << 20), "seg_nodes = ", seg_nodes, " must divide num_nodes = ", n);
+    pfn_ok(pfn_graph_segments_async(graph_ws.data_ptr(), n, e_stored, seg_nodes, stream), "pfn_graph_segments_async");
+}
+void graph_poison(const Tensor& graph_ws, int64_t n, int64_t e_stored, Tensor& out, void* stream) {
+    pfn_ok(pfn_graph_poison_if_bad(graph_ws.data_ptr(), n, e_stored, out.data_ptr<float>(), out.numel(), stream), "pfn_graph_poison_if_bad");
+}
 
 // rows padded to the library's ld = roundup(F, 4) with zero pad columns (pfn_padded_ld); a no-op when F % 4 == 0
 Tensor pad_rows(const Tensor& x, int64_t f) {
@@ -103,17 +122,41 @@ Tensor graph_build(const Tensor& edge_index, int64_t num_nodes, int64_t mode) {
            "pfn_graph_build");
     return ws;
 }
+// ---- validation with a read-back (once per topology): raises RuntimeError when edge_index held a node id outside
+// [0, num_nodes) (the reference's index_select raises in its forward, networks/MPN.py:53); returns (the is_directed verdict of
+// networks/MPN.py:498-504, the effective edge count after undirect_graph)
+std::tuple<bool, int64_t> graph_check(const Tensor& graph_ws, int64_t num_nodes, int64_t e_stored) {
+    want_graph(graph_ws, graph_ws, num_nodes, e_stored);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(graph_ws.device());
+    int32_t directed = 0;
+    int64_t e_eff = 0;
+    pfn_ok(pfn_graph_info(graph_ws.data_ptr(), num_nodes, e_stored, &directed, &e_eff, cur_stream(graph_ws)), "pfn_graph_info");
+    return {directed != 0, e_eff};
+}
+// ---- is the batch a disjoint union of index-contiguous graphs of seg_nodes nodes (PyG's Batch of one case)?  With a read-back;
+// a caller that got True may pass seg_nodes and validated=True to the model operators
+bool graph_segments(Tensor graph_ws, int64_t num_nodes, int64_t e_stored, int64_t seg_nodes) {
+    want_graph(graph_ws, graph_ws, num_nodes, e_stored);
+    const c10::hip::HIPGuardMasqueradingAsCUDA guard(graph_ws.device());
+    int32_t ok = 0;
+    pfn_ok(pfn_graph_segments(graph_ws.data_ptr(), num_nodes, e_stored, seg_nodes, &ok, cur_stream(graph_ws)), "pfn_graph_segments");
+    return ok != 0;
+}
 
 // ---- MaskEmbdMultiMPN.forward, networks/MPN.py:525-559.  Returns (out [N, output_dim], ws: what mpn_backward needs)
 std::tuple<Tensor, Tensor> mpn_forward(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, at::IntArrayRef dims, double dropout,
                                        bool training, bool need_backward, at::TensorList params, const Tensor& x, const Tensor& pred_mask,
-                                       const Tensor& edge_attr, const c10::optional<Tensor>& rng_state, bool defer_out = false) {
+                                       const Tensor& edge_attr, const c10::optional<Tensor>& rng_state, bool defer_out = false,
+                                       bool validated = false) {
     // defer_out: the output rows are left to mpn_backward_mse (where mpn_mse_tail_ok says so); `out` comes back unwritten
+    // validated: the caller ran graph_check (and graph_segments for its seg_nodes) on this workspace -- see graph_precheck
+    TORCH_CHECK(validated || !defer_out, "defer_out needs a validated graph (graph_check / graph_segments): the NaN poison of an unvalidated one "
+                                         "travels through `out`");
     TORCH_CHECK(x.defined() && x.dim() == 2, "x must be [N, nfeature_dim]");
     const pfn_mpn_config c = config_of(dims, dropout, training, need_backward);
     TORCH_CHECK(x.size(1) == c.nfeature_dim, "x must be [N, ", c.nfeature_dim, "], got [", x.size(0), ", ", x.size(1), "]");
     want_f32(x, "x", x);
-    want_graph(graph_ws, x);
+    want_graph(graph_ws, x, x.size(0), e_stored);
     want(pred_mask, "pred_mask", pred_mask.scalar_type(), x);
     TORCH_CHECK(pred_mask.sizes() == x.sizes(), "pred_mask must have x's shape");
     want_f32(edge_attr, "edge_attr", x);
@@ -132,10 +175,12 @@ std::tuple<Tensor, Tensor> mpn_forward(const Tensor& graph_ws, int64_t e_stored,
     Tensor out = at::empty({n, pfn_padded_ld(c.output_dim)}, x.options());
     const size_t bytes = pfn_mpn_workspace_bytes(&c, n, e_stored);
     Tensor ws = at::empty({(int64_t)bytes}, x.options().dtype(at::kByte));
+    if (!validated) graph_precheck(graph_ws, n, e_stored, seg_nodes, cur_stream(x));
     pfn_ok(pfn_mpn_forward(&c, graph_ws.data_ptr(), n, e_stored, pp.data(), x.data_ptr<float>(), pred_mask.data_ptr(), mask_dtype_of(pred_mask),
                            edge_attr.data_ptr<float>(), defer_out ? nullptr : out.data_ptr<float>(), ws.data_ptr(), bytes, rng, seg_nodes,
                            cur_stream(x)),
            "pfn_mpn_forward");
+    if (!validated) graph_poison(graph_ws, n, e_stored, out, cur_stream(x));
     return {unpad_rows(out, c.output_dim), ws};
 }
 
@@ -154,7 +199,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> mpn_backward_mse(const Tensor& graph_
                                                             Tensor loss_ws, bool need_grad_x) {
     const pfn_mpn_config c = config_of(dims, dropout, training, true);
     want_f32(x, "x", x);
-    want_graph(graph_ws, x);
+    want_graph(graph_ws, x, x.size(0), e_stored);
     want(ws, "ws", at::kByte, x);
     want_f32(edge_attr, "edge_attr", x);
     want_f32(y, "y", x);
@@ -196,7 +241,7 @@ std::tuple<Tensor, Tensor, Tensor> mpn_backward(const Tensor& graph_ws, int64_t 
                                                 bool need_grad_edge_attr) {
     const pfn_mpn_config c = config_of(dims, dropout, training, true);
     want_f32(x, "x", x);
-    want_graph(graph_ws, x);
+    want_graph(graph_ws, x, x.size(0), e_stored);
     want(ws, "ws", at::kByte, x);
     want_f32(edge_attr, "edge_attr", x);
     want_f32(grad_out, "grad_out", x);
@@ -231,7 +276,7 @@ std::tuple<Tensor, Tensor, Tensor> mpn_backward(const Tensor& graph_ws, int64_t 
 std::tuple<Tensor, Tensor> edge_aggr_forward(const Tensor& graph_ws, int64_t e_stored, const Tensor& x, const Tensor& edge_attr, const Tensor& w1,
                                              const Tensor& b1, const Tensor& w2, const Tensor& b2) {
     want_f32(x, "x", x);
-    want_graph(graph_ws, x);
+    want_graph(graph_ws, x, x.size(0), e_stored);
     want_f32(edge_attr, "edge_attr", x);
     want_f32(w1, "W1", x); want_f32(b1, "b1", x); want_f32(w2, "W2", x); want_f32(b2, "b2", x);
     TORCH_CHECK(x.dim() == 2 && edge_attr.dim() == 2 && w1.dim() == 2 && w2.dim() == 2, "x, edge_attr, W1, W2 must be matrices");
@@ -247,6 +292,7 @@ std::tuple<Tensor, Tensor> edge_aggr_forward(const Tensor& graph_ws, int64_t e_s
                                  edge_attr.data_ptr<float>(), w1.data_ptr<float>(), b1.data_ptr<float>(), w2.data_ptr<float>(), b2.data_ptr<float>(),
                                  out.data_ptr<float>(), out.size(1), ws.data_ptr(), bytes, cur_stream(x)),
            "pfn_edge_aggr_forward");
+    graph_poison(graph_ws, n, e_stored, out, cur_stream(x));
     return {unpad_rows(out, fo), ws};
 }
 // Returns (grad_x, grad_edge_attr, grad_W1, grad_b1, grad_W2, grad_b2)
@@ -255,7 +301,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> edge_aggr_backward(co
                                                                               const Tensor& w2, const Tensor& b2, const Tensor& grad_out,
                                                                               const Tensor& ws) {
     want_f32(x, "x", x);
-    want_graph(graph_ws, x);
+    want_graph(graph_ws, x, x.size(0), e_stored);
     want(ws, "ws", at::kByte, x);
     want_f32(edge_attr, "edge_attr", x); want_f32(grad_out, "grad_out", x);
     want_f32(w1, "W1", x); want_f32(b1, "b1", x); want_f32(w2, "W2", x); want_f32(b2, "b2", x);
@@ -278,7 +324,7 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> edge_aggr_backward(co
 std::tuple<Tensor, Tensor> tag_conv_forward(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, const Tensor& x, at::TensorList weights,
                                             const c10::optional<Tensor>& bias) {
     want_f32(x, "x", x);
-    want_graph(graph_ws, x);
+    want_graph(graph_ws, x, x.size(0), e_stored);
     TORCH_CHECK(x.dim() == 2 && !weights.empty(), "x must be a matrix and weights non-empty");
     const int64_t n = x.size(0), cin = x.size(1), cout = weights[0].size(0), K = (int64_t)weights.size() - 1;
     for (const Tensor& w : weights) TORCH_CHECK(w.dim() == 2 && w.size(0) == cout && w.size(1) == cin, "every TAGConv weight must be (out, in)");
@@ -294,16 +340,18 @@ std::tuple<Tensor, Tensor> tag_conv_forward(const Tensor& graph_ws, int64_t e_st
     Tensor out = at::empty({n, pfn_padded_ld(cout)}, x.options());
     const size_t bytes = pfn_tag_conv_workspace_bytes(n, e_stored, (int)cin, (int)cout, (int)K);
     Tensor ws = at::empty({(int64_t)bytes}, x.options().dtype(at::kByte));
+    graph_precheck(graph_ws, n, e_stored, seg_nodes, cur_stream(x));
     pfn_ok(pfn_tag_conv_forward(graph_ws.data_ptr(), n, e_stored, (int)cin, (int)cout, (int)K, xp.data_ptr<float>(), xp.size(1), wp.data(), bp,
                                 out.data_ptr<float>(), out.size(1), ws.data_ptr(), bytes, seg_nodes, cur_stream(x)),
            "pfn_tag_conv_forward");
+    graph_poison(graph_ws, n, e_stored, out, cur_stream(x));
     return {unpad_rows(out, cout), ws};
 }
 // Returns (grad_x, grad_bias (empty when has_bias is false), grad_weights...)
 std::tuple<Tensor, Tensor, std::vector<Tensor>> tag_conv_backward(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, const Tensor& x,
                                                                   at::TensorList weights, const Tensor& grad_out, const Tensor& ws, bool has_bias) {
     want_f32(x, "x", x);
-    want_graph(graph_ws, x);
+    want_graph(graph_ws, x, x.size(0), e_stored);
     want(ws, "ws", at::kByte, x);
     want_f32(grad_out, "grad_out", x);
     TORCH_CHECK(x.dim() == 2 && !weights.empty(), "x must be a matrix and weights non-empty");
@@ -331,13 +379,14 @@ std::tuple<Tensor, Tensor, std::vector<Tensor>> tag_conv_backward(const Tensor& 
 // ---- PyG propagate(aggr='add') alone: out[i] = sum_{e -> i} x[src(e)]
 Tensor scatter_add(const Tensor& graph_ws, int64_t e_stored, const Tensor& x) {
     want_f32(x, "x", x);
-    want_graph(graph_ws, x);
+    want_graph(graph_ws, x, x.size(0), e_stored);
     TORCH_CHECK(x.dim() == 2, "x must be [N, F]");
     const c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
     const int64_t f = x.size(1);
     Tensor xp = pad_rows(x, f);
     Tensor out = at::empty_like(xp);
     pfn_ok(pfn_scatter_add(graph_ws.data_ptr(), x.size(0), e_stored, xp.data_ptr<float>(), out.data_ptr<float>(), f, cur_stream(x)), "pfn_scatter_add");
+    graph_poison(graph_ws, x.size(0), e_stored, out, cur_stream(x));
     return unpad_rows(out, f);
 }
 
@@ -392,11 +441,11 @@ struct MpnFunction : public torch::autograd::Function<MpnFunction> {
     static Tensor forward(torch::autograd::AutogradContext* ctx, const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes,
                           std::vector<int64_t> dims, double dropout, bool training, const Tensor& flat_params, std::vector<int64_t> numels,
                           const Tensor& x, const Tensor& pred_mask, const Tensor& edge_attr, const c10::optional<Tensor>& rng_state,
-                          bool need) {
+                          bool need, bool validated) {
         // (need: decided by the caller -- inside `apply` grad mode is off and says nothing)
         at::AutoDispatchBelowADInplaceOrView guard;
         const std::vector<Tensor> params = views_of(flat_params, numels);
-        auto res = mpn_forward(graph_ws, e_stored, seg_nodes, dims, dropout, training, need, params, x, pred_mask, edge_attr, rng_state);
+        auto res = mpn_forward(graph_ws, e_stored, seg_nodes, dims, dropout, training, need, params, x, pred_mask, edge_attr, rng_state, false, validated);
         if (need) {
             ctx->save_for_backward({graph_ws, x, pred_mask, edge_attr, std::get<1>(res), flat_params});
             ctx->saved_data["e_stored"] = e_stored;
@@ -421,8 +470,8 @@ struct MpnFunction : public torch::autograd::Function<MpnFunction> {
                                 ctx->saved_data["dropout"].toDouble(), ctx->saved_data["training"].toBool(), params, x, pred_mask, edge_attr,
                                 grad_outputs[0].contiguous(), ws, need_gx, need_gea);
         // inputs in order: graph_ws, e_stored, seg_nodes, dims, dropout, training, flat_params, numels, x, pred_mask, edge_attr,
-        // rng_state, need
-        torch::autograd::variable_list grads(13, Tensor());
+        // rng_state, need, validated
+        torch::autograd::variable_list grads(14, Tensor());
         grads[6] = std::get<0>(res);            // the flat gradient of every parameter (the cat's backward hands out its slices)
         grads[8] = std::get<1>(res);            // x
         grads[10] = std::get<2>(res);           // edge_attr
@@ -431,7 +480,7 @@ struct MpnFunction : public torch::autograd::Function<MpnFunction> {
 };
 Tensor mpn_autograd(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, at::IntArrayRef dims, double dropout, bool training,
                     at::TensorList params, const Tensor& x, const Tensor& pred_mask, const Tensor& edge_attr,
-                    const c10::optional<Tensor>& rng_state) {
+                    const c10::optional<Tensor>& rng_state, bool validated) {
     bool need = x.requires_grad() || edge_attr.requires_grad();
     std::vector<Tensor> flats;
     std::vector<int64_t> numels;
@@ -442,7 +491,7 @@ Tensor mpn_autograd(const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes,
     }
     need = need && at::GradMode::is_enabled();
     return MpnFunction::apply(graph_ws, e_stored, seg_nodes, dims.vec(), dropout, training, at::cat(flats), numels, x, pred_mask, edge_attr,
-                              rng_state, need);
+                              rng_state, need, validated);
 }
 
 // ---- the two layers as differentiable operators (what the reference's other model classes compose, networks/MPN.py:143-453)
@@ -511,8 +560,10 @@ int64_t abi_version() { return pfn_abi_version(); }
 TORCH_LIBRARY(pfn, m) {
     m.def("abi_version() -> int", &abi_version);
     m.def("graph_build(Tensor edge_index, int num_nodes, int mode=-1) -> Tensor");
+    m.def("graph_check(Tensor graph_ws, int num_nodes, int e_stored) -> (bool, int)");
+    m.def("graph_segments(Tensor(a!) graph_ws, int num_nodes, int e_stored, int seg_nodes) -> bool");
     m.def("mpn_forward(Tensor graph_ws, int e_stored, int seg_nodes, int[] dims, float dropout, bool training, bool need_backward, "
-          "Tensor[] params, Tensor x, Tensor pred_mask, Tensor edge_attr, Tensor? rng_state=None, bool defer_out=False) -> (Tensor, Tensor)");
+          "Tensor[] params, Tensor x, Tensor pred_mask, Tensor edge_attr, Tensor? rng_state=None, bool defer_out=False, bool validated=False) -> (Tensor, Tensor)");
     m.def("mpn_mse_tail_ok(int num_nodes, int e_stored, int seg_nodes, int[] dims, float dropout, bool training) -> bool", &mpn_mse_tail_ok);
     m.def("mpn_backward_mse(Tensor graph_ws, int e_stored, int seg_nodes, int[] dims, float dropout, bool training, Tensor[] params, Tensor x, "
           "Tensor edge_attr, Tensor y, Tensor(a!) out, Tensor ws, Tensor(b!) loss_ws, bool need_grad_x=False) -> (Tensor, Tensor, Tensor, Tensor)");
@@ -529,7 +580,7 @@ TORCH_LIBRARY(pfn, m) {
     m.def("edge_aggr(Tensor graph_ws, int e_stored, Tensor x, Tensor edge_attr, Tensor w1, Tensor b1, Tensor w2, Tensor b2) -> Tensor");
     m.def("tag_conv(Tensor graph_ws, int e_stored, int seg_nodes, Tensor x, Tensor[] weights, Tensor? bias=None) -> Tensor");
     m.def("mpn(Tensor graph_ws, int e_stored, int seg_nodes, int[] dims, float dropout, bool training, Tensor[] params, Tensor x, "
-          "Tensor pred_mask, Tensor edge_attr, Tensor? rng_state=None) -> Tensor");
+          "Tensor pred_mask, Tensor edge_attr, Tensor? rng_state=None, bool validated=False) -> Tensor");
     m.def("mse_loss(Tensor out, Tensor y, Tensor(a!) ws) -> (Tensor, Tensor)");
     m.def("adamw_step_(Tensor(a!) param, Tensor grad, Tensor(b!) exp_avg, Tensor(c!) exp_avg_sq, float lr, float beta1, float beta2, float eps, "
           "float weight_decay, Tensor(d!) step) -> ()");
@@ -538,6 +589,8 @@ TORCH_LIBRARY(pfn, m) {
 // One backend key: these operators exist for HIP tensors only (a CPU tensor finds no kernel -> the dispatcher's own RuntimeError)
 TORCH_LIBRARY_IMPL(pfn, CUDA, m) {
     m.impl("graph_build", &graph_build);
+    m.impl("graph_check", &graph_check);
+    m.impl("graph_segments", &graph_segments);
     m.impl("mpn_forward", &mpn_forward);
     m.impl("mpn_backward", &mpn_backward);
     m.impl("mpn_backward_mse", &mpn_backward_mse);
@@ -559,8 +612,9 @@ TORCH_LIBRARY_IMPL(pfn, Autograd, m) {
 TORCH_LIBRARY_IMPL(pfn, CUDA, m) {
     m.impl("mpn", [](const Tensor& graph_ws, int64_t e_stored, int64_t seg_nodes, at::IntArrayRef dims, double dropout, bool training,
                      at::TensorList params, const Tensor& x, const Tensor& pred_mask, const Tensor& edge_attr,
-                     const c10::optional<Tensor>& rng_state) {
-        return std::get<0>(mpn_forward(graph_ws, e_stored, seg_nodes, dims, dropout, training, false, params, x, pred_mask, edge_attr, rng_state));
+                     const c10::optional<Tensor>& rng_state, bool validated) {
+        return std::get<0>(mpn_forward(graph_ws, e_stored, seg_nodes, dims, dropout, training, false, params, x, pred_mask, edge_attr, rng_state,
+                                       false, validated));
     });
     m.impl("edge_aggr", [](const Tensor& graph_ws, int64_t e_stored, const Tensor& x, const Tensor& edge_attr, const Tensor& w1, const Tensor& b1,
                            const Tensor& w2, const Tensor& b2) { return std::get<0>(edge_aggr_forward(graph_ws, e_stored, x, edge_attr, w1, b1, w2, b2)); });

@@ -21,7 +21,7 @@ from . import _lib as L
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libpfn_torch.so")
 
-OPS = ("abi_version", "graph_build", "mpn", "mpn_forward", "mpn_backward", "mpn_mse_tail_ok", "mpn_backward_mse", "edge_aggr", "tag_conv", "edge_aggr_forward", "edge_aggr_backward",
+OPS = ("abi_version", "graph_build", "graph_check", "graph_segments", "mpn", "mpn_forward", "mpn_backward", "mpn_mse_tail_ok", "mpn_backward_mse", "edge_aggr", "tag_conv", "edge_aggr_forward", "edge_aggr_backward",
        "tag_conv_forward", "tag_conv_backward", "scatter_add", "mse_loss", "adamw_step_")
 
 _loaded = False

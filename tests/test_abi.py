@@ -132,7 +132,7 @@ def test_every_environment_switch_of_the_library_is_documented():
 
 def test_isa_of_the_async_operand_fragments_is_hazard_free():
     """seg_tile.hpp seg_load_a_async: 17 inline-asm loads whose registers hold garbage until a hand-placed wait.  The compiler does
-    not know; tools/check_async_fragments.py compiles the two sources (hipcc -S, no GPU needed) and reads the ISA: every fragment
+    not know; tools/check_async_fragments.py reads the ISA of the objects that are linked (csrc/Makefile keeps it, -save-temps; no GPU needed): every fragment
     has its wait sequence, and nothing names a fragment register between its load and its wait."""
     import os
     import subprocess

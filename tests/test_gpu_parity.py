@@ -832,77 +832,6 @@ torch.save({{"out": out.detach().cpu(), "gx": d.x.grad.cpu(), "g": m.flat_grad()
         assert_close(res[tag]["g"], res["generic"]["g"], RTOL, f"{tag}: flat parameter gradient")
 
 
-def test_chain_kernels_are_bit_identical_to_the_launch_per_phase_path(tmp_path):
-    """seg_chain.hip: for batches of small graphs everything between the front launch and the last layer's 129 -> 4 Linear --
-    `act(S W2^T + deg b2)` + K hops, the TAGConv product, the next EdgeAggregation's P | Q product + edge walk, times L - 1
-    (networks/MPN.py:541-547) -- runs in ONE persistent launch whose workgroups hand columns to each other through per-graph
-    barriers instead of kernel boundaries.  Same MFMA k / term order, trailing-column chains, epilogue expressions and edge order
-    as seg_lin_hops / gemm_nt / ea_seg, so outputs and all gradients carry the SAME BITS as the launch-per-phase path
-    (the chain launch is opt-in, PFN_SEG_CHAIN=1 -- measured slower than the launches it replaces, profiles/r05_chain_phase_timestamps.txt;
-    read once per process -> child processes): train mode (dropout), eval, inference (no P | Q stores),
-    case118v2 x 128 (one graph per workgroup, all 512 workgroups), case14 x 37 (eight graphs per workgroup, a last block with
-    fewer rows, idle workgroups in the grid), dense 16-node graphs whose edges exceed the LDS adjacency slice, and a second pass
-    over the same workspace (the counters are re-armed by the launch in front)."""
-    import os
-    import subprocess
-    import sys
-    script = f"""
-import sys, torch
-sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
-from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
-from poweflownet_amd.synth import make_batch, make_graph, make_topology
-from poweflownet_amd.data import Batch
-from poweflownet_amd import _lib as L
-res = {{}}
-def run(tag, m, d, grad=True):
-    d = d.to("cuda:0")
-    if grad: d.x.requires_grad_(True)
-    L.profile_report(reset=True); L.profile_enable(True)
-    if grad:
-        out = m(d)
-        torch.nn.MSELoss()(out, d.y).backward()
-    else:
-        with torch.no_grad(): out = m(d)
-    torch.cuda.synchronize()
-    L.profile_enable(False)
-    rep = L.profile_report(reset=True)
-    res[tag + ".launches"] = {{k: v["count"] for k, v in rep.items() if not k.startswith("__")}}
-    res[tag + ".out"] = out.detach().cpu()
-    if grad:
-        res[tag + ".gx"], res[tag + ".g"] = d.x.grad.cpu(), m.flat_grad().cpu()
-        m.zero_grad(set_to_none=True)
-torch.manual_seed(5)
-m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.2).to("cuda:0")
-m.seed_dropout(77)
-m.train()
-run("train118", m, make_batch("118v2", 128, seed=1))
-run("train118b", m, make_batch("118v2", 128, seed=4))
-m.eval()
-run("eval118", m, make_batch("118v2", 128, seed=2))
-run("infer118", m, make_batch("118v2", 128, seed=6), grad=False)
-run("eval14", m, make_batch("14", 37, seed=3))
-topo = make_topology(16, 100, 0)
-run("dense16", m, Batch.from_data_list([make_graph(16, 100, seed=50 + b, edge_index=topo) for b in range(21)]))
-torch.save(res, sys.argv[1])
-"""
-    res = {}
-    for tag, env in (("chain", {"PFN_NT_TINY_MAX_TILES": "0", "PFN_SEG_CHAIN": "1"}), ("phases", {"PFN_NT_TINY_MAX_TILES": "0"})):
-        path = str(tmp_path / f"{tag}.pt")
-        subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=600)
-        res[tag] = torch.load(path)
-    for case in ("train118", "train118b", "eval118", "infer118", "eval14", "dense16"):
-        lc, lp = res["chain"][case + ".launches"], res["phases"][case + ".launches"]
-        # L = 4: three (E, T) pairs; forward 3 x (seg_lin_hops + gemm_nt + ea_seg_fwd) -> one launch
-        assert lc.get("seg_chain_fwd") == 1 and "ea_seg_fwd" not in lc and "seg_lin_hops_fwd" not in lc, lc
-        assert "seg_chain_fwd" not in lp and lp.get("ea_seg_fwd") == 3 and lp.get("seg_lin_hops_fwd") == 3, lp
-        for key in ("out", "gx", "g"):
-            if f"{case}.{key}" not in res["chain"]:
-                continue
-            a, b = res["chain"][f"{case}.{key}"], res["phases"][f"{case}.{key}"]
-            assert a.abs().max() > 0 and torch.isfinite(a).all(), f"{case}.{key}"
-            assert torch.equal(a, b), f"{case}.{key}: the chain launch differs from the launch-per-phase path by {(a - b).abs().max().item():.3e}"
-
-
 def test_fused_linear_hops_are_bit_identical_to_two_launches(tmp_path):
     """seg_lin_hops.hip: for batches of small graphs the Linear in front of a TAGConv's hops -- forward `act(S W2^T + deg b2)`, backward
     `(dP W1i + dQ W1j)[gate]` -- and the K hops over its output run in ONE launch per (graph, 32-column quarter) (networks/MPN.py:541-547:

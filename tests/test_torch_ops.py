@@ -15,6 +15,7 @@ def test_library_loads_and_registers_every_operator():
         assert hasattr(ops, name), name
     s = str(torch.ops.pfn.mpn_forward.default._schema)
     assert "Tensor graph_ws" in s and "int[] dims" in s and "Tensor? rng_state" in s and "-> (Tensor, Tensor)" in s
+    assert "bool validated=False" in s
     s = str(torch.ops.pfn.adamw_step_.default._schema)
     assert "Tensor(a!) param" in s and "Tensor(d!) step" in s
 
@@ -91,7 +92,10 @@ def test_mse_tail_ops_match_the_three_op_path_bit_for_bit(train):
     out, ws = ops.mpn_forward(gws, e, g_seg, dims, m.dropout_rate, train, True, params, d.x, d.pred_mask, d.edge_attr, rng())
     lo, gr = ops.mse_loss(out, d.y, torch.zeros(264, device="cuda:0"))
     flat, gx, _ = ops.mpn_backward(gws, e, g_seg, dims, m.dropout_rate, train, params, d.x, d.pred_mask, d.edge_attr, gr, ws, True, False)
-    out2, ws2 = ops.mpn_forward(gws, e, g_seg, dims, m.dropout_rate, train, True, params, d.x, d.pred_mask, d.edge_attr, rng(), True)
+    assert ops.graph_check(gws, d.x.shape[0], e)[1] == 2 * e and ops.graph_segments(gws, d.x.shape[0], e, g_seg)
+    with pytest.raises(RuntimeError, match="validated"):       # the poison of an unvalidated graph would travel through `out`
+        ops.mpn_forward(gws, e, g_seg, dims, m.dropout_rate, train, True, params, d.x, d.pred_mask, d.edge_attr, rng(), True)
+    out2, ws2 = ops.mpn_forward(gws, e, g_seg, dims, m.dropout_rate, train, True, params, d.x, d.pred_mask, d.edge_attr, rng(), True, True)
     out2.fill_(float("nan"))               # deferred: whatever it holds now is not the output
     loss_ws = torch.zeros(1028, device="cuda:0")
     for _ in range(2):                     # (twice: the arrival counter in loss_ws is left zero)
@@ -229,3 +233,49 @@ def test_adamw_op_matches_flat_adamw_and_bad_inputs_raise():
         ops.graph_build(torch.zeros(3, 3, dtype=torch.int64, device="cuda:0"), 3, -1)
     with pytest.raises(RuntimeError):          # an out-of-range mode
         ops.graph_build(torch.zeros(2, 3, dtype=torch.int64, device="cuda:0"), 3, 7)
+
+
+@pytest.mark.gpu
+def test_ops_never_return_plausible_numbers_for_a_bad_graph():
+    """through torch.ops a graph workspace is a byte tensor taken on trust.  Now: a workspace of another (num_nodes,
+    e_stored) is refused (the kernels index it by those numbers); a node id outside [0, num_nodes) raises in graph_check and, for a
+    caller that never checks, turns every operator's output into NaN; a seg_nodes the batch does not honour (an edge between two
+    graphs) is caught on the device in front of the forward -- NaN again, never a silently wrong result; `validated=True` skips
+    both riders and gives the same bits for a good graph.  (The reference raises in index_select, networks/MPN.py:53.)"""
+    ops = torch_ops.load()
+    m, d = _setup()
+    n, e = d.x.shape[0], d.edge_index.shape[1]
+    params = [p.detach() for p in m._ordered_params()]
+    dims = torch_ops.model_dims(m)
+    run = lambda gws, ee, seg, ea, validated=False: ops.mpn(gws, ee, seg, dims, 0.0, False, params, d.x, d.pred_mask, ea, None, validated)
+    gws = ops.graph_build(d.edge_index, n, -1)
+    directed, e_eff = ops.graph_check(gws, n, e)
+    assert directed and e_eff == 2 * e and ops.graph_segments(gws, n, e, 14) and not ops.graph_segments(gws, n, e, 7)
+    good = run(gws, e, 14, d.edge_attr)
+    assert torch.isfinite(good).all() and torch.equal(good, m(d).detach())
+    assert ops.graph_segments(gws, n, e, 14) and torch.equal(run(gws, e, 14, d.edge_attr, True), good)
+    # a workspace built for another batch
+    for bad_n, bad_e in ((n, e - 1), (n - 14, e)):
+        with pytest.raises(RuntimeError, match="built for another batch"):
+            ops.scatter_add(gws, bad_e, d.x[:bad_n].contiguous())
+    with pytest.raises(RuntimeError, match="built for another batch"):
+        run(gws, e - 1, 14, d.edge_attr[:e - 1].contiguous())
+    # a node id out of range
+    ei = d.edge_index.clone()
+    ei[1, 5] = n + 3
+    gbad = ops.graph_build(ei, n, -1)
+    with pytest.raises(RuntimeError, match="outside"):
+        ops.graph_check(gbad, n, e)
+    assert torch.isnan(run(gbad, e, 0, d.edge_attr)).all()
+    assert torch.isnan(ops.scatter_add(gbad, e, d.x)).all()
+    w = [torch.randn(4, 4, device="cuda:0") for _ in range(3)]
+    assert torch.isnan(ops.tag_conv(gbad, e, 0, d.x, w, None)).all()
+    # an edge between two graphs of the batch, seg_nodes passed on trust
+    ei = d.edge_index.clone()
+    ei[1, 5] = (int(ei[1, 5]) + 14) % n
+    gcross = ops.graph_build(ei, n, -1)
+    ops.graph_check(gcross, n, e)                        # ids are fine
+    assert torch.isnan(run(gcross, e, 14, d.edge_attr)).all()
+    assert torch.isnan(ops.tag_conv(gcross, e, 14, d.x, w, None)).all()
+    assert torch.isfinite(run(gcross, e, 0, d.edge_attr)).all()          # (without the segment promise it is a legal graph)
+    assert not ops.graph_segments(gcross, n, e, 14)

@@ -4,18 +4,19 @@ the 17 loads of a fragment are inline asm, hidden from hipcc, and their destinat
 `s_waitcnt vmcnt(16 - m)` of chunk m.  Nothing may read or write those registers in between -- a copy, a spill, a register handed
 to something else.  hipcc does not know that, so this script reads the ISA it produced:
 
-    python tools/check_async_fragments.py            # compiles ea_seg.hip and seg_lin_hops.hip for gfx950 (hipcc -S) and checks
-    python tools/check_async_fragments.py file.s ... # checks assembly that is already there
+    python tools/check_async_fragments.py            # checks the assembly of the objects csrc/Makefile links (csrc/isa/*.s)
+    python tools/check_async_fragments.py file.s ... # checks assembly that is already there (the Makefile calls it this way
+                                                     # on every build of ea_seg.o / seg_lin_hops.o: a problem fails the build)
 
 For every kernel with async fragment loads: each group of 17 loads must be followed by at least one complete wait sequence
 (vmcnt 16, 15, .. 0: one per exclusive multiply block), and for every such sequence no instruction between a load and the wait of
 its chunk may name a destination register of that load -- scanning the text from the load to the wait but skipping the OTHER
 sequences' blocks (they are exclusive branches).  Exit code 1 and a list of offending lines otherwise."""
+import glob
 import os
 import re
 import subprocess
 import sys
-import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "poweflownet_amd", "csrc")
@@ -96,20 +97,25 @@ def check_text(text):
     return groups, problems
 
 
-def compile_to_asm(src, out):
-    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-S", "--cuda-device-only", src, "-o", out]
-    subprocess.run(cmd, check=True, cwd=CSRC, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+def linked_assembly():
+    """The device assembly of the objects that are LINKED into libpfn_hip.so: csrc/Makefile compiles the async sources with
+    -save-temps=obj (its own HIPCC / CXXFLAGS / ARCH, whatever they are set to) and keeps the .s under csrc/isa/."""
+    objs = [s.replace(".hip", ".o") for s in SOURCES]
+    asm = lambda s: glob.glob(os.path.join(CSRC, "isa", s.replace(".hip", "") + "-hip-amdgcn-amd-amdhsa-*.s"))
+    subprocess.run(["make", "-s", "-C", CSRC] + objs, check=True, stdout=subprocess.DEVNULL)
+    if not all(asm(s) for s in SOURCES):   # objects that arrived without their temporaries (a copied tree): rebuild those two
+        subprocess.run(["make", "-s", "-B", "-C", CSRC] + objs, check=True, stdout=subprocess.DEVNULL)
+    out = []
+    for s in SOURCES:
+        hits = asm(s)
+        if len(hits) != 1:
+            raise SystemExit(f"{s}: expected one device assembly file under csrc/isa/, found {hits}")
+        out += hits
+    return out
 
 
 def main(argv):
-    files = argv[1:]
-    tmp = None
-    if not files:
-        tmp = tempfile.mkdtemp(prefix="pfn_isa_")
-        for s in SOURCES:
-            out = os.path.join(tmp, s + ".s")
-            compile_to_asm(s, out)
-            files.append(out)
+    files = argv[1:] or linked_assembly()
     total, problems = 0, []
     for f in files:
         n, p = check_text(open(f).read())

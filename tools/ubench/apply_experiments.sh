@@ -8,4 +8,3 @@ cd "$1"
 for f in ea_seg.hip edge.hip gemm.hip gemm_nt.hip seg_lin_hops.hip pfn_internal.hpp seg_tile.hpp; do
     patch -s -p0 "$f" < "$here/experiments_${f%.*}.patch.txt"
 done
-patch -s -p0 seg_chain.hip < "$here/seg_chain_timestamps.patch.txt"

@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT
 IFS=";" read -ra VARS <<< "${SLH_VARIANTS:-;-DSLH_EXP_COAL}"; for v in "${VARS[@]}"; do
 d=/tmp/exp_slh_ts; rm -rf $d; mkdir -p $d; cp -r $R/poweflownet_amd $R/bench.py $R/oracle $R/include $R/BASELINE.json $d/; bash $R/tools/ubench/apply_experiments.sh $d/poweflownet_amd/csrc
-( cd $d/poweflownet_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DSLH_EXP_TS $v -c seg_lin_hops.hip -o seg_lin_hops.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC graph.o edge.o gemm.o gemm_nt.o front.o ea_seg.o seg_lin_hops.o seg_chain.o model.o physics.o prof.o -o libpfn_hip.so ) || exit 1
+( cd $d/poweflownet_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DSLH_EXP_TS $v -c seg_lin_hops.hip -o seg_lin_hops.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC graph.o edge.o gemm.o gemm_nt.o front.o ea_seg.o seg_lin_hops.o model.o physics.o prof.o -o libpfn_hip.so ) || exit 1
 echo "######## variant: ${v:-BASE}"
 cd $d && python - <<'PY'
 import ctypes as C, torch, numpy as np, sys
