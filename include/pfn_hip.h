@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PFN_ABI_VERSION 7
+#define PFN_ABI_VERSION 8
 
 enum {
     PFN_OK = 0,
@@ -89,7 +89,8 @@ int pfn_graph_segments(void* graph_ws, int64_t n_nodes, int64_t e_stored, int64_
  * the workspace.  The caller passes seg_nodes to the model on trust and ends its forward pass with pfn_graph_poison_if_bad, which
  * overwrites `out` (count floats) with NaN when the workspace records a node id outside [0, n_nodes) or an edge that crosses a
  * segment boundary -- so a bad batch surfaces as a NaN loss instead of a silently wrong one (pfn_graph_info still reports the
- * id error, with a sync, whenever the caller can afford one).  Both calls are hipGraph-capturable.                       */
+ * id error, with a sync, whenever the caller can afford one).  Both calls are hipGraph-capturable.  seg_nodes = 0 (ABI 8): no
+ * segment promise is made -- the verdict a previous check left in this workspace is cleared, nothing is checked.               */
 int pfn_graph_segments_async(void* graph_ws, int64_t n_nodes, int64_t e_stored, int64_t seg_nodes, void* stream);
 int pfn_graph_poison_if_bad(const void* graph_ws, int64_t n_nodes, int64_t e_stored, float* out, int64_t count, void* stream);
 /* Copies the effective (post-undirect) edge list back out as int64 [2, 2*e_stored] (tests). */

@@ -34,7 +34,7 @@ class MpnConfig(C.Structure):
 
 
 _lib = None
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def load() -> C.CDLL:

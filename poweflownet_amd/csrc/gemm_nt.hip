@@ -348,7 +348,12 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     const int rem_col = 32 * a.nq;
     const int nrt = (a.M + 31) >> 5;
     const int rt_step = gridDim.x * rw;
-    int rt = blockIdx.x * rw + rsub;
+    // Row tiles are dealt ROW-SLOT-MAJOR: tile t of a round goes to (block t % gridDim.x, row slot t / gridDim.x).  Full rounds are
+    // unaffected; the LAST, partial round then hands its tiles to row slot 0 of every block first, then slot 1, ... -- one extra
+    // tile per SIMD before any SIMD gets two (a block's waves w and w + 4 share a SIMD, and the matrix pipe of a SIMD is what a
+    // round costs).  Dealt block-major (block b took tiles 8 b .. 8 b + 7) the partial round filled ALL waves of the first blocks:
+    // at 7,552 row tiles (case118v2 x 2048) 7.375 rounds cost 8 on 48 CUs while the others idled -- now 7.5.
+    int rt = rsub * (int)gridDim.x + blockIdx.x;
 
     // A fragment addresses: uniform base of the row tile (64-bit, SGPRs) + per-lane byte offset of the lane's row inside
     // the tile (rows past M are clamped to the last row; their results are never stored)

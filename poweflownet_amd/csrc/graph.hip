@@ -438,11 +438,12 @@ __global__ __launch_bounds__(256) void graph_poison_kernel(const int* __restrict
 
 int pfn_graph_segments_async(void* ws, int64_t n, int64_t e, int64_t seg_nodes, void* stream) {
     PFN_CHECK_ARG(ws != nullptr, "pfn_graph_segments_async: null workspace");
-    PFN_CHECK_ARG(seg_nodes > 0 && seg_nodes <= (1 << 20) && n > 0 && n % seg_nodes == 0,
-                  "pfn_graph_segments_async: seg_nodes must be positive and divide n_nodes");
+    PFN_CHECK_ARG(seg_nodes == 0 || (seg_nodes > 0 && seg_nodes <= (1 << 20) && n > 0 && n % seg_nodes == 0),
+                  "pfn_graph_segments_async: seg_nodes must be 0, or positive and divide n_nodes");
     GraphView g = graph_view(ws, n, e);
     hipStream_t s = static_cast<hipStream_t>(stream);
     PFN_CHECK_HIP(hipMemsetAsync(g.flags + 4, 0, sizeof(int), s));
+    if (seg_nodes == 0) return PFN_OK;   // no segment promise: the verdict of an earlier check of this workspace is withdrawn
     graph_segcheck_kernel<<<((int)n + 255) / 256, 256, 0, s>>>((int)n, (int)seg_nodes, g.rowptr_in, g.in_src, g.flags);
     PFN_CHECK_LAUNCH();
     return PFN_OK;

@@ -29,9 +29,15 @@ static double g_pair_overhead_ms = 0.0;   // interval of an event pair with NOTH
 // every ProfScope interval contains that much non-kernel time.  It is measured live (median of 33 pairs on the null
 // stream) when profiling is switched on and subtracted per launch in the report, so the event durations line up with
 // rocprofv3's GPU-clock kernel durations (profiles/).
+// Timing events only order timestamps, they publish nothing to the host: created WITHOUT the system-scope release a default event
+// carries (hipEventDisableSystemFence).  A default record writes back / invalidates the L2s between every two kernels of the
+// profiled pass, so each kernel found its predecessor's output evicted -- at case118v2 x 2048 (127 MB tensors, a good part of which
+// would still sit in the 32 MB of L2) the event figures for gemm_nt read 12 % above rocprofv3's and the kernel table summed to
+// more than the step.
+constexpr unsigned kTimingEventFlags = hipEventDisableSystemFence;
 static double measure_pair_overhead() {
     hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0.0;
+    if (hipEventCreateWithFlags(&a, kTimingEventFlags) != hipSuccess || hipEventCreateWithFlags(&b, kTimingEventFlags) != hipSuccess) return 0.0;
     std::vector<float> v;
     for (int i = 0; i < 33; ++i) {
         (void)hipEventRecord(a, nullptr);
@@ -58,7 +64,7 @@ ProfScope::ProfScope(const char* name, double bytes, double flops, hipStream_t s
         r.a = g_pool.back().first;
         r.b = g_pool.back().second;
         g_pool.pop_back();
-    } else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) {
+    } else if (hipEventCreateWithFlags(&r.a, kTimingEventFlags) != hipSuccess || hipEventCreateWithFlags(&r.b, kTimingEventFlags) != hipSuccess) {
         return;
     }
     (void)hipEventRecord(r.a, s);

@@ -59,8 +59,9 @@ void want_graph(const Tensor& g, const Tensor& like, int64_t n, int64_t e_stored
 // `seg_nodes` run on the device in front of the forward and (ii) `out` overwritten with NaN behind it when the workspace records
 // a node id outside [0, num_nodes) or an edge that crosses a segment boundary (pfn_graph_poison_if_bad).  No host sync.
 void graph_precheck(const Tensor& graph_ws, int64_t n, int64_t e_stored, int64_t seg_nodes, void* stream) {
-    if (seg_nodes <= 0) return;
-    TORCH_CHECK(n > 0 && n % seg_nodes == 0 && seg_nodes <= (1 << 20), "seg_nodes = ", seg_nodes, " must divide num_nodes = ", n);
+    // (seg_nodes = 0: no promise to check -- the call withdraws the verdict an earlier check may have left in this workspace)
+    TORCH_CHECK(seg_nodes >= 0 && (seg_nodes == 0 || (n > 0 && n % seg_nodes == 0 && seg_nodes <= (1 << 20))), "seg_nodes = ", seg_nodes,
+                " must be 0 or divide num_nodes = ", n);
     pfn_ok(pfn_graph_segments_async(graph_ws.data_ptr(), n, e_stored, seg_nodes, stream), "pfn_graph_segments_async");
 }
 void graph_poison(const Tensor& graph_ws, int64_t n, int64_t e_stored, Tensor& out, void* stream) {
@@ -288,6 +289,7 @@ std::tuple<Tensor, Tensor> edge_aggr_forward(const Tensor& graph_ws, int64_t e_s
     Tensor out = at::empty({n, pfn_padded_ld(fo)}, x.options());
     const size_t bytes = pfn_edge_aggr_workspace_bytes(n, e_stored, (int)fi, (int)fe, (int)h, (int)fo);
     Tensor ws = at::empty({(int64_t)bytes}, x.options().dtype(at::kByte));
+    graph_precheck(graph_ws, n, e_stored, 0, cur_stream(x));   // (the layer makes no segment promise: only the id-range flag may poison)
     pfn_ok(pfn_edge_aggr_forward(graph_ws.data_ptr(), n, e_stored, (int)fi, (int)fe, (int)h, (int)fo, xp.data_ptr<float>(), xp.size(1),
                                  edge_attr.data_ptr<float>(), w1.data_ptr<float>(), b1.data_ptr<float>(), w2.data_ptr<float>(), b2.data_ptr<float>(),
                                  out.data_ptr<float>(), out.size(1), ws.data_ptr(), bytes, cur_stream(x)),
@@ -385,6 +387,7 @@ Tensor scatter_add(const Tensor& graph_ws, int64_t e_stored, const Tensor& x) {
     const int64_t f = x.size(1);
     Tensor xp = pad_rows(x, f);
     Tensor out = at::empty_like(xp);
+    graph_precheck(graph_ws, x.size(0), e_stored, 0, cur_stream(x));
     pfn_ok(pfn_scatter_add(graph_ws.data_ptr(), x.size(0), e_stored, xp.data_ptr<float>(), out.data_ptr<float>(), f, cur_stream(x)), "pfn_scatter_add");
     graph_poison(graph_ws, x.size(0), e_stored, out, cur_stream(x));
     return unpad_rows(out, f);

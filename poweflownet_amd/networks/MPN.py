@@ -97,14 +97,15 @@ class GraphCSR:
 class _GraphCache:
     """Reuses the adjacency while the caller hands in the very same, unmodified edge_index tensor (identity + torch's in-place
     version counter): legitimate because every sample of a reference case shares one topology, and safe because a new or mutated
-    tensor misses.  A NEW tensor of the cached shape (what a PyG-style loader hands out per batch, train.py:90-92) is compared
-    with a private copy of the list the cached adjacency was built from -- one elementwise-equal kernel and a 1-byte read-back
-    (~0.05 ms) -- and, when the CONTENT is the same, adopts the cached, already validated build instead of the cold one
-    (~1.25 ms at case118v2 x 128: build kernels + the validation's host syncs)."""
+    tensor misses.  A NEW tensor of the cached shape (what a PyG-style loader hands out per batch, train.py:90-92) is NOT compared
+    with the cached list -- the verdict of a device-side compare has to be read back, a host sync per batch that doubled the step
+    (1.14 vs 0.58 ms at case118v2 x 128, round 5) -- but rebuilt on the device with the checks left there (`GraphCSR.unverified`:
+    no host sync, hipGraph-capturable; a node id out of range or an edge between two graphs of the batch turns the output into
+    NaN, pfn_graph_poison_if_bad, instead of raising).  Only the FIRST build of a shape is validated with a read-back (and raises)."""
 
     def __init__(self):
-        self._ref, self._key, self._graph, self._copy = None, None, None, None
-        self.content_hits = 0
+        self._ref, self._key, self._graph = None, None, None
+        self.device_rebuilds = 0      # new tensors of the cached shape that took the sync-free path
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, mode: int, seg_hint: int = 0, rebuild: bool = False) -> GraphCSR:
         """`rebuild`: the caller's topology changes per batch -- build anew from `edge_index` every time, checks left on the
@@ -113,16 +114,11 @@ class _GraphCache:
         key = (edge_index._version, edge_index.data_ptr(), tuple(edge_index.shape), num_nodes, mode, seg_hint)
         if not rebuild and self._ref is not None and self._ref() is edge_index and self._key == key:
             return self._graph
-        if (not rebuild and self._copy is not None and self._key is not None and key[2:] == self._key[2:] and not _capturing()
-                and edge_index.device == self._copy.device and edge_index.dtype == self._copy.dtype and not self._graph.unverified):
-            if bool(torch.equal(edge_index, self._copy)):          # same topology in a new tensor: the validated build stands
-                self._ref, self._key = weakref.ref(edge_index), key
-                self.content_hits += 1
-                return self._graph
-        g = GraphCSR(edge_index, num_nodes, mode, seg_hint=seg_hint, async_checks=rebuild)
+        same_shape = self._key is not None and key[2:] == self._key[2:] and self._graph is not None and edge_index.device == self._graph.device
+        if same_shape and not rebuild:
+            self.device_rebuilds += 1
+        g = GraphCSR(edge_index, num_nodes, mode, seg_hint=seg_hint, async_checks=rebuild or same_shape)
         self._ref, self._key, self._graph = weakref.ref(edge_index), key, g
-        # (a private copy: the caller's tensor may be freed or mutated; 16 bytes per stored edge.  Not for per-batch rebuilds.)
-        self._copy = None if (rebuild or _capturing()) else edge_index.detach().clone()
         return g
 
 
@@ -544,6 +540,15 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
             raise RuntimeError("MaskEmbdMultiMPN.forward asserts 4 node features (networks/MPN.py:528); "
                                f"this model was built with nfeature_dim={self.nfeature_dim}")
         self._mask_seen = mask                             # (identity of the tensor as the caller holds it: Masked_L2_loss.attach)
+        try:
+            return self._forward(data, x, mask, edge_index, edge_features)
+        finally:
+            # the loss announced for THIS forward (loss.MSELoss.attach) is consumed by it or dropped with it: a forward that raises
+            # (a shape check, a bad first topology) or never reaches the autograd node must not leave it to an unrelated later one
+            self._mse_attach = None
+            self._mask_seen = None
+
+    def _forward(self, data, x, mask, edge_index, edge_features):
         params = self._ordered_params()
         L.require_device(x, mask, edge_index, edge_features, params[0], params[-1], what="MaskEmbdMultiMPN input")
         x, edge_features = L.f32c(x, "data.x"), L.f32c(edge_features, "data.edge_attr")
@@ -566,7 +571,6 @@ class MaskEmbdMultiMPN(_UndirectHelpers, nn.Module):
             out = _MpnFn.apply(self, graph, x, mask, edge_features, *params)
             if self._mse_tail is not None:     # loss.MSELoss.forward finds the arrangement on the tensor it is handed
                 out._pfn_mse_tail, self._mse_tail = self._mse_tail, None
-            self._mask_seen = None
             return out
 
 

@@ -55,6 +55,32 @@ def _backward(loss_fn, loss):
         loss.backward()
 
 
+def _unverified_batch(model) -> bool:
+    """Did the model's last forward run on an adjacency whose id-range / segment checks stayed on the device (a NEW edge_index
+    tensor per batch, `dynamic_topology`, a build inside a capture)?  Then a bad batch arrives as a NaN loss instead of an exception."""
+    g = getattr(getattr(model, "_graphs", None), "_graph", None)
+    return bool(g is not None and getattr(g, "unverified", False))
+
+
+def _guarded_opt_step(optimizer, model, loss, allreduce: bool):
+    """`optimizer.step()` of an EAGER loop body.  When the batch could not be validated on the host (`_unverified_batch`) and the
+    optimizer can skip on the device (FlatAdamW.guard), the update is decided on THIS step's own loss -- summed across ranks under
+    data parallelism, so every replica skips or none does -- and the guard is cleared again: it never outlives the step it was
+    set for (a guard left bound to an earlier loss made a later eager step decide on the wrong batch)."""
+    if not hasattr(optimizer, "guard") or optimizer.guard is not None or not _unverified_batch(model):
+        optimizer.step()
+        return
+    guard = loss.detach()
+    if allreduce and dp.active():
+        guard = guard.clone()
+        torch.distributed.all_reduce(guard, op=torch.distributed.ReduceOp.SUM)
+    optimizer.guard = guard
+    try:
+        optimizer.step()
+    finally:
+        optimizer.guard = None
+
+
 class GraphedTrainStep:
     """The per-batch body of `train_epoch` (zero_grad -> forward -> loss -> backward -> step) captured ONCE into a hipGraph
     and replayed for every following batch of the same shape and topology: the ~34 kernel launches of a step cost one
@@ -129,8 +155,23 @@ class GraphedTrainStep:
         loss = self._fwd_bwd(data)
         if self.allreduce:
             dp.allreduce_gradients(self.model)
-        self.opt.step()
+        _guarded_opt_step(self.opt, self.model, loss, self.allreduce)
         return loss
+
+    def _replay_eager_form(self):
+        """dp.GraphedStep demoted to (or asked for) its "eager" form calls the captured closure on every step: it needs the
+        state `_capture` raised around the capture -- per-batch topologies rebuilt on the device instead of the cached,
+        host-synchronising build -- and must not leave the optimizer's guard bound to this step's loss afterwards."""
+        prev = [(o, o.dynamic_topology) for o in self._topology_owners()]
+        if self.dynamic:
+            self._set_dynamic_topology(True)
+        try:
+            return self.graph.replay()
+        finally:
+            if hasattr(self.opt, "guard"):
+                self.opt.guard = None
+            for o, was in prev:
+                o.dynamic_topology = was
 
     def _eager(self, data):
         """The eager body -- on the side stream of the capture's warm-up once there is one: autograd binds a parameter's
@@ -308,7 +349,8 @@ class GraphedTrainStep:
         if self._source is None:
             for k in ("x", "y", "pred_mask", "edge_attr") + (("edge_index",) if self.dynamic else ()):
                 getattr(self.static, k).copy_(getattr(data, k))
-        self.loss = self.graph.replay()            # (graph forms: the captured loss tensor; the eager form: this step's)
+        # (graph forms: the captured loss tensor; the eager form: this step's)
+        self.loss = self._replay_eager_form() if self.graph.form == "eager" else self.graph.replay()
         return self.loss
 
 
@@ -351,7 +393,7 @@ def train_epoch(model: nn.Module, loader, loss_fn: Callable, optimizer, device, 
             _backward(loss_fn, loss)
             if allreduce:
                 dp.allreduce_gradients(model)
-            optimizer.step()
+            _guarded_opt_step(optimizer, model, loss, allreduce)
         num_samples += len(data)
         term = loss.detach().double() * len(data)
         total = term if total is None else total + term

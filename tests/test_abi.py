@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert set(declared) == set(L.SYMBOLS), (declared, L.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
-    assert lib.pfn_abi_version() == L.ABI_VERSION == 7
+    assert lib.pfn_abi_version() == L.ABI_VERSION == 8
 
 
 def test_host_only_entry_points():

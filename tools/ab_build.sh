@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # A/B of COMPILE-TIME switches inside the step: tools/ab_build.sh "-DFLAG ..." [reps] [kernel class]  -- the tree's library against the
 # same sources built with the flags; configs 2, 3 and 4: step time and the named kernel class's average launch (eager profile pass)
 R=$GRAFT_REPO_ROOT; FLAGS=$1; REPS=${2:-2}; KCLASS=${3:-gemm_tn}

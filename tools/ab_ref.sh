@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # A/B inside the replayed step: the tree's library vs the library built from the sources under ab_ref/ (a copy of another commit's
 # poweflownet_amd/csrc + include, made before the gpurun call: the box has no .git).  tools/ab_ref.sh [reps]
 R=$GRAFT_REPO_ROOT; REPS=${1:-2}

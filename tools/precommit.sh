@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # What must hold at every commit (a kernel commit landed after the last CPU run and left HEAD red): the library
 # builds from the tracked sources, the archived experiment patches still apply to them, the async-fragment ISA check passes
 # (the Makefile runs it on the linked objects' assembly), and the CPU suite is green.  Installed as .git/hooks/pre-commit by

@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # train.py end to end (the reference's loop shape, its file format, the device-resident dataset, one hipGraph launch per batch):
 # graphs/s per epoch for the three loss functions at case118v2 x 128, 8,000 samples (4,000 in the training split)
 cd $GRAFT_REPO_ROOT

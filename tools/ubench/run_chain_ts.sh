@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # phase timestamps of seg_chain_fwd_kernel (the instrumented build -- tools/ubench/seg_chain_timestamps.patch.txt, -DCH_EXP_TS -- in /tmp; per workgroup and stage, wall clock 100 MHz)
 R=$GRAFT_REPO_ROOT
 export PFN_SEG_CHAIN=1

@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # phase timestamps of ea_seg_bwd_kernel<false> (SG_EXP_TS build in /tmp): per workgroup, wall clock 100 MHz
 R=$GRAFT_REPO_ROOT; d=/tmp/exp_ts; mkdir -p $d; cp -r $R/poweflownet_amd $R/bench.py $R/oracle $R/include $R/BASELINE.json $d/; bash $R/tools/ubench/apply_experiments.sh $d/poweflownet_amd/csrc
 ( cd $d/poweflownet_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -w -DSG_EXP_TS -c ea_seg.hip -o ea_seg.o && /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC graph.o edge.o gemm.o gemm_nt.o front.o ea_seg.o seg_lin_hops.o model.o physics.o prof.o -o libpfn_hip.so ) || exit 1

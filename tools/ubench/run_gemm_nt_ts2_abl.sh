@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # per-wave cycle accounting (NT_EXP_TS2) with one ingredient removed at a time (results WRONG by design): what are the flush's cycles?
 R=$GRAFT_REPO_ROOT
 for v in BASE NOSTORE NOREFILL "NOSTORE -DPFN_EXP_NOREFILL"; do

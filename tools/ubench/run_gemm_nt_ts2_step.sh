@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # gemm_nt's per-wave cycle accounting (NT_EXP_TS2 build in /tmp) INSIDE the replayed step of configs 3 and 4, and back to back in
 # the harness: pipe occupancy in shader cycles and the shader clock (s_memtime / wall_clock64) the launches actually ran at
 R=$GRAFT_REPO_ROOT; d=/tmp/exp_ts2r; rm -rf $d; mkdir -p $d

@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # experiment: two waves per SIMD (512 threads) against three (768; PFN_EXP_NT_THREADS) in the stationary gemm_nt, K = N = 128 (the
 # shape that fits 168 registers without spills), in SHADER CYCLES (the harness runs power-capped: times mean nothing).
 # pipe cycles a SIMD needs: 12940 tiles x 4 quarters x terms x 64 MFMAs x 64 / 1024 = 207,040 x terms

@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # gemm_tn's per-wave cycle stamps (T3_EXP_TS build in /tmp) for the LAST launch of an eager training step: where do the cycles
 # between "kernel start" and "partials published" go?  tools/ubench/run_gemm_tn_ts.sh ["bench args"]
 R=$GRAFT_REPO_ROOT; d=/tmp/exp_t3ts; rm -rf $d; mkdir -p $d

@@ -1,4 +1,5 @@
 #!/bin/bash
+export ASYNC_CHECK=${GRAFT_REPO_ROOT:-/root/repo}/tools/check_async_fragments.py   # (csrc/Makefile checks the ISA of the async-fragment objects it links)
 # phase timestamps of seg_lin_hops_kernel (SLH_EXP_TS build in /tmp; per workgroup, wall clock 100 MHz), optionally with the A
 # fragments loaded from contiguous addresses (SLH_EXP_COAL: wrong results, timing only)
 R=$GRAFT_REPO_ROOT
