@@ -101,10 +101,13 @@ class _GraphCache:
     with the cached list -- the verdict of a device-side compare has to be read back, a host sync per batch that doubled the step
     (1.14 vs 0.58 ms at case118v2 x 128, round 5) -- but rebuilt on the device with the checks left there (`GraphCSR.unverified`:
     no host sync, hipGraph-capturable; a node id out of range or an edge between two graphs of the batch turns the output into
-    NaN, pfn_graph_poison_if_bad, instead of raising).  Only the FIRST build of a shape is validated with a read-back (and raises)."""
+    NaN, pfn_graph_poison_if_bad, instead of raising).  Only the FIRST build of a shape is validated with a read-back (and raises).
+    The last VALIDATED build is kept next to the current one: a caller that comes back to that very tensor (evaluation between
+    training batches, two loaders taking turns) gets the validated adjacency -- and with it the loss tail -- back."""
 
     def __init__(self):
         self._ref, self._key, self._graph = None, None, None
+        self._validated = None        # (weakref of its edge_index, key, graph) of the last build whose checks were read back
         self.device_rebuilds = 0      # new tensors of the cached shape that took the sync-free path
 
     def get(self, edge_index: torch.Tensor, num_nodes: int, mode: int, seg_hint: int = 0, rebuild: bool = False) -> GraphCSR:
@@ -114,11 +117,16 @@ class _GraphCache:
         key = (edge_index._version, edge_index.data_ptr(), tuple(edge_index.shape), num_nodes, mode, seg_hint)
         if not rebuild and self._ref is not None and self._ref() is edge_index and self._key == key:
             return self._graph
+        if not rebuild and self._validated is not None and self._validated[0]() is edge_index and self._validated[1] == key:
+            self._ref, self._key, self._graph = self._validated
+            return self._graph
         same_shape = self._key is not None and key[2:] == self._key[2:] and self._graph is not None and edge_index.device == self._graph.device
         if same_shape and not rebuild:
             self.device_rebuilds += 1
         g = GraphCSR(edge_index, num_nodes, mode, seg_hint=seg_hint, async_checks=rebuild or same_shape)
         self._ref, self._key, self._graph = weakref.ref(edge_index), key, g
+        if not g.unverified:
+            self._validated = (self._ref, key, g)
         return g
 
 
