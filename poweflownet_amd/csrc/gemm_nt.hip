@@ -331,7 +331,13 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
 // kernel the CT = 2 build had no registers left for the one-step tail):
 //   0: 17 chunks, the last chunk is ONE MFMA step (K = 129)     1: 17 chunks, last chunk 4 steps
 //   2: 16 chunks (K = 128), no trailing column                  3: generic (per-chunk guards, 4 trailing columns; CT < 2 only)
-template <int CT, int VAR>
+//   PAIR: every piece's partial sum is formed on its own and the pieces are added in piece order (round 6), instead of ONE fp32 chain
+//         through all k's of all terms.  A TAGConv product is a 516-deep sum; as one chain its rounding error is 2-4 x that of
+//         "K + 1 products, added" -- which is what PyG's TAGConv, the oracle and gemm_nt_tiny_kernel compute (profiles/
+//         r06_accumulation_order.txt: the whole distance between the HIP forward and the fp32 dataflow against float64).  Costs a
+//         second accumulator set (16 registers per quarter): the CT = 1 kernels have them, the CT = 2 / streaming kernels (256
+//         registers) do not.
+template <int CT, int VAR, bool PAIR = false>
 __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CTE = CT > 0 ? CT : 1;
@@ -431,6 +437,14 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
         for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
     float racc[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x16 psum[PAIR ? CTE : 1];                         // PAIR: the finished pieces of the current output tile
+    float prsum[4] = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (PAIR) {
+#pragma unroll
+        for (int ct = 0; ct < CTE; ++ct)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) psum[ct][q] = 0.f;
+    }
     const int nr = rem_on ? (a.nrem > 1 ? 4 : 1) : 0;   // trailing columns this wave owns (the generic path always computes 4)
     const float* extra = a.gate ? a.gate : a.resid;     // at most one of rowscale / gate / resid per GEMM
     const int ldx = a.gate ? a.ldg : a.ldr;
@@ -540,6 +554,20 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
             if (CT > 0) {
                 if (CT == 2) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[CTE - 1]));
                 else asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]));
+            }
+            if constexpr (PAIR) {   // (earlier pieces) + this one: the pieces in piece order
+#pragma unroll
+                for (int ct = 0; ct < CTE; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        acc[ct][q] = psum[ct][q] + acc[ct][q];
+                        psum[ct][q] = 0.f;
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    racc[e] = prsum[e] + racc[e];
+                    prsum[e] = 0.f;
+                }
             }
             float* C = a.C[group];
             const int gf = a.gflags[group];
@@ -693,6 +721,23 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
                 for (int q = 0; q < 16; ++q) acc[ct][q] = 0.f;
             racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
+        }
+        if constexpr (PAIR) {
+            if (!flush_after) {   // a piece of the tile is done, more follow: its sum joins the finished ones, the chain starts anew
+                if (CT > 0) asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]));   // (XDL write -> VALU read, see the flush)
+#pragma unroll
+                for (int ct = 0; ct < CTE; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        psum[ct][q] += acc[ct][q];
+                        acc[ct][q] = 0.f;
+                    }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    prsum[e] += racc[e];
+                    racc[e] = 0.f;
+                }
+            }
         }
         if (!more) break;
         p = np;
@@ -1097,11 +1142,11 @@ __global__ __launch_bounds__(64 * TINY_MAX_PIECES) void gemm_nt_tiny_kernel(cons
     }
 }
 
-template <int CT, int VAR>
+template <int CT, int VAR, bool PAIR = false>
 static int launch_variant(const NtArgs& k, dim3 grid, size_t lds_bytes, hipStream_t s) {
     static std::atomic<uint64_t> lds_raised{0};
-    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<CT, VAR>), NT_LDS_BYTES, lds_raised));
-    gemm_nt_kernel<CT, VAR><<<grid, NT_THREADS, lds_bytes, s>>>(k);
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<CT, VAR, PAIR>), NT_LDS_BYTES, lds_raised));
+    gemm_nt_kernel<CT, VAR, PAIR><<<grid, NT_THREADS, lds_bytes, s>>>(k);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
@@ -1339,7 +1384,12 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
         int rc = PFN_EINVAL;
         const int var = pick_variant(k, CT);
         const size_t lb = used + bias_bytes;
-#define PFN_NT_CASE(CT_, V_) if (CT == CT_ && var == V_) rc = launch_variant<CT_, V_>(k, grid, lb, s)
+        // pieces summed one by one and added in piece order (gemm_nt_kernel's PAIR): the K = 129 products of three or more terms (a
+        // TAGConv's lins, forward and backward) where the kernel has the registers -- one quarter per wave
+        static const bool no_pair = diag_env("PFN_NO_NT_PAIR") != nullptr;   // A/B switch: one chain through all terms
+        const bool pair = !no_pair && CT == 1 && (var == 0 || var == 1) && k.npiece >= 3;
+        if (pair) rc = var == 0 ? launch_variant<1, 0, true>(k, grid, lb, s) : launch_variant<1, 1, true>(k, grid, lb, s);
+#define PFN_NT_CASE(CT_, V_) if (!pair && CT == CT_ && var == V_) rc = launch_variant<CT_, V_>(k, grid, lb, s)
         PFN_NT_CASE(0, 0); PFN_NT_CASE(0, 1); PFN_NT_CASE(0, 2); PFN_NT_CASE(0, 3);
         PFN_NT_CASE(1, 0); PFN_NT_CASE(1, 1); PFN_NT_CASE(1, 2); PFN_NT_CASE(1, 3);
         PFN_NT_CASE(2, 0); PFN_NT_CASE(2, 1); PFN_NT_CASE(2, 2);
