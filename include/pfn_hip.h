@@ -283,6 +283,8 @@ int pfn_adamw_step_guarded(float* param, const float* grad, float* exp_avg, floa
  *                           (default: recomputed in the backward front, which forms those gradients itself)
  *   PFN_FRONT_NO_THREAD_ROWS=1   inference front: the row-per-wave / block kernels instead of one row per thread
  *   PFN_NT_CT=1|2           gemm_nt: quarters per wave
+ *   PFN_NO_NT_ILF=1         gemm_nt, one-piece tiles at two quarters per wave: every tile flushed behind its own multiply (default: parked
+ *                           and flushed inside the wave's next multiply, between its own MFMAs)
  *   PFN_NO_NT_PAIR=1        gemm_nt, products of >= 3 terms at one quarter per wave: ONE fp32 chain through all terms (default: every
  *                           term summed on its own, the terms added in order -- PyG's TAGConv dataflow)
  *   PFN_NT_TINY_MAX_TILES=<n> gemm_nt: the split-K small-batch kernel up to n row tiles of 32 rows (default 256; 0 = never)

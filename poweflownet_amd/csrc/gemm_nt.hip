@@ -127,15 +127,19 @@ __device__ __forceinline__ float dpp_xor2(float x) {
     return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
 }
 __device__ __forceinline__ void quad_transpose(float (&v)[4], int lane) {
+    // (every result a plain select of two values: written as `if (o1) { v[0] = ..; v[2] = ..; } else { v[1] = ..; v[3] = ..; }` hipcc
+    //  if-converts the assignments into "v[o1 ? 0 : 1] = .." -- a dynamic index, four compares and four selects per assignment;
+    //  found in the ISA of the interleaved flush, round 6: ~12 vector instructions per register group, in every flush)
     const bool o1 = lane & 1, o2 = lane & 2;
-    {   // exchange across lane ^ 1: (v0,v1) and (v2,v3)
-        const float s01 = dpp_xor1(o1 ? v[0] : v[1]), s23 = dpp_xor1(o1 ? v[2] : v[3]);
-        if (o1) { v[0] = s01; v[2] = s23; } else { v[1] = s01; v[3] = s23; }
-    }
-    {   // exchange across lane ^ 2: (v0,v2) and (v1,v3)
-        const float s02 = dpp_xor2(o2 ? v[0] : v[2]), s13 = dpp_xor2(o2 ? v[1] : v[3]);
-        if (o2) { v[0] = s02; v[1] = s13; } else { v[2] = s02; v[3] = s13; }
-    }
+    // exchange across lane ^ 1: (v0,v1) and (v2,v3)
+    const float s01 = dpp_xor1(o1 ? v[0] : v[1]), s23 = dpp_xor1(o1 ? v[2] : v[3]);
+    const float a0 = o1 ? s01 : v[0], a1 = o1 ? v[1] : s01, a2 = o1 ? s23 : v[2], a3 = o1 ? v[3] : s23;
+    // exchange across lane ^ 2: (v0,v2) and (v1,v3)
+    const float s02 = dpp_xor2(o2 ? a0 : a2), s13 = dpp_xor2(o2 ? a1 : a3);
+    v[0] = o2 ? s02 : a0;
+    v[1] = o2 ? s13 : a1;
+    v[2] = o2 ? a2 : s02;
+    v[3] = o2 ? a3 : s13;
 }
 
 // Per-element epilogue.  Every operand arrives BY VALUE (kernel-uniform scalars live in SGPRs; `aux` = rowscale[row] when
@@ -217,6 +221,15 @@ __device__ __forceinline__ void vstore_x4_sv(const char* sbase, uint32_t voff, f
     if (WT) asm volatile("global_store_dwordx4 %0, %1, %2 sc1\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
     else asm volatile("global_store_dwordx4 %0, %1, %2\n\ts_nop 1" : : "v"(voff), "v"(v), "s"(sbase) : "memory");
 }
+// the same store under a lane mask held in SGPRs -- exec narrowed and restored INSIDE the asm block: no branch, so the store stays
+// in the basic block of the MFMAs it is interleaved with (gemm_nt_kernel's ILF); a lane whose mask bit is clear stores nothing
+__device__ __forceinline__ void vstore_x4_sv_masked(const char* sbase, uint32_t voff, f32x4 v, uint64_t mask) {
+    uint64_t keep;
+    asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tglobal_store_dwordx4 %1, %2, %3\n\ts_mov_b64 exec, %0\n\ts_nop 1"
+                 : "=&s"(keep)
+                 : "v"(voff), "v"(v), "s"(sbase), "s"(mask)
+                 : "memory");
+}
 template <bool WT = false>
 __device__ __forceinline__ void vstore_x4(float* p, f32x4 v) {
     // the s_nop is the ISA's "VMEM store wider than 64 bits -> VALU overwrites its data registers" hazard (2 wait states),
@@ -249,12 +262,23 @@ __device__ __forceinline__ void wait_a(f32x4& v) {   // the fragment chunk about
 // than strictly needed, never for the stores).
 //   XW   : vector-memory ops the wave issues between the end of one piece's refills and the first chunk of the next (the
 //          streaming kernel's 9 weight DMAs): they are younger than every pending fragment chunk, so every wait count grows by XW.
-template <int CT, int NR, int NFAST, int LS, int XW = 0, bool DIET = true>
+//   SL   : a functor called once per chunk, behind the chunk's MFMAs and in their basic block: the INTERLEAVED FLUSH (round 6,
+//          gemm_nt_kernel's ILF) hands in the previous tile's epilogue, one register group per call, so that its vector
+//          instructions issue between the wave's own MFMAs.
+struct NtNoSlice {
+    __device__ __forceinline__ void operator()(int) const {}
+};
+template <int CT, int NR, int NFAST, int LS, int XW = 0, bool DIET = true, class SL = NtNoSlice>
 __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], float (&racc)[4], f32x4 (&a_cur)[NCH],
                                             const float* S, int klen, int tps, int tsel, uint32_t kh4, int r32,
-                                            const char* nbase, uint32_t nvoff, int nkmax, uint32_t nkscale) {
+                                            const char* nbase, uint32_t nvoff, int nkmax, uint32_t nkscale, SL&& slice = SL()) {
     constexpr bool FAST = NFAST != 0;
     constexpr int CTE = CT > 0 ? CT : 1, NRE = NR > 0 ? NR : 1;
+    // the trailing column's weights are read one chunk ahead like the tiles' -- except under the interleaved flush, which has no
+    // registers for the second set (12 short: hipcc then parks three chunks of the NEXT fragment in scratch): there they are read
+    // at the head of their own chunk; only the trailing column's fma chain waits for them, never an MFMA
+    constexpr bool SLICED = !std::is_same<typename std::decay<SL>::type, NtNoSlice>::value;
+    constexpr bool R1BUF = false && SLICED;
     const int tile_floats = FAST ? NFAST * 8 * 32 : klen * 32;
     const float* Bt = S + tsel * tile_floats + (kh4 * 8 + r32) * 4;
     const float* Rt = S + tps * tile_floats + kh4 * 4;
@@ -264,8 +288,10 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
     f32x4 b_nxt[CTE], r_nxt[NRE];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) b_nxt[ct] = *reinterpret_cast<const f32x4*>(Bt + ct * tile_floats);
+    if (!R1BUF) {
 #pragma unroll
-    for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + c * 4);
+        for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + c * 4);
+    }
 #pragma unroll
     for (int m = 0; m < NCH; ++m) {
         const bool live = FAST ? m < NFAST : 8 * m < klen;
@@ -274,12 +300,14 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) b[ct] = b_nxt[ct];
 #pragma unroll
-            for (int c = 0; c < NR; ++c) r[c] = r_nxt[c];
+            for (int c = 0; c < NR; ++c) r[c] = R1BUF ? *reinterpret_cast<const f32x4*>(Rt + m * 32 + c * 4) : r_nxt[c];
             if (m + 1 < NCH && (FAST ? m + 1 < NFAST : 8 * (m + 1) < klen)) {
 #pragma unroll
                 for (int ct = 0; ct < CT; ++ct) b_nxt[ct] = *reinterpret_cast<const f32x4*>(Bt + ct * tile_floats + (m + 1) * 256);
+                if (!R1BUF) {
 #pragma unroll
-                for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + (m + 1) * 32 + c * 4);
+                    for (int c = 0; c < NR; ++c) r_nxt[c] = *reinterpret_cast<const f32x4*>(Rt + (m + 1) * 32 + c * 4);
+                }
             }
             // (refills are issued per GROUP of four chunks, below: chunk m has 16 - (m & 3) younger loads)
             switch (m & 3) {
@@ -295,6 +323,15 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
                 for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], b[ct][i], acc[ct], 0, 0, 0);
 #pragma unroll
                 for (int c = 0; c < NR; ++c) racc[c] = fmaf(av[i], r[c][i], racc[c]);
+            }
+            slice(m);
+            // Under the interleaved flush the trailing column's sum is consumed in a LATER basic block only (the tile is parked behind
+            // the multiply), and LLVM's MachineSink then moves the WHOLE 65-fma chain there -- with all 17 weight vectors and a second
+            // copy of the fragment (the refills overwrite the first) kept alive through the multiply: 136 + 68 registers, spills of
+            // in-flight fragment registers.  Naming the sum here pins every chunk's fmas to their chunk.
+            if (SLICED) {
+#pragma unroll
+                for (int c = 0; c < NR; ++c) asm volatile("" : "+v"(racc[c]));
             }
         }
         // chunks consumed: refill them IN PLACE for the next piece -- four at a time.  A 128-byte line of a row holds four
@@ -337,7 +374,19 @@ __device__ __forceinline__ void nt_multiply(f32x16 (&acc)[CT > 0 ? CT : 1], floa
 //         r06_accumulation_order.txt: the whole distance between the HIP forward and the fp32 dataflow against float64).  Costs a
 //         second accumulator set (16 registers per quarter): the CT = 1 kernels have them, the CT = 2 / streaming kernels (256
 //         registers) do not.
-template <int CT, int VAR, bool PAIR = false>
+//   ILF : INTERLEAVED FLUSH (round 6), for launches whose EVERY piece ends an output tile (S W2^T, P | Q, dS: one K = 129 piece per
+//         32 x 64 tile) without per-element epilogue operands (no gate / residual / dropout / raw sums).  Measured: with the flush
+//         compiled away these launches run 27-31 % faster (tools/ubench/run_gemm_nt_noflush.sh: 0.61 -> 0.83 of the fp32 MFMA peak in
+//         the config-3 step) -- not because a flush is much work (~300 vector instructions and 8 stores per tile) but because the
+//         SIMD partner's fp32 MFMA stream lets 0.6 vector and 0.12 vector-memory instructions per MFMA through to a wave that is
+//         not itself multiplying (profiles/r04_gemm_nt_cycle_accounting.txt; tools/ubench/mfma_pace.hip: pausing the stream with
+//         s_nop does not free the slots either -- they are blocked while the MFMA EXECUTES).  A wave's vector instructions do issue
+//         between its OWN MFMAs.  So a finished tile is parked in a second accumulator set and flushed by the NEXT piece's multiply:
+//         one register group (quad transpose, bias / row scale as one fma, ReLU as a max against 0 or -inf, one exec-masked store
+//         inside an asm block: straight-line, no branch) behind the MFMAs of every other chunk, the trailing column behind chunk
+//         15.  The fragment waits keep their counts: the slices' stores only make them stricter (vmcnt counts stores; a masked-off
+//         store may not count, so no count may rely on one).  Same expressions, same order: bit-identical to the plain flush.
+template <int CT, int VAR, bool PAIR = false, bool ILF = false>
 __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int CTE = CT > 0 ? CT : 1;
@@ -445,6 +494,29 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 #pragma unroll
             for (int q = 0; q < 16; ++q) psum[ct][q] = 0.f;
     }
+    // ILF: the parked tile -- sums, the scale its bias image takes per register group (the row scale, or 1 / 0 for a plain bias /
+    // none), the floor of its activation, where it goes and which lanes store
+    f32x16 il_acc[ILF ? CTE : 1];
+    float il_racc = 0.f, il_sc = 0.f, il_lo = 0.f;   // il_sc: lane (r32, .) holds the scale of the parked tile's row r32
+    uint64_t il_ok[4] = {0ull, 0ull, 0ull, 0ull}, il_okr = 0ull;
+    float* il_C = a.C[0];
+    int il_rbase = 0;
+    // (addresses of the slices without a branch on the layout -- a branch would split the basic block the slice shares with its
+    //  MFMAs: element (row, 32 q + c) lies at row * il_rs_ + q * il_qs_ + the lane's part, row-major and chunk-major alike)
+    const int il_rs_ = a.c_cm_rows > 0 ? 4 : a.ldc, il_qs_ = a.c_cm_rows > 0 ? 32 * a.c_cm_rows : 32;
+    const int il_rq_ = (rem_col >> 2) * (a.c_cm_rows > 0 ? 4 * a.c_cm_rows : 4);
+    const uint32_t il_vc = (uint32_t)((r32 & 3) + 4 * kh) * (uint32_t)il_rs_ * 4u + (uint32_t)(r32 >> 2) * (a.c_cm_rows > 0 ? (uint32_t)a.c_cm_rows * 16u : 16u);
+    const uint32_t il_vr = (uint32_t)r32 * (uint32_t)il_rs_ * 4u;
+    if constexpr (ILF) {
+#pragma unroll
+        for (int ct = 0; ct < CTE; ++ct) {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) il_acc[ct][q] = 0.f;
+        }
+        // the activation as ONE max: against 0 (ReLU) or against a quiet NaN (none: max(x, NaN) = x, and a NaN x stays NaN -- the
+        // poison of an unvalidated topology must come through a GEMM without activation as it does through the plain flush)
+        il_lo = a.act == ACT_RELU ? 0.f : __builtin_nanf("");
+    }
     const int nr = rem_on ? (a.nrem > 1 ? 4 : 1) : 0;   // trailing columns this wave owns (the generic path always computes 4)
     const float* extra = a.gate ? a.gate : a.resid;     // at most one of rowscale / gate / resid per GEMM
     const int ldx = a.gate ? a.ldg : a.ldr;
@@ -505,12 +577,20 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         //  component-wise loads below no longer coalesce into them and the copy into place runs before the hidden load has landed;
         //  cleared only under has_aux, one register of the CT = 2 kernels spills)
         f32x4 aux[CTE][4], raux;
+        float il_rs = 0.f;   // ILF: the tile's row scales, row r32's in lane (r32, .) (requested here, used by the NEXT multiply: a register
+                             // group's four rows are fetched from their lanes by the slice -- 2 registers instead of 10)
+        if constexpr (ILF) {
+            if (a.rowscale)   // (clamped rows; loaded IN PLACE: a fresh output register would be merged into il_rs by a copy that runs
+                              //  before the hidden load has landed)
+                asm volatile("global_load_dword %0, %1, %2" : "+v"(il_rs)
+                             : "v"((uint32_t)min(r32, a.M - 1 - rbase) * 4u), "s"(reinterpret_cast<const char*>(a.rowscale + rbase)) : "memory");
+        }
 #pragma unroll
         for (int ct = 0; ct < CTE; ++ct)
 #pragma unroll
             for (int g = 0; g < 4; ++g) aux[ct][g] = f32x4{0.f, 0.f, 0.f, 0.f};
         raux = f32x4{0.f, 0.f, 0.f, 0.f};
-        const bool has_aux = flush_after && (a.rowscale || extra);
+        const bool has_aux = !ILF && flush_after && (a.rowscale || extra);
         if (has_aux) {
             if (a.rowscale) {
                 // (one dword per row, loaded straight into its component of `aux` -- unconditionally, from a clamped row: a masked load
@@ -541,6 +621,72 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         {
             const float* S = lds + cur_lds;
             const int klen = cur_klen, tsel = cg * CT;
+            if constexpr (ILF) {
+                // one register group of the parked tile per call: (quarter u >> 2, group u & 3) behind chunk 2 u, the trailing
+                // column behind chunk 15 (chunk 16 is two MFMAs long)
+                auto il_unit = [&](int u) {
+                    const int ct = u >> 2, g = u & 3;
+                    float t[4] = {il_acc[ct][4 * g], il_acc[ct][4 * g + 1], il_acc[ct][4 * g + 2], il_acc[ct][4 * g + 3]};
+                    quad_transpose(t, lane);
+                    const int q = tile0 + ct;
+                    const f32x4 cb = *reinterpret_cast<const f32x4*>(lds + a.bias_lds_off + 32 * q + (r32 & ~3));   // (LDS: 8 registers less)
+                    const float sc = __shfl(il_sc, jrow + 8 * g);   // the scale of this lane's row of the group
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) t[e] = fmaxf(fmaf(sc, cb[e], t[e]), il_lo);
+                    const size_t ub = (size_t)(il_rbase + 8 * g) * il_rs_ + (size_t)q * il_qs_;
+                    vstore_x4_sv_masked(reinterpret_cast<const char*>(il_C + ub), il_vc, f32x4{t[0], t[1], t[2], t[3]}, il_ok[g]);
+                };
+                auto il_rem = [&]() {
+                    const float tot = il_racc + __shfl_xor(il_racc, 32);   // the two k halves
+                    const float x = fmaxf(fmaf(il_sc, lds[a.bias_lds_off + rem_col], tot), il_lo);
+                    const size_t ub = (size_t)il_rbase * il_rs_ + il_rq_;
+                    vstore_x4_sv_masked(reinterpret_cast<const char*>(il_C + ub), il_vr, f32x4{x, 0.f, 0.f, 0.f}, il_okr);
+                };
+                auto slice = [&](int m) {
+                    if (m < 4 * CT * 2 && (m & 1) == 0) il_unit(m >> 1);
+                    if (NR > 0 && m == 15) il_rem();
+                };
+                nt_multiply<CT, NR, NFAST, LS, 0, true>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax,
+                                                        (uint32_t)nx_kscale, slice);
+                // ---- the tile just multiplied is parked (every piece of an ILF launch ends one); the next multiply flushes it
+                asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[CTE - 1]));   // (XDL write -> VALU read, see the flush)
+                const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
+                if (a.rowscale) {   // the row scales requested before the multiply: the 17 refills (and the slices' stores) are younger
+                    asm volatile("s_waitcnt vmcnt(17)" : "+v"(il_rs));
+                    il_sc = il_rs;
+                } else {
+                    il_sc = use_bias ? 1.f : 0.f;
+                }
+#pragma unroll
+                for (int ct = 0; ct < CTE; ++ct)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        il_acc[ct][q] = acc[ct][q];
+                        acc[ct][q] = 0.f;
+                    }
+                il_racc = racc[0];
+                racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
+                il_C = a.C[group];
+                il_rbase = rbase;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) il_ok[g] = __ballot(rbase + jrow + 8 * g < a.M);
+                il_okr = __ballot(rem_on && kh == 0 && rbase + r32 < a.M);
+                if (!more) {   // the wave's last tile: flushed here
+#pragma unroll
+                    for (int u = 0; u < 4 * CT; ++u) {
+                        il_unit(u);
+                        __builtin_amdgcn_sched_barrier(0);   // (one unit's temporaries at a time)
+                    }
+                    if (NR > 0) il_rem();
+                    break;
+                }
+                p = np;
+                rt = nrt_;
+                cur_gl = nx_gl;
+                cur_lds = nx_lds;
+                cur_klen = nx_klen;
+                continue;
+            }
             nt_multiply<CT, NR, NFAST, LS>(acc, racc, a_cur, S, klen, a.tps, tsel, kh4, r32, nbase, nvoff, nkmax,
                                            (uint32_t)nx_kscale);
         }
@@ -1142,11 +1288,11 @@ __global__ __launch_bounds__(64 * TINY_MAX_PIECES) void gemm_nt_tiny_kernel(cons
     }
 }
 
-template <int CT, int VAR, bool PAIR = false>
+template <int CT, int VAR, bool PAIR = false, bool ILF = false>
 static int launch_variant(const NtArgs& k, dim3 grid, size_t lds_bytes, hipStream_t s) {
     static std::atomic<uint64_t> lds_raised{0};
-    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<CT, VAR, PAIR>), NT_LDS_BYTES, lds_raised));
-    gemm_nt_kernel<CT, VAR, PAIR><<<grid, NT_THREADS, lds_bytes, s>>>(k);
+    PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(gemm_nt_kernel<CT, VAR, PAIR, ILF>), NT_LDS_BYTES, lds_raised));
+    gemm_nt_kernel<CT, VAR, PAIR, ILF><<<grid, NT_THREADS, lds_bytes, s>>>(k);
     PFN_CHECK_LAUNCH();
     return PFN_OK;
 }
@@ -1389,7 +1535,15 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
         static const bool no_pair = diag_env("PFN_NO_NT_PAIR") != nullptr;   // A/B switch: one chain through all terms
         const bool pair = !no_pair && CT == 1 && (var == 0 || var == 1) && k.npiece >= 3;
         if (pair) rc = var == 0 ? launch_variant<1, 0, true>(k, grid, lb, s) : launch_variant<1, 1, true>(k, grid, lb, s);
-#define PFN_NT_CASE(CT_, V_) if (!pair && CT == CT_ && var == V_) rc = launch_variant<CT_, V_>(k, grid, lb, s)
+        // the interleaved flush (gemm_nt_kernel's ILF): two quarters per wave, K = 129, every piece ends a tile, an epilogue of
+        // bias / row-scaled bias / ReLU only, whole quarters, every wave owns a tile
+        static const bool no_ilf = diag_env("PFN_NO_NT_ILF") != nullptr;   // A/B switch: the flush behind its own multiply
+        bool ilf = !no_ilf && CT == 2 && var == 0 && !a.gate && !a.resid && (a.act == ACT_NONE || a.act == ACT_RELU) && tps % 2 == 0 &&
+                   nq % tps == 0 && a.ldc == 32 * nq + (remv > 0 ? 4 : 0);
+        for (int i = 0; i < k.npiece; ++i) ilf = ilf && (k.piece[i].gl >> 8) != 0;
+        for (int g = 0; g < 8; ++g) ilf = ilf && k.gflags[g] == 0;
+        if (ilf) rc = launch_variant<2, 0, false, true>(k, grid, lb, s);
+#define PFN_NT_CASE(CT_, V_) if (!pair && !ilf && CT == CT_ && var == V_) rc = launch_variant<CT_, V_>(k, grid, lb, s)
         PFN_NT_CASE(0, 0); PFN_NT_CASE(0, 1); PFN_NT_CASE(0, 2); PFN_NT_CASE(0, 3);
         PFN_NT_CASE(1, 0); PFN_NT_CASE(1, 1); PFN_NT_CASE(1, 2); PFN_NT_CASE(1, 3);
         PFN_NT_CASE(2, 0); PFN_NT_CASE(2, 1); PFN_NT_CASE(2, 2);

@@ -894,6 +894,60 @@ torch.save(res, sys.argv[1])
             assert torch.equal(a, b), f"{case}.{key}: fused Linear + hops differs from gemm_nt + fused_hops by {(a - b).abs().max().item():.3e}"
 
 
+def test_interleaved_flush_is_bit_identical_to_the_plain_flush(tmp_path):
+    """gemm_nt_kernel's ILF (round 6): in large-M launches whose every K = 129 piece ends an output tile -- `act(S W2^T + deg b2)`
+    without dropout, `P | Q = x [W1i | W1j]^T (+ b1)`, the backward `dS = g W2` products without a gate (networks/MPN.py:17-21,
+    :28) -- a finished tile is parked in a second accumulator set and flushed one register group at a time between the MFMAs of the
+    wave's NEXT multiply.  Same expressions in the same order (bias / row-scaled bias as one fma, ReLU as a max, the trailing column's
+    two half-chains): every output and gradient carries the SAME BITS as the flush behind its own multiply (PFN_NO_NT_ILF=1; read
+    once per process -> child processes).  case118v2 x 600 (row-major operands, 70,800 rows: a partial last row tile), eval and train
+    mode (train: only P | Q qualifies in the forward pass), and case6470rte x 11 (chunk-major operands and outputs around the big-graph hops)."""
+    import os
+    import subprocess
+    import sys
+    script = f"""
+import sys, torch
+sys.path.insert(0, {repr(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))})
+from poweflownet_amd.networks.MPN import MaskEmbdMultiMPN
+from poweflownet_amd.synth import make_batch
+res = {{}}
+def run(tag, m, d, grad=True):
+    d = d.to("cuda:0")
+    if grad:
+        d.x.requires_grad_(True)
+        out = m(d)
+        torch.nn.MSELoss()(out, d.y).backward()
+        res[tag + ".gx"], res[tag + ".g"] = d.x.grad.cpu(), m.flat_grad().cpu()
+        m.zero_grad(set_to_none=True)
+    else:
+        with torch.no_grad():
+            out = m(d)
+    torch.cuda.synchronize()
+    res[tag + ".out"] = out.detach().cpu()
+torch.manual_seed(9)
+m = MaskEmbdMultiMPN(4, 2, 4, 129, 4, 3, 0.2).to("cuda:0")
+m.seed_dropout(123)
+m.eval()
+run("infer118", m, make_batch("118v2", 600, seed=1), grad=False)
+run("eval118", m, make_batch("118v2", 600, seed=2))
+m.train()
+run("train118", m, make_batch("118v2", 600, seed=3))
+m.eval()
+run("eval6470", m, make_batch("6470rte", 11, seed=4))
+torch.save(res, sys.argv[1])
+"""
+    res = {}
+    for tag, env in (("ilf", {}), ("plain", {"PFN_NO_NT_ILF": "1"})):
+        path = str(tmp_path / f"{tag}.pt")
+        subprocess.run([sys.executable, "-c", script, path], check=True, env=dict(os.environ, **env), timeout=900)
+        res[tag] = torch.load(path)
+    assert set(res["ilf"]) == set(res["plain"]) and len(res["ilf"]) == 10
+    for key in sorted(res["ilf"]):
+        a, b = res["ilf"][key], res["plain"][key]
+        assert a.abs().max() > 0 and torch.isfinite(a).all(), key
+        assert torch.equal(a, b), f"{key}: the interleaved flush differs from the plain one by {(a - b).abs().max().item():.3e}"
+
+
 def test_fused_front_and_first_edge_stage_are_bit_identical_to_two_launches(tmp_path):
     """ea_seg.hip front_seg_fwd_kernel: for batches of small graphs mask_embd + residual (networks/MPN.py:533-537) AND the first
     EdgeAggregation's edge stage run in ONE graph-resident launch per (graph, 32-column quarter) -- front.hip's row-per-wave
