@@ -549,6 +549,13 @@ def main():
                 fl = r["flops"] / cnt
                 row.update(bound="mfma", achieved=round(fl / avg_s / 1e12, 2), unit="TFLOP/s",
                            frac=round(fl / avg_s / MFMA_F32_PEAK, 4), per_launch=fl)
+                if r.get("bytes", 0) > 0:
+                    # the same launches against the OTHER roof: their algorithmic operand + output bytes over the same time.  A class
+                    # whose two fractions are comparable sits at the ridge (gemm_nt's one-piece products at large M: DESIGN.md
+                    # section 9) -- neither roof alone bounds it
+                    by = r["bytes"] / cnt
+                    row.update(hbm_side_bytes_per_launch=by, hbm_side_frac=round(by / avg_s / HBM_PEAK, 4),
+                               flop_per_byte=round(fl / by, 1), ridge_flop_per_byte=round(MFMA_F32_PEAK / HBM_PEAK, 1))
             kernels[name] = row
         rated = {k: v for k, v in kernels.items() if "bound" in v}
         if rated:
