@@ -393,7 +393,26 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r32 = lane & 31, kh = lane >> 5;
-    const int slice = blockIdx.y;
+    // The column slices of one row group share an XCD (round 6).  Workgroups go to the eight XCDs round-robin in launch order
+    // (blockIdx.x fastest), so (bx, slice 0) and (bx, slice 1) of a dim3(gx, 2) grid landed on XCDs bx % 8 and (bx + gx) % 8: every
+    // operand row was fetched into TWO L2s (config 2: 83 MB of fabric traffic per launch for 39 MB of operands and results).  The
+    // launch-order id is re-read as [chunk of 8 row groups][slice][row group in chunk]: the slices of a row group are launched
+    // eight apart -- same XCD, same moment -- and the second one's fragment gathers hit that L2.  (A tail of gx % 8 row groups
+    // keeps the old order.)
+    int bx = blockIdx.x, slice = blockIdx.y;
+    {
+        const int gx = gridDim.x, ns = gridDim.y, full = gx & ~7;
+        const int lin = blockIdx.y * gx + blockIdx.x;
+        if (ns > 1 && lin < full * ns) {
+            const int chunk = lin / (8 * ns), r = lin - chunk * 8 * ns;
+            slice = r >> 3;
+            bx = chunk * 8 + (r & 7);
+        } else if (ns > 1) {
+            const int t = lin - full * ns, tail = gx - full;
+            slice = t / tail;
+            bx = full + (t - slice * tail);
+        }
+    }
     const int cg = wave & ((1 << a.cshift) - 1);       // column group of this wave inside the slice
     const int rsub = wave >> a.cshift;                  // its row tile inside the block's step
     const int rw = NT_WAVES >> a.cshift;                // row tiles per block step
@@ -408,7 +427,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
     // tile per SIMD before any SIMD gets two (a block's waves w and w + 4 share a SIMD, and the matrix pipe of a SIMD is what a
     // round costs).  Dealt block-major (block b took tiles 8 b .. 8 b + 7) the partial round filled ALL waves of the first blocks:
     // at 7,552 row tiles (case118v2 x 2048) 7.375 rounds cost 8 on 48 CUs while the others idled -- now 7.5.
-    int rt = rsub * (int)gridDim.x + blockIdx.x;
+    int rt = rsub * (int)gridDim.x + bx;
 
     // A fragment addresses: uniform base of the row tile (64-bit, SGPRs) + per-lane byte offset of the lane's row inside
     // the tile (rows past M are clamped to the last row; their results are never stored)
