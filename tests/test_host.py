@@ -167,3 +167,39 @@ def test_evaluation_metrics_and_evaluate_epoch_v2():
     lens = [len(b) for b in batches]
     want = (terms[0]["total"].item() + sum(t["total"].item() * n for t, n in zip(terms[1:], lens[1:]))) / sum(lens)
     assert abs(got["total"] - want) < 1e-6 and set(got) == {"total", "balanced total", "vm", "va", "p", "q"}
+
+
+def test_gemm_nt_block_order_covers_every_row_group_and_slice_once():
+    """gemm_nt_kernel reads its launch-order id as [chunk of 8 row groups][slice][row group in chunk] so that the column slices of a
+    row group share an XCD (csrc/gemm_nt.hip, round 6; a tail of gx % 8 row groups keeps the plain order).  The mapping restated here
+    line by line must be a bijection onto (row group, slice) for every grid the launcher can produce, and must put the slices of a
+    row group of a full chunk on launch ids that are equal modulo 8 (= the same XCD under round-robin dispatch)."""
+    import re
+    src = open(os.path.join(ROOT, "poweflownet_amd", "csrc", "gemm_nt.hip")).read()
+    # (the test follows the source: if these lines change, restate the mapping below)
+    for line in ("const int chunk = lin / (8 * ns), r = lin - chunk * 8 * ns;", "slice = r >> 3;", "bx = chunk * 8 + (r & 7);",
+                 "const int t = lin - full * ns, tail = gx - full;", "slice = t / tail;", "bx = full + (t - slice * tail);"):
+        assert line in src, line
+    assert re.search(r"full = gx & ~7", src)
+
+    def block_of(lin, gx, ns):
+        full = gx & ~7
+        if ns > 1 and lin < full * ns:
+            chunk, r = divmod(lin, 8 * ns)
+            return chunk * 8 + (r & 7), r >> 3
+        if ns > 1:
+            t, tail = lin - full * ns, gx - full
+            s = t // tail
+            return full + (t - s * tail), s
+        return lin % gx, lin // gx
+
+    for ns in (1, 2, 3, 4):
+        for gx in list(range(1, 40)) + [59, 118, 120, 127, 128, 256]:
+            seen = {}
+            for lin in range(gx * ns):
+                seen.setdefault(block_of(lin, gx, ns), []).append(lin)
+            assert sorted(seen) == [(b, s) for b in range(gx) for s in range(ns)], (gx, ns)
+            assert all(len(v) == 1 for v in seen.values())
+            if ns > 1:
+                for b in range(gx & ~7):
+                    assert len({seen[(b, s)][0] % 8 for s in range(ns)}) == 1, (gx, ns, b)
