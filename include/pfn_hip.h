@@ -282,6 +282,8 @@ int pfn_adamw_step_guarded(float* param, const float* grad, float* exp_avg, floa
  *   PFN_FRONT_STORE_MEH=1   training beyond 32 k rows: mask_embd's hidden layer is stored and its weight gradients go through gemm_tn
  *                           (default: recomputed in the backward front, which forms those gradients itself)
  *   PFN_FRONT_NO_THREAD_ROWS=1   inference front: the row-per-wave / block kernels instead of one row per thread
+ *   PFN_NO_SERPENTINE=1     the row-streaming kernels (gemm_nt, LDS-resident walks / hops, the generic forward walk) all visit their rows
+ *                           first to last (default: consecutive launches alternate, so a consumer starts with what its producer wrote last)
  *   PFN_NT_CT=1|2           gemm_nt: quarters per wave
  *   PFN_NO_NT_ILF=1         gemm_nt, one-piece tiles at two quarters per wave: every tile flushed behind its own multiply (default: parked
  *                           and flushed inside the wave's next multiply, between its own MFMAs)

@@ -251,11 +251,11 @@ constexpr int RH_NBPT = 4;                      // staged neighbour ids per thre
 __global__ __launch_bounds__(RH_THREADS, 4) void row_hops_kernel(int n, int rows_pb, int nchunk, int nb_cap,
                                                                 const int* __restrict__ rowptr, const int* __restrict__ nbr,
                                                                 const float* __restrict__ dinv, const float* __restrict__ x0,
-                                                                float* __restrict__ xk, size_t stride, int ld, int K) {
+                                                                float* __restrict__ xk, size_t stride, int ld, int K, int reverse) {
     extern __shared__ __attribute__((aligned(16))) float4 rh_tile[];          // [rows_pb * nchunk] | rp u16 [rows_pb + 2] | nb u16 [nb_cap]
     unsigned short* s_rp = reinterpret_cast<unsigned short*>(rh_tile + (size_t)rows_pb * nchunk);
     unsigned short* s_nb = s_rp + ((rows_pb + 2 + 7) & ~7);
-    const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0), t = threadIdx.x;
+    const int r0 = (reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * rows_pb, rows = min(rows_pb, n - r0), t = threadIdx.x;
     const int items = rows * nchunk;
     const int e0 = rowptr[r0], ne = rowptr[r0 + rows] - e0;
     const bool nb_in_lds = ne <= nb_cap && ne < 65536 && ne <= RH_NBPT * RH_THREADS;
@@ -359,7 +359,7 @@ int launch_fused_hops(const GraphView& g, const FusedHopsArgs& a, hipStream_t s)
             ProfScope ps(adjt_rh ? "fused_hops_bwd" : "fused_hops_fwd", 0.0, 0.0, s);
             row_hops_kernel<<<(g.n + rows_pb - 1) / rows_pb, RH_THREADS, lds_total, s>>>(
                 g.n, rows_pb, nchunk, nb_cap, adjt_rh ? g.rowptr_out : g.rowptr_in, adjt_rh ? g.out_dst : g.in_src, g.dinv, a.x0, a.xk,
-                a.stride, a.ld, a.K);
+                a.stride, a.ld, a.K, next_sweep_direction());   // (serpentine sweeps, pfn_internal.hpp)
             PFN_CHECK_LAUNCH();
             return PFN_OK;
         }
@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
                                                        const float* __restrict__ ea, const float* __restrict__ w1,
                                                        float* __restrict__ S, int ld, int h, int fi, int fe_rt,
                                                        unsigned* __restrict__ mask, const int* __restrict__ rp4,
-                                                       const float* __restrict__ b1) {
+                                                       const float* __restrict__ b1, int reverse) {
     extern __shared__ __attribute__((aligned(16))) float we[];   // [fe][ld] (| FLY: wi [4][ld] | wj [4][ld] | b1 [ld])
     const int fe = FE > 0 ? FE : fe_rt;
     const int ldw = 2 * fi + fe;
@@ -814,8 +814,10 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
     // pointers, its P chunk) is requested while the item before it is walked: one level less in every item's chain of dependent loads
     const long stride = (long)gridDim.x * blockDim.x, total = (long)n * nchunk;
     long item = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    int row = (int)(item / nchunk);
-    int col = (int)(item - (long)row * nchunk) * 4;
+    // (serpentine sweeps, pfn_internal.hpp: `reverse` walks the items from the last to the first -- item i stands for total - 1 - i)
+    const long flip = reverse ? total - 1 : 0, sgn = reverse ? -1 : 1;
+    int row = (int)((flip + sgn * item) / nchunk);
+    int col = (int)((flip + sgn * item) - (long)row * nchunk) * 4;
     EdgeRowHead hd;
     if (item < total) hd = edge_row_head<MASK, FLY>(row, col, rowptr, P, ld, rp4);
     for (int i = threadIdx.x; i < fe * ld; i += blockDim.x) {
@@ -825,8 +827,8 @@ __global__ __launch_bounds__(256) void edge_fwd_kernel(int n, int nchunk, int e_
     if (FLY) stage_fly_weights(we + fe * ld, w1, b1, ld, h, ldw);
     __syncthreads();
     while (item < total) {
-        const long nitem = item + stride;
-        const int nrow = (int)(nitem / nchunk), ncol = (int)(nitem - (long)nrow * nchunk) * 4;
+        const long nitem = item + stride, nphys = nitem < total ? flip + sgn * nitem : 0;
+        const int nrow = (int)(nphys / nchunk), ncol = (int)(nphys - (long)nrow * nchunk) * 4;
         EdgeRowHead hn = hd;
         if (nitem < total) hn = edge_row_head<MASK, FLY>(nrow, ncol, rowptr, P, ld, rp4);
         st4_wt(S + (size_t)row * ld + col, edge_sum_chunk<FE, MASK, FLY>(row, col, e_stored, rowptr, nbr, eid, P, Q, ea, we, ld, fe, mask, hd));
@@ -850,7 +852,8 @@ __global__ __launch_bounds__(256) void edge_fwd_out_kernel(int n, int nchunk, in
                                                            const float* __restrict__ w1, float* __restrict__ S,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
                                                            const float* __restrict__ deg, float* __restrict__ out, int ld,
-                                                           int h, int fi, int fo, unsigned* __restrict__ mask, const int* __restrict__ rp4) {
+                                                           int h, int fi, int fo, unsigned* __restrict__ mask, const int* __restrict__ rp4,
+                                                           int reverse) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* we = smem;
     float* w2s = smem + FE * ld;
@@ -862,7 +865,7 @@ __global__ __launch_bounds__(256) void edge_fwd_out_kernel(int n, int nchunk, in
     }
     stage_w2(w2s, w2, h, fo, ld);
     const int r = threadIdx.x / nchunk, c = threadIdx.x - r * nchunk;
-    const int row = blockIdx.x * rows_pb + r, col = 4 * c;
+    const int row = (reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * rows_pb + r, col = 4 * c;   // (serpentine sweeps)
     const bool on = r < rows_pb && row < n;
     EdgeRowHead hd;
     if (on) hd = edge_row_head<MASK>(row, col, rowptr, P, ld, rp4);
@@ -906,7 +909,7 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
                                                                      const float* __restrict__ w1, float* __restrict__ S, int ld,
                                                                      int h, int fi, const float* __restrict__ w2,
                                                                      const float* __restrict__ b2, const float* __restrict__ deg,
-                                                                     float* __restrict__ out, int fo, const float* __restrict__ b1) {
+                                                                     float* __restrict__ out, int fo, const float* __restrict__ b1, int reverse) {
     // `out` != null: the network's LAST layer (Fo <= 4): out[row] = S[row] W2^T + deg[row] b2 is formed here and S itself (which
     // only a backward pass reads) is not written
     extern __shared__ __attribute__((aligned(16))) float4 er_tile[];   // Q [rows_pb * nchunk] | we [2 * nchunk] | w2 [4 * nchunk] | ea float2 [nb_cap] | rp u16 | nb u16
@@ -916,7 +919,7 @@ __global__ __launch_bounds__(ER_THREADS, 4) void edge_rows_fwd_kernel(int n, int
     float2* s_ea = reinterpret_cast<float2*>(s_w2 + (FLY ? 9 : 4) * nchunk);
     unsigned short* s_rp = reinterpret_cast<unsigned short*>(s_ea + nb_cap);
     unsigned short* s_nb = s_rp + ((rows_pb + 2 + 7) & ~7);
-    const int r0 = blockIdx.x * rows_pb, rows = min(rows_pb, n - r0), t = threadIdx.x;
+    const int r0 = (reverse ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x) * rows_pb, rows = min(rows_pb, n - r0), t = threadIdx.x;
     const int items = rows * nchunk;
     const int e0 = rowptr[r0], ne = rowptr[r0 + rows] - e0;
     const bool in_lds = ne <= nb_cap && ne < 65536 && ne <= ER_NBPT * ER_THREADS;
@@ -1068,6 +1071,7 @@ static int edge_rows_graphs_per_block(int seg, int nchunk) {
 
 bool edge_fwd_out_ok(int fe, int h, int fo, int ldo) { return fe == 2 && fo >= 1 && fo <= 4 && ldo == 4 && ld_of(h) / 4 <= 256; }
 int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
+    const int rev = g.n > 0 ? next_sweep_direction() : 0;   // every kernel of this launcher walks its rows either way (serpentine sweeps)
     if (g.n == 0) return PFN_OK;
     const int nchunk = a.ld / 4;
     const bool fly = a.x0 != nullptr;
@@ -1092,12 +1096,12 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
                 PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(edge_rows_fwd_kernel<true>), 160 * 1024, lds_raised_erf));
                 edge_rows_fwd_kernel<true><<<(g.n + rows_pb - 1) / rows_pb, ER_THREADS, lds_total, s>>>(
                     g.n, rows_pb, nchunk, nb_cap, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.x0, a.x0, a.edge_attr, a.w1, a.S, a.ld, a.h,
-                    a.fi, nullptr, nullptr, g.deg, nullptr, 0, a.b1);
+                    a.fi, nullptr, nullptr, g.deg, nullptr, 0, a.b1, rev);
             } else {
                 PFN_TRY(ensure_dynamic_lds(reinterpret_cast<const void*>(edge_rows_fwd_kernel<false>), 160 * 1024, lds_raised_er));
                 edge_rows_fwd_kernel<false><<<(g.n + rows_pb - 1) / rows_pb, ER_THREADS, lds_total, s>>>(
                     g.n, rows_pb, nchunk, nb_cap, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q, a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi,
-                    a.w2, a.b2, g.deg, a.out, a.fo, nullptr);
+                    a.w2, a.b2, g.deg, a.out, a.fo, nullptr, rev);
             }
             PFN_CHECK_LAUNCH();
             return PFN_OK;
@@ -1118,20 +1122,20 @@ int launch_edge_fwd(const GraphView& g, const EdgeFwdArgs& a, hipStream_t s) {
         if (a.mask)
             edge_fwd_out_kernel<2, true><<<grid_out, 256, lds_out, s>>>(g.n, nchunk, rows_pb, g.e_stored, g.rowptr_in, g.in_src, g.in_eid,
                                                                       a.P, a.Q, a.edge_attr, a.w1, a.S, a.w2, a.b2, g.deg, a.out, a.ld,
-                                                                      a.h, a.fi, a.fo, a.mask, g.rp4);
+                                                                      a.h, a.fi, a.fo, a.mask, g.rp4, rev);
         else
             edge_fwd_out_kernel<2, false><<<grid_out, 256, lds_out, s>>>(g.n, nchunk, rows_pb, g.e_stored, g.rowptr_in, g.in_src, g.in_eid,
                                                                        a.P, a.Q, a.edge_attr, a.w1, a.S, a.w2, a.b2, g.deg, a.out, a.ld,
-                                                                       a.h, a.fi, a.fo, nullptr, nullptr);
+                                                                       a.h, a.fi, a.fo, nullptr, nullptr, rev);
         PFN_CHECK_LAUNCH();
         return PFN_OK;
     }
 #define PFN_EDGE_FWD(FE_, M_)                                                                                                  \
     edge_fwd_kernel<FE_, M_><<<blocks, 256, lds, s>>>(g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.P, a.Q,          \
-                                                      a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe, a.mask, g.rp4, nullptr)
+                                                      a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe, a.mask, g.rp4, nullptr, rev)
 #define PFN_EDGE_FWD_FLY(M_)                                                                                                   \
     edge_fwd_kernel<2, M_, true><<<blocks, 256, lds + (size_t)9 * a.ld * sizeof(float), s>>>(                                  \
-        g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.x0, a.x0, a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe, a.mask, g.rp4, a.b1)
+        g.n, nchunk, g.e_stored, g.rowptr_in, g.in_src, g.in_eid, a.x0, a.x0, a.edge_attr, a.w1, a.S, a.ld, a.h, a.fi, a.fe, a.mask, g.rp4, a.b1, rev)
     if (fly && a.mask) PFN_EDGE_FWD_FLY(true);
     else if (fly) PFN_EDGE_FWD_FLY(false);
     else if (a.fe == 2 && a.mask) PFN_EDGE_FWD(2, true);

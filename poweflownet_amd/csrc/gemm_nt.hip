@@ -177,6 +177,7 @@ struct NtArgs {
     int nrem, bias_group, ldr, ldg;
     int kuni, bias_lds_off;      // k length shared by every piece of the launch, or 0; float offset of the bias image in LDS
     int c_cm_rows, aux_cm_rows;  // > 0: C (every group) / the gate-or-residual tensor is CHUNK-major with that many rows per plane
+    int reverse;                 // 1: the row tiles are walked from the last to the first (serpentine sweeps, pfn_internal.hpp)
     int klast, row0;             // 1: in every piece only the first MFMA step of the last chunk has real k's (K = 129); else 4.
                                  // row0: global index of row 0 (dropout counter)
     NtPiece piece[NT_MAX_PIECES];
@@ -431,11 +432,12 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
 
     // A fragment addresses: uniform base of the row tile (64-bit, SGPRs) + per-lane byte offset of the lane's row inside
     // the tile (rows past M are clamped to the last row; their results are never stored)
+    auto prt = [&](int t) { return a.reverse ? nrt - 1 - t : t; };   // the row tile a loop index stands for (serpentine sweeps)
     auto a_base = [&](int rt2, int p2) -> const char* {
-        return reinterpret_cast<const char*>(a.piece[p2].A + (size_t)rt2 * 32 * a.piece[p2].lda);
+        return reinterpret_cast<const char*>(a.piece[p2].A + (size_t)prt(rt2) * 32 * a.piece[p2].lda);
     };
     auto a_voff = [&](int rt2, int p2) -> uint32_t {
-        const int lrow = min(r32, a.M - 1 - rt2 * 32);
+        const int lrow = min(r32, a.M - 1 - prt(rt2) * 32);
         return (uint32_t)(lrow * a.piece[p2].lda) * 4u;
     };
 
@@ -568,12 +570,12 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_kernel(const NtArgs a) 
         const NtPieceK nx = pk + pi;
         const float* nxA = nx->A;
         const int nx_lda = nx->lda, nx_kscale = nx->kscale, nkmax = nx->kmax, nx_klen = nx->klen, nx_gl = nx->gl, nx_lds = nx->lds_off;
-        const int nrt2 = more ? nrt_ : rt;
+        const int nrt2 = prt(more ? nrt_ : rt);
         const char* nbase = reinterpret_cast<const char*>(nxA + (size_t)nrt2 * 32 * nx_lda);
         const uint32_t nvoff = (uint32_t)(min(r32, a.M - 1 - nrt2 * 32) * nx_lda) * 4u;
         // ---- per-row epilogue operands of the flush that follows this piece: requested NOW (hidden loads), so they are
         // older than the 17 refills issued inside the multiply; the flush waits for them with vmcnt(17)
-        const int rbase = rt * 32;
+        const int rbase = prt(rt) * 32;
         // Addresses of the flush (these loads and the stores): lane (u = r32 >> 2, j = r32 & 3, kh) holds, after the quad transpose,
         // row rbase + j + 4 kh + 8 g and the four columns 32 q + 4 u .. of quarter q for register group g -- the lane's part of the
         // address does not depend on the tile, the group or the quarter, so it is ONE 32-bit offset per tensor and everything else
@@ -971,12 +973,13 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
     const int rem_col = 128;
     const int bias_off = 2 * WS_IMG;
 
+    auto prt = [&](int t) { return a.reverse ? nrt - 1 - t : t; };   // the row tile a loop index stands for (serpentine sweeps)
     auto a_base = [&](int rt2, int p2) -> const char* {
-        const int rc = rt2 < nrt ? rt2 : nrt - 1;           // a wave past the last row tile keeps pace on the last tile; it stores nothing
+        const int rc = prt(rt2 < nrt ? rt2 : nrt - 1);      // a wave past the last row tile keeps pace on the last tile; it stores nothing
         return reinterpret_cast<const char*>(a.piece[p2].A + (size_t)rc * 32 * a.piece[p2].lda);
     };
     auto a_voff = [&](int rt2, int p2) -> uint32_t {
-        const int rc = rt2 < nrt ? rt2 : nrt - 1;
+        const int rc = prt(rt2 < nrt ? rt2 : nrt - 1);
         const int lrow = min(r32, a.M - 1 - rc * 32);
         return (uint32_t)(lrow * a.piece[p2].lda) * 4u;
     };
@@ -1072,7 +1075,7 @@ __global__ __launch_bounds__(NT_THREADS, 1) void gemm_nt_ws_kernel(const NtArgs 
         if (flush_after) {
             // the accumulators are still being written by the last MFMAs (see the stationary kernel's flush)
             asm volatile("s_nop 15\n\ts_nop 7" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]));
-            const int rbase = rt * 32;
+            const int rbase = prt(rt < nrt ? rt : nrt - 1) * 32;
             const bool live = rt < nrt;
             float* C = a.C[group];
             const bool use_bias = a.bias && (a.bias_group < 0 || a.bias_group == group);
@@ -1432,6 +1435,7 @@ static int launch_gemm_nt_rows(const GemmArgs& a, hipStream_t s, bool top) {
     k.bias = a.bias; k.rowscale = a.rowscale; k.rowbias = a.rowbias; k.resid = a.resid; k.gate = a.gate;
     k.rng = a.rng; k.rng_stream = a.rng_stream; k.act = a.act; k.p_drop = a.p_drop; k.gate_scale = a.gate_scale;
     k.row0 = a.row0;
+    k.reverse = top ? next_sweep_direction() : 0;
     k.c_cm_rows = a.c_cm_rows;
     k.aux_cm_rows = a.aux_cm_rows;
 

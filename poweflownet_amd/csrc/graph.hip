@@ -6,6 +6,7 @@
 // reach the output).  One histogram pass, a two-launch scan, one fill, one placement pass (rows in edge-id order); no host sync:
 // the "directed" decision of the reference's first-edge heuristic is taken on device and consumed by
 // the later kernels through flags[].
+#include <atomic>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -26,6 +27,11 @@ void set_error(const char* fmt, ...) {
 const char* last_error() { return g_err; }
 
 const char* diag_env(const char* name) { return getenv(name); }
+int next_sweep_direction() {   // (pfn_internal.hpp: serpentine sweeps)
+    static const bool off = diag_env("PFN_NO_SERPENTINE") != nullptr;   // A/B switch: every launch walks its rows first to last
+    static thread_local unsigned n = 0;
+    return off ? 0 : (int)(n++ & 1u);
+}
 
 int device_cus() {
     static std::atomic<int> cus[64];          // zero-initialised; 0 = not asked yet

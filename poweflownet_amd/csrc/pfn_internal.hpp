@@ -52,6 +52,14 @@ int device_cus();
 // include/pfn_hip.h (A/B aids for tests and tuning; unset = the product's behaviour).  Call sites keep the value in a
 // function-local static, i.e. a switch is read once per process.
 const char* diag_env(const char* name);
+// SERPENTINE SWEEPS (round 6).  The kernels that stream whole activation tensors (gemm_nt, the LDS-resident walks and hops, the
+// generic forward walk) can visit their rows first-to-last or last-to-first with identical results.  Consecutive launches alternate:
+// a consumer then starts with the rows its producer wrote LAST -- still in L2 / Infinity Cache -- instead of with the rows written
+// first, which a 128-255 MB tensor has pushed out by the time it is complete (case118v2 x 2048: 2.29 -> 2.23 ms per forward; with
+// `nt` stores, i.e. nothing left behind for the consumer, the same step takes 2.55).  next_sweep_direction() = the direction of the
+// next such launch: the parity of a thread-local count of them (PFN_NO_SERPENTINE=1: always 0).  It orders memory traffic only --
+// no result depends on it.
+int next_sweep_direction();
 int ensure_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done);
 
 static inline int64_t round_up(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
